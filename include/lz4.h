@@ -1,0 +1,61 @@
+/*
+ * lz4.h -- block API of the MI355X-native LZ4 codec (liblz4_amd).
+ *
+ * Drop-in declarations for the block-codec entry points of the reference library
+ * (lz4/lz4 v1.10.0, lib/lz4.h); each prototype cites the reference declaration it replaces.
+ * Same names, argument meaning and return conventions; host pointers in and out.  The work is
+ * done by hand-written gfx950 kernels (see include/lz4amd.h for the batch interface the
+ * kernels are really built for).  Compressed bytes may differ from the CPU library's but are
+ * legal LZ4 blocks and decode to the same data with any conforming decoder.
+ *
+ * Not provided (out of the hot-path scope): streaming / dictionary
+ * variants (LZ4_compress_fast_continue, LZ4_loadDict, ...), LZ4_compress_destSize,
+ * LZ4_decompress_safe_partial and the deprecated LZ4_decompress_fast family.
+ */
+#ifndef LZ4_AMD_LZ4_H
+#define LZ4_AMD_LZ4_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference lz4.h:131-140 */
+#define LZ4_VERSION_MAJOR    1
+#define LZ4_VERSION_MINOR   10
+#define LZ4_VERSION_RELEASE  0
+#define LZ4_VERSION_NUMBER (LZ4_VERSION_MAJOR *100*100 + LZ4_VERSION_MINOR *100 + LZ4_VERSION_RELEASE)
+#define LZ4_VERSION_STRING "1.10.0"
+
+/* reference lz4.h:214-215 */
+#define LZ4_MAX_INPUT_SIZE        0x7E000000
+#define LZ4_COMPRESSBOUND(isize)  ((unsigned)(isize) > (unsigned)LZ4_MAX_INPUT_SIZE ? 0 : (isize) + ((isize)/255) + 16)
+
+/* reference lz4.h:673-675 */
+#define LZ4_DISTANCE_MAX 65535
+
+/* reference lz4.h:729: size a caller must provide for an external compression state */
+#define LZ4_STREAM_MINSIZE  ((1UL << 14) + 32)
+
+int         LZ4_versionNumber(void);                                              /* lz4.h:142 */
+const char* LZ4_versionString(void);                                              /* lz4.h:143 */
+
+/* lz4.h:191.  Returns the number of bytes written to dst (<= dstCapacity), 0 if the block does
+ * not fit.  Always succeeds when dstCapacity >= LZ4_compressBound(srcSize). */
+int LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);
+
+/* lz4.h:208.  Returns the number of bytes decoded (<= dstCapacity), or a negative value if src
+ * is malformed or dst too small.  Never reads outside src[0,compressedSize) nor writes outside
+ * dst[0,dstCapacity). */
+int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
+
+int LZ4_compressBound(int inputSize);                                              /* lz4.h:226 */
+int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:236 */
+int LZ4_sizeofState(void);                                                         /* lz4.h:245 */
+int LZ4_compress_fast_extState(void* state, const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:246 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

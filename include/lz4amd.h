@@ -1,0 +1,80 @@
+/*
+ * lz4amd.h -- batch (block-table) entry points of the MI355X-native LZ4 block codec.
+ *
+ * This is the shape in which the reference itself drives the block codec when it has many
+ * independent blocks: programs/bench.c:347-355 (`blockParam_t` = {srcPtr, srcSize, cPtr, cRoom,
+ * cSize, resPtr, resSize}) looped over LZ4_compress_fast / LZ4_decompress_safe_usingDict
+ * (bench.c:466-480, 522-542), and programs/lz4io.c:1130-1160 (one job per 4 MB chunk).
+ * Here the whole table is handed to the GPU at once; every block is an independent LZ4 block
+ * with exactly the semantics of
+ *     LZ4_compress_default   (lib/lz4.h:191)   -> result = compressed size, 0 = failure
+ *     LZ4_decompress_safe    (lib/lz4.h:208)   -> result = decoded size, < 0 = malformed / too small
+ * Plain C ABI: pointers and sizes only.  Buffers named d_* are DEVICE (HBM) pointers; everything
+ * else is host memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *
+ * There is no CPU fallback: every call fails (LZ4AMD_E_NODEVICE) when no HIP device is usable.
+ */
+#ifndef LZ4AMD_H
+#define LZ4AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZ4AMD_OK            0
+#define LZ4AMD_E_NODEVICE  (-1)   /* no usable HIP device / runtime error at init */
+#define LZ4AMD_E_ARG       (-2)
+#define LZ4AMD_E_MEMORY    (-3)
+#define LZ4AMD_E_RUNTIME   (-4)   /* a HIP call failed; see lz4amd_last_error() */
+
+typedef struct lz4amd_ctx  lz4amd_ctx;    /* per-device context */
+typedef struct lz4amd_plan lz4amd_plan;   /* one block table bound to device buffers */
+
+typedef enum {
+    LZ4AMD_OP_COMPRESS   = 0,   /* LZ4_compress_default per block (lz4.c:1472) */
+    LZ4AMD_OP_DECOMPRESS = 1,   /* LZ4_decompress_safe per block (lz4.c:2451) */
+    LZ4AMD_OP_COMPRESS_HC = 2,  /* LZ4_compress_HC per block (lz4hc.c:1519) */
+    LZ4AMD_OP_XXH32 = 3         /* XXH32(seed 0) per block (xxhash.c:392); result = hash as int */
+} lz4amd_op;
+
+int         lz4amd_ctx_create(lz4amd_ctx** out, int device);
+void        lz4amd_ctx_destroy(lz4amd_ctx* ctx);
+const char* lz4amd_last_error(void);
+int         lz4amd_device_cus(const lz4amd_ctx* ctx);
+
+/* LZ4_compressBound (lz4.h:226) - pure arithmetic, usable without a device */
+int         lz4amd_compress_bound(int src_size);
+
+/* Bind a table of n blocks.  d_src[i]/d_dst[i] are device pointers, src_sizes/dst_caps host
+ * arrays (copied).  level is used by LZ4AMD_OP_COMPRESS_HC only. */
+int  lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
+                        const void* const* d_src, const int* src_sizes,
+                        void* const* d_dst, const int* dst_caps, int level);
+void lz4amd_plan_destroy(lz4amd_plan* plan);
+/* enqueue the whole table on `stream` (asynchronous) */
+int  lz4amd_plan_launch(lz4amd_plan* plan, void* stream);
+/* same, bracketing every kernel with HIP events on `stream`; blocks until done.
+ * kernel_ms[0..3] receive the durations of the (up to 4) kernels of the op, total_ms their span. */
+int  lz4amd_plan_launch_timed(lz4amd_plan* plan, void* stream, float kernel_ms[4], float* total_ms);
+/* per-block results: device-resident int[n], or copied to the host (synchronises `stream`) */
+const int* lz4amd_plan_device_results(const lz4amd_plan* plan);
+int  lz4amd_plan_results(lz4amd_plan* plan, int* results, void* stream);
+
+/* one-shot conveniences: plan + launch + results (synchronous) */
+int  lz4amd_compress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
+                           void* const* d_dst, const int* dst_caps, int* results, int n, void* stream);
+int  lz4amd_decompress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
+                             void* const* d_dst, const int* dst_caps, int* results, int n, void* stream);
+
+/* raw device-memory helpers for C callers that do not link the HIP runtime themselves */
+void* lz4amd_dev_malloc(size_t bytes);
+void  lz4amd_dev_free(void* d_ptr);
+int   lz4amd_dev_upload(void* d_dst, const void* h_src, size_t bytes);
+int   lz4amd_dev_download(void* h_dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""ctypes binding of the C ABI in include/lz4amd.h and include/lz4.h.
+
+Mirrors the reference's block-table driving code (programs/bench.c:347-355 blockParam_t,
+466-480 compress loop, 522-542 decompress loop): a BlockTable is the list of
+(src pointer, src size, dst pointer, dst capacity) rows, a Plan binds it to the device.
+"""
+import ctypes
+import os
+
+OP_COMPRESS, OP_DECOMPRESS, OP_COMPRESS_HC, OP_XXH32 = 0, 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Lz4AmdError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "liblz4_amd.so")
+
+
+def lib():
+    """Load liblz4_amd.so (built in-tree by `python -m lz4_amd.build`).  Fails loudly."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise Lz4AmdError(f"{path} is missing: run `python -m lz4_amd.build` (there is no fallback codec)")
+    L = ctypes.CDLL(path)
+    vp, ip, i, fp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_float)
+    L.lz4amd_ctx_create.argtypes = [ctypes.POINTER(vp), i]
+    L.lz4amd_ctx_destroy.argtypes = [vp]
+    L.lz4amd_last_error.restype = ctypes.c_char_p
+    L.lz4amd_device_cus.argtypes = [vp]
+    L.lz4amd_compress_bound.argtypes = [i]
+    L.lz4amd_plan_create.argtypes = [vp, ctypes.POINTER(vp), i, i, ctypes.POINTER(vp), ip, ctypes.POINTER(vp), ip, i]
+    L.lz4amd_plan_destroy.argtypes = [vp]
+    L.lz4amd_plan_launch.argtypes = [vp, vp]
+    L.lz4amd_plan_launch_timed.argtypes = [vp, vp, fp, fp]
+    L.lz4amd_plan_results.argtypes = [vp, ip, vp]
+    L.lz4amd_plan_device_results.argtypes = [vp]
+    L.lz4amd_plan_device_results.restype = vp
+    for name in ("LZ4_compress_default", "LZ4_decompress_safe"):
+        getattr(L, name).argtypes = [ctypes.c_char_p, ctypes.c_char_p, i, i]
+    L.LZ4_compress_fast.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i, i, i]
+    L.LZ4_compressBound.argtypes = [i]
+    L.LZ4_versionString.restype = ctypes.c_char_p
+    _LIB = L
+    return L
+
+
+def compress_bound(n):
+    return lib().lz4amd_compress_bound(int(n))
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().lz4amd_last_error()
+        raise Lz4AmdError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+class Context:
+    """Per-device context (lz4amd_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        _check(lib().lz4amd_ctx_create(ctypes.byref(self._h), int(device)), "lz4amd_ctx_create")
+        self.device = device
+
+    @property
+    def cus(self):
+        return lib().lz4amd_device_cus(self._h)
+
+    def close(self):
+        if self._h:
+            lib().lz4amd_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BlockTable:
+    """Rows of (device src pointer, src size, device dst pointer, dst capacity)."""
+
+    def __init__(self, src_ptrs, src_sizes, dst_ptrs, dst_caps):
+        n = len(src_ptrs)
+        assert len(src_sizes) == n and len(dst_ptrs) == n and len(dst_caps) == n
+        self.n = n
+        self.src_ptrs = (ctypes.c_void_p * n)(*[int(p) for p in src_ptrs])
+        self.dst_ptrs = (ctypes.c_void_p * n)(*[int(p) for p in dst_ptrs])
+        self.src_sizes = (ctypes.c_int * n)(*[int(s) for s in src_sizes])
+        self.dst_caps = (ctypes.c_int * n)(*[int(s) for s in dst_caps])
+
+
+class Plan:
+    """A block table bound to the device (lz4amd_plan)."""
+
+    def __init__(self, ctx, op, table, level=0):
+        self._h = ctypes.c_void_p()
+        self.ctx, self.op, self.table = ctx, op, table
+        _check(lib().lz4amd_plan_create(ctx._h, ctypes.byref(self._h), int(op), table.n,
+                                        table.src_ptrs, table.src_sizes, table.dst_ptrs, table.dst_caps,
+                                        int(level)), "lz4amd_plan_create")
+
+    def launch(self, stream=0):
+        _check(lib().lz4amd_plan_launch(self._h, ctypes.c_void_p(stream)), "lz4amd_plan_launch")
+
+    def launch_timed(self, stream=0):
+        """Run once with HIP events around every kernel; returns (kernel_ms[4], total_ms)."""
+        k = (ctypes.c_float * 4)()
+        t = ctypes.c_float()
+        _check(lib().lz4amd_plan_launch_timed(self._h, ctypes.c_void_p(stream), k, ctypes.byref(t)),
+               "lz4amd_plan_launch_timed")
+        return list(k), t.value
+
+    def results(self, stream=0):
+        out = (ctypes.c_int * self.table.n)()
+        _check(lib().lz4amd_plan_results(self._h, out, ctypes.c_void_p(stream)), "lz4amd_plan_results")
+        return list(out)
+
+    def close(self):
+        if self._h:
+            lib().lz4amd_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _stream_handle(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    return getattr(stream, "cuda_stream", stream)
+
+
+def compress_blocks(ctx, data, block_size, stream=None):
+    """Compress a CUDA uint8 tensor as independent blocks of `block_size` bytes.
+    Returns (comp tensor [n, stride], sizes list, plan)."""
+    import torch
+    assert data.is_cuda and data.dtype == torch.uint8 and data.dim() == 1
+    total = data.numel()
+    n = (total + block_size - 1) // block_size
+    stride = (compress_bound(block_size) + 255) & ~255
+    comp = torch.empty((max(n, 1), stride), dtype=torch.uint8, device=data.device)
+    base, cbase = data.data_ptr(), comp.data_ptr()
+    sizes = [min(block_size, total - i * block_size) for i in range(n)]
+    table = BlockTable([base + i * block_size for i in range(n)], sizes,
+                       [cbase + i * stride for i in range(n)], [stride] * n)
+    plan = Plan(ctx, OP_COMPRESS, table)
+    s = _stream_handle(stream)
+    plan.launch(s)
+    return comp, plan.results(s), plan
+
+
+def decompress_blocks(ctx, comp, csizes, block_size, total, stream=None):
+    """Inverse of compress_blocks.  Returns (out tensor [total], results list, plan)."""
+    import torch
+    n = len(csizes)
+    out = torch.empty(max(total, 1), dtype=torch.uint8, device=comp.device)
+    stride = comp.stride(0)
+    caps = [min(block_size, total - i * block_size) for i in range(n)]
+    table = BlockTable([comp.data_ptr() + i * stride for i in range(n)], csizes,
+                       [out.data_ptr() + i * block_size for i in range(n)], caps)
+    plan = Plan(ctx, OP_DECOMPRESS, table)
+    s = _stream_handle(stream)
+    plan.launch(s)
+    return out[:total], plan.results(s), plan

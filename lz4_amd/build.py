@@ -1,0 +1,77 @@
+"""Build the in-tree native artefacts (hipcc cross-compiles gfx950 without a GPU).
+
+    python -m lz4_amd.build            # product library + tools
+    python -m lz4_amd.build --all      # ... plus oracle and CPU-interpreter test twins
+
+Outputs (git-ignored, shipped to the GPU box by gpurun):
+    lz4_amd/liblz4_amd.so    the product: HIP kernels + C host code, C ABI of include/*.h
+    tools/libdatagen.so      synthetic data generator (tests / bench)
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "lz4_amd", "csrc")
+LIB = os.path.join(ROOT, "lz4_amd", "liblz4_amd.so")
+HOST_C = ["lz4amd_batch.c", "lz4_api.c"]
+
+
+def _run(cmd, cwd=None):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=cwd)
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _all_sources():
+    out = []
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files]
+    out += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    return out
+
+
+def build_product(force=False):
+    if not force and not _newer(LIB, _all_sources()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for c in HOST_C:
+        o = os.path.join(objdir, c.replace(".c", ".o"))
+        _run(["gcc", "-O2", "-fPIC", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-Wextra", "-c", os.path.join(CSRC, c), "-o", o])
+        objs.append(o)
+    dev_o = os.path.join(objdir, "lz4amd_device.o")
+    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+          os.path.join(CSRC, "lz4amd_device.hip"), "-o", dev_o])
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_o] + objs + ["-lpthread"])
+    return LIB
+
+
+def build_tools(force=False):
+    src = os.path.join(ROOT, "tools", "datagen.c")
+    so = os.path.join(ROOT, "tools", "libdatagen.so")
+    if force or _newer(so, [src]):
+        _run(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src])
+    return so
+
+
+def build_test_infra():
+    """oracle (+ the real reference into oracle/_ref when /root/reference exists) and the
+    CPU-interpreted kernel twins used by the not-gpu unit tests."""
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
+    _run(["sh", os.path.join(ROOT, "tests", "simt", "build.sh")])
+
+
+if __name__ == "__main__":
+    build_product(force="--force" in sys.argv)
+    build_tools()
+    if "--all" in sys.argv:
+        build_test_infra()

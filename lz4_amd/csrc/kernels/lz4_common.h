@@ -1,0 +1,92 @@
+// lz4_common.h -- device-side helpers shared by the LZ4 block codec kernels (gfx950).
+// Included AFTER a platform header (platform_hip.h in the product build).
+#pragma once
+#include <stdint.h>
+
+namespace lz4amd {
+
+// Block format constants (doc/lz4_Block_format.md; lz4.c:242-263)
+enum : uint32_t {
+    kMinMatch = 4,
+    kMfLimit = 12,        // last match must start >= 12 bytes before the end of the block
+    kLastLiterals = 5,    // last 5 bytes are always literals
+    kMaxDistance = 65535,
+};
+
+// per-block status codes returned in result[] when negative
+// (the reference returns -(consumed)-1, lz4.c:2443; callers only test < 0)
+__device__ __forceinline__ int err_at(uint32_t pos) { return -(int)(pos & 0x7FFFFFFFu) - 1; }
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint32_t ld_u8(const uint8_t* p) { return *p; }
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+struct alignas(16) U32x4 { uint32_t x, y, z, w; };
+
+// ---- wave-level inclusive scans (64 lanes) ------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(v, d);
+        if (lane >= d && y > v) v = y;
+    }
+    return v;
+}
+
+// ---- block-level exclusive sum of two values per thread (a: u32, b: u64) ---------------
+// scratch: 3 * nwaves uint32 in LDS.  Returns exclusive prefixes; totals via ta, tb.
+// Contains two __syncthreads(); every thread of the block must call it.
+__device__ __forceinline__ uint64_t wave_incl_sum64(uint64_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint64_t y = __shfl_up(v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+__device__ __forceinline__ void block_excl_sum2(uint32_t a, uint64_t b, uint32_t* scratch,
+                                                uint32_t& ea, uint64_t& eb, uint32_t& ta, uint64_t& tb) {
+    const uint32_t lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
+    const uint32_t ia = wave_incl_sum(a);
+    const uint64_t ib = wave_incl_sum64(b);
+    __syncthreads();                         // scratch may still be in use by a previous call
+    if (lane == 63) { scratch[w] = ia; scratch[nw + 2 * w] = (uint32_t)ib; scratch[nw + 2 * w + 1] = (uint32_t)(ib >> 32); }
+    __syncthreads();
+    uint32_t ba = 0, sa = 0; uint64_t bb = 0, sb = 0;
+    for (uint32_t i = 0; i < nw; i++) {
+        const uint32_t xa = scratch[i];
+        const uint64_t xb = (uint64_t)scratch[nw + 2 * i] | ((uint64_t)scratch[nw + 2 * i + 1] << 32);
+        if (i < w) { ba += xa; bb += xb; }
+        sa += xa; sb += xb;
+    }
+    ea = ba + ia - a; eb = bb + ib - b; ta = sa; tb = sb;
+}
+
+// block-level inclusive max-scan, one value per thread. scratch: nwaves uint32.
+__device__ __forceinline__ uint32_t block_incl_max(uint32_t v, uint32_t* scratch) {
+    const uint32_t lane = lane_id(), w = wave_id();
+    uint32_t iv = wave_incl_max(v);
+    __syncthreads();
+    if (lane == 63) scratch[w] = iv;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < w; i++) { uint32_t x = scratch[i]; if (x > base) base = x; }
+    return iv > base ? iv : base;
+}
+
+} // namespace lz4amd

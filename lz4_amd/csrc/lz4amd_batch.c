@@ -1,0 +1,236 @@
+/*
+ * lz4amd_batch.c -- host side (plain C) of the batch block codec: contexts, block-table plans,
+ * launch sequencing.  All GPU work goes through the thin FFI of lz4amd_ffi.h.
+ *
+ * A "plan" is the device-resident image of the reference's block table
+ * (programs/bench.c:347-355 blockParam_t): per-block source/destination pointers and sizes,
+ * per-block results, and the scratch the kernels need (sequence tables for the decoder,
+ * match records / sub-chunk tables for the compressor).
+ */
+#include "../../include/lz4amd.h"
+#include "lz4amd_ffi.h"
+#include "lz4amd_internal.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+static __thread char g_last_error[256] = "";
+
+void lz4amd_set_error(const char* msg)
+{
+    snprintf(g_last_error, sizeof g_last_error, "%s", msg ? msg : "");
+}
+const char* lz4amd_last_error(void) { return g_last_error; }
+
+int lz4amd_compress_bound(int n)
+{   /* lz4.h:214-215 LZ4_COMPRESSBOUND */
+    if (n < 0 || (unsigned)n > 0x7E000000u) return 0;
+    return n + n / 255 + 16;
+}
+
+/* ------------------------------------------------------------------ context */
+int lz4amd_ctx_create(lz4amd_ctx** out, int device)
+{
+    lz4amd_ctx* c;
+    int cus = 0;
+    if (!out) return LZ4AMD_E_ARG;
+    *out = NULL;
+    if (lz4amd_hip_init(device, &cus) != 0) {
+        lz4amd_set_error(lz4amd_hip_errstr());
+        fprintf(stderr, "lz4_amd: cannot use HIP device %d: %s (this library has no CPU fallback)\n",
+                device, lz4amd_hip_errstr());
+        return LZ4AMD_E_NODEVICE;
+    }
+    c = (lz4amd_ctx*)calloc(1, sizeof *c);
+    if (!c) return LZ4AMD_E_MEMORY;
+    c->device = device;
+    c->n_cus = cus > 0 ? cus : 1;
+    *out = c;
+    return LZ4AMD_OK;
+}
+
+void lz4amd_ctx_destroy(lz4amd_ctx* ctx) { free(ctx); }
+int lz4amd_device_cus(const lz4amd_ctx* ctx) { return ctx ? ctx->n_cus : 0; }
+
+void* lz4amd_dev_malloc(size_t bytes) { return lz4amd_hip_malloc(bytes); }
+void  lz4amd_dev_free(void* p) { lz4amd_hip_free(p); }
+int   lz4amd_dev_upload(void* d, const void* h, size_t n)
+{ if (lz4amd_hip_h2d(d, h, n, NULL) || lz4amd_hip_sync(NULL)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; } return 0; }
+int   lz4amd_dev_download(void* h, const void* d, size_t n)
+{ if (lz4amd_hip_d2h(h, d, n, NULL) || lz4amd_hip_sync(NULL)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; } return 0; }
+
+/* --------------------------------------------------------------------- plan */
+static void* dev_array(const void* host, size_t bytes, int* err)
+{
+    void* d = lz4amd_hip_malloc(bytes ? bytes : 16);
+    if (!d) { *err = LZ4AMD_E_MEMORY; return NULL; }
+    if (host && bytes && lz4amd_hip_h2d(d, host, bytes, NULL)) *err = LZ4AMD_E_RUNTIME;
+    return d;
+}
+
+void lz4amd_plan_destroy(lz4amd_plan* p)
+{
+    int i;
+    if (!p) return;
+    for (i = 0; i < LZ4AMD_PLAN_MAX_BUFS; i++) lz4amd_hip_free(p->bufs[i]);
+    for (i = 0; i < 5; i++) lz4amd_hip_event_destroy(p->ev[i]);
+    free(p);
+}
+
+int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
+                       const void* const* d_src, const int* src_sizes,
+                       void* const* d_dst, const int* dst_caps, int level)
+{
+    lz4amd_plan* p;
+    int err = 0, nb = 0, i;
+    size_t un = (size_t)(n > 0 ? n : 0);
+    if (!ctx || !out || n < 0 || (n > 0 && (!d_src || !src_sizes || !d_dst || !dst_caps))) return LZ4AMD_E_ARG;
+    *out = NULL;
+    p = (lz4amd_plan*)calloc(1, sizeof *p);
+    if (!p) return LZ4AMD_E_MEMORY;
+    p->ctx = ctx; p->op = op; p->n = n; p->level = level;
+
+    /* the block table itself */
+    void* dsrc  = p->bufs[nb++] = dev_array(d_src, un * sizeof(void*), &err);
+    void* dssz  = p->bufs[nb++] = dev_array(src_sizes, un * sizeof(int), &err);
+    void* ddst  = p->bufs[nb++] = dev_array(d_dst, un * sizeof(void*), &err);
+    void* dcap  = p->bufs[nb++] = dev_array(dst_caps, un * sizeof(int), &err);
+    void* dres  = p->bufs[nb++] = dev_array(NULL, un * sizeof(int), &err);
+    p->d_results = (int*)dres;
+
+    if (op == LZ4AMD_OP_DECOMPRESS) {
+        unsigned max_c = 0, grid;
+        lz4amd_dec_params* q = &p->dec;
+        for (i = 0; i < n; i++) if (src_sizes[i] > 0 && (unsigned)src_sizes[i] > max_c) max_c = (unsigned)src_sizes[i];
+        /* one 1024-thread workgroup owns a CU's LDS; blocks are pulled from a ticket counter */
+        grid = (unsigned)ctx->n_cus;
+        if ((unsigned)n < grid) grid = (unsigned)n;
+        p->grid = grid;
+        q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
+        q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
+        q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
+        q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c) + 255) & ~(uint64_t)255;
+        q->ticket = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
+        q->scratch = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)q->scratch_stride * (grid ? grid : 1), &err));
+    } else if (op == LZ4AMD_OP_COMPRESS) {
+        lz4amd_comp_params* q = &p->comp;
+        const uint32_t sub = LZ4AMD_SUB_BYTES;
+        uint32_t* blk_sub0 = (uint32_t*)malloc((un + 1) * sizeof(uint32_t));
+        uint32_t* sub_block;
+        uint64_t ns = 0; uint32_t k = 0;
+        if (!blk_sub0) { lz4amd_plan_destroy(p); return LZ4AMD_E_MEMORY; }
+        for (i = 0; i < n; i++) {
+            uint32_t sz = (src_sizes[i] > 0 && (unsigned)src_sizes[i] <= 0x7E000000u) ? (uint32_t)src_sizes[i] : 0;
+            blk_sub0[i] = (uint32_t)ns;
+            ns += (sz + sub - 1) / sub;
+        }
+        blk_sub0[n] = (uint32_t)ns;
+        if (ns > 0x7FFFFFFFu) { free(blk_sub0); lz4amd_plan_destroy(p); return LZ4AMD_E_ARG; }
+        sub_block = (uint32_t*)malloc((size_t)(ns ? ns : 1) * sizeof(uint32_t));
+        if (!sub_block) { free(blk_sub0); lz4amd_plan_destroy(p); return LZ4AMD_E_MEMORY; }
+        for (i = 0; i < n; i++) for (; k < blk_sub0[i + 1]; k++) sub_block[k] = (uint32_t)i;
+        q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
+        q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
+        q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
+        q->n_subs = (uint32_t)ns; q->sub_bytes = sub;
+        q->recs_per_sub = lz4amd_hip_comp_recs_per_sub(sub);
+        q->sub_block = (const uint32_t*)(p->bufs[nb++] = dev_array(sub_block, (size_t)ns * 4, &err));
+        q->blk_sub0 = (const uint32_t*)(p->bufs[nb++] = dev_array(blk_sub0, (un + 1) * 4, &err));
+        q->recs = p->bufs[nb++] = dev_array(NULL, (size_t)ns * q->recs_per_sub * 8, &err);
+        q->sub_n = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
+        q->sub_enc = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
+        q->sub_tail = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
+        q->sub_out = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
+        q->sub_carry = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
+        q->sub_tail_dst = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
+        /* uploads above are asynchronous copies from these host arrays: finish them first */
+        if (lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
+        free(sub_block); free(blk_sub0);
+    } else {
+        lz4amd_set_error("operation not implemented on the device yet");
+        lz4amd_plan_destroy(p);
+        return LZ4AMD_E_ARG;
+    }
+    if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
+    if (err) {
+        lz4amd_set_error(err == LZ4AMD_E_MEMORY ? "device allocation failed" : lz4amd_hip_errstr());
+        lz4amd_plan_destroy(p);
+        return err;
+    }
+    *out = p;
+    return LZ4AMD_OK;
+}
+
+static int launch_stage(lz4amd_plan* p, int stage, void* stream)
+{
+    if (p->op == LZ4AMD_OP_DECOMPRESS)
+        return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
+    switch (stage) {
+    case 0: return lz4amd_hip_launch_match(&p->comp, stream);
+    case 1: return lz4amd_hip_launch_offsets(&p->comp, stream);
+    case 2: return lz4amd_hip_launch_emit(&p->comp, stream);
+    default: return 0;
+    }
+}
+static int n_stages(const lz4amd_plan* p) { return p->op == LZ4AMD_OP_DECOMPRESS ? 1 : 3; }
+
+int lz4amd_plan_launch(lz4amd_plan* p, void* stream)
+{
+    int s;
+    if (!p) return LZ4AMD_E_ARG;
+    for (s = 0; s < n_stages(p); s++)
+        if (launch_stage(p, s, stream)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
+    return LZ4AMD_OK;
+}
+
+int lz4amd_plan_launch_timed(lz4amd_plan* p, void* stream, float kernel_ms[4], float* total_ms)
+{
+    int s, ns;
+    if (!p) return LZ4AMD_E_ARG;
+    ns = n_stages(p);
+    for (s = 0; s <= ns; s++)
+        if (!p->ev[s] && !(p->ev[s] = lz4amd_hip_event_create())) { lz4amd_set_error("hipEventCreate failed"); return LZ4AMD_E_RUNTIME; }
+    for (s = 0; s < ns; s++) {
+        if (lz4amd_hip_event_record(p->ev[s], stream) || launch_stage(p, s, stream)) {
+            lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME;
+        }
+    }
+    if (lz4amd_hip_event_record(p->ev[ns], stream) || lz4amd_hip_event_sync(p->ev[ns])) {
+        lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME;
+    }
+    for (s = 0; s < 4; s++) if (kernel_ms) kernel_ms[s] = s < ns ? lz4amd_hip_event_ms(p->ev[s], p->ev[s + 1]) : 0.f;
+    if (total_ms) *total_ms = lz4amd_hip_event_ms(p->ev[0], p->ev[ns]);
+    return LZ4AMD_OK;
+}
+
+const int* lz4amd_plan_device_results(const lz4amd_plan* p) { return p ? p->d_results : NULL; }
+
+int lz4amd_plan_results(lz4amd_plan* p, int* results, void* stream)
+{
+    if (!p || (p->n && !results)) return LZ4AMD_E_ARG;
+    if (lz4amd_hip_d2h(results, p->d_results, (size_t)p->n * sizeof(int), stream) || lz4amd_hip_sync(stream)) {
+        lz4amd_set_error(lz4amd_hip_errstr());
+        return LZ4AMD_E_RUNTIME;
+    }
+    return LZ4AMD_OK;
+}
+
+static int one_shot(lz4amd_ctx* ctx, lz4amd_op op, const void* const* d_src, const int* src_sizes,
+                    void* const* d_dst, const int* dst_caps, int* results, int n, void* stream)
+{
+    lz4amd_plan* p = NULL;
+    int rc = lz4amd_plan_create(ctx, &p, op, n, d_src, src_sizes, d_dst, dst_caps, 0);
+    if (rc) return rc;
+    rc = lz4amd_plan_launch(p, stream);
+    if (!rc) rc = lz4amd_plan_results(p, results, stream);
+    lz4amd_plan_destroy(p);
+    return rc;
+}
+
+int lz4amd_compress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
+                          void* const* d_dst, const int* dst_caps, int* results, int n, void* stream)
+{ return one_shot(ctx, LZ4AMD_OP_COMPRESS, d_src, src_sizes, d_dst, dst_caps, results, n, stream); }
+
+int lz4amd_decompress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
+                            void* const* d_dst, const int* dst_caps, int* results, int n, void* stream)
+{ return one_shot(ctx, LZ4AMD_OP_DECOMPRESS, d_src, src_sizes, d_dst, dst_caps, results, n, stream); }

@@ -1,0 +1,101 @@
+// lz4amd_device.hip -- the only HIP translation unit of liblz4_amd: gfx950 kernels plus the thin
+// extern "C" launch / memory wrappers declared in lz4amd_ffi.h.  Kernel bodies live in kernels/*.h.
+#include "kernels/platform_hip.h"
+#include "kernels/lz4_decompress_kernel.h"
+#include "kernels/lz4_compress_kernel.h"
+#include "lz4amd_ffi.h"
+#include <stdio.h>
+
+using namespace lz4amd;
+
+// ------------------------------------------------------------------------------- kernels
+__global__ void __launch_bounds__(kDecThreads) lz4amd_k_decompress(lz4amd_dec_params p) { decompress_batch_body(p); }
+__global__ void __launch_bounds__(64) lz4amd_k_match(lz4amd_comp_params p) { match_subchunk_body(p); }
+__global__ void __launch_bounds__(64) lz4amd_k_offsets(lz4amd_comp_params p) { offsets_body(p); }
+__global__ void __launch_bounds__(64) lz4amd_k_emit(lz4amd_comp_params p) { emit_subchunk_body(p); }
+
+// ------------------------------------------------------------------------------- runtime glue
+static thread_local char g_err[256] = "";
+static int fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return -1;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(e_, #call); } while (0)
+
+extern "C" const char* lz4amd_hip_errstr(void) { return g_err; }
+
+extern "C" int lz4amd_hip_init(int device, int* n_cus) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        snprintf(g_err, sizeof g_err, "no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return -1;
+    }
+    if (device < 0 || device >= count) { snprintf(g_err, sizeof g_err, "device %d out of range (%d)", device, count); return -1; }
+    HIPCHK(hipSetDevice(device));
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (n_cus) *n_cus = cus;
+    // the decoder uses ~150 KB of the CU's 160 KB LDS: opt in to large dynamic LDS
+    HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
+    return 0;
+}
+
+extern "C" void* lz4amd_hip_malloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { fail(e, "hipMalloc"); return nullptr; }
+    return p;
+}
+extern "C" void lz4amd_hip_free(void* d) { if (d) (void)hipFree(d); }
+extern "C" int lz4amd_hip_h2d(void* d, const void* h, size_t n, void* s) {
+    if (!n) return 0;
+    HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s)); return 0;
+}
+extern "C" int lz4amd_hip_d2h(void* h, const void* d, size_t n, void* s) {
+    if (!n) return 0;
+    HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s)); return 0;
+}
+extern "C" int lz4amd_hip_memset(void* d, int v, size_t n, void* s) {
+    if (!n) return 0;
+    HIPCHK(hipMemsetAsync(d, v, n, (hipStream_t)s)); return 0;
+}
+extern "C" int lz4amd_hip_sync(void* s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
+extern "C" void* lz4amd_hip_event_create(void) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void*)e; }
+extern "C" void lz4amd_hip_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int lz4amd_hip_event_record(void* ev, void* s) { HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return 0; }
+extern "C" int lz4amd_hip_event_sync(void* ev) { HIPCHK(hipEventSynchronize((hipEvent_t)ev)); return 0; }
+extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.f;
+    return ms;
+}
+
+extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return (size_t)dec_scratch_bytes(max_csize); }
+extern "C" unsigned lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes) { return sub_bytes / 4 + 8; }
+
+extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* s) {
+    if (!p->n_blocks || !grid) return 0;
+    HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
+    hipLaunchKernelGGL(lz4amd_k_decompress, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int lz4amd_hip_launch_match(const lz4amd_comp_params* p, void* s) {
+    if (!p->n_subs) return 0;
+    hipLaunchKernelGGL(lz4amd_k_match, dim3(p->n_subs), dim3(64), kMatchLdsBytes, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int lz4amd_hip_launch_offsets(const lz4amd_comp_params* p, void* s) {
+    if (!p->n_blocks) return 0;
+    hipLaunchKernelGGL(lz4amd_k_offsets, dim3(p->n_blocks), dim3(64), 0, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int lz4amd_hip_launch_emit(const lz4amd_comp_params* p, void* s) {
+    if (!p->n_subs) return 0;
+    hipLaunchKernelGGL(lz4amd_k_emit, dim3(p->n_subs), dim3(64), 0, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

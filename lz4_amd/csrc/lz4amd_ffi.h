@@ -1,0 +1,40 @@
+/* lz4amd_ffi.h -- the thin extern "C" seam between the C host code (lz4amd_batch.c, lz4_api.c,
+ * lz4frame_api.c) and the HIP translation unit (lz4amd_device.hip).  Everything the host code
+ * needs from the HIP runtime goes through these functions, so the host side stays plain C. */
+#ifndef LZ4AMD_FFI_H
+#define LZ4AMD_FFI_H
+#include <stddef.h>
+#include "lz4amd_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int         lz4amd_hip_init(int device, int* n_cus);            /* 0 ok */
+const char* lz4amd_hip_errstr(void);
+void*       lz4amd_hip_malloc(size_t bytes);
+void        lz4amd_hip_free(void* d);
+int         lz4amd_hip_h2d(void* d, const void* h, size_t n, void* stream);
+int         lz4amd_hip_d2h(void* h, const void* d, size_t n, void* stream);
+int         lz4amd_hip_memset(void* d, int value, size_t n, void* stream);
+int         lz4amd_hip_sync(void* stream);
+void*       lz4amd_hip_event_create(void);
+void        lz4amd_hip_event_destroy(void* ev);
+int         lz4amd_hip_event_record(void* ev, void* stream);
+int         lz4amd_hip_event_sync(void* ev);
+float       lz4amd_hip_event_ms(void* start, void* stop);
+
+/* kernel geometry facts the host needs for sizing */
+size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize);
+unsigned    lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes);
+
+/* launches (asynchronous on `stream`) */
+int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* stream);
+int lz4amd_hip_launch_match(const lz4amd_comp_params* p, void* stream);
+int lz4amd_hip_launch_offsets(const lz4amd_comp_params* p, void* stream);
+int lz4amd_hip_launch_emit(const lz4amd_comp_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,33 @@
+/* lz4amd_internal.h -- private structures of the C host code. */
+#ifndef LZ4AMD_INTERNAL_H
+#define LZ4AMD_INTERNAL_H
+#include "../../include/lz4amd.h"
+#include "lz4amd_params.h"
+
+#define LZ4AMD_SUB_BYTES (64u << 10)     /* compressor sub-chunk (one wave each) */
+#define LZ4AMD_PLAN_MAX_BUFS 20
+
+struct lz4amd_ctx {
+    int device;
+    int n_cus;
+};
+
+struct lz4amd_plan {
+    lz4amd_ctx* ctx;
+    lz4amd_op op;
+    int n;
+    int level;
+    unsigned grid;
+    int* d_results;
+    void* bufs[LZ4AMD_PLAN_MAX_BUFS];   /* every device allocation owned by the plan */
+    void* ev[5];                        /* HIP events for the timed launch */
+    lz4amd_dec_params dec;
+    lz4amd_comp_params comp;
+};
+
+void lz4amd_set_error(const char* msg);
+
+/* process-wide default context used by the classic one-block API (lz4_api.c) */
+lz4amd_ctx* lz4amd_default_ctx(void);
+
+#endif

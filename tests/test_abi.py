@@ -1,0 +1,68 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares; the
+device-dependent entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from lz4_amd import build
+    return build.build_product()
+
+
+def _declared_functions():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for h in os.listdir(inc):
+        text = open(os.path.join(inc, h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+        for m in re.finditer(r"\b((?:LZ4F?|lz4amd)_[A-Za-z0-9_]+)\s*\(", text):
+            names.add(m.group(1))
+    return names
+
+
+def test_exports_every_declared_symbol(libpath):
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    declared = _declared_functions()
+    assert declared, "no prototypes parsed"
+    missing = sorted(declared - exported)
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+
+
+def test_pure_arithmetic_entry_points(libpath):
+    L = ctypes.CDLL(libpath)
+    assert L.LZ4_compressBound(4 << 20) == 4210768
+    assert L.LZ4_compressBound(65536) == 65809
+    assert L.LZ4_compressBound(0x7E000001) == 0
+    assert L.lz4amd_compress_bound(262144) == 263188
+    L.LZ4_versionString.restype = ctypes.c_char_p
+    assert L.LZ4_versionNumber() == 11000 and L.LZ4_versionString() == b"1.10.0"
+    assert L.LZ4_sizeofState() == 16416
+
+
+def test_no_silent_cpu_fallback(libpath):
+    """Without a device the classic API must report failure, not quietly run on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = ctypes.CDLL(libpath)
+    dst = ctypes.create_string_buffer(128)
+    assert L.LZ4_compress_default(b"hello hello hello hello", dst, 23, 128) == 0
+    assert L.LZ4_decompress_safe(b"\x00", dst, 1, 128) < 0
+    h = ctypes.c_void_p()
+    assert L.lz4amd_ctx_create(ctypes.byref(h), 0) == -1     # LZ4AMD_E_NODEVICE
+
+
+def test_product_does_not_link_oracle(libpath):
+    out = subprocess.run(["nm", "-D", libpath], capture_output=True, text=True, check=True).stdout
+    assert "lz4o_" not in out
+    ldd = subprocess.run(["ldd", libpath], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd and "liblz4_ref" not in ldd

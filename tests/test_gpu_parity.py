@@ -1,0 +1,205 @@
+"""Parity tests proper: the gfx950 kernels, called through the C ABI (include/lz4amd.h, include/lz4.h),
+against the oracle on the same inputs, the reference's golden vectors, and -- at BASELINE sizes --
+size-independent properties (round trip, ratio window, canaries)."""
+import ctypes
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lz4_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    c = lz4_amd.Context(0)          # raises loudly if the HIP library / device is missing
+    assert c.cus >= 1
+    return c
+
+
+def _dev(b, pad=0, fill=0xEE):
+    t = torch.full((len(b) + pad,), fill, dtype=torch.uint8, device="cuda")
+    if len(b):
+        t[:len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    return t
+
+
+def gpu_decompress(ctx, comps, caps, guard=64):
+    import lz4_amd
+    srcs = [_dev(c, pad=16) for c in comps]
+    dsts = [torch.full((max(c, 0) + guard,), 0xEE, dtype=torch.uint8, device="cuda") for c in caps]
+    table = lz4_amd.BlockTable([s.data_ptr() for s in srcs], [len(c) for c in comps],
+                               [d.data_ptr() for d in dsts], caps)
+    plan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, table)
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    res = plan.results(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for r, d, cap in zip(res, dsts, caps):
+        h = d.cpu().numpy().tobytes()
+        assert h[max(cap, 0):] == b"\xEE" * guard, "wrote past dst[cap]"     # fuzzer.c:547-552
+        outs.append((r, h[:max(r, 0)]))
+    return outs
+
+
+def gpu_compress(ctx, datas, caps=None, guard=64):
+    import lz4_amd
+    caps = caps or [lz4_amd.compress_bound(len(d)) for d in datas]
+    srcs = [_dev(d, pad=16) for d in datas]
+    dsts = [torch.full((max(c, 0) + guard,), 0xEE, dtype=torch.uint8, device="cuda") for c in caps]
+    table = lz4_amd.BlockTable([s.data_ptr() for s in srcs], [len(d) for d in datas],
+                               [d.data_ptr() for d in dsts], caps)
+    plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, table)
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    res = plan.results(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for r, d, cap in zip(res, dsts, caps):
+        h = d.cpu().numpy().tobytes()
+        assert h[max(cap, 0):] == b"\xEE" * guard, "wrote past dst[cap]"
+        outs.append((r, h[:max(r, 0)]))
+    return outs
+
+
+@pytest.fixture(scope="module")
+def corpus(datagen):
+    specs = [(65536, 50, 0), (100, 50, 1), (0, 50, 0), (13, 50, 0), (12, 50, 0), (200000, 60, 2), (1 << 20, 60, 3),
+             (300000, 90, 4), (50000, 0, 5), (1, 50, 0), (65547, 50, 1), (65546, 50, 1), (131073, 60, 1),
+             (4 << 20, 60, 0), (262144, 60, 1)]
+    datas = [datagen(*s) for s in specs]
+    datas += [b"\x00" * 300000, b"abcd" * 70000, b"a" * 40000 + os.urandom(3000) + b"a" * 40000,
+              os.urandom(70000), b"ab" * 9, b"x" * 64, b"x" * 65]
+    return datas
+
+
+def test_decompress_reference_bytes(ctx, ocodec, corpus):
+    comps = [ocodec.compress(d)[1] for d in corpus]                # byte-identical to the reference
+    for d, (r, o) in zip(corpus, gpu_decompress(ctx, comps, [len(d) for d in corpus])):
+        assert r == len(d) and o == d
+
+
+def test_decompress_golden_reference_blocks(ctx, golden):
+    from conftest import GOLDEN_DIR, md5
+    names = [k for k, g in golden["blocks"].items() if "file" in g]    # includes an HC-9 stream
+    comps = [open(os.path.join(GOLDEN_DIR, golden["blocks"][k]["file"]), "rb").read() for k in names]
+    outs = gpu_decompress(ctx, comps, [golden["blocks"][k]["src_size"] for k in names])
+    for k, (r, o) in zip(names, outs):
+        assert r == golden["blocks"][k]["src_size"] and md5(o) == golden["blocks"][k]["src_md5"], k
+
+
+def test_decompress_capacity_edges(ctx, ocodec, datagen):
+    d = datagen(200000, 60, 2)
+    c = ocodec.compress(d)[1]
+    n = len(d)
+    caps = [n, n + 1, n + 100, n - 1, n - 10, n // 2, 0, 5]          # fuzzer.c:545-586
+    for cap, (r, o) in zip(caps, gpu_decompress(ctx, [c] * len(caps), caps)):
+        ro, oo = ocodec.decompress(c, cap)
+        assert (r < 0) == (ro < 0), cap
+        if r >= 0:
+            assert r == ro and o == oo
+    assert gpu_decompress(ctx, [b"\x00", b"\x01", b""], [0, 0, 10]) [0][0] == 0
+
+
+def test_decompress_hostile_input_matches_oracle(ctx, ocodec, datagen, golden):
+    rnd = random.Random(11)
+    muts, caps = [], []
+    for size, count in ((150000, 400), (3000, 400)):
+        base = ocodec.compress(datagen(size, 60, 9))[1]
+        for t in range(count):
+            cc = bytearray(base[:rnd.randint(1, len(base))] if t % 3 == 0 else base)
+            for _ in range(rnd.randint(1, 3)):
+                cc[rnd.randrange(len(cc))] = rnd.randrange(256)
+            muts.append(bytes(cc)); caps.append(size)
+    muts.append(bytes.fromhex(golden["known"]["malformed_17_hex"])); caps.append(100)
+    outs = gpu_decompress(ctx, muts, caps)
+    for cc, cap, (r, o) in zip(muts, caps, outs):
+        ro, oo = ocodec.decompress(cc, cap)
+        assert (r < 0) == (ro < 0)
+        if r >= 0:
+            assert r == ro and o == oo
+    assert outs[-1][0] < 0                                             # fuzzer.c:1110-1119
+
+
+def test_compress_decodes_with_oracle_decoder(ctx, ocodec, corpus):
+    outs = gpu_compress(ctx, corpus)
+    for d, (r, c) in zip(corpus, outs):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+    assert outs[2][1] == b"\x00"                                       # fuzzer.c:1125-1131
+
+
+def test_compress_decodes_with_real_reference_when_present(ctx, corpus):
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "liblz4_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not shipped")
+    ref = ctypes.CDLL(so)
+    for d, (r, c) in zip(corpus, gpu_compress(ctx, corpus)):
+        out = ctypes.create_string_buffer(len(d) + 8)
+        assert ref.LZ4_decompress_safe(c, out, r, len(d)) == len(d) and out.raw[:len(d)] == d
+
+
+def test_compress_capacity_semantics(ctx, ocodec, datagen):
+    d = datagen(100000, 50, 3)
+    (r, c), = gpu_compress(ctx, [d])
+    (r2, c2), (r3, _), (r4, _) = gpu_compress(ctx, [d, d, d], caps=[r, r - 1, 1])
+    assert r2 == r and c2 == c                                         # fuzzer.c:698-700
+    assert r3 == 0 and r4 == 0                                         # fuzzer.c:718-726
+
+
+def test_classic_host_pointer_api(ctx, ocodec, datagen):
+    import lz4_amd
+    L = lz4_amd.lib()
+    d = datagen(65536, 50, 0)                                          # BASELINE config 1 input
+    dst = ctypes.create_string_buffer(L.LZ4_compressBound(len(d)))
+    r = L.LZ4_compress_default(d, dst, len(d), len(dst))
+    assert r > 0
+    assert abs(r - 36996) / 36996 < 0.03                               # reference size
+    ro, o = ocodec.decompress(dst.raw[:r], len(d))
+    assert ro == len(d) and o == d
+    back = ctypes.create_string_buffer(len(d))
+    assert L.LZ4_decompress_safe(dst.raw[:r], back, r, len(d)) == len(d) and back.raw == d
+    assert L.LZ4_decompress_safe(dst.raw[:r], back, r, len(d) - 1) < 0
+    assert L.LZ4_compress_default(d, dst, len(d), 100) == 0
+    assert L.LZ4_compress_default(b"", dst, 0, 10) == 1 and dst.raw[0] == 0
+    # reference-compressed bytes through our decoder
+    _, c = ocodec.compress(d)
+    assert L.LZ4_decompress_safe(c, back, len(c), len(d)) == len(d) and back.raw == d
+
+
+def test_full_size_roundtrip_properties(ctx, golden, datagen, ocodec):
+    """BASELINE config 2 shape at 256 MiB: independent 4 MiB datagen -P60 blocks, device resident."""
+    import lz4_amd
+    bs, nblk = 4 << 20, 64
+    host = bytearray()
+    for s in range(4):                                                # 4 x 64 MiB streams, seeds 0..3
+        host += datagen(nblk // 4 * bs, 60, s)
+    data = torch.frombuffer(host, dtype=torch.uint8).cuda()
+    comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs)
+    assert all(0 < c <= lz4_amd.compress_bound(bs) for c in csizes)
+    out, res, _ = lz4_amd.decompress_blocks(ctx, comp, csizes, bs, data.numel())
+    assert res == [bs] * nblk
+    assert torch.equal(out, data)                                      # round trip, bit exact
+    # ratio window: first 4 blocks are exactly the golden 16 MiB of seed 0
+    g = golden["ratio"]["p60_16m_4m_blocks"]
+    assert abs(sum(csizes[:4]) - g["csize"]) / g["csize"] < 0.03
+    # a sample of blocks through the CPU oracle decoder
+    hc = comp.cpu().numpy()
+    for i in (0, 17, 63):
+        ro, o = ocodec.decompress(hc[i, :csizes[i]].tobytes(), bs)
+        assert ro == bs and o == bytes(host[i * bs:(i + 1) * bs])
+
+
+def test_many_small_blocks(ctx, datagen, ocodec):
+    """64 KiB blocks (BASELINE config 1 shape), 512 of them, ragged tail."""
+    import lz4_amd
+    host = datagen(512 * 65536 - 12345, 50, 5)
+    data = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
+    comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, 65536)
+    out, res, _ = lz4_amd.decompress_blocks(ctx, comp, csizes, 65536, data.numel())
+    assert torch.equal(out, data)
+    assert res[-1] == 65536 - 12345
+    ro, o = ocodec.decompress(comp[3, :csizes[3]].cpu().numpy().tobytes(), 65536)
+    assert o == host[3 * 65536:4 * 65536]

@@ -1,0 +1,155 @@
+"""Kernel LOGIC tests without a GPU: the kernel bodies of lz4_amd/csrc/kernels/*.h are compiled
+against the CPU SIMT interpreter (tests/simt) and checked against the oracle.  This is test
+infrastructure, not a product path -- the -m gpu tests exercise the real gfx950 code."""
+import ctypes
+import os
+import random
+
+import pytest
+
+CANARY = 0xEE
+
+
+def emu_decompress(emu, blocks, caps, grid=0, align=0):
+    n = len(blocks)
+    srcs = [ctypes.create_string_buffer(b, len(b)) if b else ctypes.create_string_buffer(1) for b in blocks]
+    dsts = [ctypes.create_string_buffer(max(c, 0) + 96) for c in caps]
+    for d in dsts:
+        ctypes.memset(d, CANARY, len(d))
+    ptr = lambda buf: ((ctypes.addressof(buf) + 15) & ~15) + align
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs])
+    dp = (ctypes.c_void_p * n)(*[ptr(d) for d in dsts])
+    ss = (ctypes.c_int32 * n)(*[len(b) for b in blocks])
+    dc = (ctypes.c_int32 * n)(*caps)
+    res = (ctypes.c_int32 * n)()
+    emu.emu_decompress_batch(sp, ss, dp, dc, res, n, grid)
+    outs = []
+    for i in range(n):
+        off = ptr(dsts[i]) - ctypes.addressof(dsts[i])
+        raw = dsts[i].raw
+        cap = max(caps[i], 0)
+        assert raw[off + cap:off + cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
+        assert raw[:off] == bytes([CANARY]) * off
+        outs.append((res[i], raw[off:off + max(res[i], 0)]))
+    return outs
+
+
+def emu_compress(emu, datas, caps=None, sub=0):
+    n = len(datas)
+    caps = caps or [len(d) + len(d) // 255 + 16 for d in datas]
+    srcs = [ctypes.create_string_buffer(d, len(d)) if d else ctypes.create_string_buffer(1) for d in datas]
+    dsts = [ctypes.create_string_buffer(max(c, 0) + 64) for c in caps]
+    for d in dsts:
+        ctypes.memset(d, CANARY, len(d))
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs])
+    dp = (ctypes.c_void_p * n)(*[ctypes.addressof(d) for d in dsts])
+    ss = (ctypes.c_int32 * n)(*[len(d) for d in datas])
+    dc = (ctypes.c_int32 * n)(*caps)
+    res = (ctypes.c_int32 * n)()
+    emu.emu_compress_batch(sp, ss, dp, dc, res, n, sub)
+    outs = []
+    for i in range(n):
+        raw = dsts[i].raw
+        cap = max(caps[i], 0)
+        assert raw[cap:cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
+        outs.append((res[i], raw[:max(res[i], 0)]))
+    return outs
+
+
+@pytest.fixture(scope="module")
+def corpus(datagen):
+    specs = [(65536, 50, 0), (100, 50, 1), (0, 50, 0), (13, 50, 0), (12, 50, 0), (200000, 60, 2), (1 << 20, 60, 3),
+             (300000, 90, 4), (50000, 0, 5), (1, 50, 0), (65547, 50, 1), (65546, 50, 1), (131073, 60, 1)]
+    datas = [datagen(*s) for s in specs]
+    datas += [b"\x00" * 300000, b"abcd" * 70000, b"a" * 40000 + os.urandom(3000) + b"a" * 40000,
+              os.urandom(70000), b"ab" * 9, b"x" * 64, b"x" * 65]
+    return datas
+
+
+def test_decompress_reference_style_blocks(emu, ocodec, corpus):
+    comps = [ocodec.compress(d)[1] for d in corpus]            # oracle == reference bytes
+    outs = emu_decompress(emu, comps, [len(d) for d in corpus])
+    for d, (r, o) in zip(corpus, outs):
+        assert r == len(d) and o == d
+
+
+def test_decompress_golden_reference_blocks(emu, golden, datagen):
+    from conftest import GOLDEN_DIR, md5
+    names = [k for k, g in golden["blocks"].items() if "file" in g]
+    comps = [open(os.path.join(GOLDEN_DIR, golden["blocks"][k]["file"]), "rb").read() for k in names]
+    outs = emu_decompress(emu, comps, [golden["blocks"][k]["src_size"] for k in names])
+    for k, (r, o) in zip(names, outs):
+        assert r == golden["blocks"][k]["src_size"] and md5(o) == golden["blocks"][k]["src_md5"], k
+
+
+def test_decompress_capacities_and_alignment(emu, ocodec, datagen):
+    d = datagen(200000, 60, 2)
+    c = ocodec.compress(d)[1]
+    n = len(d)
+    caps = [n, n + 1, n + 100, n - 1, n - 10, n // 2, 0, 5]
+    for cap, (r, o) in zip(caps, emu_decompress(emu, [c] * len(caps), caps)):
+        ro, oo = ocodec.decompress(c, cap)
+        assert (r < 0) == (ro < 0)
+        if r >= 0:
+            assert r == ro and o == oo
+    for al in (1, 3, 8):
+        (r, o), = emu_decompress(emu, [c], [n], align=al)
+        assert r == n and o == d
+
+
+def test_decompress_4mib_block(emu, ocodec, datagen):
+    d = datagen(4 << 20, 60, 0)
+    (r, o), = emu_decompress(emu, [ocodec.compress(d)[1]], [len(d)])
+    assert r == len(d) and o == d
+
+
+def test_decompress_hostile_input_matches_oracle(emu, ocodec, datagen, golden):
+    rnd = random.Random(5)
+    muts, caps = [], []
+    for size, count in ((150000, 300), (3000, 300)):
+        base = ocodec.compress(datagen(size, 60, 9))[1]
+        for t in range(count):
+            cc = bytearray(base[:rnd.randint(1, len(base))] if t % 3 == 0 else base)
+            for _ in range(rnd.randint(1, 3)):
+                cc[rnd.randrange(len(cc))] = rnd.randrange(256)
+            muts.append(bytes(cc)); caps.append(size)
+    muts.append(bytes.fromhex(golden["known"]["malformed_17_hex"])); caps.append(100)
+    accepted = 0
+    for cc, cap, (r, o) in zip(muts, caps, emu_decompress(emu, muts, caps)):
+        ro, oo = ocodec.decompress(cc, cap)
+        assert (r < 0) == (ro < 0)
+        if r >= 0:
+            accepted += 1
+            assert r == ro and o == oo
+    assert 0 < accepted < len(muts)
+    assert emu_decompress(emu, [muts[-1]], [100])[0][0] < 0      # fuzzer.c:1110-1119
+
+
+def test_compress_roundtrip_through_oracle_decoder(emu, ocodec, corpus):
+    outs = emu_compress(emu, corpus)
+    for d, (r, c) in zip(corpus, outs):
+        assert r > 0 and r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+    assert outs[2][1] == b"\x00"                                  # empty input -> single 00 byte
+
+
+def test_compress_exact_capacity_and_one_less(emu, ocodec, datagen):
+    d = datagen(100000, 50, 3)
+    (r, c), = emu_compress(emu, [d])
+    (r2, c2), (r3, _), (r4, _) = emu_compress(emu, [d, d, d], caps=[r, r - 1, 1])
+    assert r2 == r and c2 == c          # fuzzer.c:698-700: exact size still succeeds
+    assert r3 == 0 and r4 == 0          # fuzzer.c:718-726: one byte less must fail
+
+
+def test_compress_ratio_within_3pct_of_reference(emu, golden, datagen):
+    g = golden["ratio"]["p60_16m_4m_blocks"]
+    data = datagen(8 << 20, 60, 0)
+    ours = sum(r for r, _ in emu_compress(emu, [data[:4 << 20], data[4 << 20:]]))
+    # golden: reference on the first 16 MiB of the same stream (4 blocks); compare on 2 blocks
+    ref_per_block = g["csize"] / (g["src"] / g["block"])
+    assert abs(ours / 2 - ref_per_block) / ref_per_block < 0.03
+    g = golden["ratio"]["p50_4m_64k_blocks"]
+    data = datagen(4 << 20, 50, 0)
+    ours = sum(r for r, _ in emu_compress(emu, [data[o:o + 65536] for o in range(0, len(data), 65536)]))
+    assert abs(ours - g["csize"]) / g["csize"] < 0.03
