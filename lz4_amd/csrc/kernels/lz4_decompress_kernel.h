@@ -294,6 +294,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
         {
             uint32_t j = first, pos = rb;
             bool done = !active;
+            uint32_t idle = 0;                          // safety net: never spin forever
             for (;;) {
                 if (!done) {
                     bool blocked = false;
@@ -348,6 +349,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
                     }
                 }
                 if (__all(done)) break;
+                if (++idle > (1u << 22)) { misc[M_ERR] = 0x7FFFFFF0u; break; }   // cannot happen: see header
                 spin_pause();
             }
         }
@@ -363,6 +365,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
         }
         tb = te; i0 = i_next;
         __syncthreads();
+        if (misc[M_ERR] != kNone) { if (tid == 0) P.result[b] = err_at(misc[M_ERR]); return; }
     }
 }
 
