@@ -62,6 +62,10 @@ int  lz4amd_plan_launch_timed(lz4amd_plan* plan, void* stream, float kernel_ms[4
 const int* lz4amd_plan_device_results(const lz4amd_plan* plan);
 int  lz4amd_plan_results(lz4amd_plan* plan, int* results, void* stream);
 
+/* developer aid (set LZ4AMD_PROF=1 before plan_create): per-workgroup phase cycle stamps of the
+ * decoder, 8 words per workgroup; returns the number of words copied */
+int  lz4amd_plan_profile(lz4amd_plan* plan, unsigned long long* words, int max_words);
+
 /* one-shot conveniences: plan + launch + results (synchronous) */
 int  lz4amd_compress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                            void* const* d_dst, const int* dst_caps, int* results, int n, void* stream);

@@ -65,6 +65,36 @@ __device__ __forceinline__ uint8_t* put_len_ext(uint8_t* p, uint32_t rest) {
 }
 
 // ------------------------------------------------------------------------------ K_match
+// hash flavours of the reference (lz4.c:777-795): 4-byte multiplicative hash into 13 bits for
+// inputs below 64 KB + 11, 5-byte hash into 12 bits above.  The 5-byte hash matters for more than
+// parity: candidates that agree in only 4 bytes save one byte at best and triple the number of
+// sequences the decoder has to walk.
+__device__ __forceinline__ uint32_t hash_small(uint32_t v) { return (v * 2654435761u) >> (32 - 13); }
+__device__ __forceinline__ uint32_t hash_large(uint64_t v8) { return (uint32_t)(((v8 << 24) * 889523592379ull) >> (64 - 12)); }
+
+// The reference probes a literal run with a growing stride: 64 probes at stride 1, 64 at stride 2,
+// ... restarting after every match (lz4.c:1022-1053, LZ4_skipTrigger = 6).  Positions it jumps
+// over are neither tested nor INDEXED, and with a 4096-entry table that matters: indexing every
+// byte of a long literal run evicts the older entries the next match needs (ratio -2.5 % on the
+// datagen inputs).  x = distance from the start of the run; true if the reference would probe it.
+__device__ __forceinline__ bool is_probe_position(uint32_t x) {
+    if (x < 64) return true;
+    uint32_t j = (uint32_t)((sqrtf(1.0f + (float)x * 0.125f) - 1.0f) * 0.5f);   // 32 j (j+1) <= x
+    while (32u * j * (j + 1) > x) j--;
+    while (32u * (j + 1) * (j + 2) <= x) j++;
+    const uint32_t k = x - 32u * j * (j + 1), d = j + 1;
+    const uint32_t t = (uint32_t)((float)k / (float)d + 0.5f);
+    return t * d == k;
+}
+
+// number of equal leading bytes (0..8) of two 8-byte little-endian words
+__device__ __forceinline__ uint32_t equal_bytes8(uint64_t x, uint64_t y) {
+    const uint64_t d = x ^ y;
+    if (d == 0) return 8;
+    const uint32_t lo = (uint32_t)d;
+    return lo ? (uint32_t)(__ffs((int)lo) - 1) >> 3 : 4 + ((uint32_t)(__ffs((int)(uint32_t)(d >> 32)) - 1) >> 3);
+}
+
 __device__ __forceinline__ void match_subchunk_body(const CompBatch& P) {
     LZ4AMD_DYN_LDS(smem);
     uint16_t* tab = (uint16_t*)smem;
@@ -78,42 +108,56 @@ __device__ __forceinline__ void match_subchunk_body(const CompBatch& P) {
     uint32_t ce = cs + P.sub_bytes; if (ce > n || ce < cs) ce = n;
     MatchRec* recs = (MatchRec*)P.recs + (uint64_t)k * P.recs_per_sub;
 
-    const uint32_t hbits = (n < kSmallBlockLimit) ? 13u : 12u;
-    const uint32_t hshift = 32 - hbits;
+    const bool small = n < kSmallBlockLimit;
     // -- clear table (16-byte stores)
     {
         U32x4 z; z.x = z.y = z.z = z.w = 0;
-        const uint32_t n16 = (2u << hbits) / 16;
+        const uint32_t n16 = small ? 1024u : 512u;
         for (uint32_t i = lane; i < n16; i += 64) ((U32x4*)tab)[i] = z;
     }
+    wave_lds_fence();
     uint32_t nseq = 0, enc = 0, anchor = cs;
     // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= ce
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
-        const uint32_t last_q = n - kMfLimit;                  // inclusive
+        const uint32_t last_q = n - kMfLimit;                  // inclusive; q + 8 <= n - 4 holds for all probes
         uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
         // -- seed with the window that precedes the sub-chunk
         const uint32_t low = cs > kMaxDistance ? cs - kMaxDistance : 0;
         for (uint32_t p = low; p < cs; p += 64) {
             const uint32_t q = p + lane;
-            if (q < cs) tab[(ld_u32(src + q) * 2654435761u) >> hshift] = (uint16_t)q;
+            if (q < cs) {
+                const uint64_t v8 = ld_u64(src + q);
+                tab[small ? hash_small((uint32_t)v8) : hash_large(v8)] = (uint16_t)q;
+            }
         }
-        uint32_t p = cs;
+        wave_lds_fence();
+        uint32_t p = cs, cur = cs;                             // cur: first position not yet covered
+        uint32_t run0 = cs;                                    // start of the current literal run's probe schedule
+        uint64_t vpre = 0; uint32_t ppre = kNoOutput;          // source words fetched one window ahead
         while (p < ce && p <= last_q) {
             const uint32_t q = p + lane;
             const bool valid = q < ce && q <= last_q;
-            uint32_t v = 0, h = 0, c1 = 0, c2 = 0;
+            uint64_t v8 = 0;
+            if (ppre == p) v8 = vpre; else if (valid) v8 = ld_u64(src + q);
+            {   // prefetch the next window (discarded when a long match jumps over it)
+                const uint32_t qn = q + 64;
+                ppre = p + 64;
+                vpre = (qn < ce && qn <= last_q) ? ld_u64(src + qn) : 0ull;
+            }
+            const uint32_t v = (uint32_t)v8;
+            uint32_t h = 0, c1 = 0, c2 = 0;
             bool ok1 = false;
             if (valid) {
-                v = ld_u32(src + q);
-                h = (v * 2654435761u) >> hshift;
+                h = small ? hash_small(v) : hash_large(v8);
                 const uint32_t d1 = (q - tab[h]) & 0xFFFFu;
                 c1 = q - d1;
                 ok1 = d1 != 0 && d1 <= q && c1 >= low;
             }
+            wave_lds_fence();                              // every lane probes before any lane inserts
             // candidates closer than one window are invisible to the table probe (the window's own
-            // positions are indexed after selection): catch the short periods 1..4 (runs, 16/32-bit
+            // positions are inserted after the probe): catch the short periods 1..4 (runs, 16/32-bit
             // patterns) by comparing with the neighbouring lanes' bytes instead
-            bool f1 = ok1 && ld_u32(src + c1) == v;
+            const bool f1 = ok1 && (uint32_t)ld_u32(src + c1) == v;
             bool f2 = false;
 #pragma unroll
             for (uint32_t d = 4; d >= 1; d--) {
@@ -123,65 +167,72 @@ __device__ __forceinline__ void match_subchunk_body(const CompBatch& P) {
             }
             f2 = f2 && !f1;
             const uint32_t cand = f1 ? c1 : c2;
+            const bool e_old = valid && q >= run0 && is_probe_position(q - run0);
+            const unsigned long long em = __ballot(e_old);
+            uint32_t firstcur = kNoOutput;              // end of the first match taken in this window
             unsigned long long m = __ballot(f1 || f2);
-            uint32_t cur = p;                           // first position not yet covered
-            unsigned long long covered = 0;             // window positions swallowed by matches
+            // window positions swallowed by matches are not indexed, except cur-2 (lz4.c:1236-1242);
+            // a window that starts inside the previous match (p = cur-2) only indexes its lane 0
+            unsigned long long covered = 0;
+            if (cur > p) covered = ((cur - p >= 64) ? ~0ull : ((1ull << (cur - p)) - 1)) & ~(1ull << (cur - 2 - p));
             while (m) {
                 const uint32_t l = (uint32_t)__ffsll((long long)m) - 1;
                 m &= m - 1;
                 uint32_t qm = p + l;
+                const uint32_t qfound = qm;
                 if (qm < cur) continue;
+                if (firstcur == kNoOutput && !((em >> l) & 1)) continue;     // not on the probe schedule
                 uint32_t cm = (uint32_t)__shfl((int)cand, (int)l);
-                // -- backward extension over pending literals (lz4.c:1105-1109)
-                {
-                    uint32_t room = qm - anchor; if (cm < room) room = cm;
-                    uint32_t back = 0;
-                    while (back < room) {
-                        const uint32_t i = back + lane;
-                        const bool same = i < room && src[qm - 1 - i] == src[cm - 1 - i];
-                        const unsigned long long ne = __ballot(!same);
-                        if (ne) { back += (uint32_t)__ffsll((long long)ne) - 1; break; }
-                        back += 64;
+                if (qm + kMinMatch > mlimit) continue;          // the 4 verified bytes cross the cut
+                // -- forward (lz4.c:680-703 LZ4_count) and backward (lz4.c:1105-1109) extension
+                //    in one memory round trip: 8 bytes per lane forward, 1 byte per lane backward
+                uint32_t room = qm - anchor; if (cm < room) room = cm;
+                uint32_t ml = kMinMatch, back = 0;
+                bool fwd_done = false, back_done = room == 0;
+                uint32_t fbase = kMinMatch, bbase = 0;
+                while (!fwd_done || !back_done) {
+                    uint32_t same = 8; bool beq = true;
+                    if (!fwd_done) {
+                        const uint32_t a = qm + fbase + 8 * lane, c = cm + fbase + 8 * lane;
+                        if (a >= mlimit) same = 0;
+                        else if (a + 8 <= n) { same = equal_bytes8(ld_u64(src + a), ld_u64(src + c)); if (same > mlimit - a) same = mlimit - a; }
+                        else { same = 0; while (a + same < mlimit && src[a + same] == src[c + same]) same++; }
                     }
-                    if (back > room) back = room;
-                    qm -= back; cm -= back;
+                    if (!back_done) {
+                        const uint32_t i = bbase + lane;
+                        beq = i < room && src[qm - 1 - i] == src[cm - 1 - i];
+                    }
+                    if (!fwd_done) {
+                        const unsigned long long brk = __ballot(same < 8);
+                        if (brk) {
+                            const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
+                            ml = fbase + 8 * fl + (uint32_t)__shfl((int)same, (int)fl);
+                            fwd_done = true;
+                        } else fbase += 512;
+                    }
+                    if (!back_done) {
+                        const unsigned long long ne = __ballot(!beq);
+                        if (ne) { back = bbase + (uint32_t)__ffsll((long long)ne) - 1; back_done = true; }
+                        else bbase += 64;
+                    }
                 }
-                // -- forward extension, 4 bytes per lane per round (lz4.c:680-703 LZ4_count)
-                uint32_t ml = kMinMatch;
-                for (;;) {
-                    const uint32_t a = qm + ml + 4 * lane;
-                    uint32_t same_bytes = 0;
-                    if (a + 4 <= mlimit) {
-                        const uint32_t x = ld_u32(src + a) ^ ld_u32(src + (cm + ml + 4 * lane));
-                        same_bytes = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4;
-                    } else if (a < mlimit) {
-                        const uint32_t lim = mlimit - a;
-                        while (same_bytes < lim && src[a + same_bytes] == src[cm + ml + 4 * lane + same_bytes]) same_bytes++;
-                    }
-                    const unsigned long long brk = __ballot(same_bytes < 4);
-                    if (brk) {
-                        const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
-                        ml += 4 * fl + (uint32_t)__shfl((int)same_bytes, (int)fl);
-                        break;
-                    }
-                    ml += 256;
-                }
-                // (the 4 verified bytes may reach past mlimit only if qm+4 > mlimit: skip then)
-                if (qm + kMinMatch > mlimit) continue;
+                qm -= back; cm -= back; ml += back;
                 const uint32_t ll = qm - anchor;
                 if (lane == 0) { MatchRec r; r.ll = ll; r.mo = (qm - cm) | ((ml - kMinMatch) << 16); recs[nseq] = r; }
                 enc += enc_size(ll, ml - kMinMatch);
                 nseq++;
                 anchor = cur = qm + ml;
+                run0 = cur;
+                if (firstcur == kNoOutput) firstcur = cur;
                 {   // window lanes inside [qm, cur) are not indexed, except cur-2 (lz4.c:1236-1242)
-                    const uint32_t a0 = qm > p ? qm - p : 0;
+                    const uint32_t a0 = qfound - p;     // positions passed over before the hit stay indexed
                     const uint32_t a1 = cur - p < 64 ? cur - p : 64;
                     if (a1 > a0) covered |= ((a1 - a0 >= 64) ? ~0ull : ((1ull << (a1 - a0)) - 1)) << a0;
                     if (cur - 2 >= p && cur - 2 < p + 64) covered &= ~(1ull << (cur - 2 - p));
                 }
             }
-            if (valid && !((covered >> lane) & 1)) tab[h] = (uint16_t)q;
-            p = (cur > p + 64) ? cur : p + 64;
+            if (valid && !((covered >> lane) & 1) && (q >= firstcur || q < run0 || e_old)) tab[h] = (uint16_t)q;
+            p = (cur > p + 66) ? cur - 2 : p + 64;
         }
     }
     if (lane == 0) {

@@ -16,7 +16,33 @@ __device__ __forceinline__ void lds_or_release(uint32_t* w, uint32_t bits) {
 __device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* w) {
     return __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ uint64_t lds_load_acquire64(const uint64_t* w) {
+    return __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(uint32_t* w, uint32_t v) {
+    __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release64(uint64_t* w, uint64_t v) {
+    __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS operations of one wave are issued and serviced in program order; this only keeps the
+// compiler from moving LDS accesses of the wave across the point (the CPU interpreter used by the
+// unit tests needs a real rendezvous here, because its lanes do not run in lockstep).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+
+// {hi,lo} >> (8 * (sh & 3)), low 32 bits (v_alignbyte_b32)
+__device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+// unaligned 16-byte global accesses (gfx950 global memory takes any byte alignment)
+struct alignas(16) lz4amd_u32x4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ lz4amd_u32x4 ld_global16_raw(const uint8_t* p) { lz4amd_u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ uint64_t clock_ticks() { return __builtin_readcyclecounter(); }
 
 // device-scope work-queue ticket
 __device__ __forceinline__ uint32_t take_ticket(uint32_t* counter) {

@@ -99,9 +99,12 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
     p->d_results = (int*)dres;
 
     if (op == LZ4AMD_OP_DECOMPRESS) {
-        unsigned max_c = 0, grid;
+        unsigned max_c = 0, max_cap = 0, grid;
         lz4amd_dec_params* q = &p->dec;
-        for (i = 0; i < n; i++) if (src_sizes[i] > 0 && (unsigned)src_sizes[i] > max_c) max_c = (unsigned)src_sizes[i];
+        for (i = 0; i < n; i++) {
+            if (src_sizes[i] > 0 && (unsigned)src_sizes[i] > max_c) max_c = (unsigned)src_sizes[i];
+            if (dst_caps[i] > 0 && (unsigned)dst_caps[i] > max_cap) max_cap = (unsigned)dst_caps[i];
+        }
         /* one 1024-thread workgroup owns a CU's LDS; blocks are pulled from a ticket counter */
         grid = (unsigned)ctx->n_cus;
         if ((unsigned)n < grid) grid = (unsigned)n;
@@ -109,12 +112,28 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
-        q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c) + 255) & ~(uint64_t)255;
+        q->table_bytes = lz4amd_hip_dec_table_bytes(max_c);
+        q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c, max_cap) + 255) & ~(uint64_t)255;
+        q->prof = NULL;
+        if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase timestamps */
+            q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
+            if (q->prof && lz4amd_hip_memset(q->prof, 0, (size_t)(grid ? grid : 1) * 64, NULL)) err = LZ4AMD_E_RUNTIME;
+        }
         q->ticket = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
         q->scratch = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)q->scratch_stride * (grid ? grid : 1), &err));
     } else if (op == LZ4AMD_OP_COMPRESS) {
         lz4amd_comp_params* q = &p->comp;
-        const uint32_t sub = LZ4AMD_SUB_BYTES;
+        /* sub-chunk = the unit one wave parses.  Bigger sub-chunks cost less (the 64 KB of table
+         * seeding in front of each is amortised) and cut the stream less often; smaller ones give
+         * more waves.  Take the largest of 256/128/64 KB that still yields >= 16 waves per CU. */
+        uint32_t sub = LZ4AMD_SUB_BYTES_MAX;
+        uint64_t total_bytes = 0;
+        int any_small = 0;
+        for (i = 0; i < n; i++) if (src_sizes[i] > 0 && (unsigned)src_sizes[i] <= 0x7E000000u) {
+            total_bytes += (unsigned)src_sizes[i];
+            if ((unsigned)src_sizes[i] < 65536u + 11u) any_small = 1;
+        }
+        while (sub > LZ4AMD_SUB_BYTES_MIN && total_bytes / sub < 16ull * (uint64_t)ctx->n_cus) sub >>= 1;
         uint32_t* blk_sub0 = (uint32_t*)malloc((un + 1) * sizeof(uint32_t));
         uint32_t* sub_block;
         uint64_t ns = 0; uint32_t k = 0;
@@ -133,6 +152,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
         q->n_subs = (uint32_t)ns; q->sub_bytes = sub;
+        p->match_lds = any_small ? 16384u : 8192u;   /* 8192 x u16 (13-bit hash) or 4096 x u16 (12-bit) */
         q->recs_per_sub = lz4amd_hip_comp_recs_per_sub(sub);
         q->sub_block = (const uint32_t*)(p->bufs[nb++] = dev_array(sub_block, (size_t)ns * 4, &err));
         q->blk_sub0 = (const uint32_t*)(p->bufs[nb++] = dev_array(blk_sub0, (un + 1) * 4, &err));
@@ -166,7 +186,7 @@ static int launch_stage(lz4amd_plan* p, int stage, void* stream)
     if (p->op == LZ4AMD_OP_DECOMPRESS)
         return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
     switch (stage) {
-    case 0: return lz4amd_hip_launch_match(&p->comp, stream);
+    case 0: return lz4amd_hip_launch_match(&p->comp, p->match_lds, stream);
     case 1: return lz4amd_hip_launch_offsets(&p->comp, stream);
     case 2: return lz4amd_hip_launch_emit(&p->comp, stream);
     default: return 0;
@@ -201,6 +221,16 @@ int lz4amd_plan_launch_timed(lz4amd_plan* p, void* stream, float kernel_ms[4], f
     for (s = 0; s < 4; s++) if (kernel_ms) kernel_ms[s] = s < ns ? lz4amd_hip_event_ms(p->ev[s], p->ev[s + 1]) : 0.f;
     if (total_ms) *total_ms = lz4amd_hip_event_ms(p->ev[0], p->ev[ns]);
     return LZ4AMD_OK;
+}
+
+int lz4amd_plan_profile(lz4amd_plan* p, unsigned long long* words, int max_words)
+{   /* 8 words per workgroup: cycle stamps after WALK, FIX, (SCAN+)EMIT, COPY; nseq, total, csize */
+    int n;
+    if (!p || p->op != LZ4AMD_OP_DECOMPRESS || !p->dec.prof) return 0;
+    n = (int)p->grid * 8;
+    if (n > max_words) n = max_words;
+    if (lz4amd_hip_d2h(words, p->dec.prof, (size_t)n * 8, NULL) || lz4amd_hip_sync(NULL)) return 0;
+    return n;
 }
 
 const int* lz4amd_plan_device_results(const lz4amd_plan* p) { return p ? p->d_results : NULL; }

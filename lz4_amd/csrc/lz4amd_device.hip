@@ -71,7 +71,8 @@ extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
     return ms;
 }
 
-extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return (size_t)dec_scratch_bytes(max_csize); }
+extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize, unsigned max_cap) { return (size_t)dec_scratch_bytes(max_csize, max_cap); }
+extern "C" size_t lz4amd_hip_dec_table_bytes(unsigned max_csize) { return (size_t)dec_table_bytes(max_csize); }
 extern "C" unsigned lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes) { return sub_bytes / 4 + 8; }
 
 extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* s) {
@@ -81,9 +82,9 @@ extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned
     HIPCHK(hipGetLastError());
     return 0;
 }
-extern "C" int lz4amd_hip_launch_match(const lz4amd_comp_params* p, void* s) {
+extern "C" int lz4amd_hip_launch_match(const lz4amd_comp_params* p, unsigned lds_bytes, void* s) {
     if (!p->n_subs) return 0;
-    hipLaunchKernelGGL(lz4amd_k_match, dim3(p->n_subs), dim3(64), kMatchLdsBytes, (hipStream_t)s, *p);
+    hipLaunchKernelGGL(lz4amd_k_match, dim3(p->n_subs), dim3(64), lds_bytes ? lds_bytes : kMatchLdsBytes, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -25,12 +25,13 @@ int         lz4amd_hip_event_sync(void* ev);
 float       lz4amd_hip_event_ms(void* start, void* stop);
 
 /* kernel geometry facts the host needs for sizing */
-size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize);
+size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize, unsigned max_cap);
+size_t      lz4amd_hip_dec_table_bytes(unsigned max_csize);
 unsigned    lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes);
 
 /* launches (asynchronous on `stream`) */
 int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* stream);
-int lz4amd_hip_launch_match(const lz4amd_comp_params* p, void* stream);
+int lz4amd_hip_launch_match(const lz4amd_comp_params* p, unsigned lds_bytes, void* stream);
 int lz4amd_hip_launch_offsets(const lz4amd_comp_params* p, void* stream);
 int lz4amd_hip_launch_emit(const lz4amd_comp_params* p, void* stream);
 

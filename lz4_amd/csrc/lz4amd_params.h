@@ -14,6 +14,8 @@ typedef struct lz4amd_dec_params {
     uint32_t* ticket;               /* work-queue counter, zero before launch */
     uint8_t* scratch;               /* grid * scratch_stride bytes (sequence tables) */
     uint64_t scratch_stride;
+    uint64_t table_bytes;           /* offset of the region index inside a workgroup's scratch */
+    uint64_t* prof;                 /* optional: 8 words per workgroup of phase timestamps */
 } lz4amd_dec_params;
 
 typedef struct lz4amd_comp_params {

@@ -21,6 +21,7 @@
 #define SIMT_EMU_H
 
 #include <cstdint>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
