@@ -26,8 +26,8 @@ __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __bui
 __device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
 using U32x4 = ::lz4amd_u32x4;             // 16 bytes as four dwords (platform header)
-__device__ __forceinline__ U32x4 ld_global16(const uint8_t* p) { return ld_global16_raw(p); }
-__device__ __forceinline__ void st_global16(uint8_t* p, const U32x4& v) { st_global16_raw(p, v); }
+template <class Ptr> __device__ __forceinline__ U32x4 ld_global16(Ptr p) { return ld_global16_raw(p); }
+template <class Ptr> __device__ __forceinline__ void st_global16(Ptr p, const U32x4& v) { st_global16_raw(p, v); }
 
 // ---- wave-level inclusive scans (64 lanes) ------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {

@@ -111,7 +111,7 @@ __device__ __forceinline__ void match_subchunk_body(const CompBatch& P) {
     const bool small = n < kSmallBlockLimit;
     // -- clear table (16-byte stores)
     {
-        U32x4 z; z.x = z.y = z.z = z.w = 0;
+        U32x4 z; z[0] = z[1] = z[2] = z[3] = 0;
         const uint32_t n16 = small ? 1024u : 512u;
         for (uint32_t i = lane; i < n16; i += 64) ((U32x4*)tab)[i] = z;
     }

@@ -5,8 +5,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+typedef uint32_t lz4amd_u32x4 __attribute__((ext_vector_type(4)));   // a first-class register quad
+
 // All LDS lives in the dynamic region, 16-byte aligned (CDNA guide G17).
 #define LZ4AMD_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+
+// pointer to LDS that keeps its address space through structs and selects (a generic pointer would
+// turn every access into a flat_load)
+#define LZ4AMD_LDS_PTR(T) __attribute__((address_space(3))) T*
+#define LZ4AMD_TO_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+// block pointers are loaded from the block table, so the compiler cannot see that they are global:
+// say so, or every access through them becomes a flat_load / flat_store
+typedef __attribute__((address_space(1))) const uint8_t* lz4amd_gsrc;
+typedef __attribute__((address_space(1))) uint8_t* lz4amd_gdst;
+#define LZ4AMD_TO_GSRC(p) ((lz4amd_gsrc)(p))
+#define LZ4AMD_TO_GDST(p) ((lz4amd_gdst)(p))
 
 // workgroup-scope release/acquire on LDS words (waves of one workgroup hand data to each
 // other through LDS without a barrier; LDS is coherent inside a workgroup).
@@ -25,6 +38,11 @@ __device__ __forceinline__ void lds_store_release(uint32_t* w, uint32_t v) {
 __device__ __forceinline__ void lds_store_release64(uint64_t* w, uint64_t v) {
     __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// one 16-byte LDS read of a {u64, u32, u32} entry (a lane's 16 bytes are read in one LDS pass)
+template <class E> __device__ __forceinline__ E lds_load_ent(const E* p) {
+    const lz4amd_u32x4 v = *(const volatile lz4amd_u32x4*)p; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    E e; __builtin_memcpy(&e, &v, sizeof(E)); return e;
+}
 // LDS operations of one wave are issued and serviced in program order; this only keeps the
 // compiler from moving LDS accesses of the wave across the point (the CPU interpreter used by the
 // unit tests needs a real rendezvous here, because its lanes do not run in lockstep).
@@ -39,9 +57,10 @@ __device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 // unaligned 16-byte global accesses (gfx950 global memory takes any byte alignment)
-struct alignas(16) lz4amd_u32x4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ lz4amd_u32x4 ld_global16_raw(const uint8_t* p) { lz4amd_u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ lz4amd_u32x4 ld_global16_raw(lz4amd_gsrc p) { lz4amd_u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st_global16_raw(lz4amd_gdst p, const lz4amd_u32x4& v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ uint64_t clock_ticks() { return __builtin_readcyclecounter(); }
 
 // device-scope work-queue ticket

@@ -36,7 +36,7 @@ extern "C" int lz4amd_hip_init(int device, int* n_cus) {
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     if (n_cus) *n_cus = cus;
-    // the decoder uses ~150 KB of the CU's 160 KB LDS: opt in to large dynamic LDS
+    // the decoder uses ~152 KB of the CU's 160 KB LDS: opt in to large dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
     return 0;
 }
@@ -71,8 +71,7 @@ extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
     return ms;
 }
 
-extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize, unsigned max_cap) { return (size_t)dec_scratch_bytes(max_csize, max_cap); }
-extern "C" size_t lz4amd_hip_dec_table_bytes(unsigned max_csize) { return (size_t)dec_table_bytes(max_csize); }
+extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return (size_t)dec_scratch_bytes(max_csize); }
 extern "C" unsigned lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes) { return sub_bytes / 4 + 8; }
 
 extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* s) {

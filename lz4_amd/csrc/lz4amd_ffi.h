@@ -25,8 +25,7 @@ int         lz4amd_hip_event_sync(void* ev);
 float       lz4amd_hip_event_ms(void* start, void* stop);
 
 /* kernel geometry facts the host needs for sizing */
-size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize, unsigned max_cap);
-size_t      lz4amd_hip_dec_table_bytes(unsigned max_csize);
+size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize);
 unsigned    lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes);
 
 /* launches (asynchronous on `stream`) */

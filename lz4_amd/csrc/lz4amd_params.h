@@ -12,9 +12,8 @@ typedef struct lz4amd_dec_params {
     int32_t* result;                /* [n] decoded size, or negative on error */
     uint32_t n_blocks;
     uint32_t* ticket;               /* work-queue counter, zero before launch */
-    uint8_t* scratch;               /* grid * scratch_stride bytes (sequence tables) */
+    uint8_t* scratch;               /* grid * scratch_stride bytes (per-workgroup segment tables) */
     uint64_t scratch_stride;
-    uint64_t table_bytes;           /* offset of the region index inside a workgroup's scratch */
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase timestamps */
 } lz4amd_dec_params;
 

@@ -10,19 +10,17 @@ extern "C" int emu_decompress_batch(const uint8_t* const* src, const int32_t* sr
                                     uint8_t* const* dst, const int32_t* dst_cap,
                                     int32_t* result, uint32_t n, uint32_t grid) {
     using namespace lz4amd;
-    uint32_t max_c = 0, max_cap = 0;
-    for (uint32_t i = 0; i < n; i++) {
+    uint32_t max_c = 0;
+    for (uint32_t i = 0; i < n; i++)
         if (src_size[i] > 0 && (uint32_t)src_size[i] > max_c) max_c = src_size[i];
-        if (dst_cap[i] > 0 && (uint32_t)dst_cap[i] > max_cap) max_cap = dst_cap[i];
-    }
     if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
-    uint64_t stride = (dec_scratch_bytes(max_c, max_cap) + 15) & ~15ull;
+    uint64_t stride = (dec_scratch_bytes(max_c) + 15) & ~15ull;
     std::vector<uint8_t> scratch((size_t)(stride * grid + 64));
     uint32_t ticket = 0;
     DecBatch P;
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
     P.n_blocks = n; P.ticket = &ticket;
-    P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.table_bytes = dec_table_bytes(max_c); P.prof = nullptr;
+    P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.prof = nullptr;
     simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
     return 0;
 }

@@ -3,17 +3,24 @@
 #pragma once
 #include "simt_emu.h"
 #include <stdint.h>
+#define LZ4AMD_LDS_PTR(T) T*
+#define LZ4AMD_TO_LDS_PTR(T, p) ((T*)(p))
+typedef const uint8_t* lz4amd_gsrc;
+typedef uint8_t* lz4amd_gdst;
+#define LZ4AMD_TO_GSRC(p) ((lz4amd_gsrc)(p))
+#define LZ4AMD_TO_GDST(p) ((lz4amd_gdst)(p))
 static inline void lds_or_release(uint32_t* w, uint32_t bits) { *w |= bits; }
 static inline uint32_t lds_load_acquire(const uint32_t* w) { return *(volatile const uint32_t*)w; }
 static inline uint64_t lds_load_acquire64(const uint64_t* w) { return *(volatile const uint64_t*)w; }
 static inline void lds_store_release(uint32_t* w, uint32_t v) { *(volatile uint32_t*)w = v; }
 static inline void lds_store_release64(uint64_t* w, uint64_t v) { *(volatile uint64_t*)w = v; }
+template <class E> static inline E lds_load_ent(const E* p) { E e; memcpy(&e, (const void*)p, sizeof(E)); return e; }
 static inline void wave_lds_fence() { (void)__ballot(1); }
-static inline void spin_pause() {}
+static inline void spin_pause() { simt::yield_to_sched(); }
 static inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
 }
-struct alignas(16) lz4amd_u32x4 { uint32_t x, y, z, w; };
+typedef uint32_t lz4amd_u32x4 __attribute__((vector_size(16)));
 static inline lz4amd_u32x4 ld_global16_raw(const uint8_t* p) { lz4amd_u32x4 v; memcpy(&v, p, 16); return v; }
 static inline void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { memcpy(p, &v, 16); }
 static inline uint64_t clock_ticks() { return 0; }

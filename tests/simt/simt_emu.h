@@ -143,6 +143,7 @@ void launch(unsigned grid, unsigned block, size_t smem_bytes, const std::functio
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define __noinline__ __attribute__((noinline))
 
 #define threadIdx (simt::dim3_t{simt::cur()->tid, 0, 0})
 #define blockIdx  (simt::g_blk->bIdx)

@@ -17,9 +17,12 @@ L = lz4_amd.lib()
 w = (ctypes.c_ulonglong * (256 * 8))()
 n = L.lz4amd_plan_profile(plan._h, w, len(w))
 import statistics
-names = ["walk", "fix", "scan+emit", "copy"]
-for k in range(4):
-    d = [w[i * 8 + k + 1] - w[i * 8 + k] for i in range(n // 8)]
-    print(names[k], "cycles median", statistics.median(d), "max", max(d))
-print("nseq", w[5], "total", w[6], "csize", w[7])
+nw = n // 8
+pre = [w[i * 8 + 1] - w[i * 8 + 0] for i in range(nw)]
+emit = [w[i * 8 + 2] for i in range(nw)]
+copy = [w[i * 8 + 3] for i in range(nw)]
+tot = [w[i * 8 + 4] - w[i * 8 + 0] for i in range(nw)]
+for name, d in (("preparse", pre), ("stream.emit+load+index", emit), ("stream.copy", copy), ("total", tot)):
+    print(name, "cycles median", statistics.median(d), "max", max(d))
+print("preparse: count+scan", statistics.median([w[i*8+5] for i in range(nw)]), "walk", statistics.median([w[i*8+6] for i in range(nw)]), "fix", statistics.median([w[i*8+7] & ((1<<48)-1) for i in range(nw)]), "fix iterations", statistics.median([w[i*8+7] >> 48 for i in range(nw)]))
 assert torch.equal(out, data)
