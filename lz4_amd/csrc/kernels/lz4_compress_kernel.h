@@ -4,87 +4,95 @@
 // block in LZ4_compress_default (lib/lz4.c:1472 -> LZ4_compress_fast_extState lz4.c:1382 ->
 // LZ4_compress_generic_validated lz4.c:930-1338): greedy single-candidate hash-table LZ77 parse,
 // emitted as one legal LZ4 block (doc/lz4_Block_format.md; end-of-block rules MFLIMIT /
-// LASTLITERALS lz4.c:242-263, 963-964).  The bytes differ from the CPU library's (the parse is
-// done 64 positions at a time) but decode identically with any LZ4 decoder; the table-size policy
-// mirrors the reference (13-bit 4-byte hash for blocks < 64 KB+11, lz4.c:1389; 12 bits above) so
-// the ratio stays within a few tenths of a percent of it on the datagen inputs.
+// LASTLITERALS lz4.c:242-263, 963-964).  The bytes differ from the CPU library's but decode
+// identically with any LZ4 decoder, and the compressed size stays within about 1 % of the
+// reference's on the datagen inputs (tests/test_gpu_parity.py asserts the +-3 % window).
 //
-// Not a port: the reference is one serial loop over one block.  Here a block is cut in sub-chunks
-// of `sub_bytes` (64 KB) and the work is three launches over ALL sub-chunks of ALL blocks:
+// Not a port: the reference is one serial loop over one block, whose hash table changes after
+// every probe.  Here ONE 1024-thread workgroup (16 waves, one CU, ~150 KB of its LDS) streams
+// through a block in TILES of 8 KB, and everything the inner loops touch lives in LDS:
 //
-//   K_match   one wave per sub-chunk.  The wave seeds a private LDS hash table with the 64 KB that
-//             precede its sub-chunk (so the window is not lost at the cut), then slides a
-//             64-position window: every lane hashes its position, probes and updates the table,
-//             verifies its candidate (4 bytes); found matches are taken greedily in position order
-//             (ballot + ctz), extended backwards over pending literals and forwards by a
-//             wave-wide 256-byte compare.  Output: 8-byte (literals, match, offset) records plus
-//             the encoded size of the sub-chunk.  No bytes of the final stream are written yet.
-//   K_offsets one wave per block: prefix-sum of sub-chunk sizes, literal-run carry across
-//             sub-chunk cuts, capacity check (0 = does not fit, lz4.c:1114-1117 semantics),
-//             final literal run header.
-//   K_emit    one wave per sub-chunk: wave prefix-sums over 64 sequences at a time give every
-//             token its byte offset; lanes write their token/length/offset fields, then the wave
-//             copies the literal runs (coalesced byte lanes).  Literals that are carried into a
-//             later sequence are still copied by the wave that owns their source bytes, so
-//             incompressible blocks are copied by all waves in parallel.
+//   source ring   100 KB of the block around the tile (the 64 KB LZ4 window + the tile + the
+//                 prefetched next tile), filled with coalesced 16-byte loads; candidates are
+//                 verified and matches extended against it, never against HBM;
+//   hash table    8192 x u32 (5-byte multiplicative hash of the reference, lz4.c:785-795, 13 bits),
+//                 FROZEN while a tile is parsed: every position of the tile probes the state left
+//                 by the previous tiles, and the tile's own positions are inserted afterwards with
+//                 atomicMax (order independent, so the output is deterministic).  That decouples
+//                 match FINDING from the parse order, which is what makes the tile parallel:
+//   strips        the tile is cut in 16 strips of 512 bytes, one wave each.  A wave slides a
+//                 64-position window over its strip: every lane hashes its position, probes,
+//                 measures up to 24 matching bytes forwards and 8 backwards (over
+//                 literals that may still be pending) on its own; found matches
+//                 are taken greedily in position order (ballot + ctz), long ones are extended by a
+//                 wave-wide 512-byte compare.  Matches end at the strip's end; literals pending at
+//                 a strip's end are carried into the next sequence (of any later strip or tile).
+//   offsets       after a barrier one thread turns the strips' encoded sizes into output offsets
+//                 (running across tiles), while the other waves insert the tile into the table;
+//   emit          each wave writes the sequences of its strip: lanes place their token / length /
+//                 offset bytes by a wave prefix sum, then the wave copies the literal runs out of
+//                 the source ring (HBM for runs that started more than a window ago).
 //
-// HBM traffic: source read once by K_match (+ the 64 KB seeding overlap, L2-resident), literals
-// re-read by K_emit (mostly L2/MALL hits), compressed stream written once.  No MFMA.
+// HBM traffic per block: source read once (plus the final literal run if it is longer than the
+// ring), compressed stream written once.  No scratch, no second kernel.  No MFMA: byte shuffling.
 #pragma once
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
 
 namespace lz4amd {
 
+using CompBatch = ::lz4amd_comp_params;   // argument block (lz4amd_params.h)
+
 struct alignas(8) MatchRec { uint32_t ll; uint32_t mo; };   // mo = offset | (matchlen-4) << 16
 
 enum : uint32_t {
-    kSubBytes = 64u << 10,             // default sub-chunk
-    kMaxRecsPerSub = (kSubBytes / 4) + 8,
+    kCmpThreads = 1024,
+    kCmpWaves = kCmpThreads / 64,
+    kTileMax = 8192,                   // blocks >= 64 KB + 11 (which are probed at every second position)
+    kTileMaxSmall = 2048,              // smaller blocks (4-byte hash, like the reference: lz4.c:1389)
+    kTileMin = 1024,
+    kStripMin = 256,
+    kSrcRing = 100u << 10,
+    kSrcPad = 32,                      // mirror of the ring's first bytes: unaligned reads never wrap
+    kHashBits = 13,
+    kRecsPerStrip = 128,               // matches a strip may take (the rest of it becomes literals)
+    kLaneLenCap = 24,                  // match bytes a lane measures on its own
+    kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
-    kMatchLdsBytes = 16384,            // 8192 x u16 (13-bit) or 4096 x u16 (12-bit)
-    kNoOutput = 0xFFFFFFFFu,
 };
-
-using CompBatch = ::lz4amd_comp_params;   // argument block (lz4amd_params.h)
+// LDS carve-up (bytes)
+enum : uint32_t {
+    kCOffMisc = 0,                                        // u32[32]
+    kCOffStrip = kCOffMisc + 32 * 4,                      // u32[6][16] per-strip summaries
+    kCOffTab = kCOffStrip + 6 * kCmpWaves * 4,            // u32[1 << kHashBits]
+    kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[kCmpWaves][kRecsPerStrip]
+    kCOffRing = kCOffRecs + kCmpWaves * kRecsPerStrip * 8,
+    kCmpLdsBytes = kCOffRing + kSrcRing + kSrcPad,
+};
+enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3 };
+enum : uint32_t { S_N = 0, S_ENC = 1, S_LL0 = 2, S_TAIL = 3, S_OUT = 4, S_CARRY = 5 };
 
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t len_minus_nibble_base) {
     // bytes needed after the token for a length field whose value is >= 15 (block format doc)
     return 1 + len_minus_nibble_base / 255;
 }
+__device__ __forceinline__ uint32_t lit_hdr_ext(uint32_t ll) { return ll >= 15 ? len_ext_bytes(ll - 15) : 0; }
 __device__ __forceinline__ uint32_t enc_size(uint32_t ll, uint32_t mlm4) {
     uint32_t s = 1 + ll + 2;
     if (ll >= 15) s += len_ext_bytes(ll - 15);
     if (mlm4 >= 15) s += len_ext_bytes(mlm4 - 15);
     return s;
 }
-__device__ __forceinline__ uint8_t* put_len_ext(uint8_t* p, uint32_t rest) {
+template <class Ptr> __device__ __forceinline__ Ptr put_len_ext(Ptr p, uint32_t rest) {
     while (rest >= 255) { *p++ = 255; rest -= 255; }
     *p++ = (uint8_t)rest;
     return p;
 }
 
-// ------------------------------------------------------------------------------ K_match
-// hash flavours of the reference (lz4.c:777-795): 4-byte multiplicative hash into 13 bits for
-// inputs below 64 KB + 11, 5-byte hash into 12 bits above.  The 5-byte hash matters for more than
-// parity: candidates that agree in only 4 bytes save one byte at best and triple the number of
-// sequences the decoder has to walk.
-__device__ __forceinline__ uint32_t hash_small(uint32_t v) { return (v * 2654435761u) >> (32 - 13); }
-__device__ __forceinline__ uint32_t hash_large(uint64_t v8) { return (uint32_t)(((v8 << 24) * 889523592379ull) >> (64 - 12)); }
-
-// The reference probes a literal run with a growing stride: 64 probes at stride 1, 64 at stride 2,
-// ... restarting after every match (lz4.c:1022-1053, LZ4_skipTrigger = 6).  Positions it jumps
-// over are neither tested nor INDEXED, and with a 4096-entry table that matters: indexing every
-// byte of a long literal run evicts the older entries the next match needs (ratio -2.5 % on the
-// datagen inputs).  x = distance from the start of the run; true if the reference would probe it.
-__device__ __forceinline__ bool is_probe_position(uint32_t x) {
-    if (x < 64) return true;
-    uint32_t j = (uint32_t)((sqrtf(1.0f + (float)x * 0.125f) - 1.0f) * 0.5f);   // 32 j (j+1) <= x
-    while (32u * j * (j + 1) > x) j--;
-    while (32u * (j + 1) * (j + 2) <= x) j++;
-    const uint32_t k = x - 32u * j * (j + 1), d = j + 1;
-    const uint32_t t = (uint32_t)((float)k / (float)d + 0.5f);
-    return t * d == k;
+// the reference's hashes (lz4.c:777-795): 5 bytes for inputs >= 64 KB + 11, 4 bytes below; 13 bits here
+__device__ __forceinline__ uint32_t hash_pos(uint64_t v8, bool small) {
+    return small ? ((uint32_t)v8 * 2654435761u) >> (32 - kHashBits)
+                 : (uint32_t)(((v8 << 24) * 889523592379ull) >> (64 - kHashBits));
 }
 
 // number of equal leading bytes (0..8) of two 8-byte little-endian words
@@ -95,260 +103,183 @@ __device__ __forceinline__ uint32_t equal_bytes8(uint64_t x, uint64_t y) {
     return lo ? (uint32_t)(__ffs((int)lo) - 1) >> 3 : 4 + ((uint32_t)(__ffs((int)(uint32_t)(d >> 32)) - 1) >> 3);
 }
 
-__device__ __forceinline__ void match_subchunk_body(const CompBatch& P) {
-    LZ4AMD_DYN_LDS(smem);
-    uint16_t* tab = (uint16_t*)smem;
-    const uint32_t lane = lane_id();
-    const uint32_t k = blockIdx.x;                    // one wave per sub-chunk
-    const uint32_t b = P.sub_block[k];
-    const uint8_t* __restrict__ src = P.src[b];
-    const int32_t n_i = P.src_size[b];
-    const uint32_t n = n_i > 0 ? (uint32_t)n_i : 0;
-    const uint32_t cs = (k - P.blk_sub0[b]) * P.sub_bytes;
-    uint32_t ce = cs + P.sub_bytes; if (ce > n || ce < cs) ce = n;
-    MatchRec* recs = (MatchRec*)P.recs + (uint64_t)k * P.recs_per_sub;
+// ring offset of block position pos
+__device__ __forceinline__ uint32_t src_ring_off(uint32_t pos) { return pos % kSrcRing; }
+// offset `d` bytes before / after ring offset o (d < kSrcRing)
+__device__ __forceinline__ uint32_t ring_back(uint32_t o, uint32_t d) { return o >= d ? o - d : o + kSrcRing - d; }
+__device__ __forceinline__ uint32_t ring_fwd(uint32_t o, uint32_t d) { const uint32_t x = o + d; return x >= kSrcRing ? x - kSrcRing : x; }
+// 8 bytes at ring offset o, any alignment: two ALIGNED 8-byte reads and a funnel shift (a misaligned
+// ds_read_b64 costs about five aligned ones on gfx950; the pad covers the read past the ring's end)
+__device__ __forceinline__ uint64_t funnel8(uint64_t lo, uint64_t hi, uint32_t byte_shift) {
+    const uint32_t s = byte_shift * 8;
+    return s ? (lo >> s) | (hi << (64 - s)) : lo;
+}
+__device__ __forceinline__ uint64_t ring_ld8(const uint8_t* ring, uint32_t o) {
+    const uint64_t* a = (const uint64_t*)(ring + (o & ~7u));
+    return funnel8(a[0], a[1], o & 7);
+}
 
-    const bool small = n < kSmallBlockLimit;
-    // -- clear table (16-byte stores)
-    {
-        U32x4 z; z[0] = z[1] = z[2] = z[3] = 0;
-        const uint32_t n16 = small ? 1024u : 512u;
-        for (uint32_t i = lane; i < n16; i += 64) ((U32x4*)tab)[i] = z;
+// 16 source bytes at block position P (multiple of 16) -> ring
+__device__ __forceinline__ void ring_commit16(uint8_t* ring, uint32_t P, const U32x4& v) {
+    const uint32_t o = src_ring_off(P);
+    *(U32x4*)(ring + o) = v;
+    if (o < kSrcPad) *(U32x4*)(ring + kSrcRing + o) = v;
+}
+__device__ __forceinline__ U32x4 load_src16(lz4amd_gsrc src, uint32_t n, uint32_t P) {
+    if (P + 16 <= n) return ld_global16(src + P);
+    uint32_t a = 0, b = 0, c = 0, d = 0;
+#pragma nounroll
+    for (uint32_t i = 0; i < 16 && P + i < n; i++) {
+        const uint32_t v = (uint32_t)src[P + i] << ((i & 3) * 8), k = i >> 2;
+        a |= k == 0 ? v : 0; b |= k == 1 ? v : 0; c |= k == 2 ? v : 0; d |= k == 3 ? v : 0;
     }
-    wave_lds_fence();
-    uint32_t nseq = 0, enc = 0, anchor = cs;
+    U32x4 r; r[0] = a; r[1] = b; r[2] = c; r[3] = d;
+    return r;
+}
+
+// tile geometry at block position t0: small tiles first, so that small blocks (and the start of
+// every block) are not parsed against an empty table for long
+__device__ __forceinline__ void tile_geometry(uint32_t t0, bool small, uint32_t& tile_len, uint32_t& strip_len) {
+    const uint32_t tmax = small ? kTileMaxSmall : kTileMax;
+    uint32_t t = kTileMin;
+    while (t < tmax && t * 4 <= t0) t <<= 1;
+    tile_len = t;
+    strip_len = t / kCmpWaves; if (strip_len < kStripMin) strip_len = kStripMin;
+}
+
+// ------------------------------------------------------------------------------ match (one strip)
+__device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint32_t* strip,
+                                            uint32_t w, uint32_t n, uint32_t cs, uint32_t ce) {
+    const uint32_t lane = lane_id();
+    const bool small = n < kSmallBlockLimit;
+    uint32_t nseq = 0, enc = 0, ll0 = 0, anchor = cs;
     // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= ce
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         const uint32_t last_q = n - kMfLimit;                  // inclusive; q + 8 <= n - 4 holds for all probes
         uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
-        // -- seed with the window that precedes the sub-chunk
-        const uint32_t low = cs > kMaxDistance ? cs - kMaxDistance : 0;
-        for (uint32_t p = low; p < cs; p += 64) {
-            const uint32_t q = p + lane;
-            if (q < cs) {
-                const uint64_t v8 = ld_u64(src + q);
-                tab[small ? hash_small((uint32_t)v8) : hash_large(v8)] = (uint16_t)q;
-            }
-        }
-        wave_lds_fence();
+        const uint32_t cs_off = src_ring_off(cs);
+        // big blocks probe every second position (the backward extension recovers the odd starts):
+        // half the work for about 4 % of the matches, which the larger table more than pays for
+        const uint32_t sh = small ? 0u : 1u, span = 64u << sh;
         uint32_t p = cs, cur = cs;                             // cur: first position not yet covered
-        uint32_t run0 = cs;                                    // start of the current literal run's probe schedule
-        uint64_t vpre = 0; uint32_t ppre = kNoOutput;          // source words fetched one window ahead
-        while (p < ce && p <= last_q) {
-            const uint32_t q = p + lane;
-            const bool valid = q < ce && q <= last_q;
-            uint64_t v8 = 0;
-            if (ppre == p) v8 = vpre; else if (valid) v8 = ld_u64(src + q);
-            {   // prefetch the next window (discarded when a long match jumps over it)
-                const uint32_t qn = q + 64;
-                ppre = p + 64;
-                vpre = (qn < ce && qn <= last_q) ? ld_u64(src + qn) : 0ull;
-            }
-            const uint32_t v = (uint32_t)v8;
-            uint32_t h = 0, c1 = 0, c2 = 0;
-            bool ok1 = false;
+        while (p < ce && p <= last_q && nseq < kRecsPerStrip) {
+            const uint32_t q = p + (lane << sh);
+            const bool valid = q < ce && q <= last_q && q != 0;
+            const uint32_t qo = ring_fwd(cs_off, q - cs);
+            uint32_t c = 0, len = 0, back = 0;
+            bool f = false;
             if (valid) {
-                h = small ? hash_small(v) : hash_large(v8);
-                const uint32_t d1 = (q - tab[h]) & 0xFFFFu;
-                c1 = q - d1;
-                ok1 = d1 != 0 && d1 <= q && c1 >= low;
+                // stage 1: my bytes q-8 .. q+24 (independent of the table)
+                const uint64_t v8 = ring_ld8(ring, qo), v16 = ring_ld8(ring, ring_fwd(qo, 8)), v24 = ring_ld8(ring, ring_fwd(qo, 16));
+                const uint64_t vb = ring_ld8(ring, ring_back(qo, 8));
+                // stage 2: the candidate
+                c = tab[hash_pos(v8, small)];
+                const uint32_t d = q - c;
+                if (c < q && d <= kMaxDistance) {
+                    // stage 3: its bytes c-8 .. c+24
+                    const uint32_t co = ring_back(qo, d);
+                    const uint64_t c8 = ring_ld8(ring, co), c16 = ring_ld8(ring, ring_fwd(co, 8)), c24 = ring_ld8(ring, ring_fwd(co, 16));
+                    const uint64_t cb = ring_ld8(ring, ring_back(co, 8));
+                    len = equal_bytes8(v8, c8);
+                    if (len == 8) { len += equal_bytes8(v16, c16); if (len == 16) len += equal_bytes8(v24, c24); }
+                    f = len >= kMinMatch;
+                    // how far back, over literals that may still be pending (lz4.c:1105-1109)?
+                    if (c >= 8) { const uint64_t x = vb ^ cb; back = x ? (uint32_t)__clzll((long long)x) >> 3 : 8u; }
+                }
             }
-            wave_lds_fence();                              // every lane probes before any lane inserts
-            // candidates closer than one window are invisible to the table probe (the window's own
-            // positions are inserted after the probe): catch the short periods 1..4 (runs, 16/32-bit
-            // patterns) by comparing with the neighbouring lanes' bytes instead
-            const bool f1 = ok1 && (uint32_t)ld_u32(src + c1) == v;
-            bool f2 = false;
-#pragma unroll
-            for (uint32_t d = 4; d >= 1; d--) {
-                const uint32_t vd = __shfl_up(v, d);
-                const bool vld = (bool)__shfl_up((int)valid, d);
-                if (lane >= d && valid && vld && vd == v) { c2 = q - d; f2 = true; }
-            }
-            f2 = f2 && !f1;
-            const uint32_t cand = f1 ? c1 : c2;
-            const bool e_old = valid && q >= run0 && is_probe_position(q - run0);
-            const unsigned long long em = __ballot(e_old);
-            uint32_t firstcur = kNoOutput;              // end of the first match taken in this window
-            unsigned long long m = __ballot(f1 || f2);
-            // window positions swallowed by matches are not indexed, except cur-2 (lz4.c:1236-1242);
-            // a window that starts inside the previous match (p = cur-2) only indexes its lane 0
-            unsigned long long covered = 0;
-            if (cur > p) covered = ((cur - p >= 64) ? ~0ull : ((1ull << (cur - p)) - 1)) & ~(1ull << (cur - 2 - p));
+            unsigned long long m = __ballot(f);
             while (m) {
                 const uint32_t l = (uint32_t)__ffsll((long long)m) - 1;
                 m &= m - 1;
-                uint32_t qm = p + l;
-                const uint32_t qfound = qm;
+                uint32_t qm = p + (l << sh);
                 if (qm < cur) continue;
-                if (firstcur == kNoOutput && !((em >> l) & 1)) continue;     // not on the probe schedule
-                uint32_t cm = (uint32_t)__shfl((int)cand, (int)l);
-                if (qm + kMinMatch > mlimit) continue;          // the 4 verified bytes cross the cut
-                // -- forward (lz4.c:680-703 LZ4_count) and backward (lz4.c:1105-1109) extension
-                //    in one memory round trip: 8 bytes per lane forward, 1 byte per lane backward
-                uint32_t room = qm - anchor; if (cm < room) room = cm;
-                uint32_t ml = kMinMatch, back = 0;
-                bool fwd_done = false, back_done = room == 0;
-                uint32_t fbase = kMinMatch, bbase = 0;
-                while (!fwd_done || !back_done) {
-                    uint32_t same = 8; bool beq = true;
-                    if (!fwd_done) {
-                        const uint32_t a = qm + fbase + 8 * lane, c = cm + fbase + 8 * lane;
-                        if (a >= mlimit) same = 0;
-                        else if (a + 8 <= n) { same = equal_bytes8(ld_u64(src + a), ld_u64(src + c)); if (same > mlimit - a) same = mlimit - a; }
-                        else { same = 0; while (a + same < mlimit && src[a + same] == src[c + same]) same++; }
-                    }
-                    if (!back_done) {
-                        const uint32_t i = bbase + lane;
-                        beq = i < room && src[qm - 1 - i] == src[cm - 1 - i];
-                    }
-                    if (!fwd_done) {
+                if (qm + kMinMatch > mlimit) break;            // nothing later in the window fits either
+                uint32_t cm = wave_readlane(c, l);
+                uint32_t ml = wave_readlane(len, l);
+                uint32_t bk = wave_readlane(back, l);
+                if (ml >= kLaneLenCap && qm + ml < mlimit) {
+                    // long match: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
+                    const uint32_t qmo = ring_fwd(cs_off, qm - cs), cmo = ring_back(qmo, qm - cm);
+                    for (;;) {
+                        const uint32_t a = qm + ml + 8 * lane;
+                        uint32_t same = 0;
+                        if (a < mlimit) {
+                            same = equal_bytes8(ring_ld8(ring, ring_fwd(qmo, ml + 8 * lane)), ring_ld8(ring, ring_fwd(cmo, ml + 8 * lane)));
+                            if (same > mlimit - a) same = mlimit - a;
+                        }
                         const unsigned long long brk = __ballot(same < 8);
                         if (brk) {
                             const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
-                            ml = fbase + 8 * fl + (uint32_t)__shfl((int)same, (int)fl);
-                            fwd_done = true;
-                        } else fbase += 512;
-                    }
-                    if (!back_done) {
-                        const unsigned long long ne = __ballot(!beq);
-                        if (ne) { back = bbase + (uint32_t)__ffsll((long long)ne) - 1; back_done = true; }
-                        else bbase += 64;
+                            ml += 8 * fl + wave_readlane(same, fl);
+                            break;
+                        }
+                        ml += 512;
                     }
                 }
-                qm -= back; cm -= back; ml += back;
+                if (qm + ml > mlimit) ml = mlimit - qm;
+                if (bk > qm - anchor) bk = qm - anchor;
+                qm -= bk; cm -= bk; ml += bk;
                 const uint32_t ll = qm - anchor;
                 if (lane == 0) { MatchRec r; r.ll = ll; r.mo = (qm - cm) | ((ml - kMinMatch) << 16); recs[nseq] = r; }
+                if (nseq == 0) ll0 = ll;
                 enc += enc_size(ll, ml - kMinMatch);
                 nseq++;
                 anchor = cur = qm + ml;
-                run0 = cur;
-                if (firstcur == kNoOutput) firstcur = cur;
-                {   // window lanes inside [qm, cur) are not indexed, except cur-2 (lz4.c:1236-1242)
-                    const uint32_t a0 = qfound - p;     // positions passed over before the hit stay indexed
-                    const uint32_t a1 = cur - p < 64 ? cur - p : 64;
-                    if (a1 > a0) covered |= ((a1 - a0 >= 64) ? ~0ull : ((1ull << (a1 - a0)) - 1)) << a0;
-                    if (cur - 2 >= p && cur - 2 < p + 64) covered &= ~(1ull << (cur - 2 - p));
-                }
+                if (nseq >= kRecsPerStrip) break;
+                if (cur - p >= span) break;
+                m &= ~0ull << ((cur - p + sh) >> sh);          // lanes inside the match
             }
-            if (valid && !((covered >> lane) & 1) && (q >= firstcur || q < run0 || e_old)) tab[h] = (uint16_t)q;
-            p = (cur > p + 66) ? cur - 2 : p + 64;
+            p = cur > p + span ? (cur + sh) & ~sh : p + span;
         }
     }
     if (lane == 0) {
-        P.sub_n[k] = nseq;
-        P.sub_enc[k] = enc;
-        P.sub_tail[k] = ce - anchor;
+        strip[S_N * kCmpWaves + w] = nseq;
+        strip[S_ENC * kCmpWaves + w] = enc;
+        strip[S_LL0 * kCmpWaves + w] = ll0;
+        strip[S_TAIL * kCmpWaves + w] = ce - anchor;
     }
 }
 
-// ---------------------------------------------------------------------------- K_offsets
-// one wave per block; lanes stride over the block's sub-chunks in order (serial carry chain,
-// <= a few hundred sub-chunks for the block sizes of interest; 32768 for a 2 GB block).
-__device__ __forceinline__ void offsets_body(const CompBatch& P) {
-    const uint32_t b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    const int32_t n_i = P.src_size[b];
-    const int32_t cap_i = P.dst_cap[b];
-    const uint32_t s0 = P.blk_sub0[b], s1 = P.blk_sub0[b + 1];
-    if (n_i < 0 || (uint32_t)n_i > 0x7E000000u || cap_i <= 0 || P.dst[b] == nullptr) { P.result[b] = 0; return; }
-    uint8_t* dst = P.dst[b];
-    if (n_i == 0) { dst[0] = 0; P.result[b] = 1; return; }         // lz4.c:1361-1371
-    const uint32_t n = (uint32_t)n_i, cap = (uint32_t)cap_i;
-    // pass 1: sizes
-    uint64_t out = 0; uint32_t carry = 0;
-    for (uint32_t k = s0; k < s1; k++) {
-        const uint32_t nk = P.sub_n[k];
-        if (nk) {
-            // first sequence of this sub-chunk absorbs the carried literals
-            const uint32_t ll0 = ((const MatchRec*)P.recs)[(uint64_t)k * P.recs_per_sub].ll;
-            uint32_t delta = carry;
-            const uint32_t a = ll0 >= 15 ? len_ext_bytes(ll0 - 15) : 0;
-            const uint32_t bb = (ll0 + carry) >= 15 ? len_ext_bytes(ll0 + carry - 15) : 0;
-            delta += bb - a;
-            P.sub_out[k] = (uint32_t)out;
-            P.sub_carry[k] = carry;
-            out += (uint64_t)P.sub_enc[k] + delta;
-            carry = P.sub_tail[k];
-        } else {
-            P.sub_out[k] = (uint32_t)out; P.sub_carry[k] = 0;
-            carry += P.sub_tail[k];
-        }
-    }
-    const uint32_t last_run = carry;
-    const uint64_t total = out + 1 + (last_run >= 15 ? len_ext_bytes(last_run - 15) : 0) + last_run;
-    if (total > cap) {                                   // does not fit: 0 (lz4.c:1116,1210,1314)
-        P.result[b] = 0;
-        for (uint32_t k = s0; k < s1; k++) P.sub_out[k] = kNoOutput;
-        return;
-    }
-    // pass 2: destinations of tail literals.  A tail run belongs to the next sequence that
-    // exists (its literals end right before that sequence's offset field) or to the last run.
-    {
-        uint8_t* p = dst + out;
-        if (last_run >= 15) { *p++ = 0xF0; p = put_len_ext(p, last_run - 15); }
-        else *p++ = (uint8_t)(last_run << 4);
-        uint32_t lit_end = (uint32_t)(p - dst) + last_run;      // end of the pending literal area
-        for (uint32_t k = s1; k-- > s0;) {
-            const uint32_t tail = P.sub_tail[k];
-            P.sub_tail_dst[k] = lit_end - tail;
-            if (P.sub_n[k]) {
-                // earlier tails feed this sub-chunk's first sequence: its literal area ends
-                // where its own (non-carried) ll0 literals begin
-                const uint32_t ll0 = ((const MatchRec*)P.recs)[(uint64_t)k * P.recs_per_sub].ll;
-                const uint32_t c = P.sub_carry[k];
-                const uint32_t hdr = 1 + ((ll0 + c) >= 15 ? len_ext_bytes(ll0 + c - 15) : 0);
-                lit_end = P.sub_out[k] + hdr + c;
-            } else {
-                lit_end -= tail;
-            }
-        }
-    }
-    (void)n;
-    P.result[b] = (int32_t)total;
-}
-
-// ------------------------------------------------------------------------------- K_emit
-__device__ __forceinline__ void wave_copy_bytes(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, uint32_t n) {
-    for (uint32_t i = lane_id(); i < n; i += 64) d[i] = s[i];
-}
-
-__device__ __forceinline__ void emit_subchunk_body(const CompBatch& P) {
+// wave copy of `len` literal bytes from block position sp to dst + d: out of the ring when the
+// bytes are still there, else from HBM
+__device__ __forceinline__ void copy_literals(lz4amd_gdst dst, uint32_t d, lz4amd_gsrc src, const uint8_t* ring,
+                                              uint32_t sp, uint32_t len, uint32_t ring_lo) {
     const uint32_t lane = lane_id();
-    const uint32_t k = blockIdx.x;
-    const uint32_t out0 = P.sub_out[k];
-    if (out0 == kNoOutput) return;                      // block failed / nothing to do (uniform)
-    const uint32_t b = P.sub_block[k];
-    const uint8_t* __restrict__ src = P.src[b];
-    uint8_t* __restrict__ dst = P.dst[b];
-    const uint32_t n = (uint32_t)P.src_size[b];
-    const uint32_t cs = (k - P.blk_sub0[b]) * P.sub_bytes;
-    uint32_t ce = cs + P.sub_bytes; if (ce > n || ce < cs) ce = n;
-    const uint32_t nk = P.sub_n[k];
-    const uint32_t carry = P.sub_carry[k];
-    const MatchRec* recs = (MatchRec*)P.recs + (uint64_t)k * P.recs_per_sub;
+    if (sp >= ring_lo) {
+        const uint32_t o = src_ring_off(sp);
+        for (uint32_t i = lane; i < len; i += 64) dst[d + i] = ring[ring_fwd(o, i)];
+    } else {
+        for (uint32_t i = lane; i < len; i += 64) dst[d + i] = src[sp + i];
+    }
+}
 
-    uint32_t ipos = cs;            // source position of the next sequence's literals
-    uint32_t opos = out0;          // dst position of the next sequence's token
+// ------------------------------------------------------------------------------ emit (one strip)
+__device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* recs, const uint32_t* strip,
+                                           uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t cs, uint32_t ring_lo) {
+    const uint32_t lane = lane_id();
+    const uint32_t nk = strip[S_N * kCmpWaves + w];
+    const uint32_t carry = strip[S_CARRY * kCmpWaves + w];
+    uint32_t ipos = cs;            // source position of the next sequence's own literals
+    uint32_t opos = strip[S_OUT * kCmpWaves + w];      // dst position of the next sequence's token
     for (uint32_t base = 0; base < nk; base += 64) {
         const uint32_t i = base + lane;
         const bool have = i < nk;
         uint32_t ll = 0, mlm4 = 0, off = 0, extra = 0;
         if (have) { const MatchRec r = recs[i]; ll = r.ll; off = r.mo & 0xFFFFu; mlm4 = r.mo >> 16; }
-        if (i == 0) extra = carry;                       // literals inherited from earlier sub-chunks
+        if (i == 0) extra = carry;                       // literals inherited from earlier strips
         const uint32_t e = have ? enc_size(ll + extra, mlm4) : 0;
         const uint32_t adv = have ? ll + mlm4 + kMinMatch : 0;
         const uint32_t e_incl = wave_incl_sum(e), a_incl = wave_incl_sum(adv);
         const uint32_t my_o = opos + e_incl - e;
-        const uint32_t my_i = ipos + a_incl - adv;       // source pos of my own ll literals
+        const uint32_t my_i = ipos + a_incl - adv - extra;   // source pos of my literals (carried ones included)
         uint32_t lit_dst = 0;
+        const uint32_t tl = ll + extra;
         if (have) {
-            uint8_t* p = dst + my_o;
-            const uint32_t tl = ll + extra;
+            lz4amd_gdst p = dst + my_o;
             const uint32_t tok_ll = tl >= 15 ? 15u : tl, tok_ml = mlm4 >= 15 ? 15u : mlm4;
             *p++ = (uint8_t)((tok_ll << 4) | tok_ml);
             if (tl >= 15) p = put_len_ext(p, tl - 15);
-            lit_dst = (uint32_t)(p - dst) + extra;       // my own literals follow the carried ones
+            lit_dst = (uint32_t)(p - dst);
             p += tl;
             p[0] = (uint8_t)off; p[1] = (uint8_t)(off >> 8); p += 2;
             if (mlm4 >= 15) p = put_len_ext(p, mlm4 - 15);
@@ -356,18 +287,158 @@ __device__ __forceinline__ void emit_subchunk_body(const CompBatch& P) {
         // literal runs, one sequence at a time, all lanes copying
         const uint32_t cnt = nk - base < 64 ? nk - base : 64;
         for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t jl = (uint32_t)__shfl((int)ll, (int)j);
+            const uint32_t jl = wave_readlane(tl, j);
             if (jl == 0) continue;
-            const uint32_t jd = (uint32_t)__shfl((int)lit_dst, (int)j);
-            const uint32_t js = (uint32_t)__shfl((int)my_i, (int)j);
-            wave_copy_bytes(dst + jd, src + js, jl);
+            copy_literals(dst, wave_readlane(lit_dst, j), src, ring, wave_readlane(my_i, j), jl, ring_lo);
         }
-        opos += (uint32_t)__shfl((int)e_incl, 63);
-        ipos += (uint32_t)__shfl((int)a_incl, 63);
+        opos += wave_readlane(e_incl, 63);
+        ipos += wave_readlane(a_incl, 63);
     }
-    // tail literals of this sub-chunk (carried into a later sequence or the final run)
-    const uint32_t tail = P.sub_tail[k];
-    if (tail) wave_copy_bytes(dst + P.sub_tail_dst[k], src + (ce - tail), tail);
+}
+
+// ------------------------------------------------------------------------------ one block
+__device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t b, char* smem) {
+    const uint32_t tid = threadIdx.x, w = wave_id();
+    uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
+    uint32_t* strip = (uint32_t*)(smem + kCOffStrip);
+    uint32_t* tab = (uint32_t*)(smem + kCOffTab);
+    MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + w * kRecsPerStrip;
+    uint8_t* ring = (uint8_t*)(smem + kCOffRing);
+
+    const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
+    const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
+    const int32_t n_i = P.src_size[b];
+    const int32_t cap_i = P.dst_cap[b];
+    if (n_i < 0 || (uint32_t)n_i > kMaxInput || cap_i <= 0 || P.dst[b] == nullptr || (P.src[b] == nullptr && n_i != 0)) {
+        if (tid == 0) P.result[b] = 0;                               // lz4.c:1360
+        return;
+    }
+    if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }      // lz4.c:1361-1371
+    const uint32_t n = (uint32_t)n_i, cap = (uint32_t)cap_i;
+    const bool small = n < kSmallBlockLimit;
+
+    for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
+    if (tid == 0) { misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; }
+    // first tile straight into the ring; later tiles are prefetched one tile ahead
+    uint32_t t0 = 0, tile_len, strip_len;
+    tile_geometry(0, small, tile_len, strip_len);
+    uint32_t loaded = 0;                                  // ring holds [.., loaded)
+    uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
+    uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
+    if (prof) tq = clock_ticks();
+    {
+        uint32_t hi = tile_len + 16; if (hi > n) hi = n;
+        for (uint32_t Pp = 16 * tid; Pp < hi; Pp += 16 * kCmpThreads) ring_commit16(ring, Pp, load_src16(src, n, Pp));
+        loaded = (hi + 15) & ~15u;
+    }
+    while (t0 < n) {
+        uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
+        // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
+        uint32_t nt_len, nt_strip;
+        tile_geometry(t1, small, nt_len, nt_strip);
+        uint32_t pf_hi = loaded + nt_len; if (pf_hi > n || pf_hi < loaded) pf_hi = n;     // stays 16 bytes ahead of the tile
+        const uint32_t Pp = loaded + 16 * tid;
+        U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;
+        if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 16 * kCmpThreads
+        __syncthreads();                                       // ring (and table) ready for this tile
+        if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
+        // -- match: one wave per strip
+        const uint32_t nstrips = (t1 - t0 + strip_len - 1) / strip_len;
+        if (w < nstrips) {
+            const uint32_t cs = t0 + w * strip_len;
+            uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
+            match_strip(ring, tab, recs, strip, w, n, cs, ce);
+        }
+        if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
+        __syncthreads();
+        if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
+        // -- offsets (wave 0: lane k holds strip k; the carry chain runs through readlane) ...
+        if (w == 0) {
+            const uint32_t lane = lane_id();
+            const bool mine = lane < nstrips;
+            const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, en = mine ? strip[S_ENC * kCmpWaves + lane] : 0;
+            const uint32_t l0 = mine ? strip[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip[S_TAIL * kCmpWaves + lane] : 0;
+            uint32_t out = misc[CM_OUT], carry = misc[CM_CARRY], fail = misc[CM_FAIL];
+            uint32_t my_out = 0, my_carry = 0;
+            for (uint32_t k = 0; k < nstrips; k++) {
+                const uint32_t nk_k = wave_readlane(nk, k), tail_k = wave_readlane(tl, k);
+                if (nk_k) {
+                    const uint32_t ll0 = wave_readlane(l0, k);
+                    const uint32_t sz = wave_readlane(en, k) + carry + lit_hdr_ext(ll0 + carry) - lit_hdr_ext(ll0);
+                    // a strip is only written if it fits (the block then fails as a whole, lz4.c:1116)
+                    if ((uint64_t)out + sz > cap) fail = 1;
+                    if (lane == k) { my_out = out; my_carry = carry; }
+                    if (!fail) out += sz;
+                    carry = tail_k;
+                } else {
+                    carry += tail_k;
+                }
+            }
+            if (mine) { strip[S_OUT * kCmpWaves + lane] = my_out; strip[S_CARRY * kCmpWaves + lane] = my_carry; }
+            if (lane == 0) { misc[CM_OUT] = out; misc[CM_CARRY] = carry; misc[CM_FAIL] = fail; }
+        }
+        // -- ... while everybody inserts the tile into the table (positions that may start a match):
+        //    16 consecutive positions per thread, hashed out of three aligned 8-byte words
+        if (n >= kMfLimit + 1) {
+            const uint32_t last_q = n - kMfLimit;
+            const uint32_t q0 = t0 + 16 * tid;                      // t0 is a multiple of 1024
+            if (q0 < t1 && q0 <= last_q) {
+                const uint32_t o = src_ring_off(q0);                // multiple of 16: o + 24 <= ring + pad
+                const uint64_t* a = (const uint64_t*)(ring + o);
+                const uint64_t w0 = a[0], w1 = a[1], w2 = a[2];
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t q = q0 + i;
+                    const uint64_t v8 = i < 8 ? funnel8(w0, w1, i) : funnel8(w1, w2, i - 8);
+                    if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos(v8, small)], q);
+                }
+            }
+        }
+        __syncthreads();
+        if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
+        // -- emit
+        const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
+        if (w < nstrips && !misc[CM_FAIL] && strip[S_N * kCmpWaves + w])
+            emit_strip(ring, recs, strip, w, src, dst, t0 + w * strip_len, ring_lo);
+        __syncthreads();                                       // ring readers done: commit the prefetch
+        if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
+        if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
+        if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
+        t0 = t1; tile_len = nt_len; strip_len = nt_strip;
+    }
+    __syncthreads();
+    if (prof && tid == 0) { prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = tp[4]; }
+    // -- final literal run (lz4.c:1302-1329)
+    const uint32_t out = misc[CM_OUT], run = misc[CM_CARRY];
+    const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;
+    if (misc[CM_FAIL] || total > cap) { if (tid == 0) P.result[b] = 0; return; }
+    const uint32_t lit_dst = out + 1 + lit_hdr_ext(run);
+    if (tid == 0) {
+        lz4amd_gdst p = dst + out;
+        if (run >= 15) { *p++ = 0xF0; put_len_ext(p, run - 15); }
+        else *p++ = (uint8_t)(run << 4);
+        P.result[b] = (int32_t)total;
+    }
+    {
+        const uint32_t sp = n - run;
+        const uint32_t full = run & ~15u;
+        for (uint32_t i = 16 * tid; i < full; i += 16 * kCmpThreads) st_global16(dst + lit_dst + i, ld_global16(src + sp + i));
+        for (uint32_t i = full + tid; i < run; i += kCmpThreads) dst[lit_dst + i] = src[sp + i];
+    }
+}
+
+// Workgroups pull blocks from a device-wide ticket counter (load balance for ragged batches).
+__device__ __forceinline__ void compress_batch_body(const CompBatch& P) {
+    LZ4AMD_DYN_LDS(smem);
+    uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) misc[CM_BLOCK] = take_ticket(P.ticket);
+        __syncthreads();
+        const uint32_t b = misc[CM_BLOCK];
+        if (b >= P.n_blocks) break;
+        compress_one_block(P, b, smem);
+    }
 }
 
 } // namespace lz4amd

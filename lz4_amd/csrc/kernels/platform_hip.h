@@ -63,6 +63,9 @@ __device__ __forceinline__ lz4amd_u32x4 ld_global16_raw(lz4amd_gsrc p) { lz4amd_
 __device__ __forceinline__ void st_global16_raw(lz4amd_gdst p, const lz4amd_u32x4& v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ uint64_t clock_ticks() { return __builtin_readcyclecounter(); }
 
+// value of v in lane l (l wave-uniform): v_readlane_b32, no LDS round trip
+__device__ __forceinline__ uint32_t wave_readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
 // device-scope work-queue ticket
 __device__ __forceinline__ uint32_t take_ticket(uint32_t* counter) {
     return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

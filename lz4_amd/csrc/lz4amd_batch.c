@@ -121,49 +121,20 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->scratch = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)q->scratch_stride * (grid ? grid : 1), &err));
     } else if (op == LZ4AMD_OP_COMPRESS) {
         lz4amd_comp_params* q = &p->comp;
-        /* sub-chunk = the unit one wave parses.  Bigger sub-chunks cost less (the 64 KB of table
-         * seeding in front of each is amortised) and cut the stream less often; smaller ones give
-         * more waves.  Take the largest of 256/128/64 KB that still yields >= 16 waves per CU. */
-        uint32_t sub = LZ4AMD_SUB_BYTES_MAX;
-        uint64_t total_bytes = 0;
-        int any_small = 0;
-        for (i = 0; i < n; i++) if (src_sizes[i] > 0 && (unsigned)src_sizes[i] <= 0x7E000000u) {
-            total_bytes += (unsigned)src_sizes[i];
-            if ((unsigned)src_sizes[i] < 65536u + 11u) any_small = 1;
-        }
-        while (sub > LZ4AMD_SUB_BYTES_MIN && total_bytes / sub < 16ull * (uint64_t)ctx->n_cus) sub >>= 1;
-        uint32_t* blk_sub0 = (uint32_t*)malloc((un + 1) * sizeof(uint32_t));
-        uint32_t* sub_block;
-        uint64_t ns = 0; uint32_t k = 0;
-        if (!blk_sub0) { lz4amd_plan_destroy(p); return LZ4AMD_E_MEMORY; }
-        for (i = 0; i < n; i++) {
-            uint32_t sz = (src_sizes[i] > 0 && (unsigned)src_sizes[i] <= 0x7E000000u) ? (uint32_t)src_sizes[i] : 0;
-            blk_sub0[i] = (uint32_t)ns;
-            ns += (sz + sub - 1) / sub;
-        }
-        blk_sub0[n] = (uint32_t)ns;
-        if (ns > 0x7FFFFFFFu) { free(blk_sub0); lz4amd_plan_destroy(p); return LZ4AMD_E_ARG; }
-        sub_block = (uint32_t*)malloc((size_t)(ns ? ns : 1) * sizeof(uint32_t));
-        if (!sub_block) { free(blk_sub0); lz4amd_plan_destroy(p); return LZ4AMD_E_MEMORY; }
-        for (i = 0; i < n; i++) for (; k < blk_sub0[i + 1]; k++) sub_block[k] = (uint32_t)i;
+        /* one 1024-thread workgroup streams through a block (source ring + hash table in LDS);
+         * blocks are pulled from a ticket counter */
+        unsigned grid = (unsigned)ctx->n_cus;
+        if ((unsigned)n < grid) grid = (unsigned)n;
+        p->grid = grid;
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
-        q->n_subs = (uint32_t)ns; q->sub_bytes = sub;
-        p->match_lds = any_small ? 16384u : 8192u;   /* 8192 x u16 (13-bit hash) or 4096 x u16 (12-bit) */
-        q->recs_per_sub = lz4amd_hip_comp_recs_per_sub(sub);
-        q->sub_block = (const uint32_t*)(p->bufs[nb++] = dev_array(sub_block, (size_t)ns * 4, &err));
-        q->blk_sub0 = (const uint32_t*)(p->bufs[nb++] = dev_array(blk_sub0, (un + 1) * 4, &err));
-        q->recs = p->bufs[nb++] = dev_array(NULL, (size_t)ns * q->recs_per_sub * 8, &err);
-        q->sub_n = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
-        q->sub_enc = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
-        q->sub_tail = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
-        q->sub_out = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
-        q->sub_carry = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
-        q->sub_tail_dst = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)ns * 4, &err));
-        /* uploads above are asynchronous copies from these host arrays: finish them first */
-        if (lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
-        free(sub_block); free(blk_sub0);
+        q->ticket = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
+        q->prof = NULL;
+        if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase cycle counts */
+            q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
+            if (q->prof && lz4amd_hip_memset(q->prof, 0, (size_t)(grid ? grid : 1) * 64, NULL)) err = LZ4AMD_E_RUNTIME;
+        }
     } else {
         lz4amd_set_error("operation not implemented on the device yet");
         lz4amd_plan_destroy(p);
@@ -183,14 +154,9 @@ static int launch_stage(lz4amd_plan* p, int stage, void* stream)
 {
     if (p->op == LZ4AMD_OP_DECOMPRESS)
         return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
-    switch (stage) {
-    case 0: return lz4amd_hip_launch_match(&p->comp, p->match_lds, stream);
-    case 1: return lz4amd_hip_launch_offsets(&p->comp, stream);
-    case 2: return lz4amd_hip_launch_emit(&p->comp, stream);
-    default: return 0;
-    }
+    return stage == 0 ? lz4amd_hip_launch_compress(&p->comp, p->grid, stream) : 0;
 }
-static int n_stages(const lz4amd_plan* p) { return p->op == LZ4AMD_OP_DECOMPRESS ? 1 : 3; }
+static int n_stages(const lz4amd_plan* p) { (void)p; return 1; }
 
 int lz4amd_plan_launch(lz4amd_plan* p, void* stream)
 {
@@ -224,10 +190,13 @@ int lz4amd_plan_launch_timed(lz4amd_plan* p, void* stream, float kernel_ms[4], f
 int lz4amd_plan_profile(lz4amd_plan* p, unsigned long long* words, int max_words)
 {   /* 8 words per workgroup: start stamp, stamp after the pre-parse, cycles in EMIT/LOAD/INDEX, cycles in COPY, end stamp; nseq, total, csize */
     int n;
-    if (!p || p->op != LZ4AMD_OP_DECOMPRESS || !p->dec.prof) return 0;
+    const uint64_t* src;
+    if (!p) return 0;
+    src = p->op == LZ4AMD_OP_DECOMPRESS ? p->dec.prof : p->comp.prof;
+    if (!src) return 0;
     n = (int)p->grid * 8;
     if (n > max_words) n = max_words;
-    if (lz4amd_hip_d2h(words, p->dec.prof, (size_t)n * 8, NULL) || lz4amd_hip_sync(NULL)) return 0;
+    if (lz4amd_hip_d2h(words, src, (size_t)n * 8, NULL) || lz4amd_hip_sync(NULL)) return 0;
     return n;
 }
 

@@ -10,9 +10,7 @@ using namespace lz4amd;
 
 // ------------------------------------------------------------------------------- kernels
 __global__ void __launch_bounds__(kDecThreads) lz4amd_k_decompress(lz4amd_dec_params p) { decompress_batch_body(p); }
-__global__ void __launch_bounds__(64) lz4amd_k_match(lz4amd_comp_params p) { match_subchunk_body(p); }
-__global__ void __launch_bounds__(64) lz4amd_k_offsets(lz4amd_comp_params p) { offsets_body(p); }
-__global__ void __launch_bounds__(64) lz4amd_k_emit(lz4amd_comp_params p) { emit_subchunk_body(p); }
+__global__ void __launch_bounds__(kCmpThreads) lz4amd_k_compress(lz4amd_comp_params p) { compress_batch_body(p); }
 
 // ------------------------------------------------------------------------------- runtime glue
 static thread_local char g_err[256] = "";
@@ -38,6 +36,7 @@ extern "C" int lz4amd_hip_init(int device, int* n_cus) {
     if (n_cus) *n_cus = cus;
     // the decoder uses ~152 KB of the CU's 160 KB LDS: opt in to large dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCmpLdsBytes));
     return 0;
 }
 
@@ -72,8 +71,6 @@ extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
 }
 
 extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return (size_t)dec_scratch_bytes(max_csize); }
-extern "C" unsigned lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes) { return sub_bytes / 4 + 8; }
-
 extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* s) {
     if (!p->n_blocks || !grid) return 0;
     HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
@@ -81,21 +78,10 @@ extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned
     HIPCHK(hipGetLastError());
     return 0;
 }
-extern "C" int lz4amd_hip_launch_match(const lz4amd_comp_params* p, unsigned lds_bytes, void* s) {
-    if (!p->n_subs) return 0;
-    hipLaunchKernelGGL(lz4amd_k_match, dim3(p->n_subs), dim3(64), lds_bytes ? lds_bytes : kMatchLdsBytes, (hipStream_t)s, *p);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-extern "C" int lz4amd_hip_launch_offsets(const lz4amd_comp_params* p, void* s) {
-    if (!p->n_blocks) return 0;
-    hipLaunchKernelGGL(lz4amd_k_offsets, dim3(p->n_blocks), dim3(64), 0, (hipStream_t)s, *p);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-extern "C" int lz4amd_hip_launch_emit(const lz4amd_comp_params* p, void* s) {
-    if (!p->n_subs) return 0;
-    hipLaunchKernelGGL(lz4amd_k_emit, dim3(p->n_subs), dim3(64), 0, (hipStream_t)s, *p);
+extern "C" int lz4amd_hip_launch_compress(const lz4amd_comp_params* p, unsigned grid, void* s) {
+    if (!p->n_blocks || !grid) return 0;
+    HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
+    hipLaunchKernelGGL(lz4amd_k_compress, dim3(grid), dim3(kCmpThreads), kCmpLdsBytes, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -26,13 +26,10 @@ float       lz4amd_hip_event_ms(void* start, void* stop);
 
 /* kernel geometry facts the host needs for sizing */
 size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize);
-unsigned    lz4amd_hip_comp_recs_per_sub(unsigned sub_bytes);
 
 /* launches (asynchronous on `stream`) */
 int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* stream);
-int lz4amd_hip_launch_match(const lz4amd_comp_params* p, unsigned lds_bytes, void* stream);
-int lz4amd_hip_launch_offsets(const lz4amd_comp_params* p, void* stream);
-int lz4amd_hip_launch_emit(const lz4amd_comp_params* p, void* stream);
+int lz4amd_hip_launch_compress(const lz4amd_comp_params* p, unsigned grid, void* stream);
 
 #ifdef __cplusplus
 }

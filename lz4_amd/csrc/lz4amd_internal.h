@@ -4,8 +4,6 @@
 #include "../../include/lz4amd.h"
 #include "lz4amd_params.h"
 
-#define LZ4AMD_SUB_BYTES_MIN (64u << 10)    /* compressor sub-chunk (one wave each): 64..256 KB */
-#define LZ4AMD_SUB_BYTES_MAX (256u << 10)
 #define LZ4AMD_PLAN_MAX_BUFS 20
 
 struct lz4amd_ctx {
@@ -19,7 +17,6 @@ struct lz4amd_plan {
     int n;
     int level;
     unsigned grid;
-    unsigned match_lds;                 /* dynamic LDS of the match kernel (hash table) */
     int* d_results;
     void* bufs[LZ4AMD_PLAN_MAX_BUFS];   /* every device allocation owned by the plan */
     void* ev[5];                        /* HIP events for the timed launch */

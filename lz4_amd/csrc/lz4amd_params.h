@@ -24,18 +24,8 @@ typedef struct lz4amd_comp_params {
     const int32_t* dst_cap;
     int32_t* result;                /* [n_blocks] compressed size, 0 = failure */
     uint32_t n_blocks;
-    uint32_t n_subs;                /* total sub-chunks in the batch */
-    uint32_t sub_bytes;             /* sub-chunk length */
-    const uint32_t* sub_block;      /* [n_subs] owning block */
-    const uint32_t* blk_sub0;       /* [n_blocks + 1] first sub-chunk of each block */
-    void* recs;                     /* [n_subs * recs_per_sub] 8-byte match records */
-    uint32_t recs_per_sub;
-    uint32_t* sub_n;                /* K_match -> : sequences found per sub-chunk */
-    uint32_t* sub_enc;              /* encoded bytes of those sequences (no carry) */
-    uint32_t* sub_tail;             /* literal bytes after the last match */
-    uint32_t* sub_out;              /* K_offsets -> : dst offset of the first token */
-    uint32_t* sub_carry;            /* literals carried into the first sequence */
-    uint32_t* sub_tail_dst;         /* dst offset of the tail literals */
+    uint32_t* ticket;               /* work-queue counter, zero before launch */
+    uint64_t* prof;                 /* optional: 8 words per workgroup of phase cycle counts */
 } lz4amd_comp_params;
 
 #endif

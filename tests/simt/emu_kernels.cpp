@@ -27,29 +27,13 @@ extern "C" int emu_decompress_batch(const uint8_t* const* src, const int32_t* sr
 
 extern "C" int emu_compress_batch(const uint8_t* const* src, const int32_t* src_size,
                                   uint8_t* const* dst, const int32_t* dst_cap,
-                                  int32_t* result, uint32_t n, uint32_t sub_bytes) {
+                                  int32_t* result, uint32_t n, uint32_t grid) {
     using namespace lz4amd;
-    if (!sub_bytes) sub_bytes = kSubBytes;
-    std::vector<uint32_t> sub_block, blk_sub0(n + 1);
-    for (uint32_t b = 0; b < n; b++) {
-        blk_sub0[b] = (uint32_t)sub_block.size();
-        uint32_t sz = src_size[b] > 0 ? (uint32_t)src_size[b] : 0;
-        for (uint32_t o = 0; o < sz; o += sub_bytes) sub_block.push_back(b);
-    }
-    blk_sub0[n] = (uint32_t)sub_block.size();
-    const uint32_t ns = (uint32_t)sub_block.size();
-    const uint32_t rps = sub_bytes / 4 + 8;
-    std::vector<MatchRec> recs((size_t)ns * rps + 1);
-    std::vector<uint32_t> sn(ns + 1), senc(ns + 1), stail(ns + 1), sout(ns + 1), scarry(ns + 1), stdst(ns + 1);
+    if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
+    uint32_t ticket = 0;
     CompBatch P;
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
-    P.n_blocks = n; P.n_subs = ns; P.sub_bytes = sub_bytes;
-    P.sub_block = sub_block.data(); P.blk_sub0 = blk_sub0.data();
-    P.recs = recs.data(); P.recs_per_sub = rps;
-    P.sub_n = sn.data(); P.sub_enc = senc.data(); P.sub_tail = stail.data();
-    P.sub_out = sout.data(); P.sub_carry = scarry.data(); P.sub_tail_dst = stdst.data();
-    if (ns) simt::launch(ns, 64, kMatchLdsBytes, [&] { match_subchunk_body(P); });
-    if (n) simt::launch(n, 64, 16, [&] { offsets_body(P); });
-    if (ns) simt::launch(ns, 64, 16, [&] { emit_subchunk_body(P); });
+    P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr;
+    if (n) simt::launch(grid, kCmpThreads, kCmpLdsBytes, [&] { compress_batch_body(P); });
     return 0;
 }
