@@ -52,6 +52,13 @@ int         lz4amd_compress_bound(int src_size);
 int  lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
                         const void* const* d_src, const int* src_sizes,
                         void* const* d_dst, const int* dst_caps, int level);
+/* LZ4AMD_OP_DECOMPRESS with history: block i may copy from the prefix_sizes[i] bytes that sit in
+ * device memory right before d_dst[i] (LZ4_decompress_safe_usingDict in prefix mode, lz4.c:2719-2732
+ * -> 2479 / 2504; this is how lz4frame decodes linked blocks, lz4frame.c:1901-1915).  At most the
+ * last 64 KB are used.  The caller orders the launches so that the history is final. */
+int  lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                               const void* const* d_src, const int* src_sizes,
+                               void* const* d_dst, const int* dst_caps, const int* prefix_sizes);
 void lz4amd_plan_destroy(lz4amd_plan* plan);
 /* enqueue the whole table on `stream` (asynchronous) */
 int  lz4amd_plan_launch(lz4amd_plan* plan, void* stream);

@@ -1,0 +1,110 @@
+/*
+ * lz4frame.h -- LZ4 frame container API of the MI355X-native LZ4 codec (liblz4_amd).
+ *
+ * Drop-in declarations for the one-shot frame entry points of the reference library
+ * (lz4/lz4 v1.10.0, lib/lz4frame.h); types have the reference's layout (they are ABI), each
+ * prototype cites the reference declaration it replaces.  Frames written here are standard LZ4
+ * frames (doc/lz4_Frame_format.md) and decode with any conforming decoder (`lz4 -d`); frames
+ * written by the reference (`lz4 -B# -BI/-BD -BX`, LZ4F_compressFrame) decode here.
+ *
+ * The block payloads are compressed / decompressed by the gfx950 batch kernels (all blocks of a
+ * frame in one launch), block checksums by the batched XXH32 kernel; the container fields, the
+ * header checksum and the content checksum (one strictly serial XXH32 over the whole content,
+ * lib/xxhash.c:352-389 - it cannot be split across lanes) are host C.
+ *
+ * Differences from the reference, all within the frame format:
+ *  - LZ4F_compressFrame always writes INDEPENDENT blocks (FLG.B.Indep = 1, lz4frame.c:787-792),
+ *    whatever prefs->frameInfo.blockMode asks for: that is what lets one launch compress the whole
+ *    frame.  Decoding accepts both independent and linked frames.
+ *  - compressionLevel is accepted and ignored (fast mode); HC levels are SURVEY section 8(f) "next".
+ *  - LZ4F_decompress buffers the frame and decodes it when it is complete; the bytes delivered and
+ *    the return convention (0 = frame done, else a hint > 0, errors per LZ4F_isError) are the
+ *    reference's, the pacing is not.
+ * Not provided: the streaming compression context (LZ4F_compressBegin/Update/End), dictionaries.
+ */
+#ifndef LZ4_AMD_LZ4FRAME_H
+#define LZ4_AMD_LZ4FRAME_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef size_t LZ4F_errorCode_t;                                   /* lz4frame.h:105 */
+unsigned    LZ4F_isError(LZ4F_errorCode_t code);                   /* lz4frame.h:107 */
+const char* LZ4F_getErrorName(LZ4F_errorCode_t code);              /* lz4frame.h:108 */
+
+/* lz4frame.h:123-198: parameter enums and structures (layout is ABI) */
+typedef enum { LZ4F_default = 0, LZ4F_max64KB = 4, LZ4F_max256KB = 5, LZ4F_max1MB = 6, LZ4F_max4MB = 7 } LZ4F_blockSizeID_t;
+typedef enum { LZ4F_blockLinked = 0, LZ4F_blockIndependent } LZ4F_blockMode_t;
+typedef enum { LZ4F_noContentChecksum = 0, LZ4F_contentChecksumEnabled } LZ4F_contentChecksum_t;
+typedef enum { LZ4F_noBlockChecksum = 0, LZ4F_blockChecksumEnabled } LZ4F_blockChecksum_t;
+typedef enum { LZ4F_frame = 0, LZ4F_skippableFrame } LZ4F_frameType_t;
+
+typedef struct {
+    LZ4F_blockSizeID_t     blockSizeID;
+    LZ4F_blockMode_t       blockMode;
+    LZ4F_contentChecksum_t contentChecksumFlag;
+    LZ4F_frameType_t       frameType;
+    unsigned long long     contentSize;
+    unsigned               dictID;
+    LZ4F_blockChecksum_t   blockChecksumFlag;
+} LZ4F_frameInfo_t;
+
+typedef struct {
+    LZ4F_frameInfo_t frameInfo;
+    int      compressionLevel;
+    unsigned autoFlush;
+    unsigned favorDecSpeed;
+    unsigned reserved[3];
+} LZ4F_preferences_t;
+
+#define LZ4F_VERSION 100                                            /* lz4frame.h:256 */
+unsigned LZ4F_getVersion(void);                                     /* lz4frame.h:257 */
+
+/* lz4frame.h:212, 224.  Result: frame size, or an error code (LZ4F_isError). */
+size_t LZ4F_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* preferencesPtr);
+size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                          const LZ4F_preferences_t* preferencesPtr);
+
+/* lz4frame.h:366-382 */
+typedef struct LZ4F_dctx_s LZ4F_dctx;
+typedef LZ4F_dctx* LZ4F_decompressionContext_t;
+typedef struct {
+    unsigned stableDst;
+    unsigned skipChecksums;
+    unsigned reserved1;
+    unsigned reserved0;
+} LZ4F_decompressOptions_t;
+
+LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version);   /* lz4frame.h:398 */
+LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx);                           /* lz4frame.h:399 */
+void             LZ4F_resetDecompressionContext(LZ4F_dctx* dctx);                          /* lz4frame.h:547 */
+
+/* lz4frame.h:452: frame parameters from the header in src; *srcSizePtr receives the bytes consumed */
+size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* frameInfoPtr, const void* srcBuffer, size_t* srcSizePtr);
+
+/* lz4frame.h:497.  Returns 0 when the frame is completely decoded and delivered, a hint > 0
+ * otherwise, or an error code.  *dstSizePtr / *srcSizePtr: in = capacity / available, out =
+ * bytes written / consumed. */
+size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr,
+                       const void* srcBuffer, size_t* srcSizePtr, const LZ4F_decompressOptions_t* dOptPtr);
+
+/* lz4frame.h:656-686: error codes, in the reference's order */
+typedef enum {
+    LZ4F_OK_NoError = 0, LZ4F_ERROR_GENERIC, LZ4F_ERROR_maxBlockSize_invalid, LZ4F_ERROR_blockMode_invalid,
+    LZ4F_ERROR_parameter_invalid, LZ4F_ERROR_compressionLevel_invalid, LZ4F_ERROR_headerVersion_wrong,
+    LZ4F_ERROR_blockChecksum_invalid, LZ4F_ERROR_reservedFlag_set, LZ4F_ERROR_allocation_failed,
+    LZ4F_ERROR_srcSize_tooLarge, LZ4F_ERROR_dstMaxSize_tooSmall, LZ4F_ERROR_frameHeader_incomplete,
+    LZ4F_ERROR_frameType_unknown, LZ4F_ERROR_frameSize_wrong, LZ4F_ERROR_srcPtr_wrong,
+    LZ4F_ERROR_decompressionFailed, LZ4F_ERROR_headerChecksum_invalid, LZ4F_ERROR_contentChecksum_invalid,
+    LZ4F_ERROR_frameDecoding_alreadyStarted, LZ4F_ERROR_compressionState_uninitialized,
+    LZ4F_ERROR_parameter_null, LZ4F_ERROR_io_write, LZ4F_ERROR_io_read, LZ4F_ERROR_maxCode
+} LZ4F_errorCodes;
+LZ4F_errorCodes LZ4F_getErrorCode(size_t functionResult);           /* lz4frame.h:689 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

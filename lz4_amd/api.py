@@ -48,6 +48,7 @@ def lib():
     L.LZ4_compress_fast.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i, i, i]
     L.LZ4_compressBound.argtypes = [i]
     L.LZ4_versionString.restype = ctypes.c_char_p
+    L.lz4amd_plan_create_prefix.argtypes = [vp, ctypes.POINTER(vp), i, ctypes.POINTER(vp), ip, ctypes.POINTER(vp), ip, ip]
     _LIB = L
     return L
 

@@ -77,6 +77,7 @@ enum : uint32_t {
     kIdxMask = kIdxRing - 1,
     kPreLanes = 1024,                           // pre-parse lanes per block (segments)
     kPreWarm = 768,                             // speculative warm-up distance
+    kBias = 65536,                              // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kNone = 0xFFFFFFFFu,
 };
 
@@ -203,7 +204,7 @@ __device__ __forceinline__ SeqStep seq_step_slow(const CView& V, uint32_t csize,
 // path above.
 template <bool EMIT>
 __device__ __forceinline__ WalkOut walk_chain(const CView& V, uint32_t csize, uint32_t p, uint32_t e,
-                                              SeqRec* recs, uint32_t seq, uint32_t o, uint32_t cap) {
+                                              SeqRec* recs, uint32_t seq, uint32_t o, uint32_t cap, uint32_t low) {
     const uint32_t kRecMask = 0xFFFFFFFFu;       // records go to the block's table in global memory
     WalkOut r; r.n = 0; r.ob = 0; r.err = 0;
     while (p < e) {
@@ -253,7 +254,7 @@ __device__ __forceinline__ WalkOut walk_chain(const CView& V, uint32_t csize, ui
         const uint32_t ml = s.ml + kMinMatch;
         if (EMIT) {
             const uint32_t ms = o + s.ll;        // match start in the output
-            if (s.off == 0 || s.off > ms) { r.err = p + 1; break; }      // lz4.c:2356
+            if (s.off == 0 || s.off > ms - low) { r.err = p + 1; break; } // lz4.c:2356 (low = first position with history)
             if (cap - ms < ml + kLastLiterals) { r.err = p + 1; break; } // lz4.c:2423
             SeqRec rec; rec.outpos = o; rec.litpos = s.q; rec.ll = s.ll; rec.off = s.off;
             recs[seq & kRecMask] = rec;
@@ -374,7 +375,7 @@ __device__ __forceinline__ U32x4 load_granule(lz4amd_gsrc src, uint32_t csize, u
 // lane (~120 slow steps over literals misread as tokens), the true chain inside the segment costs
 // one step per ~40 bytes, and with few lanes every lane's current cache line stays in the CU's L1.
 // Returns false (uniformly) when the block is malformed; nseq_out / total_out otherwise.
-__device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, uint32_t cap,
+__device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix,
                                                SeqRec* rectab, char* smem,
                                                uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof) {
     uint64_t pt_walk = 0, pt_fix = 0, pt_iters = 0, pt0 = 0;
@@ -442,10 +443,10 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     if (prof) { const uint64_t t1 = clock_ticks(); if (tid == 0) prof[5] = t1 - pt0; pt0 = t1; }
     // -- 4. the records, at their final place in the block's table
     if (has_seg && w.n) {
-        const WalkOut w2 = walk_chain<true>(V, csize, my_entry, e, rectab, ea, (uint32_t)eb, cap);
+        const WalkOut w2 = walk_chain<true>(V, csize, my_entry, e, rectab, ea, (uint32_t)eb + kBias, cap + kBias, kBias - prefix);
         if (w2.err) { atomicMin(&misc[M_ERR], w2.err - 1); bad = 1; }
     }
-    if (tid == 0) { SeqRec rec; rec.outpos = (uint32_t)tb; rec.litpos = csize; rec.ll = 0; rec.off = 0; rectab[ta] = rec; }
+    if (tid == 0) { SeqRec rec; rec.outpos = (uint32_t)tb + kBias; rec.litpos = csize; rec.ll = 0; rec.off = 0; rectab[ta] = rec; }
     if (__syncthreads_or(bad)) return false;
     nseq_out = ta; total_out = (uint32_t)tb;
     if (prof && tid == 0) { prof[6] = pt_walk; prof[7] = pt_fix | (pt_iters << 48); }
@@ -663,10 +664,10 @@ __device__ __forceinline__ void copy_regions(const CopyCtx& C, char* smem, uint3
                 if (pos >= c1) {
                     *(U32x4*)(ring + my_ring) = acc;
                     if (my_ring < kRingPad) *(U32x4*)(ring + kRingBytes + my_ring) = acc;   // mirror
-                    if (c1 - c0 == kChunk) st_global16(dst + c0, acc);
+                    if (c1 - c0 == kChunk) st_global16(dst + (c0 - kBias), acc);
                     else {
 #pragma nounroll
-                        for (uint32_t i = 0; i < c1 - c0; i++) dst[c0 + i] = (uint8_t)chunk_byte(acc, i);
+                        for (uint32_t i = 0; i < c1 - c0; i++) dst[c0 - kBias + i] = (uint8_t)chunk_byte(acc, i);
                     }
                     done = true; newly = true;
                 }
@@ -687,24 +688,39 @@ __device__ __forceinline__ void copy_regions(const CopyCtx& C, char* smem, uint3
 }
 
 // ------------------------------------------------------------------------------ stage B driver
-__device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst,
-                                             const SeqRec* rectab, uint32_t nseq, uint32_t total,
+__device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, uint32_t prefix,
+                                             const SeqRec* rectab, uint32_t nseq, uint32_t total_real,
                                              char* smem, uint64_t* prof) {
     const uint32_t tid = threadIdx.x;
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     uint8_t* cr = (uint8_t*)(smem + kOffCr);
     SeqRec* recs = (SeqRec*)(smem + kOffRecs);
     uint32_t* idx = (uint32_t*)(smem + kOffIdx);
+    const uint32_t total = total_real + kBias;            // positions are biased by kBias from here on
     const uint32_t nreg = (uint32_t)(((uint64_t)total + kRegion - 1) >> kRegionShift);
 
     // uniform state (every thread computes the same values)
-    uint32_t rec_head = 0, rec_tail = 0, out_emit = 0, r_next = 0;
+    uint32_t rec_head = 0, rec_tail = 0, out_emit = kBias, r_next = kBias >> kRegionShift;
     uint32_t cr_lo = 0, cr_hi = 0;
-    uint32_t R = wave_id(), myfin = 0;                    // per-wave copy cursor
+    uint32_t myfin = (kBias >> kRegionShift) / kDecWaves;                  // the history regions count as done
+    uint32_t R = wave_id() + myfin * kDecWaves;           // per-wave copy cursor
     uint64_t t_emit = 0, t_copy = 0, t0 = 0;
 
     if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = tid; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
-    if (tid < kDecWaves) ((uint32_t*)(smem + kOffFin))[tid] = 0;
+    if (tid < kDecWaves) ((uint32_t*)(smem + kOffFin))[tid] = myfin;
+    // history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
+    {
+        uint8_t* ring = (uint8_t*)(smem + kOffRing);
+        const uint32_t lo = kBias - prefix;
+        for (uint32_t v = (lo & ~15u) + 16 * tid; v < kBias; v += 16 * kDecThreads) {
+            U32x4 g; g[0] = g[1] = g[2] = g[3] = 0;
+#pragma nounroll
+            for (uint32_t i = 0; i < 16; i++) if (v + i >= lo) chunk_set_byte(g, i, (uint32_t)(dst - (kBias - (v + i)))[0]);
+            const uint32_t a = ring_addr(v);
+            *(U32x4*)(ring + a) = g;
+            if (a < kRingPad) *(U32x4*)(ring + kRingBytes + a) = g;
+        }
+    }
     // what the prefetch registers hold: window granules [pf_lo, pf_hi) and table records rec_head+tid
     uint32_t cr_lo_n = 0, cr_hi_n = csize < kCrBytes ? csize : kCrBytes;
     uint32_t pf_lo = 0, pf_hi = cr_hi_n;
@@ -801,13 +817,14 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     if (prof && tid == 0) prof[0] = clock_ticks();
 
     uint32_t nseq = 0, total = 0;
-    if (!preparse_block(src, csize, cap, rectab, smem, nseq, total, prof)) {
+    uint32_t prefix = P.prefix ? (uint32_t)P.prefix[b] : 0u; if (prefix > kBias) prefix = kBias;
+    if (!preparse_block(src, csize, cap, prefix, rectab, smem, nseq, total, prof)) {
         if (tid == 0) P.result[b] = err_at(misc[M_ERR]);
         return;
     }
     if (prof && tid == 0) prof[1] = clock_ticks();
     __syncthreads();            // record table visible to the whole workgroup; stage A's LDS is dead
-    stream_block(src, csize, dst, rectab, nseq, total, smem, prof);
+    stream_block(src, csize, dst, prefix, rectab, nseq, total, smem, prof);
     if (tid == 0) P.result[b] = (int32_t)total;
     if (prof && tid == 0) prof[4] = clock_ticks();
 }

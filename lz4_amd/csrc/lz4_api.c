@@ -17,7 +17,8 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+pthread_mutex_t lz4amd_default_lock = PTHREAD_MUTEX_INITIALIZER;   /* shared with lz4frame_api.c */
+#define g_lock lz4amd_default_lock
 static lz4amd_ctx* g_ctx = NULL;
 static int g_ctx_failed = 0;
 /* grow-only device staging buffers of the default context (guarded by g_lock) */

@@ -84,7 +84,8 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
     lz4amd_plan* p;
     int err = 0, nb = 0, i;
     size_t un = (size_t)(n > 0 ? n : 0);
-    if (!ctx || !out || n < 0 || (n > 0 && (!d_src || !src_sizes || !d_dst || !dst_caps))) return LZ4AMD_E_ARG;
+    if (!ctx || !out || n < 0 || (n > 0 && (!d_src || !src_sizes))) return LZ4AMD_E_ARG;
+    if (n > 0 && op != LZ4AMD_OP_XXH32 && (!d_dst || !dst_caps)) return LZ4AMD_E_ARG;
     *out = NULL;
     p = (lz4amd_plan*)calloc(1, sizeof *p);
     if (!p) return LZ4AMD_E_MEMORY;
@@ -111,6 +112,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
+        q->prefix = NULL;
         q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c) + 255) & ~(uint64_t)255;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase timestamps */
@@ -135,6 +137,11 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
             q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
             if (q->prof && lz4amd_hip_memset(q->prof, 0, (size_t)(grid ? grid : 1) * 64, NULL)) err = LZ4AMD_E_RUNTIME;
         }
+    } else if (op == LZ4AMD_OP_XXH32) {
+        lz4amd_xxh_params* q = &p->xxh;          /* d_dst / dst_caps are ignored: the result is the hash */
+        p->grid = (unsigned)n;
+        q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
+        q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
     } else {
         lz4amd_set_error("operation not implemented on the device yet");
         lz4amd_plan_destroy(p);
@@ -150,10 +157,27 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
     return LZ4AMD_OK;
 }
 
+int lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                              const void* const* d_src, const int* src_sizes,
+                              void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
+{
+    int rc = lz4amd_plan_create(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, d_dst, dst_caps, 0);
+    int err = 0, i;
+    if (rc || !prefix_sizes || n <= 0) return rc;
+    for (i = 0; i < LZ4AMD_PLAN_MAX_BUFS && (*out)->bufs[i]; i++) {}
+    if (i >= LZ4AMD_PLAN_MAX_BUFS) { lz4amd_plan_destroy(*out); *out = NULL; return LZ4AMD_E_MEMORY; }
+    (*out)->bufs[i] = dev_array(prefix_sizes, (size_t)n * sizeof(int), &err);
+    if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
+    if (err) { lz4amd_plan_destroy(*out); *out = NULL; return err; }
+    (*out)->dec.prefix = (const int32_t*)(*out)->bufs[i];
+    return LZ4AMD_OK;
+}
+
 static int launch_stage(lz4amd_plan* p, int stage, void* stream)
 {
     if (p->op == LZ4AMD_OP_DECOMPRESS)
         return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
+    if (p->op == LZ4AMD_OP_XXH32) return stage == 0 ? lz4amd_hip_launch_xxh32(&p->xxh, stream) : 0;
     return stage == 0 ? lz4amd_hip_launch_compress(&p->comp, p->grid, stream) : 0;
 }
 static int n_stages(const lz4amd_plan* p) { (void)p; return 1; }

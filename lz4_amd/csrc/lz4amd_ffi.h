@@ -29,6 +29,7 @@ size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize);
 
 /* launches (asynchronous on `stream`) */
 int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* stream);
+int lz4amd_hip_launch_xxh32(const lz4amd_xxh_params* p, void* stream);
 int lz4amd_hip_launch_compress(const lz4amd_comp_params* p, unsigned grid, void* stream);
 
 #ifdef __cplusplus

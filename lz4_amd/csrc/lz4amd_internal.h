@@ -22,6 +22,7 @@ struct lz4amd_plan {
     void* ev[5];                        /* HIP events for the timed launch */
     lz4amd_dec_params dec;
     lz4amd_comp_params comp;
+    lz4amd_xxh_params xxh;
 };
 
 void lz4amd_set_error(const char* msg);

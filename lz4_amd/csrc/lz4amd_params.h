@@ -9,6 +9,7 @@ typedef struct lz4amd_dec_params {
     const int32_t* src_size;        /* [n] */
     uint8_t* const* dst;            /* [n] output buffers */
     const int32_t* dst_cap;         /* [n] */
+    const int32_t* prefix;          /* [n] or NULL: bytes of history right before dst (<= 64 KB used) */
     int32_t* result;                /* [n] decoded size, or negative on error */
     uint32_t n_blocks;
     uint32_t* ticket;               /* work-queue counter, zero before launch */
@@ -27,5 +28,12 @@ typedef struct lz4amd_comp_params {
     uint32_t* ticket;               /* work-queue counter, zero before launch */
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase cycle counts */
 } lz4amd_comp_params;
+
+typedef struct lz4amd_xxh_params {
+    const uint8_t* const* src;      /* [n_blocks] */
+    const int32_t* src_size;
+    int32_t* result;                /* [n_blocks] XXH32(seed 0) of the block, as int32 */
+    uint32_t n_blocks;
+} lz4amd_xxh_params;
 
 #endif

@@ -4,11 +4,20 @@
 #include "platform_emu.h"
 #include "../../lz4_amd/csrc/kernels/lz4_decompress_kernel.h"
 #include "../../lz4_amd/csrc/kernels/lz4_compress_kernel.h"
+#include "../../lz4_amd/csrc/kernels/xxh32_kernel.h"
 #include <vector>
 
+extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int32_t* src_size,
+                                           uint8_t* const* dst, const int32_t* dst_cap,
+                                           int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix);
 extern "C" int emu_decompress_batch(const uint8_t* const* src, const int32_t* src_size,
                                     uint8_t* const* dst, const int32_t* dst_cap,
                                     int32_t* result, uint32_t n, uint32_t grid) {
+    return emu_decompress_batch_prefix(src, src_size, dst, dst_cap, result, n, grid, nullptr);
+}
+extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int32_t* src_size,
+                                           uint8_t* const* dst, const int32_t* dst_cap,
+                                           int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix) {
     using namespace lz4amd;
     uint32_t max_c = 0;
     for (uint32_t i = 0; i < n; i++)
@@ -19,7 +28,7 @@ extern "C" int emu_decompress_batch(const uint8_t* const* src, const int32_t* sr
     uint32_t ticket = 0;
     DecBatch P;
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
-    P.n_blocks = n; P.ticket = &ticket;
+    P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix;
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.prof = nullptr;
     simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
     return 0;
@@ -35,5 +44,12 @@ extern "C" int emu_compress_batch(const uint8_t* const* src, const int32_t* src_
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
     P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr;
     if (n) simt::launch(grid, kCmpThreads, kCmpLdsBytes, [&] { compress_batch_body(P); });
+    return 0;
+}
+
+extern "C" int emu_xxh32_batch(const uint8_t* const* src, const int32_t* src_size, int32_t* result, uint32_t n) {
+    using namespace lz4amd;
+    XxhBatch P; P.src = src; P.src_size = src_size; P.result = result; P.n_blocks = n;
+    if (n) simt::launch(n, 64, kXxhChunk, [&] { xxh32_block_body(P); });
     return 0;
 }

@@ -1,0 +1,149 @@
+"""Frame container and XXH32 on the GPU path, through the C ABI of
+include/lz4frame.h and include/lz4amd.h.  Parity directions as in SURVEY 8c: our frames decode with
+the oracle's (== reference's) frame decoder, frames written by the reference CLI decode here."""
+import ctypes
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class FrameInfo(ctypes.Structure):
+    _fields_ = [("blockSizeID", ctypes.c_int), ("blockMode", ctypes.c_int), ("contentChecksumFlag", ctypes.c_int),
+                ("frameType", ctypes.c_int), ("contentSize", ctypes.c_ulonglong), ("dictID", ctypes.c_uint),
+                ("blockChecksumFlag", ctypes.c_int)]
+
+
+class Prefs(ctypes.Structure):
+    _fields_ = [("frameInfo", FrameInfo), ("compressionLevel", ctypes.c_int), ("autoFlush", ctypes.c_uint),
+                ("favorDecSpeed", ctypes.c_uint), ("reserved", ctypes.c_uint * 3)]
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lz4_amd
+    lib = lz4_amd.lib()
+    st, vp = ctypes.c_size_t, ctypes.c_void_p
+    lib.LZ4F_compressFrameBound.restype = st
+    lib.LZ4F_compressFrameBound.argtypes = [st, ctypes.POINTER(Prefs)]
+    lib.LZ4F_compressFrame.restype = st
+    lib.LZ4F_compressFrame.argtypes = [ctypes.c_char_p, st, ctypes.c_char_p, st, ctypes.POINTER(Prefs)]
+    lib.LZ4F_isError.argtypes = [st]
+    lib.LZ4F_getErrorName.restype = ctypes.c_char_p
+    lib.LZ4F_getErrorName.argtypes = [st]
+    lib.LZ4F_createDecompressionContext.restype = st
+    lib.LZ4F_createDecompressionContext.argtypes = [ctypes.POINTER(vp), ctypes.c_uint]
+    lib.LZ4F_freeDecompressionContext.argtypes = [vp]
+    lib.LZ4F_decompress.restype = st
+    lib.LZ4F_decompress.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(st), ctypes.c_char_p, ctypes.POINTER(st), vp]
+    lib.LZ4F_getFrameInfo.restype = st
+    lib.LZ4F_getFrameInfo.argtypes = [vp, ctypes.POINTER(FrameInfo), ctypes.c_char_p, ctypes.POINTER(st)]
+    return lib
+
+
+def compress_frame(L, data, **kw):
+    p = Prefs()
+    for k, v in kw.items():
+        setattr(p.frameInfo, k, v)
+    cap = L.LZ4F_compressFrameBound(len(data), ctypes.byref(p))
+    assert not L.LZ4F_isError(cap)
+    dst = ctypes.create_string_buffer(cap + 16)
+    n = L.LZ4F_compressFrame(dst, cap, data, len(data), ctypes.byref(p))
+    assert not L.LZ4F_isError(n), L.LZ4F_getErrorName(n)
+    assert dst.raw[cap:cap + 16] == b"\0" * 16
+    return dst.raw[:n]
+
+
+def decompress_frame(L, frame, total, chunk_rng=None, expect_error=False):
+    d = ctypes.c_void_p()
+    assert L.LZ4F_createDecompressionContext(ctypes.byref(d), 100) == 0
+    out = bytearray()
+    pos = 0
+    try:
+        for _ in range(100000):
+            take = len(frame) - pos if chunk_rng is None else min(len(frame) - pos, chunk_rng.randint(1, 70000))
+            src = frame[pos:pos + take]
+            dst = ctypes.create_string_buffer(max(1, total if chunk_rng is None else chunk_rng.randint(1, 200000)))
+            dsz, ssz = ctypes.c_size_t(len(dst)), ctypes.c_size_t(len(src))
+            r = L.LZ4F_decompress(d, dst, ctypes.byref(dsz), src, ctypes.byref(ssz), None)
+            if L.LZ4F_isError(r):
+                assert expect_error, L.LZ4F_getErrorName(r)
+                return None
+            out += dst.raw[:dsz.value]
+            pos += ssz.value
+            if r == 0:
+                break
+            assert ssz.value or dsz.value or pos < len(frame), "no progress"
+        assert not expect_error
+        return bytes(out), pos
+    finally:
+        L.LZ4F_freeDecompressionContext(d)
+
+
+def test_xxh32_batch_on_gpu(oracle, datagen):
+    import torch
+    import lz4_amd
+    ctx = lz4_amd.Context(0)
+    datas = [b"", b"a", b"abc", bytes(range(16)), datagen(1000, 50, 1), datagen(1024, 50, 2), datagen(1025, 50, 3),
+             datagen(4 << 20, 60, 4), datagen(65536, 50, 5)[3:], b"z" * 15]
+    bufs = [torch.frombuffer(bytearray(d + b"\0"), dtype=torch.uint8).cuda() for d in datas]
+    t = lz4_amd.BlockTable([b.data_ptr() for b in bufs], [len(d) for d in datas], [0] * len(datas), [0] * len(datas))
+    plan = lz4_amd.Plan(ctx, lz4_amd.OP_XXH32, t)
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    res = plan.results(torch.cuda.current_stream().cuda_stream)
+    for d, r in zip(datas, res):
+        assert (r & 0xFFFFFFFF) == oracle.lz4o_xxh32(d, len(d), 0)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(blockSizeID=7, contentChecksumFlag=1), dict(blockSizeID=5, blockChecksumFlag=1),
+    dict(blockSizeID=4, contentChecksumFlag=1, blockChecksumFlag=1, contentSize=1), dict(blockSizeID=6, blockMode=1)])
+def test_our_frames_decode_with_the_oracle_and_here(L, oracle, datagen, kw):
+    for n, pct in ((0, 50), (1, 50), (100, 50), (65536, 50), (65537, 60), (700000, 60), (9 << 20, 60)):
+        data = datagen(n, pct, n % 7)
+        frame = compress_frame(L, data, **kw)
+        assert frame[:4] == bytes.fromhex("04224d18") and frame[4] & 0x20      # always independent blocks
+        out = ctypes.create_string_buffer(n + 1)
+        used = ctypes.c_size_t()
+        r = oracle.lz4o_frame_decompress(out, n, frame, len(frame), ctypes.byref(used))
+        assert r == n and used.value == len(frame) and out.raw[:n] == data
+        got, pos = decompress_frame(L, frame, n)
+        assert got == data and pos == len(frame)
+
+
+def test_frame_header_known_answers(L, datagen):
+    # FLG 0x64 (v1, independent, content checksum) BD 0x70 (4 MB) -> HC 0xB9; FLG 0x60 -> 0x73
+    data = datagen(5 << 20, 60, 0)
+    assert compress_frame(L, data, blockSizeID=7, contentChecksumFlag=1)[:7] == bytes.fromhex("04224d186470b9")
+    assert compress_frame(L, data, blockSizeID=7)[:7] == bytes.fromhex("04224d18607073")
+
+
+def test_reference_cli_frames_decode_here(L, golden, datagen):
+    from conftest import GOLDEN_DIR
+    rng = random.Random(3)
+    for name, g in golden["frames"].items():
+        frame = open(os.path.join(GOLDEN_DIR, name + ".lz4"), "rb").read()
+        args = g["datagen"].split()
+        data = datagen(int(args[0][2:]), int(args[1][2:]), 0)
+        got, pos = decompress_frame(L, frame, len(data))
+        assert got == data and pos == len(frame), name
+        got, pos = decompress_frame(L, frame, len(data), chunk_rng=rng)       # arbitrary input / output chunking
+        assert got == data and pos == len(frame), name
+
+
+def test_frame_errors(L, datagen):
+    data = datagen(300000, 60, 1)
+    frame = bytearray(compress_frame(L, data, blockSizeID=4, contentChecksumFlag=1, blockChecksumFlag=1))
+    bad = bytearray(frame); bad[6] ^= 1                       # header checksum
+    assert decompress_frame(L, bytes(bad), len(data), expect_error=True) is None
+    bad = bytearray(frame); bad[-1] ^= 1                      # content checksum
+    assert decompress_frame(L, bytes(bad), len(data), expect_error=True) is None
+    bad = bytearray(frame); bad[40] ^= 0x55                   # block payload -> block checksum
+    assert decompress_frame(L, bytes(bad), len(data), expect_error=True) is None
+    bad = bytearray(frame); bad[0] ^= 1                       # magic
+    assert decompress_frame(L, bytes(bad), len(data), expect_error=True) is None
+    # two frames back to back: the decoder stops exactly at the end of the first
+    got, pos = decompress_frame(L, bytes(frame) + bytes(frame), len(data))
+    assert got == data and pos == len(frame)

@@ -153,3 +153,67 @@ def test_compress_ratio_within_3pct_of_reference(emu, golden, datagen):
     data = datagen(4 << 20, 50, 0)
     ours = sum(r for r, _ in emu_compress(emu, [data[o:o + 65536] for o in range(0, len(data), 65536)]))
     assert abs(ours - g["csize"]) / g["csize"] < 0.03
+
+
+def test_xxh32_batch_matches_oracle_and_known_answers(emu, oracle, golden, datagen):
+    datas = [b"", b"a", b"abc", b"Nobody inspects the spammish repetition", bytes(range(16)),
+             datagen(1000, 50, 1), datagen(1024, 50, 2), datagen(1025, 50, 3), datagen(70001, 60, 4), b"x" * 15, b"y" * 17]
+    n = len(datas)
+    srcs = [ctypes.create_string_buffer(d, len(d)) if d else ctypes.create_string_buffer(1) for d in datas]
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) + 0 for s in srcs])
+    ss = (ctypes.c_int32 * n)(*[len(d) for d in datas])
+    res = (ctypes.c_int32 * n)()
+    emu.emu_xxh32_batch(sp, ss, res, n)
+    oracle.lz4o_xxh32.restype = ctypes.c_uint32
+    oracle.lz4o_xxh32.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+    for d, r in zip(datas, res):
+        assert (r & 0xFFFFFFFF) == oracle.lz4o_xxh32(d, len(d), 0)
+    # SURVEY App-B known answers (reference xxhash.c)
+    assert [r & 0xFFFFFFFF for r in res[:5]] == [0x02CC5D05, 0x550D7456, 0x32D153FF, 0xE2293B2F, 0xB72837F4]
+
+
+def _frame_blocks(frame):
+    """(independent?, [(raw?, payload bytes)]) of an LZ4 frame without block checksums."""
+    flg = frame[4]
+    hs = 7 + (8 if flg & 8 else 0) + (4 if flg & 1 else 0)
+    assert not flg & 0x10
+    pos, blocks = hs, []
+    while True:
+        f = int.from_bytes(frame[pos:pos + 4], "little"); pos += 4
+        if f == 0:
+            break
+        n = f & 0x7FFFFFFF
+        blocks.append((bool(f >> 31), frame[pos:pos + n])); pos += n
+    return bool(flg & 0x20), blocks
+
+
+def test_decompress_linked_blocks_with_prefix(emu, golden, datagen):
+    """Linked blocks of a frame written by the reference CLI (`lz4 -B4 -BD`): every block is decoded
+    with the previous output as history (LZ4_decompress_safe_usingDict prefix mode, lz4frame.c:1901)."""
+    from conftest import GOLDEN_DIR
+    g = golden["frames"]["f_p60_600k_B4_BD_cs"]
+    frame = open(os.path.join(GOLDEN_DIR, "f_p60_600k_B4_BD_cs.lz4"), "rb").read()
+    indep, blocks = _frame_blocks(frame)
+    assert not indep and len(blocks) > 5
+    src = datagen(600000, 60, 0)
+    out = ctypes.create_string_buffer(len(src) + 64)
+    base = ctypes.addressof(out)
+    pos = 0
+    emu.emu_decompress_batch_prefix.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    for raw, payload in blocks:
+        assert not raw
+        buf = ctypes.create_string_buffer(payload, len(payload))
+        sp = (ctypes.c_void_p * 1)(ctypes.addressof(buf)); dp = (ctypes.c_void_p * 1)(base + pos)
+        ss = (ctypes.c_int32 * 1)(len(payload)); dc = (ctypes.c_int32 * 1)(65536)
+        pre = (ctypes.c_int32 * 1)(min(pos, 65536)); res = (ctypes.c_int32 * 1)()
+        emu.emu_decompress_batch_prefix(sp, ss, dp, dc, res, 1, 1, pre)
+        assert res[0] > 0
+        pos += res[0]
+    assert pos == len(src) and out.raw[:pos] == src
+    # without the history the same block must be rejected (offset before the start of the output)
+    buf = ctypes.create_string_buffer(blocks[1][1], len(blocks[1][1]))
+    sp = (ctypes.c_void_p * 1)(ctypes.addressof(buf)); dp = (ctypes.c_void_p * 1)(base)
+    ss = (ctypes.c_int32 * 1)(len(blocks[1][1])); dc = (ctypes.c_int32 * 1)(65536); res = (ctypes.c_int32 * 1)()
+    pre = (ctypes.c_int32 * 1)(0)
+    emu.emu_decompress_batch_prefix(sp, ss, dp, dc, res, 1, 1, pre)
+    assert res[0] < 0
