@@ -8,8 +8,8 @@
  * kernels are really built for).  Compressed bytes may differ from the CPU library's but are
  * legal LZ4 blocks and decode to the same data with any conforming decoder.
  *
- * Not provided (out of the hot-path scope): streaming / dictionary
- * variants (LZ4_compress_fast_continue, LZ4_loadDict, ...), LZ4_compress_destSize,
+ * Not provided (SURVEY.md section 8f "next"): streaming / dictionary compression
+ * (LZ4_compress_fast_continue, LZ4_loadDict, ...), LZ4_compress_destSize,
  * LZ4_decompress_safe_partial and the deprecated LZ4_decompress_fast family.
  */
 #ifndef LZ4_AMD_LZ4_H
@@ -49,6 +49,11 @@ int LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacit
  * is malformed or dst too small.  Never reads outside src[0,compressedSize) nor writes outside
  * dst[0,dstCapacity). */
 int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
+
+/* lz4.h:549.  As LZ4_decompress_safe, with up to 64 KB of history in [dictStart, dictStart+dictSize)
+ * (what lz4frame passes for linked blocks, lz4frame.c:1901). */
+int LZ4_decompress_safe_usingDict(const char* src, char* dst, int compressedSize, int dstCapacity,
+                                  const char* dictStart, int dictSize);
 
 int LZ4_compressBound(int inputSize);                                              /* lz4.h:226 */
 int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:236 */

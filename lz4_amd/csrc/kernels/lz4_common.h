@@ -30,24 +30,8 @@ template <class Ptr> __device__ __forceinline__ U32x4 ld_global16(Ptr p) { retur
 template <class Ptr> __device__ __forceinline__ void st_global16(Ptr p, const U32x4& v) { st_global16_raw(p, v); }
 
 // ---- wave-level inclusive scans (64 lanes) ------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(v, d);
-        if (lane >= d) v += y;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(v, d);
-        if (lane >= d && y > v) v = y;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) { return wave_incl_sum_u32(v); }
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) { return wave_incl_max_u32(v); }
 
 // ---- block-level exclusive sum of two values per thread (a: u32, b: u64) ---------------
 // scratch: 3 * nwaves uint32 in LDS.  Returns exclusive prefixes; totals via ta, tb.

@@ -558,9 +558,7 @@ __device__ __forceinline__ void copy_regions(const CopyCtx& C, char* smem, uint3
         uint32_t g;
         for (;;) {
             uint32_t f = lds_load_acquire(&fin[lane & (kDecWaves - 1)]) * kDecWaves + (lane & (kDecWaves - 1));
-#pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)f, d); if (y < f) f = y; }
-            g = __builtin_amdgcn_readfirstlane(f);          // one value for the whole wave
+            g = __builtin_amdgcn_readfirstlane(row16_min_u32(f));   // one value for the whole wave
             if (g + kMaxLead >= R) break;
             spin_pause();
         }

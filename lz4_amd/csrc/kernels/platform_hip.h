@@ -66,6 +66,33 @@ __device__ __forceinline__ uint64_t clock_ticks() { return __builtin_readcycleco
 // value of v in lane l (l wave-uniform): v_readlane_b32, no LDS round trip
 __device__ __forceinline__ uint32_t wave_readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
+// ---- wave-wide scans and reductions on the DPP lanes (no LDS round trip, unlike __shfl = ds_bpermute).
+// gfx9 recipe: row_shr 1,2,4,8 inside the four rows of 16 lanes, then row_bcast:15 / row_bcast:31 carry
+// the row totals forward (identity 0 for lanes that receive nothing).
+#define LZ4AMD_DPP(old, v, ctrl, rowmask) (uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rowmask), 0xf, false)
+__device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v) {
+    v += LZ4AMD_DPP(0, v, 0x111, 0xf); v += LZ4AMD_DPP(0, v, 0x112, 0xf);
+    v += LZ4AMD_DPP(0, v, 0x114, 0xf); v += LZ4AMD_DPP(0, v, 0x118, 0xf);
+    v += LZ4AMD_DPP(0, v, 0x142, 0xa);          // row_bcast:15 into rows 1 and 3
+    v += LZ4AMD_DPP(0, v, 0x143, 0xc);          // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
+    uint32_t t;
+    t = LZ4AMD_DPP(0, v, 0x111, 0xf); v = t > v ? t : v; t = LZ4AMD_DPP(0, v, 0x112, 0xf); v = t > v ? t : v;
+    t = LZ4AMD_DPP(0, v, 0x114, 0xf); v = t > v ? t : v; t = LZ4AMD_DPP(0, v, 0x118, 0xf); v = t > v ? t : v;
+    t = LZ4AMD_DPP(0, v, 0x142, 0xa); v = t > v ? t : v;
+    t = LZ4AMD_DPP(0, v, 0x143, 0xc); v = t > v ? t : v;
+    return v;
+}
+// minimum over each row of 16 lanes, in every lane of the row (row_ror 8,4,2,1)
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
+    uint32_t t;
+    t = LZ4AMD_DPP(v, v, 0x128, 0xf); v = t < v ? t : v; t = LZ4AMD_DPP(v, v, 0x124, 0xf); v = t < v ? t : v;
+    t = LZ4AMD_DPP(v, v, 0x122, 0xf); v = t < v ? t : v; t = LZ4AMD_DPP(v, v, 0x121, 0xf); v = t < v ? t : v;
+    return v;
+}
+
 // device-scope work-queue ticket
 __device__ __forceinline__ uint32_t take_ticket(uint32_t* counter) {
     return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

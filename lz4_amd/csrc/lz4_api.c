@@ -111,3 +111,38 @@ int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstC
     if (compressedSize < 0) return -1;
     return run_one(LZ4AMD_OP_DECOMPRESS, src, dst, compressedSize, dstCapacity, 0, -1);
 }
+
+/* lz4.c:2719-2732 LZ4_decompress_safe_usingDict: the dictionary (its last 64 KB) is staged right
+ * before the output in device memory, which is the decoder's prefix mode (lz4.c:2479 / 2504); a
+ * dictionary elsewhere in memory (the reference's extDict branches, lz4.c:2166-2196) needs no
+ * separate code path on the device. */
+int LZ4_decompress_safe_usingDict(const char* src, char* dst, int compressedSize, int dstCapacity,
+                                  const char* dictStart, int dictSize)
+{
+    lz4amd_ctx* ctx;
+    lz4amd_plan* plan = NULL;
+    int result = -1, pre;
+    const void* dsrc; void* ddst;
+    size_t in_bytes, out_bytes;
+    if (src == NULL || dstCapacity < 0 || compressedSize < 0) return -1;
+    if (dictStart == NULL || dictSize <= 0) return LZ4_decompress_safe(src, dst, compressedSize, dstCapacity);
+    pre = dictSize > 65536 ? 65536 : dictSize;
+    in_bytes = (size_t)compressedSize; out_bytes = (size_t)dstCapacity;
+    pthread_mutex_lock(&g_lock);
+    ctx = lz4amd_default_ctx();
+    if (!ctx) goto done;
+    if (stage_reserve(&g_stage_in, &g_stage_in_cap, in_bytes + 16) ||
+        stage_reserve(&g_stage_out, &g_stage_out_cap, out_bytes + 65536 + 16)) goto done;
+    if (in_bytes && lz4amd_hip_h2d(g_stage_in, src, in_bytes, NULL)) goto done;
+    if (lz4amd_hip_h2d((char*)g_stage_out + (65536 - pre), dictStart + (dictSize - pre), (size_t)pre, NULL)) goto done;
+    dsrc = g_stage_in; ddst = (char*)g_stage_out + 65536;
+    if (lz4amd_plan_create_prefix(ctx, &plan, 1, &dsrc, &compressedSize, &ddst, &dstCapacity, &pre)) goto done;
+    if (lz4amd_plan_launch(plan, NULL) || lz4amd_plan_results(plan, &result, NULL)) { result = -1; goto done; }
+    if (result > 0 && (size_t)result <= out_bytes) {
+        if (lz4amd_hip_d2h(dst, ddst, (size_t)result, NULL) || lz4amd_hip_sync(NULL)) result = -1;
+    }
+done:
+    lz4amd_plan_destroy(plan);
+    pthread_mutex_unlock(&g_lock);
+    return result;
+}

@@ -26,4 +26,18 @@ static inline void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { memcpy(p
 static inline uint64_t clock_ticks() { return 0; }
 static inline uint32_t take_ticket(uint32_t* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED); }
 static inline uint32_t wave_readlane(uint32_t v, uint32_t l) { return (uint32_t)__shfl((int)v, (int)l); }
+static inline uint32_t wave_incl_sum_u32(uint32_t v) {
+    const uint32_t lane = simt::cur()->tid & 63u;
+    for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(v, d); if (lane >= d) v += y; }
+    return v;
+}
+static inline uint32_t wave_incl_max_u32(uint32_t v) {
+    const uint32_t lane = simt::cur()->tid & 63u;
+    for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(v, d); if (lane >= d && y > v) v = y; }
+    return v;
+}
+static inline uint32_t row16_min_u32(uint32_t v) {
+    for (int d = 8; d >= 1; d >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)v, d); if (y < v) v = y; }
+    return v;
+}
 static inline void wave_converge() { (void)__ballot(1); }

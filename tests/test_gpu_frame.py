@@ -147,3 +147,23 @@ def test_frame_errors(L, datagen):
     # two frames back to back: the decoder stops exactly at the end of the first
     got, pos = decompress_frame(L, bytes(frame) + bytes(frame), len(data))
     assert got == data and pos == len(frame)
+
+
+def test_decompress_safe_using_dict(L, golden):
+    """LZ4_decompress_safe_usingDict (lz4.c:2719): linked blocks of a reference-written frame, each
+    decoded through the classic host-pointer API with the previous output as dictionary."""
+    from conftest import GOLDEN_DIR
+    from test_kernels_emulated import _frame_blocks
+    import hashlib
+    frame = open(os.path.join(GOLDEN_DIR, "f_p60_600k_B4_BD_cs.lz4"), "rb").read()
+    indep, blocks = _frame_blocks(frame)
+    L.LZ4_decompress_safe_usingDict.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    out = b""
+    for raw, payload in blocks[:4]:
+        dst = ctypes.create_string_buffer(65536)
+        r = L.LZ4_decompress_safe_usingDict(payload, dst, len(payload), 65536, out[-65536:] if out else None, min(len(out), 65536))
+        assert r > 0
+        out += dst.raw[:r]
+    # the frame's content is datagen -g600000 -P60: compare the prefix through the golden md5 of the whole
+    full, _ = decompress_frame(L, frame, 600000)
+    assert out == full[:len(out)] and hashlib.md5(full).hexdigest() == golden["frames"]["f_p60_600k_B4_BD_cs"]["src_md5"]
