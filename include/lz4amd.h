@@ -59,6 +59,14 @@ int  lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
 int  lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                const void* const* d_src, const int* src_sizes,
                                void* const* d_dst, const int* dst_caps, const int* prefix_sizes);
+/* LZ4AMD_OP_COMPRESS with history: block i may reference the prefix_sizes[i] bytes of source that
+ * sit right before d_src[i] (linked blocks: lz4io.c:741-744, lz4frame.c:917-943 with
+ * LZ4F_blockLinked; the reference does it with LZ4_compress_fast_continue, lz4.c:1707).  The
+ * history is source data, so all blocks of a linked frame still compress in ONE launch.  The
+ * largest multiple of 8 KB up to 64 KB is used. */
+int  lz4amd_plan_create_compress_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                                        const void* const* d_src, const int* src_sizes,
+                                        void* const* d_dst, const int* dst_caps, const int* prefix_sizes);
 void lz4amd_plan_destroy(lz4amd_plan* plan);
 /* enqueue the whole table on `stream` (asynchronous) */
 int  lz4amd_plan_launch(lz4amd_plan* plan, void* stream);

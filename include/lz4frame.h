@@ -13,9 +13,10 @@
  * lib/xxhash.c:352-389 - it cannot be split across lanes) are host C.
  *
  * Differences from the reference, all within the frame format:
- *  - LZ4F_compressFrame always writes INDEPENDENT blocks (FLG.B.Indep = 1, lz4frame.c:787-792),
- *    whatever prefs->frameInfo.blockMode asks for: that is what lets one launch compress the whole
- *    frame.  Decoding accepts both independent and linked frames.
+ *  - Linked frames (the default, lz4frame.c:787-792) are compressed with all blocks in one launch
+ *    too (the history of a block is source data); they are DECODED block after block, since a
+ *    block needs the previous one's output (lz4frame.c:1901-1915) - ask for LZ4F_blockIndependent
+ *    when decode speed matters.
  *  - compressionLevel is accepted and ignored (fast mode); HC levels are SURVEY section 8(f) "next".
  *  - LZ4F_decompress buffers the frame and decodes it when it is complete; the bytes delivered and
  *    the return convention (0 = frame done, else a hint > 0, errors per LZ4F_isError) are the

@@ -305,7 +305,12 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + w * kRecsPerStrip;
     uint8_t* ring = (uint8_t*)(smem + kCOffRing);
 
-    const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
+    // history (linked blocks, lz4io.c:741-744 / LZ4_compress_fast_continue in prefix mode lz4.c:1707): the
+    // `pre` bytes right before the block are parsed into the table but not emitted.  Whole tiles only.
+    uint32_t pre = P.prefix ? (uint32_t)P.prefix[b] : 0u;
+    if (pre > kMaxDistance + 1) pre = kMaxDistance + 1;
+    pre &= ~(kTileMax - 1);
+    const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]) - pre;          // position 0 = start of the history
     const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
     const int32_t n_i = P.src_size[b];
     const int32_t cap_i = P.dst_cap[b];
@@ -314,14 +319,14 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         return;
     }
     if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }      // lz4.c:1361-1371
-    const uint32_t n = (uint32_t)n_i, cap = (uint32_t)cap_i;
+    const uint32_t n = (uint32_t)n_i + pre, cap = (uint32_t)cap_i;
     const bool small = n < kSmallBlockLimit;
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (tid == 0) { misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; }
     // first tile straight into the ring; later tiles are prefetched one tile ahead
     uint32_t t0 = 0, tile_len, strip_len;
-    tile_geometry(0, small, tile_len, strip_len);
+    tile_geometry(pre ? kTileMax * 4 : 0, small, tile_len, strip_len);
     uint32_t loaded = 0;                                  // ring holds [.., loaded)
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
@@ -335,15 +340,16 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
-        tile_geometry(t1, small, nt_len, nt_strip);
+        tile_geometry(pre ? kTileMax * 4 : t1, small, nt_len, nt_strip);
         uint32_t pf_hi = loaded + nt_len; if (pf_hi > n || pf_hi < loaded) pf_hi = n;     // stays 16 bytes ahead of the tile
         const uint32_t Pp = loaded + 16 * tid;
         U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;
         if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 16 * kCmpThreads
         __syncthreads();                                       // ring (and table) ready for this tile
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
-        // -- match: one wave per strip
-        const uint32_t nstrips = (t1 - t0 + strip_len - 1) / strip_len;
+        // -- match: one wave per strip (tiles of the history are only inserted into the table)
+        const bool parse = t0 >= pre;
+        const uint32_t nstrips = parse ? (t1 - t0 + strip_len - 1) / strip_len : 0;
         if (w < nstrips) {
             const uint32_t cs = t0 + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
@@ -353,7 +359,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
         // -- offsets (wave 0: lane k holds strip k; the carry chain runs through readlane) ...
-        if (w == 0) {
+        if (w == 0 && parse) {
             const uint32_t lane = lane_id();
             const bool mine = lane < nstrips;
             const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, en = mine ? strip[S_ENC * kCmpWaves + lane] : 0;

@@ -132,6 +132,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
         q->ticket = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
+        q->prefix = NULL;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase cycle counts */
             q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
@@ -157,11 +158,11 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
     return LZ4AMD_OK;
 }
 
-int lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
-                              const void* const* d_src, const int* src_sizes,
-                              void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
+static int plan_create_with_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
+                                   const void* const* d_src, const int* src_sizes,
+                                   void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
 {
-    int rc = lz4amd_plan_create(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, d_dst, dst_caps, 0);
+    int rc = lz4amd_plan_create(ctx, out, op, n, d_src, src_sizes, d_dst, dst_caps, 0);
     int err = 0, i;
     if (rc || !prefix_sizes || n <= 0) return rc;
     for (i = 0; i < LZ4AMD_PLAN_MAX_BUFS && (*out)->bufs[i]; i++) {}
@@ -169,9 +170,18 @@ int lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
     (*out)->bufs[i] = dev_array(prefix_sizes, (size_t)n * sizeof(int), &err);
     if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
     if (err) { lz4amd_plan_destroy(*out); *out = NULL; return err; }
-    (*out)->dec.prefix = (const int32_t*)(*out)->bufs[i];
+    if (op == LZ4AMD_OP_DECOMPRESS) (*out)->dec.prefix = (const int32_t*)(*out)->bufs[i];
+    else (*out)->comp.prefix = (const int32_t*)(*out)->bufs[i];
     return LZ4AMD_OK;
 }
+int lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                              const void* const* d_src, const int* src_sizes,
+                              void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
+{ return plan_create_with_prefix(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes); }
+int lz4amd_plan_create_compress_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                                       const void* const* d_src, const int* src_sizes,
+                                       void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
+{ return plan_create_with_prefix(ctx, out, LZ4AMD_OP_COMPRESS, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes); }
 
 static int launch_stage(lz4amd_plan* p, int stage, void* stream)
 {

@@ -23,6 +23,7 @@ typedef struct lz4amd_comp_params {
     const int32_t* src_size;
     uint8_t* const* dst;
     const int32_t* dst_cap;
+    const int32_t* prefix;          /* [n_blocks] or NULL: bytes of history right before src (<= 64 KB used) */
     int32_t* result;                /* [n_blocks] compressed size, 0 = failure */
     uint32_t n_blocks;
     uint32_t* ticket;               /* work-queue counter, zero before launch */

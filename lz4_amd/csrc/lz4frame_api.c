@@ -122,8 +122,9 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     unsigned bsid;
     lz4amd_ctx* ctx;
     lz4amd_plan *cplan = NULL, *xplan = NULL;
-    const void** d_src = NULL; void** d_dst = NULL; int *sizes = NULL, *caps = NULL, *csz = NULL, *sums = NULL;
+    const void** d_src = NULL; void** d_dst = NULL; int *sizes = NULL, *caps = NULL, *csz = NULL, *sums = NULL, *pres = NULL;
     uint32_t content_sum = 0;
+    int linked;
 
     if (prefs) p = *prefs; else memset(&p, 0, sizeof p);
     if (!dst || (!src && srcSize)) return ERR(parameter_null);
@@ -133,11 +134,12 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     if (p.frameInfo.contentSize != 0) p.frameInfo.contentSize = srcSize;       /* lz4frame.c:445-446: auto-correct */
     if (dstCapacity < LZ4F_compressFrameBound(srcSize, &p)) return ERR(dstMaxSize_tooSmall);
     nb = (srcSize + bs - 1) / bs;
+    linked = p.frameInfo.blockMode == LZ4F_blockLinked && nb > 1;          /* lz4frame.c:441-442: one block is independent */
 
     /* -- header (lz4frame.c:779-813) */
     wr32(op, MAGIC); op += 4;
     {   uint8_t* const desc = op;
-        *op++ = (uint8_t)((1u << 6) | (1u << 5) /* independent blocks */ | ((p.frameInfo.blockChecksumFlag & 1u) << 4)
+        *op++ = (uint8_t)((1u << 6) | ((linked ? 0u : 1u) << 5) | ((p.frameInfo.blockChecksumFlag & 1u) << 4)
                           | ((p.frameInfo.contentSize != 0) << 3) | ((p.frameInfo.contentChecksumFlag & 1u) << 2)
                           | (p.frameInfo.dictID != 0));
         *op++ = (uint8_t)(bsid << 4);
@@ -151,8 +153,8 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     stride = (bs + bs / 255 + 16 + 255) & ~(size_t)255;
     d_src = (const void**)malloc(nb * sizeof *d_src); d_dst = (void**)malloc(nb * sizeof *d_dst);
     sizes = (int*)malloc(nb * sizeof *sizes); caps = (int*)malloc(nb * sizeof *caps);
-    csz = (int*)malloc(nb * sizeof *csz); sums = (int*)malloc(nb * sizeof *sums);
-    if (!d_src || !d_dst || !sizes || !caps || !csz || !sums) { result = ERR(allocation_failed); goto done_unlocked; }
+    csz = (int*)malloc(nb * sizeof *csz); sums = (int*)malloc(nb * sizeof *sums); pres = (int*)malloc(nb * sizeof *pres);
+    if (!d_src || !d_dst || !sizes || !caps || !csz || !sums || !pres) { result = ERR(allocation_failed); goto done_unlocked; }
 
     pthread_mutex_lock(&lz4amd_default_lock);
     ctx = lz4amd_default_ctx();
@@ -164,8 +166,9 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
         d_src[i] = (const char*)g_stage.in + i * bs; sizes[i] = (int)chunk;
         d_dst[i] = (char*)g_stage.out + i * stride; caps[i] = (int)chunk - 1;      /* lz4frame.c:891-899: must gain a byte */
         if (caps[i] < 1) caps[i] = 1;
+        pres[i] = linked ? (int)(i * bs < 65536 ? i * bs : 65536) : 0;     /* the history is the source itself */
     }
-    if (lz4amd_plan_create(ctx, &cplan, LZ4AMD_OP_COMPRESS, (int)nb, d_src, sizes, d_dst, caps, 0)) goto done;
+    if (lz4amd_plan_create_compress_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL)) goto done;
     if (lz4amd_plan_launch(cplan, NULL)) goto done;
     if (p.frameInfo.contentChecksumFlag) content_sum = xxh32(src, srcSize);      /* the host hashes while the GPU compresses */
     if (lz4amd_plan_results(cplan, csz, NULL)) goto done;
@@ -191,10 +194,10 @@ done:
     pthread_mutex_unlock(&lz4amd_default_lock);
 done_unlocked:
     lz4amd_plan_destroy(cplan); lz4amd_plan_destroy(xplan);
-    free(d_src); free(d_dst); free(sizes); free(caps); free(csz); free(sums);
+    free(d_src); free(d_dst); free(sizes); free(caps); free(csz); free(sums); free(pres);
     return result;
 finish_frame_free:
-    free(d_src); free(d_dst); free(sizes); free(caps); free(csz); free(sums);
+    free(d_src); free(d_dst); free(sizes); free(caps); free(csz); free(sums); free(pres);
 finish_frame:
     if (nb == 0 && p.frameInfo.contentChecksumFlag) content_sum = xxh32(src, 0);
     wr32(op, 0); op += 4;                                                     /* end mark, lz4frame.c:1222 */

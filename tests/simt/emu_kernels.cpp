@@ -34,15 +34,23 @@ extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int3
     return 0;
 }
 
+extern "C" int emu_compress_batch_prefix(const uint8_t* const* src, const int32_t* src_size,
+                                         uint8_t* const* dst, const int32_t* dst_cap,
+                                         int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix);
 extern "C" int emu_compress_batch(const uint8_t* const* src, const int32_t* src_size,
                                   uint8_t* const* dst, const int32_t* dst_cap,
                                   int32_t* result, uint32_t n, uint32_t grid) {
+    return emu_compress_batch_prefix(src, src_size, dst, dst_cap, result, n, grid, nullptr);
+}
+extern "C" int emu_compress_batch_prefix(const uint8_t* const* src, const int32_t* src_size,
+                                         uint8_t* const* dst, const int32_t* dst_cap,
+                                         int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix) {
     using namespace lz4amd;
     if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
     uint32_t ticket = 0;
     CompBatch P;
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
-    P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr;
+    P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr; P.prefix = prefix;
     if (n) simt::launch(grid, kCmpThreads, kCmpLdsBytes, [&] { compress_batch_body(P); });
     return 0;
 }

@@ -104,7 +104,10 @@ def test_our_frames_decode_with_the_oracle_and_here(L, oracle, datagen, kw):
     for n, pct in ((0, 50), (1, 50), (100, 50), (65536, 50), (65537, 60), (700000, 60), (9 << 20, 60)):
         data = datagen(n, pct, n % 7)
         frame = compress_frame(L, data, **kw)
-        assert frame[:4] == bytes.fromhex("04224d18") and frame[4] & 0x20      # always independent blocks
+        assert frame[:4] == bytes.fromhex("04224d18")
+        bs = {0: 65536, 4: 65536, 5: 262144, 6: 1 << 20, 7: 4 << 20}[kw.get("blockSizeID", 0)]
+        one_block = n <= 65536 or n <= bs             # lz4frame.c:388-398 shrinks the block size id to fit a small input
+        assert bool(frame[4] & 0x20) == (kw.get("blockMode", 0) == 1 or one_block)     # linked unless asked / single block
         out = ctypes.create_string_buffer(n + 1)
         used = ctypes.c_size_t()
         r = oracle.lz4o_frame_decompress(out, n, frame, len(frame), ctypes.byref(used))
@@ -116,8 +119,10 @@ def test_our_frames_decode_with_the_oracle_and_here(L, oracle, datagen, kw):
 def test_frame_header_known_answers(L, datagen):
     # FLG 0x64 (v1, independent, content checksum) BD 0x70 (4 MB) -> HC 0xB9; FLG 0x60 -> 0x73
     data = datagen(5 << 20, 60, 0)
-    assert compress_frame(L, data, blockSizeID=7, contentChecksumFlag=1)[:7] == bytes.fromhex("04224d186470b9")
-    assert compress_frame(L, data, blockSizeID=7)[:7] == bytes.fromhex("04224d18607073")
+    assert compress_frame(L, data, blockSizeID=7, contentChecksumFlag=1, blockMode=1)[:7] == bytes.fromhex("04224d186470b9")
+    assert compress_frame(L, data, blockSizeID=7, blockMode=1)[:7] == bytes.fromhex("04224d18607073")
+    # BASELINE configs[2]: 4 MB linked blocks + content checksum -> 04 22 4D 18 44 70 1D
+    assert compress_frame(L, data, blockSizeID=7, contentChecksumFlag=1)[:7] == bytes.fromhex("04224d1844701d")
 
 
 def test_reference_cli_frames_decode_here(L, golden, datagen):

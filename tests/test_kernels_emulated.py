@@ -217,3 +217,24 @@ def test_decompress_linked_blocks_with_prefix(emu, golden, datagen):
     pre = (ctypes.c_int32 * 1)(0)
     emu.emu_decompress_batch_prefix(sp, ss, dp, dc, res, 1, 1, pre)
     assert res[0] < 0
+
+
+def test_compress_with_history_decodes_with_prefix_oracle(emu, oracle, datagen):
+    """Linked-block compression: the block may reference the 64 KB of source before it."""
+    data = datagen(300000, 60, 7)
+    pre, n = 65536, 200000
+    buf = ctypes.create_string_buffer(data, len(data))
+    cap = n + n // 255 + 16
+    dst = ctypes.create_string_buffer(cap + 32)
+    sp = (ctypes.c_void_p * 1)(ctypes.addressof(buf) + pre); dp = (ctypes.c_void_p * 1)(ctypes.addressof(dst))
+    ss = (ctypes.c_int32 * 1)(n); dc = (ctypes.c_int32 * 1)(cap); res = (ctypes.c_int32 * 1)(); pr = (ctypes.c_int32 * 1)(pre)
+    emu.emu_compress_batch_prefix.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emu.emu_compress_batch_prefix(sp, ss, dp, dc, res, 1, 1, pr)
+    assert res[0] > 0
+    (r0, _), = emu_compress(emu, [data[pre:pre + n]])
+    assert res[0] < r0                                       # the history pays
+    # the oracle's prefix decoder (== LZ4_decompress_safe_usingDict) restores the block
+    out = ctypes.create_string_buffer(data[:pre], pre + n)
+    oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+    r = oracle.lz4o_decompress_safe_prefix(dst.raw[:res[0]], ctypes.addressof(out) + pre, res[0], n, pre)
+    assert r == n and out.raw[pre:pre + n] == data[pre:pre + n]
