@@ -55,7 +55,7 @@ enum : uint32_t {
     kSrcRing = 100u << 10,
     kSrcPad = 32,                      // mirror of the ring's first bytes: unaligned reads never wrap
     kHashBits = 13,
-    kRecsPerStrip = 128,               // matches a strip may take (the rest of it becomes literals)
+    kRecsPerStrip = 64,                // matches a strip may take (the rest of it becomes literals)
     kLaneLenCap = 24,                  // match bytes a lane measures on its own
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
@@ -63,10 +63,10 @@ enum : uint32_t {
 // LDS carve-up (bytes)
 enum : uint32_t {
     kCOffMisc = 0,                                        // u32[32]
-    kCOffStrip = kCOffMisc + 32 * 4,                      // u32[6][16] per-strip summaries
-    kCOffTab = kCOffStrip + 6 * kCmpWaves * 4,            // u32[1 << kHashBits]
-    kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[kCmpWaves][kRecsPerStrip]
-    kCOffRing = kCOffRecs + kCmpWaves * kRecsPerStrip * 8,
+    kCOffStrip = kCOffMisc + 32 * 4,                      // u32[2][6][16] per-strip summaries (two tiles in flight)
+    kCOffTab = kCOffStrip + 2 * 6 * kCmpWaves * 4,        // u32[1 << kHashBits]
+    kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kCmpWaves][kRecsPerStrip]
+    kCOffRing = kCOffRecs + 2 * kCmpWaves * kRecsPerStrip * 8,
     kCmpLdsBytes = kCOffRing + kSrcRing + kSrcPad,
 };
 enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3 };
@@ -89,11 +89,15 @@ template <class Ptr> __device__ __forceinline__ Ptr put_len_ext(Ptr p, uint32_t 
     return p;
 }
 
-// the reference's hashes (lz4.c:777-795): 5 bytes for inputs >= 64 KB + 11, 4 bytes below; 13 bits here
-__device__ __forceinline__ uint32_t hash_pos(uint64_t v8, bool small) {
-    return small ? ((uint32_t)v8 * 2654435761u) >> (32 - kHashBits)
-                 : (uint32_t)(((v8 << 24) * 889523592379ull) >> (64 - kHashBits));
+// 13-bit hashes of the 4 (blocks < 64 KB + 11, lz4.c:777-783) or 5 (lz4.c:785-795) bytes at a position.
+// The 5-byte one is not the reference's 64-bit multiply (four quarter-rate 32-bit multiplies on this
+// chip) but two 32-bit multiplicative hashes of the same bytes added up; any well mixed function of
+// the 5 bytes gives the same matches up to table collisions.
+__device__ __forceinline__ uint32_t hash_pos32(uint32_t lo, uint32_t hi, bool small) {
+    const uint32_t h4 = lo * 2654435761u;
+    return (small ? h4 : h4 + (hi & 0xFFu) * 0x85EBCA77u) >> (32 - kHashBits);
 }
+__device__ __forceinline__ uint32_t hash_pos(uint64_t v8, bool small) { return hash_pos32((uint32_t)v8, (uint32_t)(v8 >> 32), small); }
 
 // number of equal leading bytes (0..8) of two 8-byte little-endian words
 __device__ __forceinline__ uint32_t equal_bytes8(uint64_t x, uint64_t y) {
@@ -117,6 +121,29 @@ __device__ __forceinline__ uint64_t funnel8(uint64_t lo, uint64_t hi, uint32_t b
 __device__ __forceinline__ uint64_t ring_ld8(const uint8_t* ring, uint32_t o) {
     const uint64_t* a = (const uint64_t*)(ring + (o & ~7u));
     return funnel8(a[0], a[1], o & 7);
+}
+
+// number of equal leading bytes (0..8) of two 8-byte strings given as dword pairs
+__device__ __forceinline__ uint32_t equal_bytes8_32(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+    const uint32_t x = a0 ^ b0, y = a1 ^ b1;
+    return x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : (y ? 4 + ((uint32_t)(__ffs((int)y) - 1) >> 3) : 8u);
+}
+// The 32 bytes [pos-8, pos+24) around ring offset o as eight dwords (b0 b1 | f0..f5): nine aligned
+// dword reads and eight v_alignbyte.  (The ring's pad makes the reads past its end harmless; a
+// window that starts before offset 0 wraps to the ring's end.)
+struct Win32 { uint32_t b0, b1, f0, f1, f2, f3, f4, f5; };
+__device__ __forceinline__ Win32 ring_window32(const uint8_t* ring, uint32_t o) {
+    uint32_t a = ring_back(o, 8);
+    const uint32_t sh = a & 3u;
+    a &= ~3u;
+    uint32_t d[9];
+#pragma unroll
+    for (uint32_t i = 0; i < 9; i++) { const uint32_t x = a + 4 * i; d[i] = *(const uint32_t*)(ring + (x >= kSrcRing ? x - kSrcRing : x)); }
+    Win32 w;
+    w.b0 = align_bytes(d[1], d[0], sh); w.b1 = align_bytes(d[2], d[1], sh);
+    w.f0 = align_bytes(d[3], d[2], sh); w.f1 = align_bytes(d[4], d[3], sh); w.f2 = align_bytes(d[5], d[4], sh);
+    w.f3 = align_bytes(d[6], d[5], sh); w.f4 = align_bytes(d[7], d[6], sh); w.f5 = align_bytes(d[8], d[7], sh);
+    return w;
 }
 
 // 16 source bytes at block position P (multiple of 16) -> ring
@@ -170,21 +197,21 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
             bool f = false;
             if (valid) {
                 // stage 1: my bytes q-8 .. q+24 (independent of the table)
-                const uint64_t v8 = ring_ld8(ring, qo), v16 = ring_ld8(ring, ring_fwd(qo, 8)), v24 = ring_ld8(ring, ring_fwd(qo, 16));
-                const uint64_t vb = ring_ld8(ring, ring_back(qo, 8));
+                const Win32 v = ring_window32(ring, qo);
                 // stage 2: the candidate
-                c = tab[hash_pos(v8, small)];
+                c = tab[hash_pos32(v.f0, v.f1, small)];
                 const uint32_t d = q - c;
                 if (c < q && d <= kMaxDistance) {
                     // stage 3: its bytes c-8 .. c+24
-                    const uint32_t co = ring_back(qo, d);
-                    const uint64_t c8 = ring_ld8(ring, co), c16 = ring_ld8(ring, ring_fwd(co, 8)), c24 = ring_ld8(ring, ring_fwd(co, 16));
-                    const uint64_t cb = ring_ld8(ring, ring_back(co, 8));
-                    len = equal_bytes8(v8, c8);
-                    if (len == 8) { len += equal_bytes8(v16, c16); if (len == 16) len += equal_bytes8(v24, c24); }
+                    const Win32 k = ring_window32(ring, ring_back(qo, d));
+                    len = equal_bytes8_32(v.f0, v.f1, k.f0, k.f1);
+                    if (len == 8) { len += equal_bytes8_32(v.f2, v.f3, k.f2, k.f3); if (len == 16) len += equal_bytes8_32(v.f4, v.f5, k.f4, k.f5); }
                     f = len >= kMinMatch;
                     // how far back, over literals that may still be pending (lz4.c:1105-1109)?
-                    if (c >= 8) { const uint64_t x = vb ^ cb; back = x ? (uint32_t)__clzll((long long)x) >> 3 : 8u; }
+                    if (c >= 8) {
+                        const uint32_t x1 = v.b1 ^ k.b1, x0 = v.b0 ^ k.b0;
+                        back = x1 ? (uint32_t)__clz((int)x1) >> 3 : (x0 ? 4 + ((uint32_t)__clz((int)x0) >> 3) : 8u);
+                    }
                 }
             }
             unsigned long long m = __ballot(f);
@@ -302,7 +329,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
     uint32_t* strip = (uint32_t*)(smem + kCOffStrip);
     uint32_t* tab = (uint32_t*)(smem + kCOffTab);
-    MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + w * kRecsPerStrip;
+    MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + w * kRecsPerStrip;      // + parity * kCmpWaves * kRecsPerStrip
     uint8_t* ring = (uint8_t*)(smem + kCOffRing);
 
     // history (linked blocks, lz4io.c:741-744 / LZ4_compress_fast_continue in prefix mode lz4.c:1707): the
@@ -336,8 +363,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         for (uint32_t Pp = 16 * tid; Pp < hi; Pp += 16 * kCmpThreads) ring_commit16(ring, Pp, load_src16(src, n, Pp));
         loaded = (hi + 15) & ~15u;
     }
+    // Two barriers per tile.  Interval A: every wave parses its strip of tile k, then writes out its
+    // strip of tile k-1 (whose output offsets were fixed in the previous interval B).  Interval B:
+    // wave 0 turns the strips' sizes of tile k into output offsets while everybody inserts tile k
+    // into the table.  Records and strip summaries are double buffered for that.
+    uint32_t par = 0;                                       // buffer parity of tile k
+    uint32_t prev_t0 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
     while (t0 < n) {
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
+        uint32_t* strip_k = strip + par * 6 * kCmpWaves;
+        uint32_t* strip_p = strip + (par ^ 1) * 6 * kCmpWaves;
+        MatchRec* recs_k = recs + par * kCmpWaves * kRecsPerStrip;
+        MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
         tile_geometry(pre ? kTileMax * 4 : t1, small, nt_len, nt_strip);
@@ -345,25 +382,30 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         const uint32_t Pp = loaded + 16 * tid;
         U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;
         if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 16 * kCmpThreads
-        __syncthreads();                                       // ring (and table) ready for this tile
+        __syncthreads();                                       // ring, table and tile k-1's offsets ready
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
-        // -- match: one wave per strip (tiles of the history are only inserted into the table)
+        // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
         const bool parse = t0 >= pre;
         const uint32_t nstrips = parse ? (t1 - t0 + strip_len - 1) / strip_len : 0;
         if (w < nstrips) {
             const uint32_t cs = t0 + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
-            match_strip(ring, tab, recs, strip, w, n, cs, ce);
+            match_strip(ring, tab, recs_k, strip_k, w, n, cs, ce);
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
+        // -- A2: emit tile k-1
+        const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
+        if (w < prev_nstrips && !misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
+            emit_strip(ring, recs_p, strip_p, w, src, dst, prev_t0 + w * prev_strip_len, ring_lo);
+        if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
-        // -- offsets (wave 0: lane k holds strip k; the carry chain runs through readlane) ...
+        // -- B: offsets (wave 0: lane k holds strip k; the carry chain runs through readlane) ...
         if (w == 0 && parse) {
             const uint32_t lane = lane_id();
             const bool mine = lane < nstrips;
-            const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, en = mine ? strip[S_ENC * kCmpWaves + lane] : 0;
-            const uint32_t l0 = mine ? strip[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip[S_TAIL * kCmpWaves + lane] : 0;
+            const uint32_t nk = mine ? strip_k[S_N * kCmpWaves + lane] : 0, en = mine ? strip_k[S_ENC * kCmpWaves + lane] : 0;
+            const uint32_t l0 = mine ? strip_k[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip_k[S_TAIL * kCmpWaves + lane] : 0;
             uint32_t out = misc[CM_OUT], carry = misc[CM_CARRY], fail = misc[CM_FAIL];
             uint32_t my_out = 0, my_carry = 0;
             for (uint32_t k = 0; k < nstrips; k++) {
@@ -380,7 +422,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                     carry += tail_k;
                 }
             }
-            if (mine) { strip[S_OUT * kCmpWaves + lane] = my_out; strip[S_CARRY * kCmpWaves + lane] = my_carry; }
+            if (mine) { strip_k[S_OUT * kCmpWaves + lane] = my_out; strip_k[S_CARRY * kCmpWaves + lane] = my_carry; }
             if (lane == 0) { misc[CM_OUT] = out; misc[CM_CARRY] = carry; misc[CM_FAIL] = fail; }
         }
         // -- ... while everybody inserts the tile into the table (positions that may start a match):
@@ -390,27 +432,33 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             const uint32_t q0 = t0 + 16 * tid;                      // t0 is a multiple of 1024
             if (q0 < t1 && q0 <= last_q) {
                 const uint32_t o = src_ring_off(q0);                // multiple of 16: o + 24 <= ring + pad
-                const uint64_t* a = (const uint64_t*)(ring + o);
-                const uint64_t w0 = a[0], w1 = a[1], w2 = a[2];
+                const uint32_t* a = (const uint32_t*)(ring + o);
+                uint32_t dw[6];
+#pragma unroll
+                for (uint32_t i = 0; i < 6; i++) dw[i] = a[i];
 #pragma unroll
                 for (uint32_t i = 0; i < 16; i++) {
                     const uint32_t q = q0 + i;
-                    const uint64_t v8 = i < 8 ? funnel8(w0, w1, i) : funnel8(w1, w2, i - 8);
-                    if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos(v8, small)], q);
+                    const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
+                    if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos32(lo, hi, small)], q);
                 }
             }
         }
-        __syncthreads();
-        if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
-        // -- emit
-        const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
-        if (w < nstrips && !misc[CM_FAIL] && strip[S_N * kCmpWaves + w])
-            emit_strip(ring, recs, strip, w, src, dst, t0 + w * strip_len, ring_lo);
-        __syncthreads();                                       // ring readers done: commit the prefetch
-        if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
+        // the prefetched granules go into ring slots that hold bytes more than a window + two tiles old
         if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
+        if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
+        prev_t0 = t0; prev_strip_len = strip_len; prev_nstrips = nstrips; par ^= 1;
         t0 = t1; tile_len = nt_len; strip_len = nt_strip;
+    }
+    __syncthreads();
+    // -- the last tile's sequences
+    {
+        const uint32_t* strip_p = strip + (par ^ 1) * 6 * kCmpWaves;
+        const MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
+        const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
+        if (w < prev_nstrips && !misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
+            emit_strip(ring, recs_p, strip_p, w, src, dst, prev_t0 + w * prev_strip_len, ring_lo);
     }
     __syncthreads();
     if (prof && tid == 0) { prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = tp[4]; }

@@ -303,11 +303,13 @@ __device__ __forceinline__ uint32_t walk_pos(const CView& V, uint32_t csize, uin
 // lane is either at a token (mode 0: decodes token + literal length, and is done with the sequence
 // unless the match length nibble is 15) or at the offset field of a long match (mode 1: decodes the
 // match-length extension).  Same input-side rules as walk_chain<false>.
-__device__ __forceinline__ WalkOut walk_count(const CView& V, uint32_t csize, uint32_t p, uint32_t e) {
+__device__ __forceinline__ WalkOut walk_count(const CView& V, uint32_t csize, uint32_t p, uint32_t e, uint32_t max_trips) {
     WalkOut r; r.n = 0; r.ob = 0; r.err = 0;
     uint32_t rp = p, pend = 0;          // read position; literal length of the sequence in mode 1
+    uint32_t trips = 0;
     bool mode1 = false;
     while (p < e) {
+        if (trips++ >= max_trips) { p = kNone; break; }           // gave up (unconfirmed re-walk)
         bool slow = !V.has8(rp);
         const uint64_t w = V.ld8_if(rp, !slow);
         uint32_t add_ob = 0, next_p = p, next_rp = rp;
@@ -395,10 +397,14 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     const uint32_t s = tid * G;
     uint32_t e = s + G; if (e > csize || e < s) e = csize;
     // -- 1. positions: speculative entry (warm-up) and exit of every segment
+    //    (the segment itself is walked with the accounting walker: sequences, output bytes and format
+    //    errors of the LAST walk of a segment are the ones that count, and that walk starts at the true entry)
     uint32_t my_entry = kNone;
+    WalkOut w; w.exit = 0; w.n = 0; w.ob = 0; w.err = 0;
     if (has_seg) {
         my_entry = s > 0 ? walk_pos(V, csize, s > kPreWarm ? s - kPreWarm : 0, s, kNone) : 0u;
-        seg_exit[tid] = walk_pos(V, csize, my_entry, e, kNone);
+        w = walk_count(V, csize, my_entry, e, kNone);
+        seg_exit[tid] = w.err ? csize : w.exit;               // a malformed chain ends the block
     }
     // -- 2. fix-point: segment j is right iff it started where segment j-1 exited.  F = first
     //    segment that is not; everything before it is the true chain, so X = exit of segment F-1 is
@@ -421,18 +427,17 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         const uint32_t X = (F == 0) ? 0u : seg_exit[F - 1];       // != kNone: segment F-1 is right
         __syncthreads();
         if (has_seg && tid >= F) {
-            if (X >= e) { my_entry = X; seg_exit[tid] = X; }              // the chain jumps over this segment
-            else if (X >= s) { my_entry = X; seg_exit[tid] = walk_pos(V, csize, X, e, kNone); }   // ... enters it at X
+            if (X >= e) { my_entry = X; seg_exit[tid] = X; w.n = 0; w.ob = 0; w.err = 0; }   // the chain jumps over this segment
+            else if (X >= s) { my_entry = X; w = walk_count(V, csize, X, e, kNone); seg_exit[tid] = w.err ? csize : w.exit; }   // ... enters it at X
             else if (want != kNone && want != my_entry) {
-                const uint32_t x = walk_pos(V, csize, want, e, recap);
-                seg_exit[tid] = x;
-                my_entry = (x == kNone) ? kNone : want;                  // gave up: not resolved yet
+                w = walk_count(V, csize, want, e, recap);
+                seg_exit[tid] = w.exit == kNone ? kNone : (w.err ? csize : w.exit);
+                my_entry = (w.exit == kNone) ? kNone : want;             // gave up: not resolved yet
             }
         }
     }
-    // -- 3. accounting walk over the (now exact) chain: sequences, output bytes, format errors
-    WalkOut w; w.exit = 0; w.n = 0; w.ob = 0; w.err = 0;
-    if (has_seg) w = walk_count(V, csize, my_entry, e);
+    // -- 3. sequence numbers and output positions of the segments
+    if (!has_seg) { w.n = 0; w.ob = 0; w.err = 0; }
     uint32_t ea, ta; uint64_t eb, tb;
     block_excl_sum2(w.n, (uint64_t)w.ob, scan, ea, eb, ta, tb);
     int bad = 0;
