@@ -187,6 +187,11 @@ def main():
     d_total /= args.steps
     assert torch.equal(out, data), "round trip is not bit exact after the timed loop"
 
+    # ---- not part of the step: the batched XXH32 kernel (frame block checksums) over the same blocks
+    xplan = lz4_amd.Plan(ctx, lz4_amd.OP_XXH32, lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb, [0] * nb, [0] * nb))
+    xplan.launch(stream); xplan.results(stream)
+    x_ms = sum(xplan.launch_timed(stream)[1] for _ in range(3)) / 3
+
     if rank == 0:
         alg = {"compress": U + C, "decompress": U + C}        # U read + C written / C read + U written
         kernels = []
@@ -224,6 +229,8 @@ def main():
                                     "frac": dec["frac_of_hbm_peak"], "traffic": traffic.get("decompress"),
                                     "algorithmic_bytes_per_launch": dec["algorithmic_bytes"], "avg_ms": dec["avg_ms"]},
             "kernels": kernels,
+            "extras": {"xxh32_batch_GBps": round(U / (x_ms * 1e-3) / 1e9, 1), "xxh32_batch_ms": round(x_ms, 3),
+                       "note": "XXH32 (seed 0) of every 4 MiB block, one wave per block; not in `value`"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(nb, bs, args.pct, plan_s["seed"])
