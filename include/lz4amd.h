@@ -84,6 +84,10 @@ int  lz4amd_plan_profile(lz4amd_plan* plan, unsigned long long* words, int max_w
 /* one-shot conveniences: plan + launch + results (synchronous) */
 int  lz4amd_compress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                            void* const* d_dst, const int* dst_caps, int* results, int n, void* stream);
+/* LZ4_compress_HC (lz4hc.h:66) per block; level as in the reference (3..9 = hash chain with 4..256
+ * attempts; values outside are mapped to the nearest of those, 0 and below to the default 9) */
+int  lz4amd_compress_hc_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
+                              void* const* d_dst, const int* dst_caps, int* results, int n, int level, void* stream);
 int  lz4amd_decompress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                              void* const* d_dst, const int* dst_caps, int* results, int n, void* stream);
 

@@ -1,0 +1,46 @@
+/*
+ * lz4hc.h -- high-compression block API of the MI355X-native LZ4 codec (liblz4_amd).
+ *
+ * Drop-in declarations for the one-shot entry points of the reference's lib/lz4hc.h (v1.10.0);
+ * each prototype cites the declaration it replaces.  Same names, argument meaning and return
+ * conventions; host pointers in and out.  The search is the hash-chain match finder of the
+ * reference's levels 3..9 re-designed for a GPU workgroup (lz4_amd/csrc/kernels/lz4_hc_kernel.h);
+ * the bytes differ from the CPU library's, decode identically with any LZ4 decoder, and the size at
+ * level 9 stays within the +-3 % window of the reference's (tests/test_gpu_hc.py).
+ *
+ * Not provided (SURVEY.md section 8f "next"): the streaming HC contexts (LZ4_createStreamHC,
+ * LZ4_compress_HC_continue, LZ4_loadDictHC, ...), LZ4_compress_HC_destSize, and the optimal parser
+ * of levels 10-12 (those levels run the level-9 search).
+ */
+#ifndef LZ4_AMD_LZ4HC_H
+#define LZ4_AMD_LZ4HC_H
+
+#include "lz4.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference lz4hc.h:47-50 */
+#define LZ4HC_CLEVEL_MIN         2
+#define LZ4HC_CLEVEL_DEFAULT     9
+#define LZ4HC_CLEVEL_OPT_MIN    10
+#define LZ4HC_CLEVEL_MAX        12
+
+/* reference lz4hc.h:252: size a caller must provide for an external HC state */
+#define LZ4_STREAMHC_MINSIZE  262200
+
+/* lz4hc.h:66.  Returns the number of bytes written to dst, 0 if the block does not fit in
+ * dstCapacity.  Always succeeds when dstCapacity >= LZ4_compressBound(srcSize). */
+int LZ4_compress_HC(const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel);
+
+int LZ4_sizeofStateHC(void);                                                        /* lz4hc.h:79 */
+/* lz4hc.h:80.  The caller-provided state is not needed by the device path (head table and chains
+ * live in LDS / device scratch); it is accepted for ABI compatibility and must be non-NULL and
+ * 8-byte aligned as in the reference (lz4hc.c:1506). */
+int LZ4_compress_HC_extStateHC(void* stateHC, const char* src, char* dst, int srcSize, int maxDstSize, int compressionLevel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

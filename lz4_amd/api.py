@@ -46,6 +46,8 @@ def lib():
     for name in ("LZ4_compress_default", "LZ4_decompress_safe"):
         getattr(L, name).argtypes = [ctypes.c_char_p, ctypes.c_char_p, i, i]
     L.LZ4_compress_fast.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i, i, i]
+    L.LZ4_compress_HC.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i, i, i]
+    L.LZ4_compress_HC_extStateHC.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, i, i, i]
     L.LZ4_compressBound.argtypes = [i]
     L.LZ4_versionString.restype = ctypes.c_char_p
     L.lz4amd_plan_create_prefix.argtypes = [vp, ctypes.POINTER(vp), i, ctypes.POINTER(vp), ip, ctypes.POINTER(vp), ip, ip]
@@ -145,8 +147,9 @@ def _stream_handle(stream):
     return getattr(stream, "cuda_stream", stream)
 
 
-def compress_blocks(ctx, data, block_size, stream=None):
-    """Compress a CUDA uint8 tensor as independent blocks of `block_size` bytes.
+def compress_blocks(ctx, data, block_size, stream=None, hc_level=None):
+    """Compress a CUDA uint8 tensor as independent blocks of `block_size` bytes (LZ4_compress_default
+    per block, or LZ4_compress_HC at `hc_level` when given).
     Returns (comp tensor [n, stride], sizes list, plan)."""
     import torch
     assert data.is_cuda and data.dtype == torch.uint8 and data.dim() == 1
@@ -158,7 +161,7 @@ def compress_blocks(ctx, data, block_size, stream=None):
     sizes = [min(block_size, total - i * block_size) for i in range(n)]
     table = BlockTable([base + i * block_size for i in range(n)], sizes,
                        [cbase + i * stride for i in range(n)], [stride] * n)
-    plan = Plan(ctx, OP_COMPRESS, table)
+    plan = Plan(ctx, OP_COMPRESS, table) if hc_level is None else Plan(ctx, OP_COMPRESS_HC, table, level=hc_level)
     s = _stream_handle(stream)
     plan.launch(s)
     return comp, plan.results(s), plan

@@ -1,0 +1,440 @@
+// lz4_hc_kernel.h -- batched LZ4 high-compression blocks (hash-chain match finder) for gfx950.
+//
+// Replaces, for a whole table of independent blocks resident in HBM, what the reference does per
+// block in LZ4_compress_HC (lib/lz4hc.c:1519 -> LZ4HC_compress_generic 1388 -> LZ4HC_compress_hashChain
+// 1121-1362) at the hash-chain levels 3..9: a 15-bit multiplicative hash of 4 bytes (lz4hc.c:121
+// LZ4HC_hashPtr), a chain of 16-bit deltas to the previous position with the same hash
+// (lz4hc.c:781-802 LZ4HC_Insert), up to nbSearches candidates per position inside the 64 KB window
+// (k_clTable lz4hc.c:92-106: 4 << (level-3), 256 at level 9), lazy match selection.  The output is a
+// legal LZ4 block (doc/lz4_Block_format.md); its bytes differ from the CPU library's, its size stays
+// within about 2 % of the reference's level-9 result on datagen, text and binaries
+// (tools/exp/hc_sim.c is the CPU model the scheme was sized with).
+//
+// Not a port.  The reference interleaves insert / search / lazy decisions in one serial loop; here the
+// three are separate, each parallel in its own way, and one 1024-thread workgroup owns a block:
+//
+//   1 chain    all positions are linked first.  A wave takes 64 consecutive positions, resolves the
+//              links inside the group with ballots, then - in position order, a token passed from
+//              wave to wave through LDS - reads / updates the 32 K-entry head table (128 KB of LDS).
+//              The chain (u16 delta per position) goes to a scratch array in HBM / L2.
+//   2 search   EVERY position looks for its longest match (the parse order is not known yet, and
+//              no longer matters).  The LZ4 window is 64 K positions x (1 source byte + 2 chain bytes)
+//              = 192 KB, more than a CU's LDS, so the window is searched in BANDS of 32 K positions:
+//              a pass streams the block through a 32 KB source ring + 64 KB chain ring, every lane
+//              walks its position's chain while the candidates are inside the band, and parks
+//              {best length, best offset, distance of the next candidate, attempts left} in scratch;
+//              the next pass streams the band 32 K further back and resumes the walks.  Every probe
+//              of the inner loop is an LDS access.  Lengths are measured up to kHcLenCap bytes.
+//   3 parse    16 strips, one wave each: the wave looks at 64 positions at a time, takes the first
+//              match that neither of the next two positions beats (lazy evaluation, the role of the
+//              reference's LZ4HC_InsertAndGetWiderMatch retries, lz4hc.c:1168-1330), extends capped
+//              matches with a wave-wide compare, and records {literal run, offset, length}.
+//              Matches end at the strip's end; pending literals carry over.
+//   4 emit     strip sizes -> output offsets (wave 0), then every wave writes its strip
+//              (emit_strip of the fast compressor).
+//
+// HBM/L2 traffic per block: source read 3 + bands times, 2 B/position of chain written once and read
+// once per band, 8 B/position of search state written and read once per band, 8 B per sequence of
+// records, compressed stream written once.  No MFMA: integer / byte work.
+#pragma once
+#include "lz4_compress_kernel.h"
+
+namespace lz4amd {
+
+using HcBatch = ::lz4amd_hc_params;     // argument block (lz4amd_params.h)
+
+enum : uint32_t {
+    kHcThreads = 1024,
+    kHcWaves = kHcThreads / 64,
+    kHcHashLog = 15,                    // lz4hc.h:226 LZ4HC_HASH_LOG
+    kHcRing = 32768,                    // positions per band (source ring bytes, chain ring entries)
+    kHcPad = 16,                        // mirror of the source ring's first bytes
+    kHcTile = 2048,                     // positions searched between two ring refills
+    kHcPosPerThread = kHcTile / kHcThreads,
+    kHcAhead = 272,                     // source bytes the rings hold past every position of the tile
+    kHcLenCap = 250,                    // longest match a lane measures on its own (<= kHcAhead - 8, fits 8 bits)
+    kHcBandStep = kHcRing - kHcAhead,   // how much further back the next band starts
+    kHcBands = 2,                       // window reached: 62944 (the tile's first position) .. 64991 (its last)
+    kHcMinStrip = 1024,
+    kHcMaxAttempts = 256,               // level 9 (lz4hc.c:102)
+};
+// LDS carve-up (bytes); the chain phase and the search phase reuse the same region
+enum : uint32_t {
+    kHOffMisc = 0,                                  // u32[32]
+    kHOffStrip = 128,                               // u32[6][16] strip summaries
+    kHOffBody = 512,
+    kHOffHead = kHOffBody,                          // phase 1: u32[1 << 15]
+    kHOffSrc = kHOffBody,                           // phase 2: source ring + pad
+    kHOffChain = kHOffSrc + kHcRing + kHcPad,       //          u16[kHcRing]
+    kHOffMine = kHOffChain + 2 * kHcRing,           //          the tile's own bytes
+    kHcMineBytes = kHcTile + kHcAhead + 16,
+    kHcLdsBytes = kHOffBody + (4u << kHcHashLog),
+};
+static_assert(kHOffMine + kHcMineBytes <= kHcLdsBytes, "search phase must fit in the chain phase's LDS");
+enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4 };
+
+// scratch layout of one workgroup, for blocks of at most n bytes
+__host__ __device__ inline uint64_t hc_chain_bytes(uint32_t n) { return ((uint64_t)2 * (n + 64) + 255) & ~255ull; }
+__host__ __device__ inline uint64_t hc_state_bytes(uint32_t n) { return ((uint64_t)8 * (n + 64) + 255) & ~255ull; }
+__host__ __device__ inline uint64_t hc_recs_bytes(uint32_t n) { return (uint64_t)8 * (n / 4 + 64 * kHcWaves); }
+__host__ __device__ inline uint64_t hc_scratch_bytes(uint32_t n) { return hc_chain_bytes(n) + hc_state_bytes(n) + hc_recs_bytes(n); }
+
+__device__ __forceinline__ uint32_t hc_attempts(int level) {
+    // k_clTable lz4hc.c:92-106 (levels below 3 and the optimal-parser levels 10-12 are served by the
+    // hash-chain search too, with the nearest depth: 4 and 256)
+    if (level < 1) level = 9;            // LZ4HC_CLEVEL_DEFAULT (lz4hc.c:110-113)
+    if (level < 3) level = 3;
+    if (level > 9) level = 9;
+    return 4u << (level - 3);
+}
+__device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHcHashLog); }
+
+struct HcState { uint32_t w0, w1; };    // w0 = best offset | next candidate distance << 16; w1 = best length | attempts left << 8
+
+// ------------------------------------------------------------------------------ phase 1: chains
+__device__ __forceinline__ void hc_build_chain(lz4amd_gsrc src, uint32_t n, uint16_t* chain_g, char* smem) {
+    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
+    uint32_t* head = (uint32_t*)(smem + kHOffHead);
+    for (uint32_t i = tid; i < (1u << kHcHashLog); i += kHcThreads) head[i] = 0;
+    if (tid == 0) misc[HM_TOKEN] = 0;
+    __syncthreads();
+    const uint32_t ngroups = (n + 63) / 64;
+    for (uint32_t g = w; g < ngroups; g += kHcWaves) {
+        const uint32_t p = g * 64 + lane;
+        const bool valid = p + 4 <= n;
+        uint32_t v = 0;
+        if (valid) __builtin_memcpy(&v, src + p, 4);
+        const uint32_t h = hc_hash(v);
+        // links inside the group: previous lane with my hash, and whether I am the last one with it
+        int pred = -1;
+        bool last = true;
+        unsigned long long rem = __ballot(valid);
+        while (rem) {
+            const uint32_t l = (uint32_t)__ffsll((long long)rem) - 1;
+            const uint32_t hk = wave_readlane(h, l);
+            const bool same = valid && h == hk;
+            const unsigned long long mm = __ballot(same);
+            rem &= ~mm;
+            if (same) {
+                const unsigned long long below = mm & ((1ull << lane) - 1);
+                pred = below ? 63 - __clzll(below) : -1;
+                last = ((mm >> lane) >> 1) == 0;
+            }
+        }
+        // my turn: groups read and update the head table in position order
+        while (lds_load_acquire(&misc[HM_TOKEN]) != g) spin_pause();
+        uint32_t old = 0;
+        if (valid && pred < 0) old = head[h];
+        wave_lds_fence();
+        if (valid && last) head[h] = p + 1;
+        wave_lds_fence();
+        if (lane == 0) lds_store_release(&misc[HM_TOKEN], g + 1);
+        const uint32_t prev1 = pred >= 0 ? g * 64 + (uint32_t)pred + 1 : old;      // previous position + 1, 0 = none
+        uint32_t delta = 0;
+        if (valid && prev1) { const uint32_t d = p + 1 - prev1; if (d <= kMaxDistance) delta = d; }
+        chain_g[p] = (uint16_t)delta;                 // the array is padded to a multiple of 64 entries
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------ phase 2: band search
+// four bytes at any alignment out of an LDS byte array (two aligned dword reads + v_alignbyte)
+__device__ __forceinline__ uint32_t lds_ld4(const uint8_t* base, uint32_t o) {
+    const uint32_t* a = (const uint32_t*)(base + (o & ~3u));
+    return align_bytes(a[1], a[0], o & 3u);
+}
+__device__ __forceinline__ void hc_commit_src(uint8_t* ring, uint32_t P, const U32x4& v) {
+    const uint32_t o = P & (kHcRing - 1);
+    *(U32x4*)(ring + o) = v;
+    if (o < kHcPad) *(U32x4*)(ring + kHcRing + o) = v;
+}
+
+__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, const uint16_t* chain_g, HcState* state_g,
+                                               uint32_t band, uint32_t attempts, char* smem) {
+    const uint32_t tid = threadIdx.x;
+    uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
+    uint16_t* cring = (uint16_t*)(smem + kHOffChain);
+    uint8_t* mine = (uint8_t*)(smem + kHOffMine);
+    const uint32_t n64 = (n + 63) & ~63u;
+    const int32_t last_q = (int32_t)n - (int32_t)kMfLimit;            // last position that may start a match
+    const int32_t shift = (int32_t)(band * kHcBandStep);
+    // the rings hold positions [H - kHcRing, H), H = t0 + kHcTile + kHcAhead - shift
+    // -- first tile: fill [0, H(0)) directly
+    {
+        const int32_t H = (int32_t)(kHcTile + kHcAhead) - shift;
+        const int32_t Ps = 16 * (int32_t)tid, Pc = 8 * (int32_t)tid;
+        if (Ps < H && (uint32_t)Ps < n) hc_commit_src(ring, (uint32_t)Ps, load_src16(src, n, (uint32_t)Ps));
+        if (Pc < H && (uint32_t)Pc < n64) *(U32x4*)(cring + (Pc & (int32_t)(kHcRing - 1))) = *(const U32x4*)(chain_g + Pc);
+        if (tid < kHcMineBytes / 16) *(U32x4*)(mine + 16 * tid) = load_src16(src, n, 16 * tid);      // zero filled past n
+    }
+    for (uint32_t t0 = 0; t0 < n; t0 += kHcTile) {
+        const int32_t H = (int32_t)(t0 + kHcTile + kHcAhead) - shift;
+        const int32_t low = H - (int32_t)kHcRing;                     // lowest candidate position of this band
+        // -- prefetch the next tile's ring granules and this tile's own bytes
+        const int32_t Ps = H + 16 * (int32_t)tid, Pc = H + 8 * ((int32_t)tid - 256);
+        const bool have_s = tid < kHcTile / 16 && Ps >= 0 && (uint32_t)Ps < n;
+        const bool have_c = tid >= 256 && tid < 256 + kHcTile / 8 && Pc >= 0 && (uint32_t)Pc < n64;
+        const uint32_t Pm = t0 + kHcTile + 16 * (tid - 512);          // the next tile's own bytes
+        const bool have_m = tid >= 512 && tid < 512 + kHcMineBytes / 16;
+        U32x4 ps, pc, pm;
+        ps[0] = ps[1] = ps[2] = ps[3] = 0; pc = ps; pm = ps;
+        if (have_s) ps = load_src16(src, n, (uint32_t)Ps);
+        if (have_c) pc = *(const U32x4*)(chain_g + Pc);
+        if (have_m && Pm < n) pm = load_src16(src, n, Pm);
+        __syncthreads();
+        // -- every thread walks the chains of its positions (no wave-wide operation inside: lanes are free
+        //    to be at different positions and different depths)
+        uint32_t slot = 0;
+        bool active = false;
+        int32_t p = 0;
+        uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0;
+        for (;;) {
+            if (!active) {
+                if (slot >= kHcPosPerThread) break;
+                p = (int32_t)(t0 + slot * kHcThreads + tid);
+                pp = slot * kHcThreads + tid;
+                slot++;
+                if ((uint32_t)p >= n) continue;
+                if (p > last_q) { if (band == 0) { HcState z; z.w0 = 0; z.w1 = 3; state_g[p] = z; } continue; }
+                if (band == 0) { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
+                else {
+                    const HcState s = state_g[p];
+                    dist = s.w0 >> 16; boff = s.w0 & 0xFFFFu; best = s.w1 & 0xFFu; att = s.w1 >> 8;
+                    if (dist == 0) continue;                            // finished in an earlier band
+                }
+                lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
+                if (lim > kHcLenCap) lim = kHcLenCap;
+                mt = lds_ld4(mine, pp + best - 3);
+                active = true;
+            }
+            uint32_t next = 0;                                          // distance to resume at in the next band
+            bool fin = false;
+            if (dist == 0 || dist > kMaxDistance || att == 0) fin = true;
+            else {
+                const int32_t q = p - (int32_t)dist;
+                if (q < low) { fin = true; next = band + 1 < kHcBands ? dist : 0; }
+                else {
+                    att--;
+                    const uint32_t qo = (uint32_t)q & (kHcRing - 1);
+                    // a longer match must agree on the four bytes that end at index `best` (for best = 3
+                    // this is the MINMATCH test; lz4hc.c:934-936)
+                    if (lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
+                        uint32_t l = 0;
+                        while (l < lim) {
+                            const uint32_t x = lds_ld4(ring, (qo + l) & (kHcRing - 1)) ^ lds_ld4(mine, pp + l);
+                            if (x) { l += (uint32_t)(__ffs((int)x) - 1) >> 3; break; }
+                            l += 4;
+                        }
+                        if (l > lim) l = lim;
+                        if (l > best) {
+                            best = l; boff = dist;
+                            if (l >= lim) fin = true;
+                            else mt = lds_ld4(mine, pp + best - 3);
+                        }
+                    }
+                    if (!fin) {
+                        const uint32_t d = cring[qo];
+                        if (d == 0) fin = true; else dist += d;
+                    }
+                }
+            }
+            if (fin) {
+                HcState s; s.w0 = boff | (next << 16); s.w1 = best | (att << 8);
+                state_g[p] = s;
+                active = false;
+            }
+        }
+        __syncthreads();
+        // -- commit the prefetched granules: they replace positions below the next tile's band
+        if (have_s) hc_commit_src(ring, (uint32_t)Ps, ps);
+        if (have_c) *(U32x4*)(cring + ((uint32_t)Pc & (kHcRing - 1))) = pc;
+        if (have_m) *(U32x4*)(mine + 16 * (tid - 512)) = pm;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------ phase 3: parse (one strip)
+// 8 source bytes at position a (a < n), zero filled past the end of the block
+__device__ __forceinline__ uint64_t hc_ld8(lz4amd_gsrc src, uint32_t n, uint32_t a) {
+    if (a + 8 <= n) { uint64_t v; __builtin_memcpy(&v, src + a, 8); return v; }
+    uint64_t v = 0;
+#pragma nounroll
+    for (uint32_t i = 0; i < 8 && a + i < n; i++) v |= (uint64_t)src[a + i] << (8 * i);
+    return v;
+}
+
+__device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, const HcState* state_g, MatchRec* recs,
+                                               uint32_t* strip, uint32_t w, uint32_t cs, uint32_t ce) {
+    const uint32_t lane = lane_id();
+    uint32_t nseq = 0, enc = 0, ll0 = 0, anchor = cs;
+    if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
+        const uint32_t last_q = n - kMfLimit;
+        uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
+        uint32_t ip = cs;
+        while (ip < ce && ip <= last_q) {
+            const uint32_t pos = ip + lane;
+            uint32_t len = 0, off = 0;
+            if (pos <= last_q && pos + kMinMatch <= mlimit) {
+                const HcState s = state_g[pos];
+                const uint32_t l = s.w1 & 0xFFu;
+                if (l >= kMinMatch) { len = l; off = s.w0 & 0xFFFFu; }
+            }
+            unsigned long long m = __ballot(len != 0);
+            uint32_t next_ip = ip + 64;
+            while (m) {
+                const uint32_t f = (uint32_t)__ffsll((long long)m) - 1;
+                if (f > 61) { next_ip = ip + f; break; }                    // the two positions after f must be in the window
+                const uint32_t L0 = wave_readlane(len, f), L1 = wave_readlane(len, f + 1), L2 = wave_readlane(len, f + 2);
+                if (L1 > L0 || L2 > L0 + 1) { m &= m - 1; continue; }      // a later start is better: f becomes a literal
+                const uint32_t x = ip + f;
+                const uint32_t of = wave_readlane(off, f);
+                uint32_t ml = L0;
+                if (ml >= kHcLenCap && x + ml < mlimit) {
+                    // capped by the search: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
+                    for (;;) {
+                        const uint32_t a = x + ml + 8 * lane;
+                        uint32_t same = 0;
+                        if (a < mlimit) {
+                            same = equal_bytes8(hc_ld8(src, n, a), hc_ld8(src, n, a - of));
+                            if (same > mlimit - a) same = mlimit - a;
+                        }
+                        const unsigned long long brk = __ballot(same < 8);
+                        if (brk) {
+                            const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
+                            ml += 8 * fl + wave_readlane(same, fl);
+                            break;
+                        }
+                        ml += 512;
+                    }
+                }
+                if (x + ml > mlimit) ml = mlimit - x;
+                if (ml > 65535u) ml = 65535u;                               // the record keeps ml - 4 in 16 bits
+                const uint32_t ll = x - anchor;
+                if (lane == 0) { MatchRec r; r.ll = ll; r.mo = of | ((ml - kMinMatch) << 16); recs[nseq] = r; }
+                if (nseq == 0) ll0 = ll;
+                enc += enc_size(ll, ml - kMinMatch);
+                nseq++;
+                anchor = x + ml;
+                if (anchor >= ip + 64) { next_ip = anchor; break; }
+                m &= ~0ull << (anchor - ip);
+            }
+            ip = next_ip;
+        }
+    }
+    if (lane == 0) {
+        strip[S_N * kCmpWaves + w] = nseq;
+        strip[S_ENC * kCmpWaves + w] = enc;
+        strip[S_LL0 * kCmpWaves + w] = ll0;
+        strip[S_TAIL * kCmpWaves + w] = ce - anchor;
+    }
+}
+
+// ------------------------------------------------------------------------------ one block
+__device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char* smem) {
+    const uint32_t tid = threadIdx.x, w = wave_id();
+    uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
+    uint32_t* strip = (uint32_t*)(smem + kHOffStrip);
+    const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
+    const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
+    const int32_t n_i = P.src_size[b];
+    const int32_t cap_i = P.dst_cap[b];
+    if (n_i < 0 || (uint32_t)n_i > kMaxInput || cap_i <= 0 || P.dst[b] == nullptr || (P.src[b] == nullptr && n_i != 0)) {
+        if (tid == 0) P.result[b] = 0;                               // lz4hc.c:1403-1404
+        return;
+    }
+    if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }
+    const uint32_t n = (uint32_t)n_i, cap = (uint32_t)cap_i;
+    uint8_t* scratch = P.scratch + (uint64_t)blockIdx.x * P.scratch_stride;
+    uint16_t* chain_g = (uint16_t*)scratch;
+    HcState* state_g = (HcState*)(scratch + hc_chain_bytes(P.max_src));
+    MatchRec* recs_g = (MatchRec*)(scratch + hc_chain_bytes(P.max_src) + hc_state_bytes(P.max_src));
+    uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
+    uint64_t tq = prof ? clock_ticks() : 0;
+
+    uint32_t nstrips = 0, strip_len = 0;
+    if (tid == 0) { misc[HM_OUT] = 0; misc[HM_CARRY] = 0; misc[HM_FAIL] = 0; }
+    if (n >= kMfLimit + 1) {
+        hc_build_chain(src, n, chain_g, smem);
+        if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[0] += t - tq; tq = t; }
+        const uint32_t attempts = hc_attempts(P.level);
+        for (uint32_t band = 0; band < kHcBands; band++) {
+            hc_search_band(src, n, chain_g, state_g, band, attempts, smem);
+            if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + band] += t - tq; tq = t; }
+        }
+        // -- parse: one wave per strip
+        nstrips = (n + kHcMinStrip - 1) / kHcMinStrip; if (nstrips > kHcWaves) nstrips = kHcWaves;
+        strip_len = (((n + nstrips - 1) / nstrips) + 63) & ~63u;
+        nstrips = (n + strip_len - 1) / strip_len;
+        const uint32_t rec_cap = strip_len / 4 + 4;
+        if (w < nstrips) {
+            const uint32_t cs = w * strip_len;
+            uint32_t ce = cs + strip_len; if (ce > n) ce = n;
+            hc_parse_strip(src, n, state_g, recs_g + (uint64_t)w * rec_cap, strip, w, cs, ce);
+        }
+        __syncthreads();
+        if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[4] += t - tq; tq = t; }
+        // -- offsets: lane k of wave 0 holds strip k; the literal carry runs through readlane
+        if (w == 0) {
+            const uint32_t lane = lane_id();
+            const bool mine = lane < nstrips;
+            const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, en = mine ? strip[S_ENC * kCmpWaves + lane] : 0;
+            const uint32_t l0 = mine ? strip[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip[S_TAIL * kCmpWaves + lane] : 0;
+            uint32_t out = 0, carry = 0, fail = 0, my_out = 0, my_carry = 0;
+            for (uint32_t k = 0; k < nstrips; k++) {
+                const uint32_t nk_k = wave_readlane(nk, k), tail_k = wave_readlane(tl, k);
+                if (nk_k) {
+                    const uint32_t ll0 = wave_readlane(l0, k);
+                    const uint32_t sz = wave_readlane(en, k) + carry + lit_hdr_ext(ll0 + carry) - lit_hdr_ext(ll0);
+                    if ((uint64_t)out + sz > cap) fail = 1;              // limitedOutput: the block fails as a whole (lz4hc.c:297-300)
+                    if (lane == k) { my_out = out; my_carry = carry; }
+                    if (!fail) out += sz;
+                    carry = tail_k;
+                } else {
+                    carry += tail_k;
+                }
+            }
+            if (mine) { strip[S_OUT * kCmpWaves + lane] = my_out; strip[S_CARRY * kCmpWaves + lane] = my_carry; }
+            if (lane == 0) { misc[HM_OUT] = out; misc[HM_CARRY] = carry; misc[HM_FAIL] = fail; }
+        }
+        __syncthreads();
+        // -- emit
+        if (w < nstrips && !misc[HM_FAIL] && strip[S_N * kCmpWaves + w])
+            emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap, strip, w, src, dst, w * strip_len, 0xFFFFFFFFu);
+        __syncthreads();
+        if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[5] += t - tq; tq = t; }
+    } else {
+        __syncthreads();
+        if (tid == 0) misc[HM_CARRY] = n;
+        __syncthreads();
+    }
+    // -- final literal run (lz4hc.c:1336-1357)
+    const uint32_t out = misc[HM_OUT], run = misc[HM_CARRY];
+    const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;
+    if (misc[HM_FAIL] || total > cap) { if (tid == 0) P.result[b] = 0; return; }
+    const uint32_t lit_dst = out + 1 + lit_hdr_ext(run);
+    if (tid == 0) {
+        lz4amd_gdst p = dst + out;
+        if (run >= 15) { *p++ = 0xF0; put_len_ext(p, run - 15); }
+        else *p++ = (uint8_t)(run << 4);
+        P.result[b] = (int32_t)total;
+    }
+    const uint32_t sp = n - run;
+    for (uint32_t i = tid; i < run; i += kHcThreads) dst[lit_dst + i] = src[sp + i];
+}
+
+// Workgroups pull blocks from a device-wide ticket counter.
+__device__ __forceinline__ void hc_batch_body(const HcBatch& P) {
+    LZ4AMD_DYN_LDS(smem);
+    uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) misc[HM_BLOCK] = take_ticket(P.ticket);
+        __syncthreads();
+        const uint32_t b = misc[HM_BLOCK];
+        if (b >= P.n_blocks) break;
+        hc_one_block(P, b, smem);
+    }
+}
+
+} // namespace lz4amd

@@ -51,7 +51,7 @@ int LZ4_compressBound(int inputSize) { return lz4amd_compress_bound(inputSize); 
 
 /* one block through the device; op selects the kernel set.  Returns the per-block result, or
  * `fail` when the device path cannot run. */
-static int run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail)
+int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail)
 {
     lz4amd_ctx* ctx;
     lz4amd_plan* plan = NULL;
@@ -88,7 +88,7 @@ int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, 
     if (srcSize < 0 || (unsigned)srcSize > (unsigned)LZ4_MAX_INPUT_SIZE) return 0;   /* lz4.c:1360 */
     if (dst == NULL || dstCapacity <= 0) return 0;
     if (src == NULL && srcSize != 0) return 0;
-    return run_one(LZ4AMD_OP_COMPRESS, src, dst, srcSize, dstCapacity, 0, 0);
+    return lz4amd_run_one(LZ4AMD_OP_COMPRESS, src, dst, srcSize, dstCapacity, 0, 0);
 }
 
 int LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity)
@@ -109,7 +109,7 @@ int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstC
 {   /* lz4.c:2451; degenerate cases lz4.c:2036, 2062-2069 decided by the kernel itself */
     if (src == NULL || dstCapacity < 0) return -1;
     if (compressedSize < 0) return -1;
-    return run_one(LZ4AMD_OP_DECOMPRESS, src, dst, compressedSize, dstCapacity, 0, -1);
+    return lz4amd_run_one(LZ4AMD_OP_DECOMPRESS, src, dst, compressedSize, dstCapacity, 0, -1);
 }
 
 /* lz4.c:2719-2732 LZ4_decompress_safe_usingDict: the dictionary (its last 64 KB) is staged right

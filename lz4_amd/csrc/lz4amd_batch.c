@@ -138,6 +138,27 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
             q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
             if (q->prof && lz4amd_hip_memset(q->prof, 0, (size_t)(grid ? grid : 1) * 64, NULL)) err = LZ4AMD_E_RUNTIME;
         }
+    } else if (op == LZ4AMD_OP_COMPRESS_HC) {
+        lz4amd_hc_params* q = &p->hc;
+        /* one 1024-thread workgroup per block at a time (head table / band rings in LDS); the chain,
+         * the per-position search state and the sequence records of the block in flight live in a
+         * per-workgroup scratch area sized for the largest block of the table */
+        unsigned grid = (unsigned)ctx->n_cus, max_n = 0;
+        for (i = 0; i < n; i++) if (src_sizes[i] > 0 && (unsigned)src_sizes[i] > max_n) max_n = (unsigned)src_sizes[i];
+        if ((unsigned)n < grid) grid = (unsigned)n;
+        p->grid = grid;
+        q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
+        q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
+        q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
+        q->level = level; q->max_src = max_n;
+        q->scratch_stride = (lz4amd_hip_hc_scratch_bytes(max_n) + 255) & ~(uint64_t)255;
+        q->prof = NULL;
+        if (getenv("LZ4AMD_PROF")) {
+            q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
+            if (q->prof && lz4amd_hip_memset(q->prof, 0, (size_t)(grid ? grid : 1) * 64, NULL)) err = LZ4AMD_E_RUNTIME;
+        }
+        q->ticket = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
+        q->scratch = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)q->scratch_stride * (grid ? grid : 1), &err));
     } else if (op == LZ4AMD_OP_XXH32) {
         lz4amd_xxh_params* q = &p->xxh;          /* d_dst / dst_caps are ignored: the result is the hash */
         p->grid = (unsigned)n;
@@ -188,6 +209,7 @@ static int launch_stage(lz4amd_plan* p, int stage, void* stream)
     if (p->op == LZ4AMD_OP_DECOMPRESS)
         return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
     if (p->op == LZ4AMD_OP_XXH32) return stage == 0 ? lz4amd_hip_launch_xxh32(&p->xxh, stream) : 0;
+    if (p->op == LZ4AMD_OP_COMPRESS_HC) return stage == 0 ? lz4amd_hip_launch_compress_hc(&p->hc, p->grid, stream) : 0;
     return stage == 0 ? lz4amd_hip_launch_compress(&p->comp, p->grid, stream) : 0;
 }
 static int n_stages(const lz4amd_plan* p) { (void)p; return 1; }
@@ -226,7 +248,7 @@ int lz4amd_plan_profile(lz4amd_plan* p, unsigned long long* words, int max_words
     int n;
     const uint64_t* src;
     if (!p) return 0;
-    src = p->op == LZ4AMD_OP_DECOMPRESS ? p->dec.prof : p->comp.prof;
+    src = p->op == LZ4AMD_OP_DECOMPRESS ? p->dec.prof : p->op == LZ4AMD_OP_COMPRESS_HC ? p->hc.prof : p->comp.prof;
     if (!src) return 0;
     n = (int)p->grid * 8;
     if (n > max_words) n = max_words;
@@ -261,6 +283,18 @@ static int one_shot(lz4amd_ctx* ctx, lz4amd_op op, const void* const* d_src, con
 int lz4amd_compress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                           void* const* d_dst, const int* dst_caps, int* results, int n, void* stream)
 { return one_shot(ctx, LZ4AMD_OP_COMPRESS, d_src, src_sizes, d_dst, dst_caps, results, n, stream); }
+
+int lz4amd_compress_hc_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
+                             void* const* d_dst, const int* dst_caps, int* results, int n, int level, void* stream)
+{
+    lz4amd_plan* p = NULL;
+    int rc = lz4amd_plan_create(ctx, &p, LZ4AMD_OP_COMPRESS_HC, n, d_src, src_sizes, d_dst, dst_caps, level);
+    if (rc) return rc;
+    rc = lz4amd_plan_launch(p, stream);
+    if (!rc) rc = lz4amd_plan_results(p, results, stream);
+    lz4amd_plan_destroy(p);
+    return rc;
+}
 
 int lz4amd_decompress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                             void* const* d_dst, const int* dst_caps, int* results, int n, void* stream)

@@ -3,6 +3,7 @@
 #include "kernels/platform_hip.h"
 #include "kernels/lz4_decompress_kernel.h"
 #include "kernels/lz4_compress_kernel.h"
+#include "kernels/lz4_hc_kernel.h"
 #include "kernels/xxh32_kernel.h"
 #include "lz4amd_ffi.h"
 #include <stdio.h>
@@ -13,6 +14,7 @@ using namespace lz4amd;
 __global__ void __launch_bounds__(kDecThreads) lz4amd_k_decompress(lz4amd_dec_params p) { decompress_batch_body(p); }
 __global__ void __launch_bounds__(kCmpThreads) lz4amd_k_compress(lz4amd_comp_params p) { compress_batch_body(p); }
 
+__global__ void __launch_bounds__(kHcThreads) lz4amd_k_compress_hc(lz4amd_hc_params p) { hc_batch_body(p); }
 __global__ void __launch_bounds__(64) lz4amd_k_xxh32(lz4amd_xxh_params p) { xxh32_block_body(p); }
 
 // ------------------------------------------------------------------------------- runtime glue
@@ -40,6 +42,7 @@ extern "C" int lz4amd_hip_init(int device, int* n_cus) {
     // the decoder uses ~152 KB of the CU's 160 KB LDS: opt in to large dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCmpLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress_hc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHcLdsBytes));
     return 0;
 }
 
@@ -74,6 +77,14 @@ extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
 }
 
 extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return (size_t)dec_scratch_bytes(max_csize); }
+extern "C" size_t lz4amd_hip_hc_scratch_bytes(unsigned max_src) { return (size_t)hc_scratch_bytes(max_src); }
+extern "C" int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned grid, void* s) {
+    if (!p->n_blocks || !grid) return 0;
+    HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
+    hipLaunchKernelGGL(lz4amd_k_compress_hc, dim3(grid), dim3(kHcThreads), kHcLdsBytes, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 extern "C" int lz4amd_hip_launch_xxh32(const lz4amd_xxh_params* p, void* s) {
     if (!p->n_blocks) return 0;
     hipLaunchKernelGGL(lz4amd_k_xxh32, dim3(p->n_blocks), dim3(64), kXxhChunk, (hipStream_t)s, *p);

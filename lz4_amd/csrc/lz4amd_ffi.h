@@ -26,11 +26,13 @@ float       lz4amd_hip_event_ms(void* start, void* stop);
 
 /* kernel geometry facts the host needs for sizing */
 size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize);
+size_t      lz4amd_hip_hc_scratch_bytes(unsigned max_src);
 
 /* launches (asynchronous on `stream`) */
 int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* stream);
 int lz4amd_hip_launch_xxh32(const lz4amd_xxh_params* p, void* stream);
 int lz4amd_hip_launch_compress(const lz4amd_comp_params* p, unsigned grid, void* stream);
+int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned grid, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@ struct lz4amd_plan {
     void* ev[5];                        /* HIP events for the timed launch */
     lz4amd_dec_params dec;
     lz4amd_comp_params comp;
+    lz4amd_hc_params hc;
     lz4amd_xxh_params xxh;
 };
 
@@ -29,5 +30,9 @@ void lz4amd_set_error(const char* msg);
 
 /* process-wide default context used by the classic one-block API (lz4_api.c) */
 lz4amd_ctx* lz4amd_default_ctx(void);
+
+/* one host block through the device (lz4_api.c): upload, one-row plan, download; `fail` is returned
+ * when the device path cannot run */
+int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail);
 
 #endif

@@ -30,6 +30,21 @@ typedef struct lz4amd_comp_params {
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase cycle counts */
 } lz4amd_comp_params;
 
+typedef struct lz4amd_hc_params {
+    const uint8_t* const* src;      /* [n_blocks] */
+    const int32_t* src_size;
+    uint8_t* const* dst;
+    const int32_t* dst_cap;
+    int32_t* result;                /* [n_blocks] compressed size, 0 = failure */
+    uint32_t n_blocks;
+    uint32_t* ticket;               /* work-queue counter, zero before launch */
+    uint8_t* scratch;               /* grid * scratch_stride bytes: per-workgroup chain / search state / sequence records */
+    uint64_t scratch_stride;
+    uint32_t max_src;               /* largest src_size of the table (fixes the scratch layout) */
+    int32_t level;                  /* LZ4_compress_HC compressionLevel (lz4hc.h:66) */
+    uint64_t* prof;                 /* optional: 8 words per workgroup of phase cycle counts */
+} lz4amd_hc_params;
+
 typedef struct lz4amd_xxh_params {
     const uint8_t* const* src;      /* [n_blocks] */
     const int32_t* src_size;

@@ -101,6 +101,13 @@ def ratio(dargs, bs, lvl=None):
 G["ratio"]["p60_16m_4m_blocks"] = ratio(["-g16M", "-P60"], 4 << 20)
 G["ratio"]["p50_4m_64k_blocks"] = ratio(["-g4M", "-P50"], 64 << 10)
 G["ratio"]["p60_4m_256k_blocks_hc9"] = ratio(["-g4M", "-P60"], 256 << 10, 9)
+# LZ4_compress_HC at other depths and on other inputs (tests/test_gpu_hc.py, test_kernels_emulated.py)
+G["ratio"]["p60_4m_256k_blocks_hc3"] = ratio(["-g4M", "-P60"], 256 << 10, 3)
+G["ratio"]["p60_4m_256k_blocks_hc6"] = ratio(["-g4M", "-P60"], 256 << 10, 6)
+G["ratio"]["p90_4m_256k_blocks_hc9"] = ratio(["-g4M", "-P90"], 256 << 10, 9)
+G["ratio"]["p20_2m_256k_blocks_hc9"] = ratio(["-g2M", "-P20"], 256 << 10, 9)
+G["ratio"]["p60_8m_4m_blocks_hc9"] = ratio(["-g8M", "-P60"], 4 << 20, 9)
+G["ratio"]["p50_1m_64k_blocks_hc9"] = ratio(["-g1M", "-P50"], 64 << 10, 9)
 
 with open(os.path.join(HERE, "golden.json"), "w") as f:
     json.dump(G, f, indent=1, sort_keys=True)

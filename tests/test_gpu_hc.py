@@ -1,0 +1,127 @@
+"""LZ4_compress_HC on the GPU (BASELINE configs[3]): the gfx950 hash-chain kernel, called through the C
+ABI (include/lz4amd.h LZ4AMD_OP_COMPRESS_HC, include/lz4hc.h), checked by decoding with the oracle, with
+the real reference decoder when oracle/_ref travelled, and with the GPU decoder; sizes against the
+reference's level-9 results in tests/golden/golden.json (+-3 % window of the north star)."""
+import ctypes
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from test_gpu_parity import _dev, ctx, corpus  # noqa: E402,F401  (shared fixtures)
+
+
+def gpu_compress_hc(ctx, datas, level=9, caps=None, guard=64):
+    import lz4_amd
+    caps = caps or [lz4_amd.compress_bound(len(d)) for d in datas]
+    srcs = [_dev(d, pad=16) for d in datas]
+    dsts = [torch.full((max(c, 0) + guard,), 0xEE, dtype=torch.uint8, device="cuda") for c in caps]
+    table = lz4_amd.BlockTable([s.data_ptr() for s in srcs], [len(d) for d in datas],
+                               [d.data_ptr() for d in dsts], caps)
+    plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS_HC, table, level=level)
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    res = plan.results(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for r, d, cap in zip(res, dsts, caps):
+        h = d.cpu().numpy().tobytes()
+        assert h[max(cap, 0):] == b"\xEE" * guard, "wrote past dst[cap]"
+        outs.append((r, h[:max(r, 0)]))
+    return outs
+
+
+def test_hc_decodes_with_oracle_and_reference(ctx, ocodec, corpus):
+    outs = gpu_compress_hc(ctx, corpus)
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "liblz4_ref.so")
+    ref = ctypes.CDLL(so) if os.path.exists(so) else None
+    for d, (r, c) in zip(corpus, outs):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        if ref is not None:
+            out = ctypes.create_string_buffer(len(d) + 8)
+            assert ref.LZ4_decompress_safe(c, out, r, len(d)) == len(d) and out.raw[:len(d)] == d
+    assert outs[2][1] == b"\x00"
+
+
+def test_hc_capacity_semantics(ctx, datagen):
+    d = datagen(100000, 50, 3)
+    (r, c), = gpu_compress_hc(ctx, [d])
+    (r2, c2), (r3, _), (r4, _) = gpu_compress_hc(ctx, [d, d, d], caps=[r, r - 1, 1])
+    assert r2 == r and c2 == c                                         # exact size still succeeds
+    assert r3 == 0 and r4 == 0                                         # one byte less fails (limitedOutput, lz4hc.c:297-300)
+
+
+def test_hc_ratio_window_level9(ctx, golden, datagen):
+    for key, pct in (("p60_4m_256k_blocks_hc9", 60), ("p90_4m_256k_blocks_hc9", 90), ("p20_2m_256k_blocks_hc9", 20),
+                     ("p50_1m_64k_blocks_hc9", 50), ("p60_8m_4m_blocks_hc9", 60)):
+        g = golden["ratio"][key]
+        data = datagen(g["src"], pct, 0)
+        blocks = [data[o:o + g["block"]] for o in range(0, len(data), g["block"])]
+        ours = sum(r for r, _ in gpu_compress_hc(ctx, blocks))
+        assert abs(ours - g["csize"]) / g["csize"] < 0.03, (key, ours, g["csize"])
+
+
+def test_hc_levels(ctx, golden, datagen):
+    data = datagen(4 << 20, 60, 0)
+    blocks = [data[o:o + 262144] for o in range(0, len(data), 262144)]
+    sizes = {lvl: sum(r for r, _ in gpu_compress_hc(ctx, blocks, level=lvl)) for lvl in (3, 6, 9, 12, 0)}
+    assert sizes[3] >= sizes[6] >= sizes[9] == sizes[12] == sizes[0]
+    for lvl in (3, 6, 9):
+        g = golden["ratio"]["p60_4m_256k_blocks_hc%d" % lvl]
+        assert abs(sizes[lvl] - g["csize"]) / g["csize"] < 0.03, lvl
+
+
+def test_hc_far_matches(ctx, ocodec):
+    rnd = random.Random(11)
+    a = bytes(rnd.randrange(256) for _ in range(3000))
+    datas = [a + os.urandom(gap - len(a)) + a + os.urandom(500) for gap in (40000, 60000)]
+    for d, (r, c) in zip(datas, gpu_compress_hc(ctx, datas)):
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        assert r < len(d) - 2500
+
+
+def test_hc_classic_host_pointer_api(ctx, ocodec, golden, datagen):
+    import lz4_amd
+    L = lz4_amd.lib()
+    d = datagen(65536, 50, 0)
+    dst = ctypes.create_string_buffer(L.LZ4_compressBound(len(d)))
+    r = L.LZ4_compress_HC(d, dst, len(d), len(dst), 9)
+    g = golden["blocks"]["p50_64k_hc9"]
+    assert r > 0 and abs(r - g["csize"]) / g["csize"] < 0.03
+    ro, o = ocodec.decompress(dst.raw[:r], len(d))
+    assert ro == len(d) and o == d
+    assert L.LZ4_compress_HC(d, dst, len(d), 100, 9) == 0
+    assert L.LZ4_compress_HC(b"", dst, 0, 10, 9) == 1 and dst.raw[0] == 0
+    assert L.LZ4_sizeofStateHC() == 262200
+    state = ctypes.create_string_buffer(262200 + 8)
+    sp = (ctypes.addressof(state) + 7) & ~7
+    assert L.LZ4_compress_HC_extStateHC(ctypes.c_void_p(sp), d, dst, len(d), len(dst), 9) == r
+    assert L.LZ4_compress_HC_extStateHC(None, d, dst, len(d), len(dst), 9) == 0
+
+
+def test_hc_config3_full_size_properties(ctx, golden, datagen, ocodec):
+    """BASELINE configs[3] at 256 MiB: datagen -P60 cut in 256 KiB blocks, LZ4_compress_HC level 9, device
+    resident; decoded by the GPU decoder (bit exact) and, for a sample, by the CPU oracle."""
+    import lz4_amd
+    bs, nblk = 256 << 10, 1024
+    host = bytearray()
+    for s in range(4):
+        host += datagen(nblk // 4 * bs, 60, s)
+    data = torch.frombuffer(host, dtype=torch.uint8).cuda()
+    comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs, hc_level=9)
+    assert all(0 < c <= lz4_amd.compress_bound(bs) for c in csizes)
+    out, res, _ = lz4_amd.decompress_blocks(ctx, comp, csizes, bs, data.numel())
+    assert res == [bs] * nblk and torch.equal(out, data)
+    g = golden["ratio"]["p60_4m_256k_blocks_hc9"]                       # the first 16 blocks are the golden 4 MiB
+    assert abs(sum(csizes[:16]) - g["csize"]) / g["csize"] < 0.03
+    fast, fsizes, _ = lz4_amd.compress_blocks(ctx, data, bs)
+    assert sum(csizes) < 0.85 * sum(fsizes)                             # HC pays: 2.6 vs 2.0 on this input
+    hcm = comp.cpu().numpy()
+    for i in (0, 511, 1023):
+        ro, o = ocodec.decompress(hcm[i, :csizes[i]].tobytes(), bs)
+        assert ro == bs and o == bytes(host[i * bs:(i + 1) * bs])

@@ -238,3 +238,94 @@ def test_compress_with_history_decodes_with_prefix_oracle(emu, oracle, datagen):
     oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
     r = oracle.lz4o_decompress_safe_prefix(dst.raw[:res[0]], ctypes.addressof(out) + pre, res[0], n, pre)
     assert r == n and out.raw[pre:pre + n] == data[pre:pre + n]
+
+
+# ------------------------------------------------------------------ LZ4_compress_HC kernel (lz4_hc_kernel.h)
+def emu_compress_hc(emu, datas, level=9, caps=None, grid=0):
+    n = len(datas)
+    caps = caps or [len(d) + len(d) // 255 + 16 for d in datas]
+    srcs = [ctypes.create_string_buffer(d, len(d)) if d else ctypes.create_string_buffer(1) for d in datas]
+    dsts = [ctypes.create_string_buffer(max(c, 0) + 64) for c in caps]
+    for d in dsts:
+        ctypes.memset(d, CANARY, len(d))
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs])
+    dp = (ctypes.c_void_p * n)(*[ctypes.addressof(d) for d in dsts])
+    ss = (ctypes.c_int32 * n)(*[len(d) for d in datas])
+    dc = (ctypes.c_int32 * n)(*caps)
+    res = (ctypes.c_int32 * n)()
+    emu.emu_compress_hc_batch(sp, ss, dp, dc, res, n, grid, level)
+    outs = []
+    for i in range(n):
+        raw = dsts[i].raw
+        cap = max(caps[i], 0)
+        assert raw[cap:cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
+        outs.append((res[i], raw[:max(res[i], 0)]))
+    return outs
+
+
+def test_hc_roundtrip_through_oracle_decoder(emu, ocodec, corpus):
+    outs = emu_compress_hc(emu, corpus)
+    fast = emu_compress(emu, corpus)
+    for d, (r, c), (rf, _) in zip(corpus, outs, fast):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        assert r <= rf + 16 + len(d) // 2000                     # the deep search never loses to the fast level (strip cuts aside)
+    assert outs[2][1] == b"\x00"                                  # empty input -> single 00 byte
+
+
+def test_hc_exact_capacity_and_one_less(emu, ocodec, datagen):
+    d = datagen(100000, 50, 3)
+    (r, c), = emu_compress_hc(emu, [d])
+    (r2, c2), (r3, _), (r4, _) = emu_compress_hc(emu, [d, d, d], caps=[r, r - 1, 1])
+    assert r2 == r and c2 == c
+    assert r3 == 0 and r4 == 0
+
+
+def test_hc_ratio_within_3pct_of_reference_level9(emu, golden, datagen):
+    """+-3 % of the reference's LZ4_compress_HC level 9 (north star) on the benchmark input of configs[3]
+    (datagen -P60 cut in 256 KB blocks) and on less / more compressible streams."""
+    for key, pct, nblk in (("p60_4m_256k_blocks_hc9", 60, 4), ("p90_4m_256k_blocks_hc9", 90, 4), ("p20_2m_256k_blocks_hc9", 20, 2)):
+        g = golden["ratio"][key]
+        data = datagen(g["src"], pct, 0)
+        blocks = [data[o:o + g["block"]] for o in range(0, len(data), g["block"])]
+        ref_per_block = g["csize"] / len(blocks)
+        ours = sum(r for r, _ in emu_compress_hc(emu, blocks[:nblk])) / nblk
+        assert abs(ours - ref_per_block) / ref_per_block < 0.03, (key, ours, ref_per_block)
+    g = golden["blocks"]["p50_64k_hc9"]
+    (r, _), = emu_compress_hc(emu, [datagen(65536, 50, 0)])
+    assert abs(r - g["csize"]) / g["csize"] < 0.03
+
+
+def test_hc_levels_trade_ratio_for_depth(emu, golden, datagen):
+    """k_clTable (lz4hc.c:92-106): 4 attempts at level 3, 32 at level 6, 256 at level 9."""
+    data = datagen(1 << 20, 60, 0)
+    blocks = [data[o:o + 262144] for o in range(0, len(data), 262144)]
+    sizes = {lvl: sum(r for r, _ in emu_compress_hc(emu, blocks[:2], level=lvl)) for lvl in (3, 6, 9, 12, 0)}
+    assert sizes[3] >= sizes[6] >= sizes[9] == sizes[12] == sizes[0]
+    for lvl in (3, 6):
+        g = golden["ratio"]["p60_4m_256k_blocks_hc%d" % lvl]
+        ref = g["csize"] / (g["src"] / g["block"]) * 2
+        assert abs(sizes[lvl] - ref) / ref < 0.03
+
+
+def test_hc_matches_beyond_32k_are_found(emu, ocodec):
+    """The window is searched in two bands of 32 K positions: a repeat 40 000 / 60 000 bytes back must be
+    found by the second band (offsets > 32 768 in the stream)."""
+    rnd = random.Random(11)
+    a = bytes(rnd.randrange(256) for _ in range(3000))
+    for gap in (40000, 60000):
+        d = a + os.urandom(gap - len(a)) + a + os.urandom(500)
+        (r, c), = emu_compress_hc(emu, [d])
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        assert r < len(d) - 2500, "the far repeat was not matched"
+
+
+def test_hc_4mib_block(emu, ocodec, golden, datagen):
+    g = golden["ratio"]["p60_8m_4m_blocks_hc9"]
+    d = datagen(4 << 20, 60, 0)
+    (r, c), = emu_compress_hc(emu, [d])
+    ro, o = ocodec.decompress(c, len(d))
+    assert ro == len(d) and o == d
+    assert abs(r - g["csize"] / 2) / (g["csize"] / 2) < 0.03

@@ -1,0 +1,27 @@
+"""Developer aid: timing and phase breakdown of the HC kernel (LZ4AMD_PROF cycle counts). GPU only."""
+import ctypes, os, sys, statistics
+os.environ["LZ4AMD_PROF"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, lz4_amd
+from bench import gen_data
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 256 << 10
+pct = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+level = int(sys.argv[4]) if len(sys.argv) > 4 else 9
+ctx = lz4_amd.Context(0)
+data = torch.from_numpy(gen_data(nb * bs, pct, 0)).cuda()
+comp, csizes, plan = lz4_amd.compress_blocks(ctx, data, bs, hc_level=level)
+s = torch.cuda.current_stream().cuda_stream
+runs = 2
+for _ in range(runs):
+    km, tot = plan.launch_timed(s)
+print("HC level %d, %d x %d B P%d: kernel ms %.2f  GB/s in %.2f  ratio %.3f" % (level, nb, bs, pct, km[0], nb * bs / km[0] / 1e6, nb * bs / sum(csizes)))
+L = lz4_amd.lib()
+w = (ctypes.c_ulonglong * (256 * 8))()
+n = L.lz4amd_plan_profile(plan._h, w, len(w))
+names = ["chain build", "search band 0", "search band 1", "-", "parse", "offsets + emit"]
+blocks_per_wg = nb / (n // 8) * (runs + 1)
+for k, name in enumerate(names):
+    d = [w[i * 8 + k] for i in range(n // 8)]
+    print("%-16s cycles per block: median %.0f  max %.0f" % (name, statistics.median(d) / blocks_per_wg, max(d) / blocks_per_wg))
