@@ -18,7 +18,8 @@ class Lz4AmdError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "liblz4_amd.so")
+    # LZ4AMD_LIB: developer override (kernel experiments built next to the product library)
+    return os.environ.get("LZ4AMD_LIB") or os.path.join(_HERE, "liblz4_amd.so")
 
 
 def lib():

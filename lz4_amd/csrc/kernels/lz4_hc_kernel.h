@@ -20,12 +20,14 @@
 //   2 search   EVERY position looks for its longest match (the parse order is not known yet, and
 //              no longer matters).  The LZ4 window is 64 K positions x (1 source byte + 2 chain bytes)
 //              = 192 KB, more than a CU's LDS, so the window is searched in BANDS of 32 K positions:
-//              a pass streams the block through a 32 KB source ring + 64 KB chain ring, every lane
-//              walks its position's chain while the candidates are inside the band, and parks
-//              {best length, best offset, distance of the next candidate, attempts left} in scratch;
-//              the next pass streams the band 32 K further back and resumes the walks.  Every probe
-//              of the inner loop is an LDS access.  Lengths are measured up to kHcLenCap bytes.
-//   3 parse    16 strips, one wave each: the wave looks at 64 positions at a time, takes the first
+//              a pass streams the block through a 32 KB source ring + 64 KB chain ring in tiles of
+//              8 K positions, every lane walks the chains of its 8 positions while the candidates are
+//              inside the band, and parks {best length, best offset, distance of the next candidate,
+//              attempts left} (6 bytes, staged in LDS, flushed coalesced); the next pass streams the
+//              band 32 K further back and resumes the walks.  Every probe of the inner loop is an LDS
+//              access.  Lengths are measured up to kHcLenCap bytes.
+//   3 parse    16 strips, one wave each (the per-position results are staged through LDS in chunks
+//              of 1 K positions): the wave looks at 64 positions at a time, takes the first
 //              match that neither of the next two positions beats (lazy evaluation, the role of the
 //              reference's LZ4HC_InsertAndGetWiderMatch retries, lz4hc.c:1168-1330), extends capped
 //              matches with a wave-wide compare, and records {literal run, offset, length}.
@@ -33,9 +35,9 @@
 //   4 emit     strip sizes -> output offsets (wave 0), then every wave writes its strip
 //              (emit_strip of the fast compressor).
 //
-// HBM/L2 traffic per block: source read 3 + bands times, 2 B/position of chain written once and read
-// once per band, 8 B/position of search state written and read once per band, 8 B per sequence of
-// records, compressed stream written once.  No MFMA: integer / byte work.
+// HBM/L2 traffic per block: source read 2 + 2 x bands times, 2 B/position of chain written once and
+// read once per band, 6 B/position of search state written and read once per band, 8 B per sequence
+// of records, compressed stream written once.  No MFMA: integer / byte work.
 #pragma once
 #include "lz4_compress_kernel.h"
 
@@ -47,18 +49,20 @@ enum : uint32_t {
     kHcThreads = 1024,
     kHcWaves = kHcThreads / 64,
     kHcHashLog = 15,                    // lz4hc.h:226 LZ4HC_HASH_LOG
+    kHcTurnGroups = 4,                  // groups of 64 positions a wave links per turn of the token
     kHcRing = 32768,                    // positions per band (source ring bytes, chain ring entries)
-    kHcPad = 16,                        // mirror of the source ring's first bytes
-    kHcTile = 2048,                     // positions searched between two ring refills
+    kHcPad = 32,                        // mirror of the source ring's first bytes (reads of up to 36 bytes: see lds_ld16)
+    kHcTile = 8192,                     // positions searched between two ring refills
     kHcPosPerThread = kHcTile / kHcThreads,
     kHcAhead = 272,                     // source bytes the rings hold past every position of the tile
     kHcLenCap = 250,                    // longest match a lane measures on its own (<= kHcAhead - 8, fits 8 bits)
     kHcBandStep = kHcRing - kHcAhead,   // how much further back the next band starts
-    kHcBands = 2,                       // window reached: 62944 (the tile's first position) .. 64991 (its last)
+    kHcBands = 3,                       // 3 x 32496 >= 65535 + kHcTile + kHcAhead: the whole LZ4 window, for every position
     kHcMinStrip = 1024,
-    kHcMaxAttempts = 256,               // level 9 (lz4hc.c:102)
+    kHcChunk = 1024,                    // positions of search results a parsing wave stages in LDS at a time
+    kHcBatch = 8,                       // links a lane chases before it verifies the candidates found
 };
-// LDS carve-up (bytes); the chain phase and the search phase reuse the same region
+// LDS carve-up (bytes); the chain phase, the search phase and the parse phase reuse the same region
 enum : uint32_t {
     kHOffMisc = 0,                                  // u32[32]
     kHOffStrip = 128,                               // u32[6][16] strip summaries
@@ -67,17 +71,27 @@ enum : uint32_t {
     kHOffSrc = kHOffBody,                           // phase 2: source ring + pad
     kHOffChain = kHOffSrc + kHcRing + kHcPad,       //          u16[kHcRing]
     kHOffMine = kHOffChain + 2 * kHcRing,           //          the tile's own bytes
-    kHcMineBytes = kHcTile + kHcAhead + 16,
-    kHcLdsBytes = kHOffBody + (4u << kHcHashLog),
+    kHcMineBytes = kHcTile + kHcAhead + 48,           // 36-byte reads at up to kHcLenCap bytes past the tile's last position
+    kHOffRes0 = kHOffMine + kHcMineBytes,           //          u32[kHcTile] per-position state, word 0
+    kHOffRes1 = kHOffRes0 + 4 * kHcTile,            //          u16[kHcTile] per-position state, word 1
+    kHcSearchEnd = kHOffRes1 + 2 * kHcTile,
+    kHOffWtab = kHOffBody + (4u << kHcHashLog),     // phase 1: u32[kHcWaves][256] duplicate detection, one table per wave
+    kHOffParse = kHOffBody,                         // phase 3: u32[kHcWaves][2 * kHcChunk]
+    kHcLdsBytes = kHcSearchEnd,
 };
-static_assert(kHOffMine + kHcMineBytes <= kHcLdsBytes, "search phase must fit in the chain phase's LDS");
+static_assert(kHOffWtab + kHcWaves * 256 * 4 <= kHcLdsBytes, "head table + duplicate tables must fit");
+static_assert(kHOffParse + kHcWaves * 2 * kHcChunk * 4 <= kHcLdsBytes, "parse staging must fit");
+static_assert(kHcLdsBytes <= 160 * 1024, "one CU's LDS");
+static_assert(kHcBands * kHcBandStep >= 65535 + kHcTile + kHcAhead, "bands must cover the LZ4 window");
+static_assert(kHOffMine % 16 == 0 && kHOffRes0 % 16 == 0 && kHOffRes1 % 16 == 0 && kHOffChain % 16 == 0, "16-byte LDS accesses");
 enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4 };
 
 // scratch layout of one workgroup, for blocks of at most n bytes
 __host__ __device__ inline uint64_t hc_chain_bytes(uint32_t n) { return ((uint64_t)2 * (n + 64) + 255) & ~255ull; }
-__host__ __device__ inline uint64_t hc_state_bytes(uint32_t n) { return ((uint64_t)8 * (n + 64) + 255) & ~255ull; }
+__host__ __device__ inline uint64_t hc_st0_bytes(uint32_t n) { return ((uint64_t)4 * (n + kHcTile) + 255) & ~255ull; }
+__host__ __device__ inline uint64_t hc_st1_bytes(uint32_t n) { return ((uint64_t)2 * (n + kHcTile) + 255) & ~255ull; }
 __host__ __device__ inline uint64_t hc_recs_bytes(uint32_t n) { return (uint64_t)8 * (n / 4 + 64 * kHcWaves); }
-__host__ __device__ inline uint64_t hc_scratch_bytes(uint32_t n) { return hc_chain_bytes(n) + hc_state_bytes(n) + hc_recs_bytes(n); }
+__host__ __device__ inline uint64_t hc_scratch_bytes(uint32_t n) { return hc_chain_bytes(n) + hc_st0_bytes(n) + hc_st1_bytes(n) + hc_recs_bytes(n); }
 
 __device__ __forceinline__ uint32_t hc_attempts(int level) {
     // k_clTable lz4hc.c:92-106 (levels below 3 and the optimal-parser levels 10-12 are served by the
@@ -89,56 +103,108 @@ __device__ __forceinline__ uint32_t hc_attempts(int level) {
 }
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHcHashLog); }
 
-struct HcState { uint32_t w0, w1; };    // w0 = best offset | next candidate distance << 16; w1 = best length | attempts left << 8
+// Per-position search state between bands: st0 = best offset | distance of the next candidate << 16 (0 = walk
+// finished), st1 = best length | (attempts left - 1) << 8.  After the last band st0 = best length | offset << 8.
 
 // ------------------------------------------------------------------------------ phase 1: chains
+// Lanes of the group that share my hash: `below` = how many lower lanes do (-> the previous position with my
+// hash is in the group), `last` = no higher lane does.  Most groups have no duplicates at all, so lanes first
+// count themselves into a 1024-slot table private to the wave; only lanes whose slot was hit more than once
+// compare hashes, one distinct value per trip.
+__device__ __forceinline__ void hc_group_links(uint32_t h, bool valid, uint32_t* wtab, uint32_t lane, int& pred, bool& last) {
+    const uint32_t word = (h >> 2) & 255u, sh = (h & 3u) * 8;      // 1024 one-byte counters in 256 words
+    if (valid) atomicAdd(&wtab[word], 1u << sh);
+    wave_lds_fence();
+    const uint32_t cnt = valid ? (wtab[word] >> sh) & 0xFFu : 0u;
+    wave_lds_fence();
+    if (valid) wtab[word] = 0;
+    wave_lds_fence();
+    pred = -1; last = true;
+    const bool crowded = cnt > 1;
+    unsigned long long rem = __ballot(crowded);
+    while (rem) {
+        const uint32_t l = (uint32_t)__ffsll((long long)rem) - 1;
+        const uint32_t hk = wave_readlane(h, l);
+        const bool same = crowded && h == hk;
+        const unsigned long long mm = __ballot(same);
+        rem &= ~mm;
+        if (same) {
+            const unsigned long long below = mm & ((1ull << lane) - 1);
+            pred = below ? 63 - __clzll(below) : -1;
+            last = ((mm >> lane) >> 1) == 0;
+        }
+    }
+}
+
 __device__ __forceinline__ void hc_build_chain(lz4amd_gsrc src, uint32_t n, uint16_t* chain_g, char* smem) {
     const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
     uint32_t* head = (uint32_t*)(smem + kHOffHead);
+    uint32_t* wtab = (uint32_t*)(smem + kHOffWtab) + w * 256;
     for (uint32_t i = tid; i < (1u << kHcHashLog); i += kHcThreads) head[i] = 0;
+    for (uint32_t i = lane; i < 256; i += 64) wtab[i] = 0;
     if (tid == 0) misc[HM_TOKEN] = 0;
     __syncthreads();
     const uint32_t ngroups = (n + 63) / 64;
-    for (uint32_t g = w; g < ngroups; g += kHcWaves) {
-        const uint32_t p = g * 64 + lane;
-        const bool valid = p + 4 <= n;
-        uint32_t v = 0;
-        if (valid) __builtin_memcpy(&v, src + p, 4);
-        const uint32_t h = hc_hash(v);
-        // links inside the group: previous lane with my hash, and whether I am the last one with it
-        int pred = -1;
-        bool last = true;
-        unsigned long long rem = __ballot(valid);
-        while (rem) {
-            const uint32_t l = (uint32_t)__ffsll((long long)rem) - 1;
-            const uint32_t hk = wave_readlane(h, l);
-            const bool same = valid && h == hk;
-            const unsigned long long mm = __ballot(same);
-            rem &= ~mm;
-            if (same) {
-                const unsigned long long below = mm & ((1ull << lane) - 1);
-                pred = below ? 63 - __clzll(below) : -1;
-                last = ((mm >> lane) >> 1) == 0;
-            }
+    const uint32_t nturns = (ngroups + kHcTurnGroups - 1) / kHcTurnGroups;
+    for (uint32_t turn = w; turn < nturns; turn += kHcWaves) {
+        uint32_t h[kHcTurnGroups], prev1[kHcTurnGroups];
+        bool valid[kHcTurnGroups], first[kHcTurnGroups], last[kHcTurnGroups];
+        // links inside each group of 64: previous lane with my hash, and whether I am the last one with it
+#pragma unroll
+        for (uint32_t j = 0; j < kHcTurnGroups; j++) {
+            const uint32_t p = (turn * kHcTurnGroups + j) * 64 + lane;
+            valid[j] = p + 4 <= n;
+            uint32_t v = 0;
+            if (valid[j]) __builtin_memcpy(&v, src + p, 4);
+            h[j] = hc_hash(v);
+            int pred;
+            hc_group_links(h[j], valid[j], wtab, lane, pred, last[j]);
+            first[j] = pred < 0;
+            prev1[j] = pred >= 0 ? (turn * kHcTurnGroups + j) * 64 + (uint32_t)pred + 1 : 0;
         }
         // my turn: groups read and update the head table in position order
-        while (lds_load_acquire(&misc[HM_TOKEN]) != g) spin_pause();
-        uint32_t old = 0;
-        if (valid && pred < 0) old = head[h];
-        wave_lds_fence();
-        if (valid && last) head[h] = p + 1;
-        wave_lds_fence();
-        if (lane == 0) lds_store_release(&misc[HM_TOKEN], g + 1);
-        const uint32_t prev1 = pred >= 0 ? g * 64 + (uint32_t)pred + 1 : old;      // previous position + 1, 0 = none
-        uint32_t delta = 0;
-        if (valid && prev1) { const uint32_t d = p + 1 - prev1; if (d <= kMaxDistance) delta = d; }
-        chain_g[p] = (uint16_t)delta;                 // the array is padded to a multiple of 64 entries
+        while (lds_load_acquire(&misc[HM_TOKEN]) != turn) spin_pause();
+#pragma unroll
+        for (uint32_t j = 0; j < kHcTurnGroups; j++) {
+            const uint32_t p = (turn * kHcTurnGroups + j) * 64 + lane;
+            if (valid[j] && first[j]) prev1[j] = head[h[j]];
+            wave_lds_order();
+            if (valid[j] && last[j]) head[h[j]] = p + 1;
+            wave_lds_order();
+        }
+        // reads, writes and the token are queued back to back: the DS unit keeps a wave's order, the next
+        // wave's accesses come after the token it has seen
+        if (lane == 0) lds_store_relaxed(&misc[HM_TOKEN], turn + 1);
+#pragma unroll
+        for (uint32_t j = 0; j < kHcTurnGroups; j++) {
+            const uint32_t p = (turn * kHcTurnGroups + j) * 64 + lane;        // prev1 = previous position + 1, 0 = none
+            uint32_t delta = 0;
+            if (valid[j] && prev1[j]) { const uint32_t d = p + 1 - prev1[j]; if (d <= kMaxDistance) delta = d; }
+            if (p < ngroups * 64) chain_g[p] = (uint16_t)delta; // the array is padded to a multiple of 64 entries
+        }
     }
     __syncthreads();
 }
 
 // ------------------------------------------------------------------------------ phase 2: band search
+// sixteen bytes at any alignment out of an LDS byte array: five aligned dwords + four v_alignbyte
+struct Q16 { uint32_t a, b, c, d; };
+__device__ __forceinline__ Q16 lds_ld16(const uint8_t* base, uint32_t o) {
+    const uint32_t* w = (const uint32_t*)(base + (o & ~3u));
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], sh = o & 3u;
+    Q16 r; r.a = align_bytes(w1, w0, sh); r.b = align_bytes(w2, w1, sh); r.c = align_bytes(w3, w2, sh); r.d = align_bytes(w4, w3, sh);
+    return r;
+}
+// number of equal leading bytes of two 16-byte strings (0..16)
+__device__ __forceinline__ uint32_t equal_bytes16(const Q16& x, const Q16& y) {
+    const uint32_t a = x.a ^ y.a, b = x.b ^ y.b, c = x.c ^ y.c, d = x.d ^ y.d;
+    if (a) return (uint32_t)(__ffs((int)a) - 1) >> 3;
+    if (b) return 4 + ((uint32_t)(__ffs((int)b) - 1) >> 3);
+    if (c) return 8 + ((uint32_t)(__ffs((int)c) - 1) >> 3);
+    if (d) return 12 + ((uint32_t)(__ffs((int)d) - 1) >> 3);
+    return 16;
+}
 // four bytes at any alignment out of an LDS byte array (two aligned dword reads + v_alignbyte)
 __device__ __forceinline__ uint32_t lds_ld4(const uint8_t* base, uint32_t o) {
     const uint32_t* a = (const uint32_t*)(base + (o & ~3u));
@@ -150,106 +216,156 @@ __device__ __forceinline__ void hc_commit_src(uint8_t* ring, uint32_t P, const U
     if (o < kHcPad) *(U32x4*)(ring + kHcRing + o) = v;
 }
 
-__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, const uint16_t* chain_g, HcState* state_g,
+__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
                                                uint32_t band, uint32_t attempts, char* smem) {
     const uint32_t tid = threadIdx.x;
     uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
     uint16_t* cring = (uint16_t*)(smem + kHOffChain);
     uint8_t* mine = (uint8_t*)(smem + kHOffMine);
+    uint32_t* res0 = (uint32_t*)(smem + kHOffRes0);
+    uint16_t* res1 = (uint16_t*)(smem + kHOffRes1);
     const uint32_t n64 = (n + 63) & ~63u;
     const int32_t last_q = (int32_t)n - (int32_t)kMfLimit;            // last position that may start a match
     const int32_t shift = (int32_t)(band * kHcBandStep);
+    const bool final_band = band + 1 == kHcBands;
     // the rings hold positions [H - kHcRing, H), H = t0 + kHcTile + kHcAhead - shift
     // -- first tile: fill [0, H(0)) directly
     {
         const int32_t H = (int32_t)(kHcTile + kHcAhead) - shift;
         const int32_t Ps = 16 * (int32_t)tid, Pc = 8 * (int32_t)tid;
         if (Ps < H && (uint32_t)Ps < n) hc_commit_src(ring, (uint32_t)Ps, load_src16(src, n, (uint32_t)Ps));
-        if (Pc < H && (uint32_t)Pc < n64) *(U32x4*)(cring + (Pc & (int32_t)(kHcRing - 1))) = *(const U32x4*)(chain_g + Pc);
+        for (int32_t P = Pc; P < H && (uint32_t)P < n64; P += 8 * (int32_t)kHcThreads)
+            *(U32x4*)(cring + (P & (int32_t)(kHcRing - 1))) = *(const U32x4*)(chain_g + P);
         if (tid < kHcMineBytes / 16) *(U32x4*)(mine + 16 * tid) = load_src16(src, n, 16 * tid);      // zero filled past n
     }
     for (uint32_t t0 = 0; t0 < n; t0 += kHcTile) {
         const int32_t H = (int32_t)(t0 + kHcTile + kHcAhead) - shift;
         const int32_t low = H - (int32_t)kHcRing;                     // lowest candidate position of this band
-        // -- prefetch the next tile's ring granules and this tile's own bytes
-        const int32_t Ps = H + 16 * (int32_t)tid, Pc = H + 8 * ((int32_t)tid - 256);
+        // -- prefetch the next tile's ring granules and own bytes
+        const int32_t Ps = H + 16 * (int32_t)tid, Pc = H + 8 * (int32_t)tid;
         const bool have_s = tid < kHcTile / 16 && Ps >= 0 && (uint32_t)Ps < n;
-        const bool have_c = tid >= 256 && tid < 256 + kHcTile / 8 && Pc >= 0 && (uint32_t)Pc < n64;
-        const uint32_t Pm = t0 + kHcTile + 16 * (tid - 512);          // the next tile's own bytes
-        const bool have_m = tid >= 512 && tid < 512 + kHcMineBytes / 16;
+        const bool have_c = Pc >= 0 && (uint32_t)Pc < n64;           // kHcTile / 8 == kHcThreads granules
+        const uint32_t Pm = t0 + kHcTile + 16 * tid;
+        const bool have_m = tid < kHcMineBytes / 16;
         U32x4 ps, pc, pm;
         ps[0] = ps[1] = ps[2] = ps[3] = 0; pc = ps; pm = ps;
         if (have_s) ps = load_src16(src, n, (uint32_t)Ps);
         if (have_c) pc = *(const U32x4*)(chain_g + Pc);
         if (have_m && Pm < n) pm = load_src16(src, n, Pm);
+        // -- the walks' state left by the previous band
+        if (band != 0) {
+            *(U32x4*)(res0 + 4 * tid) = *(const U32x4*)(st0_g + t0 + 4 * tid);
+            *(U32x4*)(res0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads));
+            *(U32x4*)(res1 + 8 * tid) = *(const U32x4*)(st1_g + t0 + 8 * tid);
+        }
         __syncthreads();
-        // -- every thread walks the chains of its positions (no wave-wide operation inside: lanes are free
-        //    to be at different positions and different depths)
-        uint32_t slot = 0;
-        bool active = false;
-        int32_t p = 0;
-        uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0;
-        for (;;) {
-            if (!active) {
-                if (slot >= kHcPosPerThread) break;
-                p = (int32_t)(t0 + slot * kHcThreads + tid);
-                pp = slot * kHcThreads + tid;
-                slot++;
-                if ((uint32_t)p >= n) continue;
-                if (p > last_q) { if (band == 0) { HcState z; z.w0 = 0; z.w1 = 3; state_g[p] = z; } continue; }
-                if (band == 0) { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
-                else {
-                    const HcState s = state_g[p];
-                    dist = s.w0 >> 16; boff = s.w0 & 0xFFFFu; best = s.w1 & 0xFFu; att = s.w1 >> 8;
-                    if (dist == 0) continue;                            // finished in an earlier band
-                }
-                lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
-                if (lim > kHcLenCap) lim = kHcLenCap;
-                mt = lds_ld4(mine, pp + best - 3);
-                active = true;
-            }
-            uint32_t next = 0;                                          // distance to resume at in the next band
-            bool fin = false;
-            if (dist == 0 || dist > kMaxDistance || att == 0) fin = true;
-            else {
-                const int32_t q = p - (int32_t)dist;
-                if (q < low) { fin = true; next = band + 1 < kHcBands ? dist : 0; }
-                else {
-                    att--;
-                    const uint32_t qo = (uint32_t)q & (kHcRing - 1);
-                    // a longer match must agree on the four bytes that end at index `best` (for best = 3
-                    // this is the MINMATCH test; lz4hc.c:934-936)
-                    if (lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
-                        uint32_t l = 0;
-                        while (l < lim) {
-                            const uint32_t x = lds_ld4(ring, (qo + l) & (kHcRing - 1)) ^ lds_ld4(mine, pp + l);
-                            if (x) { l += (uint32_t)(__ffs((int)x) - 1) >> 3; break; }
-                            l += 4;
+        // -- the walks.  A wave owns 64 * kHcPosPerThread consecutive positions of the tile and hands them to
+        //    its lanes as they fall idle (ballot + mbcnt, no atomics).  The loop is wave-synchronous and
+        //    predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
+        //    nothing else on the path), then VERIFIES the candidates found (independent reads).
+        {
+            const uint32_t lane = lane_id();
+            const uint32_t wbase = wave_id() * (64 * kHcPosPerThread);   // first tile-relative position of my wave
+            uint32_t wnext = 0;                                          // positions of the wave handed out so far
+            bool active = false;
+            int32_t p = 0;
+            uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0;
+            for (;;) {
+                // ---- hand out
+                const unsigned long long idle = __ballot(!active);
+                if (idle && wnext < 64 * kHcPosPerThread) {
+                    const uint32_t mine_i = wnext + lanes_below(idle);
+                    wnext += (uint32_t)__popcll(idle);
+                    if (!active && mine_i < 64 * kHcPosPerThread) {
+                        pp = wbase + mine_i;
+                        p = (int32_t)(t0 + pp);
+                        bool walk = true;
+                        if (band == 0) {
+                            if (p > last_q) { res0[pp] = 0; res1[pp] = 3; walk = false; }     // also the slots past the block's end
+                            else { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
+                        } else {
+                            const uint32_t s0 = res0[pp], s1 = res1[pp];
+                            dist = s0 >> 16; boff = s0 & 0xFFFFu; best = s1 & 0xFFu; att = (s1 >> 8) + 1;
+                            if (dist == 0) { if (final_band) res0[pp] = best | (boff << 8); walk = false; }   // finished earlier
                         }
-                        if (l > lim) l = lim;
-                        if (l > best) {
-                            best = l; boff = dist;
-                            if (l >= lim) fin = true;
-                            else mt = lds_ld4(mine, pp + best - 3);
+                        if (walk) {
+                            lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
+                            if (lim > kHcLenCap) lim = kHcLenCap;
+                            mt = lds_ld4(mine, pp + best - 3);
+                            active = true;
                         }
                     }
-                    if (!fin) {
-                        const uint32_t d = cring[qo];
-                        if (d == 0) fin = true; else dist += d;
+                }
+                if (!__ballot(active)) { if (wnext >= 64 * kHcPosPerThread) break; continue; }
+                // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
+                uint32_t cd[kHcBatch];
+                uint32_t next = 0;                                      // where the next band resumes
+                bool over = !active;
+#pragma unroll
+                for (uint32_t k = 0; k < kHcBatch; k++) {
+                    const int32_t q = p - (int32_t)dist;
+                    const bool in_chain = !over && dist != 0 && dist <= kMaxDistance && att != 0;
+                    const bool in_band = q >= low;
+                    const bool take = in_chain && in_band;
+                    if (in_chain && !in_band) next = final_band ? 0 : dist;
+                    over = over || !take;
+                    cd[k] = take ? dist : 0;
+                    const uint32_t d = cring[(uint32_t)q & (kHcRing - 1)];
+                    att -= take ? 1u : 0u;
+                    if (take) { if (d == 0) over = true; else dist += d; }
+                }
+                // ---- verify: a longer match must agree on the four bytes that end at index `best` (for best = 3
+                //      this is the MINMATCH test; lz4hc.c:934-936)
+                uint32_t ct[kHcBatch];
+#pragma unroll
+                for (uint32_t k = 0; k < kHcBatch; k++)
+                    ct[k] = lds_ld4(ring, ((uint32_t)(p - (int32_t)cd[k]) + best - 3) & (kHcRing - 1));
+                bool full = false;
+                const uint32_t mt0 = mt, best0 = best;                  // what the ct[] were read against
+#pragma unroll
+                for (uint32_t k = 0; k < kHcBatch; k++) {
+                    const bool hit = cd[k] != 0 && ct[k] == mt0 && !full;
+                    if (__ballot(hit)) {
+                        const uint32_t qo = (uint32_t)(p - (int32_t)cd[k]) & (kHcRing - 1);
+                        // an earlier candidate of the batch may have raised `best`: test again at the new index
+                        if (hit && (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt)) {
+                            // common length, 32 bytes per trip (all reads of a trip are independent)
+                            uint32_t l = 0;
+                            while (l < lim) {
+                                const Q16 r0 = lds_ld16(ring, (qo + l) & (kHcRing - 1)), r1 = lds_ld16(ring, (qo + l + 16) & (kHcRing - 1));
+                                const Q16 m0 = lds_ld16(mine, pp + l), m1 = lds_ld16(mine, pp + l + 16);
+                                const uint32_t e0 = equal_bytes16(r0, m0);
+                                if (e0 < 16) { l += e0; break; }
+                                const uint32_t e1 = equal_bytes16(r1, m1);
+                                l += 16 + e1;
+                                if (e1 < 16) break;
+                            }
+                            if (l > lim) l = lim;
+                            if (l > best) {
+                                best = l; boff = cd[k];
+                                if (l >= lim) full = true;
+                                else mt = lds_ld4(mine, pp + best - 3);
+                            }
+                        }
                     }
                 }
-            }
-            if (fin) {
-                HcState s; s.w0 = boff | (next << 16); s.w1 = best | (att << 8);
-                state_g[p] = s;
-                active = false;
+                if (full) { over = true; next = 0; }
+                if (active && over) {
+                    if (final_band) res0[pp] = best | (boff << 8);
+                    else { res0[pp] = boff | (next << 16); res1[pp] = (uint16_t)(best | ((next ? att - 1 : 0) << 8)); }
+                    active = false;
+                }
             }
         }
         __syncthreads();
-        // -- commit the prefetched granules: they replace positions below the next tile's band
+        // -- flush the tile's state (coalesced), commit the prefetched granules: they replace positions
+        //    below the next tile's band
+        *(U32x4*)(st0_g + t0 + 4 * tid) = *(const U32x4*)(res0 + 4 * tid);
+        *(U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(res0 + 4 * (tid + kHcThreads));
+        if (!final_band) *(U32x4*)(st1_g + t0 + 8 * tid) = *(const U32x4*)(res1 + 8 * tid);
         if (have_s) hc_commit_src(ring, (uint32_t)Ps, ps);
         if (have_c) *(U32x4*)(cring + ((uint32_t)Pc & (kHcRing - 1))) = pc;
-        if (have_m) *(U32x4*)(mine + 16 * (tid - 512)) = pm;
+        if (have_m) *(U32x4*)(mine + 16 * tid) = pm;
     }
     __syncthreads();
 }
@@ -264,21 +380,30 @@ __device__ __forceinline__ uint64_t hc_ld8(lz4amd_gsrc src, uint32_t n, uint32_t
     return v;
 }
 
-__device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, const HcState* state_g, MatchRec* recs,
-                                               uint32_t* strip, uint32_t w, uint32_t cs, uint32_t ce) {
+__device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, const uint32_t* best_g, MatchRec* recs,
+                                               uint32_t* strip, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce) {
     const uint32_t lane = lane_id();
     uint32_t nseq = 0, enc = 0, ll0 = 0, anchor = cs;
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         const uint32_t last_q = n - kMfLimit;
         uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
         uint32_t ip = cs;
+        uint32_t staged = cs;                                           // results of [staged - 2 * kHcChunk, staged) are in `stage`
         while (ip < ce && ip <= last_q) {
+            while (ip + 64 > staged) {                                  // stage the next chunk (cs is a multiple of 64; the array is padded)
+                uint32_t* dstp = stage + ((staged - cs) & (2 * kHcChunk - 1));
+#pragma unroll
+                for (uint32_t k = 0; k < kHcChunk / 256; k++)
+                    *(U32x4*)(dstp + 4 * (lane + 64 * k)) = *(const U32x4*)(best_g + staged + 4 * (lane + 64 * k));
+                staged += kHcChunk;
+                wave_lds_fence();
+            }
             const uint32_t pos = ip + lane;
             uint32_t len = 0, off = 0;
             if (pos <= last_q && pos + kMinMatch <= mlimit) {
-                const HcState s = state_g[pos];
-                const uint32_t l = s.w1 & 0xFFu;
-                if (l >= kMinMatch) { len = l; off = s.w0 & 0xFFFFu; }
+                const uint32_t s = stage[(pos - cs) & (2 * kHcChunk - 1)];
+                const uint32_t l = s & 0xFFu;
+                if (l >= kMinMatch) { len = l; off = s >> 8; }
             }
             unsigned long long m = __ballot(len != 0);
             uint32_t next_ip = ip + 64;
@@ -319,6 +444,8 @@ __device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, cons
                 if (anchor >= ip + 64) { next_ip = anchor; break; }
                 m &= ~0ull << (anchor - ip);
             }
+            // a jump past the staged chunks (a long match): restart the staging at the landing chunk
+            if (next_ip >= staged + kHcChunk) staged = cs + ((next_ip - cs) & ~(kHcChunk - 1));
             ip = next_ip;
         }
     }
@@ -347,8 +474,9 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     const uint32_t n = (uint32_t)n_i, cap = (uint32_t)cap_i;
     uint8_t* scratch = P.scratch + (uint64_t)blockIdx.x * P.scratch_stride;
     uint16_t* chain_g = (uint16_t*)scratch;
-    HcState* state_g = (HcState*)(scratch + hc_chain_bytes(P.max_src));
-    MatchRec* recs_g = (MatchRec*)(scratch + hc_chain_bytes(P.max_src) + hc_state_bytes(P.max_src));
+    uint32_t* st0_g = (uint32_t*)(scratch + hc_chain_bytes(P.max_src));
+    uint16_t* st1_g = (uint16_t*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src));
+    MatchRec* recs_g = (MatchRec*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src) + hc_st1_bytes(P.max_src));
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tq = prof ? clock_ticks() : 0;
 
@@ -358,9 +486,10 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         hc_build_chain(src, n, chain_g, smem);
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[0] += t - tq; tq = t; }
         const uint32_t attempts = hc_attempts(P.level);
+
         for (uint32_t band = 0; band < kHcBands; band++) {
-            hc_search_band(src, n, chain_g, state_g, band, attempts, smem);
-            if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + band] += t - tq; tq = t; }
+            hc_search_band(src, n, chain_g, st0_g, st1_g, band, attempts, smem);
+            if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         }
         // -- parse: one wave per strip
         nstrips = (n + kHcMinStrip - 1) / kHcMinStrip; if (nstrips > kHcWaves) nstrips = kHcWaves;
@@ -370,7 +499,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         if (w < nstrips) {
             const uint32_t cs = w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > n) ce = n;
-            hc_parse_strip(src, n, state_g, recs_g + (uint64_t)w * rec_cap, strip, w, cs, ce);
+            hc_parse_strip(src, n, st0_g, recs_g + (uint64_t)w * rec_cap, strip, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce);
         }
         __syncthreads();
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[4] += t - tq; tq = t; }

@@ -50,6 +50,20 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+// Same ordering guarantee without the wait: the DS unit executes one wave's LDS instructions in issue
+// order, so a wave may queue read / write / flag-store back to back; this only stops the compiler from
+// reordering them (and is a rendezvous for the CPU interpreter).
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_store_relaxed(uint32_t* w, uint32_t v) {
+    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// number of set bits of a ballot below my lane (v_mbcnt)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 
 // {hi,lo} >> (8 * (sh & 3)), low 32 bits (v_alignbyte_b32)
