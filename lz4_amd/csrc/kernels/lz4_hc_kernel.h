@@ -61,6 +61,9 @@ enum : uint32_t {
     kHcMinStrip = 1024,
     kHcChunk = 1024,                    // positions of search results a parsing wave stages in LDS at a time
     kHcBatch = 8,                       // links a lane chases before it verifies the candidates found
+    kHcRun = 4,                         // consecutive positions a lane takes at a time (each inherits its predecessor's match)
+    kHcSkipLen = 32,                    // an inherited match this long is kept without searching (tools/exp/hc_sim.c: < 0.1 % of size)
+    kHcRunsPerWave = 64 * kHcPosPerThread / kHcRun,
 };
 // LDS carve-up (bytes); the chain phase, the search phase and the parse phase reuse the same region
 enum : uint32_t {
@@ -216,6 +219,21 @@ __device__ __forceinline__ void hc_commit_src(uint8_t* ring, uint32_t P, const U
     if (o < kHcPad) *(U32x4*)(ring + kHcRing + o) = v;
 }
 
+// common length of the strings at ring offset qo and at `mine` offset pp, given that the first l bytes are
+// equal; 32 bytes per trip (all reads of a trip are independent), at most lim
+__device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t* mine, uint32_t qo, uint32_t pp, uint32_t l, uint32_t lim) {
+    while (l < lim) {
+        const Q16 r0 = lds_ld16(ring, (qo + l) & (kHcRing - 1)), r1 = lds_ld16(ring, (qo + l + 16) & (kHcRing - 1));
+        const Q16 m0 = lds_ld16(mine, pp + l), m1 = lds_ld16(mine, pp + l + 16);
+        const uint32_t e0 = equal_bytes16(r0, m0);
+        if (e0 < 16) { l += e0; break; }
+        const uint32_t e1 = equal_bytes16(r1, m1);
+        l += 16 + e1;
+        if (e1 < 16) break;
+    }
+    return l > lim ? lim : l;
+}
+
 __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
                                                uint32_t band, uint32_t attempts, char* smem) {
     const uint32_t tid = threadIdx.x;
@@ -266,37 +284,60 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
         {
             const uint32_t lane = lane_id();
             const uint32_t wbase = wave_id() * (64 * kHcPosPerThread);   // first tile-relative position of my wave
-            uint32_t wnext = 0;                                          // positions of the wave handed out so far
+            uint32_t wnext = 0;                                          // runs of the wave handed out so far
+            uint32_t run_left = 0;                                       // positions of my run still to start
+            uint32_t inh_len = 0, inh_off = 0;                           // what the previous position of my run leaves to the next
+            bool inh_capped = false;
             bool active = false;
             int32_t p = 0;
-            uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0;
+            uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0, best_in = 3;
             for (;;) {
-                // ---- hand out
-                const unsigned long long idle = __ballot(!active);
-                if (idle && wnext < 64 * kHcPosPerThread) {
+                // ---- hand out runs of kHcRun consecutive positions to idle lanes
+                const bool want = !active && run_left == 0;
+                const unsigned long long idle = __ballot(want);
+                if (idle && wnext < kHcRunsPerWave) {
                     const uint32_t mine_i = wnext + lanes_below(idle);
                     wnext += (uint32_t)__popcll(idle);
-                    if (!active && mine_i < 64 * kHcPosPerThread) {
-                        pp = wbase + mine_i;
-                        p = (int32_t)(t0 + pp);
-                        bool walk = true;
-                        if (band == 0) {
-                            if (p > last_q) { res0[pp] = 0; res1[pp] = 3; walk = false; }     // also the slots past the block's end
-                            else { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
-                        } else {
-                            const uint32_t s0 = res0[pp], s1 = res1[pp];
-                            dist = s0 >> 16; boff = s0 & 0xFFFFu; best = s1 & 0xFFu; att = (s1 >> 8) + 1;
-                            if (dist == 0) { if (final_band) res0[pp] = best | (boff << 8); walk = false; }   // finished earlier
-                        }
-                        if (walk) {
-                            lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
-                            if (lim > kHcLenCap) lim = kHcLenCap;
-                            mt = lds_ld4(mine, pp + best - 3);
-                            active = true;
+                    if (want && mine_i < kHcRunsPerWave) { pp = wbase + mine_i * kHcRun - 1; run_left = kHcRun; inh_len = 0; }
+                }
+                // ---- next position of my run.  In the nearest band it starts from what its predecessor found:
+                //      a match of length L at p is a match of length L - 1 at p + 1 (same offset), so inside a long
+                //      match only the first position pays for measuring it
+                if (!active && run_left) {
+                    pp++; run_left--;
+                    p = (int32_t)(t0 + pp);
+                    bool walk = true, kept = false;
+                    if (band == 0) {
+                        if (p > last_q) { res0[pp] = 0; res1[pp] = 3; walk = false; }     // also the slots past the block's end
+                        else { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
+                    } else {
+                        const uint32_t s0 = res0[pp], s1 = res1[pp];
+                        dist = s0 >> 16; boff = s0 & 0xFFFFu; best = s1 & 0xFFu; att = (s1 >> 8) + 1;
+                        if (dist == 0) { if (final_band) res0[pp] = best | (boff << 8); walk = false; }   // finished earlier
+                    }
+                    if (walk) {
+                        lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
+                        if (lim > kHcLenCap) lim = kHcLenCap;
+                        best_in = best;
+                        if (inh_len >= kMinMatch && inh_len > best) {
+                            // (in a farther band the predecessor's match was found in this band, so its bytes are in the ring)
+                            best = inh_len; boff = inh_off;
+                            // a capped predecessor may match further than it measured
+                            if (inh_capped) best = hc_count(ring, mine, (uint32_t)(p - (int32_t)boff) & (kHcRing - 1), pp, best, lim);
+                            // nothing can beat a full-length match; and inside a long match the positions after the
+                            // first are not searched at all (the reference does not visit them either)
+                            if (best >= lim || best >= kHcSkipLen) {
+                                if (final_band) res0[pp] = best | (boff << 8);
+                                else { res0[pp] = boff; res1[pp] = (uint16_t)best; }
+                                inh_len = best - 1; inh_capped = best >= lim;
+                                walk = false; kept = true;
+                            }
                         }
                     }
+                    if (walk) { mt = lds_ld4(mine, pp + best - 3); active = true; }
+                    else if (!kept) inh_len = 0;                        // nothing to hand to the next position
                 }
-                if (!__ballot(active)) { if (wnext >= 64 * kHcPosPerThread) break; continue; }
+                if (!__ballot(active)) { if (wnext >= kHcRunsPerWave && !__ballot(run_left != 0)) break; continue; }
                 // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
                 uint32_t cd[kHcBatch];
                 uint32_t next = 0;                                      // where the next band resumes
@@ -329,18 +370,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
                         const uint32_t qo = (uint32_t)(p - (int32_t)cd[k]) & (kHcRing - 1);
                         // an earlier candidate of the batch may have raised `best`: test again at the new index
                         if (hit && (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt)) {
-                            // common length, 32 bytes per trip (all reads of a trip are independent)
-                            uint32_t l = 0;
-                            while (l < lim) {
-                                const Q16 r0 = lds_ld16(ring, (qo + l) & (kHcRing - 1)), r1 = lds_ld16(ring, (qo + l + 16) & (kHcRing - 1));
-                                const Q16 m0 = lds_ld16(mine, pp + l), m1 = lds_ld16(mine, pp + l + 16);
-                                const uint32_t e0 = equal_bytes16(r0, m0);
-                                if (e0 < 16) { l += e0; break; }
-                                const uint32_t e1 = equal_bytes16(r1, m1);
-                                l += 16 + e1;
-                                if (e1 < 16) break;
-                            }
-                            if (l > lim) l = lim;
+                            const uint32_t l = hc_count(ring, mine, qo, pp, 0, lim);
                             if (l > best) {
                                 best = l; boff = cd[k];
                                 if (l >= lim) full = true;
@@ -353,6 +383,8 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
                 if (active && over) {
                     if (final_band) res0[pp] = best | (boff << 8);
                     else { res0[pp] = boff | (next << 16); res1[pp] = (uint16_t)(best | ((next ? att - 1 : 0) << 8)); }
+                    // what the next position of my run may start from (farther bands: only a match found in this band)
+                    inh_len = best > kMinMatch && (band == 0 || best > best_in) ? best - 1 : 0; inh_off = boff; inh_capped = best >= lim;
                     active = false;
                 }
             }

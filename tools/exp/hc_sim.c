@@ -17,7 +17,7 @@ int lz4amd_datagen(void* buf, size_t size, double match_p, double lit_p, uint32_
 static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> 17; }
 
-typedef struct { int W, A, cap, parse; int T; } cfg_t;
+typedef struct { int W, A, cap, parse; int T; int skipX; } cfg_t;
 static long g_steps, g_pos;
 
 static uint16_t* g_len; static uint16_t* g_off; static int32_t* g_chain; static int32_t g_head[32768];
@@ -31,6 +31,11 @@ static void find_all(const uint8_t* s, int n, cfg_t c)
     for (int p = 0; p + 4 <= n; p++) { uint32_t h = hash4(rd32(s + p)); g_chain[p] = g_head[h]; g_head[h] = p; }
     for (int p = 0; p <= last; p++) {
         int best = 0, boff = 0, att = c.A;
+        if (c.skipX && p > 0 && (p & 7) && g_len[p - 1] > c.skipX) {   /* inherit and skip the search (runs of 8) */
+            int l = g_len[p - 1] - 1, o = g_off[p - 1]; int lim = mlimit - p; if (lim > c.cap) lim = c.cap;
+            while (l < lim && s[p + l] == s[p + l - o]) l++;
+            g_len[p] = l; g_off[p] = o; g_pos++; continue;
+        }
         int q = g_chain[p];
         int lowq = 0;
         if (c.T) { int t0 = p - p % c.T; lowq = t0 + c.T + 256 - 65536; }
@@ -209,7 +214,7 @@ int main(int argc, char** argv)
     }
     printf("%s: %zu bytes, blocks of %d: ref fast %ld (%.3f)  HC9 %ld (%.3f)  HC12 %ld (%.3f)\n", argv[1], total, blk, ref1, (double)total / ref1, ref9, (double)total / ref9, ref12, (double)total / ref12);
     cfg_t cfgs[] = {
-        {65535, 256, 1 << 30, 9, 0}, {65535, 256, 1 << 30, 6, 0}, {65535, 256, 120, 6, 2048}, {65535, 256, 120, 7, 2048}, {65535, 256, 250, 6, 2048},{65535, 256, 250, 5, 2048},
+        {65535, 256, 250, 5, 0, 0}, {65535, 256, 250, 5, 0, 16}, {65535, 256, 250, 5, 0, 32}, {65535, 256, 250, 5, 0, 64}, {65535, 256, 250, 5, 0, 128},
         {65535, 256, 1 << 30, 2, 0}, {65535, 256, 1<<30, 5, 0}, {65535, 256, 64, 5, 0}, {65535, 256, 64, 5, 4096}, {65535, 256, 64, 5, 2048}, {65535, 256, 32, 5, 2048}, {65535, 256, 120, 5, 2048},
         {65535, 128, 64, 5, 2048}, {65535, 64, 64, 5, 2048},
     };
@@ -224,7 +229,7 @@ int main(int argc, char** argv)
             if (r != n || memcmp(chk, data + o, n)) { printf("  cfg %u: ROUND TRIP FAILED at block %zu (r=%d)\n", k, o / blk, r); return 2; }
             sum += cs;
         }
-        printf("  T=%4d steps/pos %5.1f", cfgs[k].T, (double)g_steps / g_pos);
+        printf("  skip>%3d steps/pos %5.1f", cfgs[k].skipX, (double)g_steps / g_pos);
         printf("  W=%5d A=%3d cap=%4d parse=%d : %ld  ratio %.3f  vs HC9 %+.2f%%\n", cfgs[k].W, cfgs[k].A, cfgs[k].cap > 65535 ? 0 : cfgs[k].cap, cfgs[k].parse,
                sum, (double)total / sum, 100.0 * ((double)sum / ref9 - 1));
     }
