@@ -60,10 +60,10 @@ enum : uint32_t {
     kHcBands = 3,                       // 3 x 32496 >= 65535 + kHcTile + kHcAhead: the whole LZ4 window, for every position
     kHcMinStrip = 1024,
     kHcChunk = 1024,                    // positions of search results a parsing wave stages in LDS at a time
-    kHcBatch = 8,                       // links a lane chases before it verifies the candidates found
+    kHcBatch = 4,                       // links a lane chases before it verifies the candidates found
     kHcRun = 4,                         // consecutive positions a lane takes at a time (each inherits its predecessor's match)
     kHcSkipLen = 32,                    // an inherited match this long is kept without searching (tools/exp/hc_sim.c: < 0.1 % of size)
-    kHcRunsPerWave = 64 * kHcPosPerThread / kHcRun,
+    kHcRunsPerTile = kHcTile / kHcRun,
 };
 // LDS carve-up (bytes); the chain phase, the search phase and the parse phase reuse the same region
 enum : uint32_t {
@@ -87,7 +87,7 @@ static_assert(kHOffParse + kHcWaves * 2 * kHcChunk * 4 <= kHcLdsBytes, "parse st
 static_assert(kHcLdsBytes <= 160 * 1024, "one CU's LDS");
 static_assert(kHcBands * kHcBandStep >= 65535 + kHcTile + kHcAhead, "bands must cover the LZ4 window");
 static_assert(kHOffMine % 16 == 0 && kHOffRes0 % 16 == 0 && kHOffRes1 % 16 == 0 && kHOffChain % 16 == 0, "16-byte LDS accesses");
-enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4 };
+enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5 };
 
 // scratch layout of one workgroup, for blocks of at most n bytes
 __host__ __device__ inline uint64_t hc_chain_bytes(uint32_t n) { return ((uint64_t)2 * (n + 64) + 255) & ~255ull; }
@@ -242,6 +242,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
     uint8_t* mine = (uint8_t*)(smem + kHOffMine);
     uint32_t* res0 = (uint32_t*)(smem + kHOffRes0);
     uint16_t* res1 = (uint16_t*)(smem + kHOffRes1);
+    uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
     const uint32_t n64 = (n + 63) & ~63u;
     const int32_t last_q = (int32_t)n - (int32_t)kMfLimit;            // last position that may start a match
     const int32_t shift = (int32_t)(band * kHcBandStep);
@@ -276,15 +277,15 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
             *(U32x4*)(res0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads));
             *(U32x4*)(res1 + 8 * tid) = *(const U32x4*)(st1_g + t0 + 8 * tid);
         }
+        if (tid == 0) misc[HM_POOL] = 0;
         __syncthreads();
-        // -- the walks.  A wave owns 64 * kHcPosPerThread consecutive positions of the tile and hands them to
-        //    its lanes as they fall idle (ballot + mbcnt, no atomics).  The loop is wave-synchronous and
-        //    predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
+        // -- the walks.  The tile is a pool of runs of kHcRun consecutive positions; idle lanes of any wave take
+        //    the next runs (which lane walks a run does not change its result).  The loop is wave-synchronous
+        //    and predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
         //    nothing else on the path), then VERIFIES the candidates found (independent reads).
         {
             const uint32_t lane = lane_id();
-            const uint32_t wbase = wave_id() * (64 * kHcPosPerThread);   // first tile-relative position of my wave
-            uint32_t wnext = 0;                                          // runs of the wave handed out so far
+            bool pool_dry = false;                                       // the tile's pool of runs is empty
             uint32_t run_left = 0;                                       // positions of my run still to start
             uint32_t inh_len = 0, inh_off = 0;                           // what the previous position of my run leaves to the next
             bool inh_capped = false;
@@ -292,13 +293,18 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
             int32_t p = 0;
             uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0, best_in = 3;
             for (;;) {
-                // ---- hand out runs of kHcRun consecutive positions to idle lanes
+                // ---- hand out runs of kHcRun consecutive positions to idle lanes, from one pool for the whole tile
+                //      (an LDS counter; asked only when a quarter of the wave is idle, or nobody works)
                 const bool want = !active && run_left == 0;
                 const unsigned long long idle = __ballot(want);
-                if (idle && wnext < kHcRunsPerWave) {
-                    const uint32_t mine_i = wnext + lanes_below(idle);
-                    wnext += (uint32_t)__popcll(idle);
-                    if (want && mine_i < kHcRunsPerWave) { pp = wbase + mine_i * kHcRun - 1; run_left = kHcRun; inh_len = 0; }
+                const uint32_t nidle = (uint32_t)__popcll(idle);
+                if (!pool_dry && (nidle >= 16 || (nidle && !__ballot(active || run_left != 0)))) {
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__ffsll((long long)idle) - 1) base = atomicAdd(&misc[HM_POOL], nidle);
+                    base = wave_readlane(base, (uint32_t)__ffsll((long long)idle) - 1);
+                    const uint32_t mine_i = base + lanes_below(idle);
+                    if (base + nidle >= kHcRunsPerTile) pool_dry = true;
+                    if (want && mine_i < kHcRunsPerTile) { pp = mine_i * kHcRun - 1; run_left = kHcRun; inh_len = 0; }
                 }
                 // ---- next position of my run.  In the nearest band it starts from what its predecessor found:
                 //      a match of length L at p is a match of length L - 1 at p + 1 (same offset), so inside a long
@@ -337,7 +343,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
                     if (walk) { mt = lds_ld4(mine, pp + best - 3); active = true; }
                     else if (!kept) inh_len = 0;                        // nothing to hand to the next position
                 }
-                if (!__ballot(active)) { if (wnext >= kHcRunsPerWave && !__ballot(run_left != 0)) break; continue; }
+                if (!__ballot(active)) { if (pool_dry && !__ballot(run_left != 0)) break; continue; }
                 // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
                 uint32_t cd[kHcBatch];
                 uint32_t next = 0;                                      // where the next band resumes
