@@ -17,6 +17,8 @@ Prints ONE JSON line on rank 0:
   kernels          the same for every kernel of the step
   cpu_baseline     the reference lib/lz4.c (oracle/_ref, kind "reference") or the oracle port,
                    timed on this box's host cores on a bounded sample of the same workload
+  hc               (N=1) BASELINE configs[3] beside it: LZ4_compress_HC level 9 on 256 KiB blocks of the
+                   same GiB, with its own roofline and the reference lz4hc.c on the host cores
 """
 import argparse
 import ctypes
@@ -95,6 +97,65 @@ def cpu_baseline(n_blocks, block_bytes, pct, seed):
             "ref_comp_bytes": full["comp_bytes"], "ref_src_bytes": full["src_bytes"]}
 
 
+def cpu_baseline_hc(block_bytes, pct, seed, level):
+    """Reference LZ4_compress_HC (oracle/_ref only: the oracle port has no HC) on the host cores,
+    bounded sample of configs[3]'s table."""
+    cores = os.cpu_count() or 1
+    exe = os.path.join(ROOT, "oracle", "_ref", "refbench")
+    if not os.path.exists(exe):
+        return None
+    sample_blocks = 2 * cores if cores >= 64 else 128        # ~0.1 s of one-thread work per thread
+    try:
+        one = json.loads(subprocess.run([exe, "1", "16", str(block_bytes), str(pct), str(seed), "1", str(level)],
+                                        capture_output=True, text=True, check=True, timeout=300).stdout)
+        full = json.loads(subprocess.run([exe, str(cores), str(sample_blocks), str(block_bytes), str(pct), str(seed), "3", str(level)],
+                                         capture_output=True, text=True, check=True, timeout=600).stdout)
+    except Exception as e:
+        return {"error": str(e)}
+    return {"value": round(full["compress_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": "reference",
+            "sample": f"{sample_blocks} x {block_bytes} B blocks of datagen -P{pct} -s{seed}, LZ4_compress_HC level {level}, best of 3, "
+                      f"static partition over {cores} threads",
+            "single_thread_GBps": round(one["compress_GBps"], 4),
+            "ref_comp_bytes": full["comp_bytes"], "ref_src_bytes": full["src_bytes"], "sample_blocks": sample_blocks}
+
+
+def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, level=9, bs=256 << 10, with_cpu=True):
+    """BASELINE configs[3]: LZ4_compress_HC level 9 on 256 KiB blocks of the same GiB, device resident.
+    Not part of `value`; reported next to it with its own roofline and CPU baseline."""
+    U = data.numel()
+    nb = U // bs
+    stride = (lz4_amd.compress_bound(bs) + 255) & ~255
+    comp = torch.empty((nb, stride), dtype=torch.uint8, device=data.device)
+    tab = lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb,
+                             [comp.data_ptr() + i * stride for i in range(nb)], [stride] * nb)
+    plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS_HC, tab, level=level)
+    plan.launch(stream)
+    cs = plan.results(stream)
+    assert all(c > 0 for c in cs), "HC compression failed"
+    dtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nb)], cs,
+                              [out.data_ptr() + i * bs for i in range(nb)], [bs] * nb)
+    dplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+    out.zero_()
+    dplan.launch(stream)
+    assert dplan.results(stream) == [bs] * nb and torch.equal(out, data), "HC round trip is not bit exact"
+    ms = min(plan.launch_timed(stream)[0][0] for _ in range(3))
+    dms = min(dplan.launch_timed(stream)[0][0] for _ in range(3))
+    C = sum(cs)
+    res = {"workload": "configs[3]: %d independent %d-byte blocks (%.2f GiB), datagen -P%d, LZ4_compress_HC level %d, device resident"
+                       % (nb, bs, U / 2**30, pct, level),
+           "compress_GBps": round(U / (ms * 1e-3) / 1e9, 2), "kernel_ms": round(ms, 3),
+           "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 2), "ratio": round(U / C, 4), "compressed_bytes": C,
+           "roofline": {"kernel": "compress_hc", "bound": "hbm", "achieved": round((U + C) / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": round((U + C) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": U + C, "avg_ms": round(ms, 3)}}
+    if with_cpu:
+        cb = cpu_baseline_hc(bs, pct, seed, level)
+        res["cpu_baseline"] = cb
+        if cb and "ref_comp_bytes" in cb:
+            res["ratio_vs_reference"] = round(cb["ref_comp_bytes"] / sum(cs[:cb["sample_blocks"]]), 4)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +165,7 @@ def main():
     ap.add_argument("--block-bytes", type=int, default=4 << 20)
     ap.add_argument("--pct", type=int, default=60, help="datagen -P compressibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hc", action="store_true", help="skip the LZ4_compress_HC (configs[3]) side measurement")
     args = ap.parse_args()
 
     import torch
@@ -232,6 +294,12 @@ def main():
             "extras": {"xxh32_batch_GBps": round(U / (x_ms * 1e-3) / 1e9, 1), "xxh32_batch_ms": round(x_ms, 3),
                        "note": "XXH32 (seed 0) of every 4 MiB block, one wave per block; not in `value`"},
         }
+        if world == 1 and not args.no_hc and U % (256 << 10) == 0:
+            try:
+                result["hc"] = bench_hc(ctx, lz4_amd, torch, data, out, stream, args.pct, plan_s["seed"],
+                                        with_cpu=not args.no_cpu_baseline)
+            except Exception as e:                           # the side measurement never kills the bench line
+                result["hc"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(nb, bs, args.pct, plan_s["seed"])
             result["cpu_baseline"] = cb

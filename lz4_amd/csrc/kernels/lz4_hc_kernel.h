@@ -60,8 +60,17 @@ enum : uint32_t {
     kHcBands = 3,                       // 3 x 32496 >= 65535 + kHcTile + kHcAhead: the whole LZ4 window, for every position
     kHcMinStrip = 1024,
     kHcChunk = 1024,                    // positions of search results a parsing wave stages in LDS at a time
-    kHcBatch = 4,                       // links a lane chases before it verifies the candidates found
-    kHcRun = 4,                         // consecutive positions a lane takes at a time (each inherits its predecessor's match)
+#ifndef LZ4AMD_HC_BATCH
+#define LZ4AMD_HC_BATCH 4
+#endif
+#ifndef LZ4AMD_HC_REFILL
+#define LZ4AMD_HC_REFILL 16
+#endif
+#ifndef LZ4AMD_HC_RUN
+#define LZ4AMD_HC_RUN 4
+#endif
+    kHcBatch = LZ4AMD_HC_BATCH,                       // links a lane chases before it verifies the candidates found
+    kHcRun = LZ4AMD_HC_RUN,                         // consecutive positions a lane takes at a time (each inherits its predecessor's match)
     kHcSkipLen = 32,                    // an inherited match this long is kept without searching (tools/exp/hc_sim.c: < 0.1 % of size)
     kHcRunsPerTile = kHcTile / kHcRun,
 };
@@ -298,7 +307,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
                 const bool want = !active && run_left == 0;
                 const unsigned long long idle = __ballot(want);
                 const uint32_t nidle = (uint32_t)__popcll(idle);
-                if (!pool_dry && (nidle >= 16 || (nidle && !__ballot(active || run_left != 0)))) {
+                if (!pool_dry && (nidle >= LZ4AMD_HC_REFILL || (nidle && !__ballot(active || run_left != 0)))) {
                     uint32_t base = 0;
                     if (lane == (uint32_t)__ffsll((long long)idle) - 1) base = atomicAdd(&misc[HM_POOL], nidle);
                     base = wave_readlane(base, (uint32_t)__ffsll((long long)idle) - 1);

@@ -7,8 +7,9 @@
  * Linked either against the real reference (oracle/_ref/liblz4_ref.so -> kind "reference") or,
  * with -DUSE_ORACLE, against the oracle restatement (kind "port").  Never part of the product.
  *
- *   refbench <threads> <nblocks> <block_bytes> <P> <seed> <reps>
- * prints one JSON object.
+ *   refbench <threads> <nblocks> <block_bytes> <P> <seed> <reps> [hc_level]
+ * prints one JSON object.  With hc_level > 0 (reference build only) the compressor is
+ * LZ4_compress_HC(level) (lz4hc.c:1519), the shape of `lz4 -b9 -B5` (BASELINE configs[3]).
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -28,6 +29,8 @@
 int LZ4_compress_default(const char*, char*, int, int);
 int LZ4_decompress_safe(const char*, char*, int, int);
 int LZ4_compressBound(int);
+int LZ4_compress_HC(const char*, char*, int, int, int);
+#define HAVE_HC 1
 #define COMPRESS(s, d, n, c) LZ4_compress_default((const char*)(s), (char*)(d), n, c)
 #define DECOMPRESS(s, d, n, c) LZ4_decompress_safe((const char*)(s), (char*)(d), n, c)
 #define BOUND(n) LZ4_compressBound(n)
@@ -36,7 +39,7 @@ int LZ4_compressBound(int);
 
 int lz4amd_datagen(void* buf, size_t size, double match_p, double lit_p, uint32_t seed);
 
-typedef struct { int t, T, nb, bs, bound, mode; char *src, *comp, *out; int* csz; int err; } job_t;
+typedef struct { int t, T, nb, bs, bound, mode, hc; char *src, *comp, *out; int* csz; int err; } job_t;
 
 static void* worker(void* arg)
 {
@@ -44,6 +47,10 @@ static void* worker(void* arg)
     int b0 = (int)((long long)j->nb * j->t / j->T), b1 = (int)((long long)j->nb * (j->t + 1) / j->T), b;
     for (b = b0; b < b1; b++) {
         if (j->mode == 0) {
+#ifdef HAVE_HC
+            if (j->hc > 0) j->csz[b] = LZ4_compress_HC(j->src + (size_t)b * j->bs, j->comp + (size_t)b * j->bound, j->bs, j->bound, j->hc);
+            else
+#endif
             j->csz[b] = COMPRESS(j->src + (size_t)b * j->bs, j->comp + (size_t)b * j->bound, j->bs, j->bound);
             if (j->csz[b] <= 0) j->err = 1;
         } else {
@@ -75,6 +82,10 @@ int main(int argc, char** argv)
     if (T < 1) T = 1; if (T > 256) T = 256;
     memset(&j, 0, sizeof j);
     j.nb = nb; j.bs = bs; j.bound = BOUND(bs);
+    j.hc = argc > 7 ? atoi(argv[7]) : 0;
+#ifndef HAVE_HC
+    if (j.hc > 0) { fprintf(stderr, "refbench: the oracle port has no HC compressor\n"); return 6; }
+#endif
     j.src = (char*)malloc((size_t)nb * bs); j.comp = (char*)malloc((size_t)nb * j.bound); j.out = (char*)malloc((size_t)nb * bs);
     j.csz = (int*)calloc(nb, sizeof(int));
     if (!j.src || !j.comp || !j.out || !j.csz) return 3;
@@ -83,10 +94,10 @@ int main(int argc, char** argv)
     for (r = 0; r < reps; r++) { double t = run(&j, T, 1); if (t < bd) bd = t; }
     if (j.err || memcmp(j.src, j.out, (size_t)nb * bs)) { fprintf(stderr, "refbench: round trip failed\n"); return 5; }
     for (b = 0; b < nb; b++) ctot += j.csz[b];
-    printf("{\"kind\": \"%s\", \"threads\": %d, \"blocks\": %d, \"block_bytes\": %d, \"P\": %d, \"seed\": %u, "
+    printf("{\"kind\": \"%s\", \"hc_level\": %d, \"threads\": %d, \"blocks\": %d, \"block_bytes\": %d, \"P\": %d, \"seed\": %u, "
            "\"src_bytes\": %lld, \"comp_bytes\": %lld, \"compress_s\": %.6f, \"decompress_s\": %.6f, "
            "\"compress_GBps\": %.4f, \"decompress_GBps\": %.4f, \"roundtrip_GBps\": %.4f}\n",
-           KIND, T, nb, bs, P, seed, (long long)nb * bs, ctot, bc, bd,
+           KIND, j.hc, T, nb, bs, P, seed, (long long)nb * bs, ctot, bc, bd,
            1e-9 * nb * bs / bc, 1e-9 * nb * bs / bd, 1e-9 * nb * bs / (bc + bd));
     return 0;
 }
