@@ -148,6 +148,12 @@ def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, level=9, bs=256 
            "roofline": {"kernel": "compress_hc", "bound": "hbm", "achieved": round((U + C) / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round((U + C) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                         "algorithmic_bytes_per_launch": U + C, "avg_ms": round(ms, 3)}}
+    try:                                                     # HBM bytes per launch from the committed PMC passes
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if nb == 4096 and bs == 256 << 10 and pct == 60 and level == 9:
+            res["roofline"]["traffic"] = pmc["compress_hc"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if with_cpu:
         cb = cpu_baseline_hc(bs, pct, seed, level)
         res["cpu_baseline"] = cb
