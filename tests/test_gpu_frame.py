@@ -43,8 +43,9 @@ def L():
     return lib
 
 
-def compress_frame(L, data, **kw):
+def compress_frame(L, data, level=0, **kw):
     p = Prefs()
+    p.compressionLevel = level
     for k, v in kw.items():
         setattr(p.frameInfo, k, v)
     cap = L.LZ4F_compressFrameBound(len(data), ctypes.byref(p))
@@ -114,6 +115,23 @@ def test_our_frames_decode_with_the_oracle_and_here(L, oracle, datagen, kw):
         assert r == n and used.value == len(frame) and out.raw[:n] == data
         got, pos = decompress_frame(L, frame, n)
         assert got == data and pos == len(frame)
+
+
+def test_hc_levels_in_frames(L, oracle, datagen):
+    """compressionLevel >= LZ4HC_CLEVEL_MIN selects the HC compressor (lz4frame.c:943-958): the frame is smaller
+    and still decodes with the oracle's frame decoder and here."""
+    data = datagen(3 << 20, 60, 5)
+    for kw in (dict(blockSizeID=5, blockMode=1, contentChecksumFlag=1), dict(blockSizeID=6)):
+        fast = compress_frame(L, data, **kw)
+        hc = compress_frame(L, data, level=9, **kw)
+        assert len(hc) < 0.85 * len(fast)
+        assert hc[:7] == fast[:7]                                      # same header: the level is not recorded
+        out = ctypes.create_string_buffer(len(data) + 1)
+        used = ctypes.c_size_t()
+        r = oracle.lz4o_frame_decompress(out, len(data), hc, len(hc), ctypes.byref(used))
+        assert r == len(data) and used.value == len(hc) and out.raw[:len(data)] == data
+        got, pos = decompress_frame(L, hc, len(data))
+        assert got == data and pos == len(hc)
 
 
 def test_frame_header_known_answers(L, datagen):
