@@ -125,3 +125,19 @@ def test_hc_config3_full_size_properties(ctx, golden, datagen, ocodec):
     for i in (0, 511, 1023):
         ro, o = ocodec.decompress(hcm[i, :csizes[i]].tobytes(), bs)
         assert ro == bs and o == bytes(host[i * bs:(i + 1) * bs])
+
+
+def test_hc_boundary_sizes(ctx, ocodec, datagen):
+    """Block sizes around the kernel's geometry (groups of 64, 1 K strips, 8 K tiles, 32 K bands + 272, 64 KB)."""
+    sizes = [14, 15, 17, 63, 64, 65, 255, 257, 1023, 1025, 4097, 8191, 8192, 8193, 8192 + 272, 8192 + 273, 16385,
+             32767, 32768, 32769, 32768 + 272, 40961, 65535, 65536, 65537, 65536 + 8192 + 272, 98305, 131071, 262143, 262145]
+    rnd = random.Random(29)
+    sizes += [rnd.randrange(18, 600000) for _ in range(20)]
+    base = datagen(700000, 70, 6)
+    datas = [base[rnd.randrange(0, 9000):][:n] for n in sizes]
+    datas += [bytes(n) for n in (13, 64, 8193, 70001, 1 << 20)] + [b"ab" * 40000, b"abcdefg" * 100000]
+    for lvl in (9, 3):
+        for d, (r, c) in zip(datas, gpu_compress_hc(ctx, datas, level=lvl)):
+            assert 0 < r <= ocodec.bound(len(d))
+            ro, o = ocodec.decompress(c, len(d))
+            assert ro == len(d) and o == d, (lvl, len(d))

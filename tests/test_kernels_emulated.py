@@ -329,3 +329,24 @@ def test_hc_4mib_block(emu, ocodec, golden, datagen):
     ro, o = ocodec.decompress(c, len(d))
     assert ro == len(d) and o == d
     assert abs(r - g["csize"] / 2) / (g["csize"] / 2) < 0.03
+
+
+def test_hc_sizes_around_tile_band_and_strip_boundaries(emu, ocodec, datagen):
+    """Block sizes that straddle the kernel's own geometry (64-position groups, 1 K strips, 8 K tiles, the
+    32 K bands and their 272-byte look-ahead, the 64 KB window) and the format's end-of-block rules."""
+    sizes = [14, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2049, 4095, 4097,
+             8191, 8192, 8193, 8192 + 271, 8192 + 272, 8192 + 273, 16383, 16385, 32767, 32768, 32769, 32768 + 272,
+             40959, 40961, 65535, 65536, 65537, 65536 + 8192 + 272, 98303, 98305, 131071]
+    rnd = random.Random(23)
+    sizes += [rnd.randrange(18, 150000) for _ in range(12)]
+    base = datagen(160000, 70, 6)
+    datas = [base[rnd.randrange(0, 9000):][:n] for n in sizes]
+    datas += [bytes(n) for n in (13, 64, 8193, 70001)] + [b"ab" * 40000, b"abcdefg" * 10000]
+    for d, (r, c) in zip(datas, emu_compress_hc(emu, datas)):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+    # low search depth takes the same paths with different state sizes
+    for d, (r, c) in zip(datas[:20], emu_compress_hc(emu, datas[:20], level=3)):
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
