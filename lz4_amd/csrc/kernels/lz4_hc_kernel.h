@@ -231,14 +231,20 @@ __device__ __forceinline__ void hc_commit_src(uint8_t* ring, uint32_t P, const U
 // common length of the strings at ring offset qo and at `mine` offset pp, given that the first l bytes are
 // equal; 32 bytes per trip (all reads of a trip are independent), at most lim
 __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t* mine, uint32_t qo, uint32_t pp, uint32_t l, uint32_t lim) {
-    while (l < lim) {
-        const Q16 r0 = lds_ld16(ring, (qo + l) & (kHcRing - 1)), r1 = lds_ld16(ring, (qo + l + 16) & (kHcRing - 1));
-        const Q16 m0 = lds_ld16(mine, pp + l), m1 = lds_ld16(mine, pp + l + 16);
-        const uint32_t e0 = equal_bytes16(r0, m0);
-        if (e0 < 16) { l += e0; break; }
-        const uint32_t e1 = equal_bytes16(r1, m1);
-        l += 16 + e1;
-        if (e1 < 16) break;
+    if (l < lim) {                                              // most matches end inside the first 16 bytes
+        const uint32_t e = equal_bytes16(lds_ld16(ring, (qo + l) & (kHcRing - 1)), lds_ld16(mine, pp + l));
+        l += e;
+        if (e == 16) {
+            while (l < lim) {
+                const Q16 r0 = lds_ld16(ring, (qo + l) & (kHcRing - 1)), r1 = lds_ld16(ring, (qo + l + 16) & (kHcRing - 1));
+                const Q16 m0 = lds_ld16(mine, pp + l), m1 = lds_ld16(mine, pp + l + 16);
+                const uint32_t e0 = equal_bytes16(r0, m0);
+                if (e0 < 16) { l += e0; break; }
+                const uint32_t e1 = equal_bytes16(r1, m1);
+                l += 16 + e1;
+                if (e1 < 16) break;
+            }
+        }
     }
     return l > lim ? lim : l;
 }
@@ -377,18 +383,26 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
                 for (uint32_t k = 0; k < kHcBatch; k++)
                     ct[k] = lds_ld4(ring, ((uint32_t)(p - (int32_t)cd[k]) + best - 3) & (kHcRing - 1));
                 bool full = false;
-                const uint32_t mt0 = mt, best0 = best;                  // what the ct[] were read against
+                const uint32_t best0 = best;                            // what the ct[] were read against
+                // candidates that pass, as a bit mask per lane; the expensive part (measuring a match) is entered
+                // once per trip for every lane's nearest passing candidate, again only for lanes that have another
+                uint32_t hits = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < kHcBatch; k++) {
-                    const bool hit = cd[k] != 0 && ct[k] == mt0 && !full;
-                    if (__ballot(hit)) {
-                        const uint32_t qo = (uint32_t)(p - (int32_t)cd[k]) & (kHcRing - 1);
+                for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt) ? 1u << k : 0u;
+                while (__ballot(hits != 0)) {
+                    if (hits) {
+                        const uint32_t k = (uint32_t)__ffs((int)hits) - 1;
+                        hits &= hits - 1;
+                        uint32_t cdk = cd[0];
+#pragma unroll
+                        for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
+                        const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
                         // an earlier candidate of the batch may have raised `best`: test again at the new index
-                        if (hit && (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt)) {
+                        if (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
                             const uint32_t l = hc_count(ring, mine, qo, pp, 0, lim);
                             if (l > best) {
-                                best = l; boff = cd[k];
-                                if (l >= lim) full = true;
+                                best = l; boff = cdk;
+                                if (l >= lim) { full = true; hits = 0; }
                                 else mt = lds_ld4(mine, pp + best - 3);
                             }
                         }
