@@ -129,8 +129,8 @@ __device__ __forceinline__ uint32_t equal_bytes8_32(uint32_t a0, uint32_t a1, ui
     return x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : (y ? 4 + ((uint32_t)(__ffs((int)y) - 1) >> 3) : 8u);
 }
 // The 32 bytes [pos-8, pos+24) around ring offset o as eight dwords (b0 b1 | f0..f5): nine aligned
-// dword reads and eight v_alignbyte.  (The ring's pad makes the reads past its end harmless; a
-// window that starts before offset 0 wraps to the ring's end.)
+// dword reads at constant offsets from one address and eight v_alignbyte.  (A window that starts before
+// offset 0 wraps to the ring's end; the pad mirrors the ring's first 32 bytes, so no read wraps.)
 struct Win32 { uint32_t b0, b1, f0, f1, f2, f3, f4, f5; };
 __device__ __forceinline__ Win32 ring_window32(const uint8_t* ring, uint32_t o) {
     uint32_t a = ring_back(o, 8);
@@ -138,7 +138,7 @@ __device__ __forceinline__ Win32 ring_window32(const uint8_t* ring, uint32_t o) 
     a &= ~3u;
     uint32_t d[9];
 #pragma unroll
-    for (uint32_t i = 0; i < 9; i++) { const uint32_t x = a + 4 * i; d[i] = *(const uint32_t*)(ring + (x >= kSrcRing ? x - kSrcRing : x)); }
+    for (uint32_t i = 0; i < 9; i++) d[i] = *(const uint32_t*)(ring + a + 4 * i);     // a <= kSrcRing - 4: the 36 bytes end inside the 32-byte pad
     Win32 w;
     w.b0 = align_bytes(d[1], d[0], sh); w.b1 = align_bytes(d[2], d[1], sh);
     w.f0 = align_bytes(d[3], d[2], sh); w.f1 = align_bytes(d[4], d[3], sh); w.f2 = align_bytes(d[5], d[4], sh);
@@ -461,7 +461,16 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             emit_strip(ring, recs_p, strip_p, w, src, dst, prev_t0 + w * prev_strip_len, ring_lo);
     }
     __syncthreads();
-    if (prof && tid == 0) { prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = tp[4]; }
+    if (prof) {
+        // developer aid: match + emit time of every wave (spread between the strips of a tile)
+        if (lane_id() == 0) misc[8 + w] = (uint32_t)((tp[1] + tp[4]) >> 4);
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t mx = 0, mn = ~0ull, sm = 0;
+            for (uint32_t i = 0; i < kCmpWaves; i++) { const uint64_t v = (uint64_t)misc[8 + i] << 4; mx = v > mx ? v : mx; mn = v < mn ? v : mn; sm += v; }
+            prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = tp[4]; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
+        }
+    }
     // -- final literal run (lz4.c:1302-1329)
     const uint32_t out = misc[CM_OUT], run = misc[CM_CARRY];
     const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;

@@ -49,7 +49,10 @@ enum : uint32_t {
     kHcThreads = 1024,
     kHcWaves = kHcThreads / 64,
     kHcHashLog = 15,                    // lz4hc.h:226 LZ4HC_HASH_LOG
-    kHcTurnGroups = 4,                  // groups of 64 positions a wave links per turn of the token
+#ifndef LZ4AMD_HC_TURN
+#define LZ4AMD_HC_TURN 2
+#endif
+    kHcTurnGroups = LZ4AMD_HC_TURN,                  // groups of 64 positions a wave links per turn of the token
     kHcRing = 32768,                    // positions per band (source ring bytes, chain ring entries)
     kHcPad = 32,                        // mirror of the source ring's first bytes (reads of up to 36 bytes: see lds_ld16)
     kHcTile = 8192,                     // positions searched between two ring refills

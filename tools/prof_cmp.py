@@ -15,7 +15,7 @@ print("compress kernel ms", km[0], "GB/s in", nb * bs / km[0] / 1e6, "ratio", nb
 L = lz4_amd.lib()
 w = (ctypes.c_ulonglong * (256 * 8))()
 n = L.lz4amd_plan_profile(plan._h, w, len(w))
-names = ["wait ring/prefetch issue", "match (wave 0)", "match barrier wait", "offsets + insert", "emit"]
+names = ["wait ring/prefetch issue", "match (wave 0)", "match barrier wait", "offsets + insert", "emit (wave 0)", "match+emit: slowest wave (sum over tiles)", "match+emit: fastest wave", "match+emit: mean wave"]
 for k, name in enumerate(names):
     d = [w[i * 8 + k] for i in range(n // 8)]
     print(name, "cycles median", statistics.median(d), "max", max(d))
