@@ -429,7 +429,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         //    16 consecutive positions per thread, hashed out of three aligned 8-byte words
         if (n >= kMfLimit + 1) {
             const uint32_t last_q = n - kMfLimit;
-            const uint32_t q0 = t0 + 16 * tid;                      // t0 is a multiple of 1024
+            // (the upper half of the workgroup first: wave 0 is busy with the offsets)
+            const uint32_t q0 = t0 + 16 * ((tid + kCmpThreads / 2) & (kCmpThreads - 1));      // t0 is a multiple of 1024
             if (q0 < t1 && q0 <= last_q) {
                 const uint32_t o = src_ring_off(q0);                // multiple of 16: o + 24 <= ring + pad
                 const uint32_t* a = (const uint32_t*)(ring + o);
