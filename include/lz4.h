@@ -8,9 +8,11 @@
  * kernels are really built for).  Compressed bytes may differ from the CPU library's but are
  * legal LZ4 blocks and decode to the same data with any conforming decoder.
  *
- * Not provided (SURVEY.md section 8f "next"): streaming / dictionary compression
- * (LZ4_compress_fast_continue, LZ4_loadDict, ...), LZ4_compress_destSize,
- * LZ4_decompress_safe_partial and the deprecated LZ4_decompress_fast family.
+ * Streaming (lz4.h:314-560): LZ4_stream_t / LZ4_streamDecode_t contexts that track up to 64 KB of
+ * history between calls, each block still a round trip through HBM (lz4_stream_api.c).
+ *
+ * Not provided (SURVEY.md section 8f "next"): LZ4_compress_destSize, LZ4_decompress_safe_partial,
+ * LZ4_attach_dictionary and the deprecated LZ4_decompress_fast family.
  */
 #ifndef LZ4_AMD_LZ4_H
 #define LZ4_AMD_LZ4_H
@@ -59,6 +61,36 @@ int LZ4_compressBound(int inputSize);                                           
 int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:236 */
 int LZ4_sizeofState(void);                                                         /* lz4.h:245 */
 int LZ4_compress_fast_extState(void* state, const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:246 */
+
+/* ---- streaming compression (reference lz4.h:314-450).  The context remembers WHERE the previous data
+ * is (the caller keeps it in place, as with the reference) and hands its last 64 KB to the device as
+ * history of the next block. */
+typedef union LZ4_stream_u {
+    char minStateSize[LZ4_STREAM_MINSIZE];                  /* lz4.h:729-733: the size is ABI */
+    struct { const char* dictionary; unsigned dictSize; } internal_donotuse;
+} LZ4_stream_t;
+LZ4_stream_t* LZ4_createStream(void);                                              /* lz4.h:331 */
+int           LZ4_freeStream(LZ4_stream_t* streamPtr);                             /* lz4.h:332 */
+LZ4_stream_t* LZ4_initStream(void* stateBuffer, size_t size);                      /* lz4.h:750 */
+void          LZ4_resetStream_fast(LZ4_stream_t* streamPtr);                       /* lz4.h:358 */
+void          LZ4_resetStream(LZ4_stream_t* streamPtr);                            /* lz4.h:876 */
+int           LZ4_loadDict(LZ4_stream_t* streamPtr, const char* dictionary, int dictSize);   /* lz4.h:371 */
+int           LZ4_compress_fast_continue(LZ4_stream_t* streamPtr, const char* src, char* dst,
+                                         int srcSize, int dstCapacity, int acceleration);    /* lz4.h:441 */
+int           LZ4_saveDict(LZ4_stream_t* streamPtr, char* safeBuffer, int maxDictSize);      /* lz4.h:450 */
+
+/* ---- streaming decompression (reference lz4.h:457-535, state as lz4.h:757-770) */
+#define LZ4_STREAMDECODE_MINSIZE 32
+typedef union LZ4_streamDecode_u {
+    char minStateSize[LZ4_STREAMDECODE_MINSIZE];
+    struct { const unsigned char* externalDict; const unsigned char* prefixEnd; size_t extDictSize; size_t prefixSize; } internal_donotuse;
+} LZ4_streamDecode_t;
+LZ4_streamDecode_t* LZ4_createStreamDecode(void);                                  /* lz4.h:465 */
+int                 LZ4_freeStreamDecode(LZ4_streamDecode_t* LZ4_stream);          /* lz4.h:466 */
+int                 LZ4_setStreamDecode(LZ4_streamDecode_t* LZ4_streamDecode, const char* dictionary, int dictSize);   /* lz4.h:477 */
+int                 LZ4_decoderRingBufferSize(int maxBlockSize);                   /* lz4.h:490 */
+int                 LZ4_decompress_safe_continue(LZ4_streamDecode_t* LZ4_streamDecode, const char* src, char* dst,
+                                                 int srcSize, int dstCapacity);   /* lz4.h:531 */
 
 #ifdef __cplusplus
 }

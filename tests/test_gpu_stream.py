@@ -1,0 +1,176 @@
+"""Streaming contexts (the callers either side of the block codec) through the C ABI of
+include/lz4.h: LZ4_stream_t / LZ4_streamDecode_t with the reference's calling patterns
+(examples/blockStreaming_doubleBuffer.c, blockStreaming_ringBuffer.c; tests/fuzzer.c:900-1060).  Parity:
+our dependent blocks decode with the oracle's prefix decoder and, when oracle/_ref travelled, with the
+reference's LZ4_decompress_safe_continue; the reference's dependent blocks decode here."""
+import ctypes
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+vp, ci = ctypes.c_void_p, ctypes.c_int
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lz4_amd
+    lib = lz4_amd.lib()
+    lib.LZ4_createStream.restype = vp
+    lib.LZ4_freeStream.argtypes = [vp]
+    lib.LZ4_resetStream_fast.argtypes = [vp]
+    lib.LZ4_loadDict.argtypes = [vp, vp, ci]
+    lib.LZ4_compress_fast_continue.argtypes = [vp, vp, vp, ci, ci, ci]
+    lib.LZ4_saveDict.argtypes = [vp, vp, ci]
+    lib.LZ4_createStreamDecode.restype = vp
+    lib.LZ4_freeStreamDecode.argtypes = [vp]
+    lib.LZ4_setStreamDecode.argtypes = [vp, vp, ci]
+    lib.LZ4_decompress_safe_continue.argtypes = [vp, vp, vp, ci, ci]
+    lib.LZ4_decompress_safe_usingDict.argtypes = [vp, vp, ci, ci, vp, ci]
+    lib.LZ4_initStream.restype = vp
+    lib.LZ4_initStream.argtypes = [vp, ctypes.c_size_t]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ref():
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "liblz4_ref.so")
+    if not os.path.exists(so):
+        return None
+    R = ctypes.CDLL(so)
+    R.LZ4_createStream.restype = vp
+    R.LZ4_freeStream.argtypes = [vp]
+    R.LZ4_loadDict.argtypes = [vp, vp, ci]
+    R.LZ4_compress_fast_continue.argtypes = [vp, vp, vp, ci, ci, ci]
+    R.LZ4_createStreamDecode.restype = vp
+    R.LZ4_freeStreamDecode.argtypes = [vp]
+    R.LZ4_setStreamDecode.argtypes = [vp, vp, ci]
+    R.LZ4_decompress_safe_continue.argtypes = [vp, vp, vp, ci, ci]
+    R.LZ4_decompress_safe_usingDict.argtypes = [vp, vp, ci, ci, vp, ci]
+    return R
+
+
+def _addr(buf, off=0):
+    return ctypes.addressof(buf) + off
+
+
+def compress_stream(lib, src_buf, total, bs, dict_buf=None):
+    """Blocks of one contiguous buffer, each referencing its predecessors (prefix mode)."""
+    s = lib.LZ4_createStream()
+    if dict_buf is not None:
+        assert lib.LZ4_loadDict(s, _addr(dict_buf), len(dict_buf) - 1) == min(len(dict_buf) - 1, 65536)
+    cap = bs + bs // 255 + 16
+    out = []
+    for o in range(0, total, bs):
+        n = min(bs, total - o)
+        dst = ctypes.create_string_buffer(cap)
+        r = lib.LZ4_compress_fast_continue(s, _addr(src_buf, o), _addr(dst), n, cap, 1)
+        assert 0 < r <= cap
+        out.append(dst.raw[:r])
+    lib.LZ4_freeStream(s)
+    return out
+
+
+def decompress_stream(lib, blocks, total, bs, dict_buf=None):
+    sd = lib.LZ4_createStreamDecode()
+    if dict_buf is not None:
+        assert lib.LZ4_setStreamDecode(sd, _addr(dict_buf), len(dict_buf) - 1) == 1
+    out = ctypes.create_string_buffer(total + 8)
+    pos = 0
+    for b in blocks:
+        cb = ctypes.create_string_buffer(b, len(b))
+        r = lib.LZ4_decompress_safe_continue(sd, _addr(cb), _addr(out, pos), len(b), min(bs, total - pos))
+        assert r > 0, r
+        pos += r
+    lib.LZ4_freeStreamDecode(sd)
+    assert pos == total
+    return out.raw[:total]
+
+
+def test_dependent_blocks_prefix_mode(L, ref, oracle, datagen):
+    total, bs = 600000, 32768
+    data = datagen(total, 60, 4)
+    src = ctypes.create_string_buffer(data, total)
+    blocks = compress_stream(L, src, total, bs)
+    # the history pays: dependent blocks are smaller than the same blocks compressed alone
+    dst = ctypes.create_string_buffer(bs + bs // 255 + 16)
+    L.LZ4_compress_default.argtypes = [vp, vp, ci, ci]
+    alone = sum(L.LZ4_compress_default(_addr(src, o), _addr(dst), min(bs, total - o), len(dst)) for o in range(0, total, bs))
+    assert sum(map(len, blocks)) < 0.97 * alone
+    # ours -> oracle's prefix decoder, block after block in one contiguous output
+    out = ctypes.create_string_buffer(total + 8)
+    oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, vp, ci, ci, ctypes.c_size_t]
+    pos = 0
+    for b in blocks:
+        r = oracle.lz4o_decompress_safe_prefix(b, _addr(out, pos), len(b), min(bs, total - pos), min(pos, 65536))
+        assert r > 0
+        pos += r
+    assert pos == total and out.raw[:total] == data
+    # ours -> ours, and ours -> the reference's streaming decoder
+    assert decompress_stream(L, blocks, total, bs) == data
+    if ref is not None:
+        assert decompress_stream(ref, blocks, total, bs) == data
+        # the reference's dependent blocks decode here
+        assert decompress_stream(L, compress_stream(ref, src, total, bs), total, bs) == data
+
+
+def test_dictionary_and_double_buffer(L, ref, datagen):
+    """LZ4_loadDict / LZ4_setStreamDecode, then blocks that alternate between two separate buffers (the previous
+    block is an external dictionary: lz4.c:1776-1779, 2656-2664)."""
+    bs, nblk = 20000, 12
+    stream = datagen(65536 + bs * nblk, 60, 9)
+    dic = ctypes.create_string_buffer(stream[:65536], 65537)
+    bufs = [ctypes.create_string_buffer(bs), ctypes.create_string_buffer(bs)]
+    cap = bs + bs // 255 + 16
+
+    def run(lib_c, lib_d):
+        s = lib_c.LZ4_createStream()
+        assert lib_c.LZ4_loadDict(s, _addr(dic), 65536) == 65536
+        sd = lib_d.LZ4_createStreamDecode()
+        assert lib_d.LZ4_setStreamDecode(sd, _addr(dic), 65536) == 1
+        outs = [ctypes.create_string_buffer(bs), ctypes.create_string_buffer(bs)]
+        sizes = []
+        for i in range(nblk):
+            chunk = stream[65536 + i * bs:65536 + (i + 1) * bs]
+            ctypes.memmove(bufs[i & 1], chunk, bs)
+            dst = ctypes.create_string_buffer(cap)
+            r = lib_c.LZ4_compress_fast_continue(s, _addr(bufs[i & 1]), _addr(dst), bs, cap, 1)
+            assert r > 0
+            sizes.append(r)
+            d = lib_d.LZ4_decompress_safe_continue(sd, _addr(dst), _addr(outs[i & 1]), r, bs)
+            assert d == bs and outs[i & 1].raw == chunk, i
+        lib_c.LZ4_freeStream(s); lib_d.LZ4_freeStreamDecode(sd)
+        return sizes
+
+    sizes = run(L, L)
+    assert all(0 < r < bs for r in sizes)
+    if ref is not None:
+        run(L, ref)
+        run(ref, L)
+
+
+def test_save_dict_and_state_api(L, ref, datagen):
+    bs = 50000
+    data = datagen(3 * bs, 60, 2)
+    a = ctypes.create_string_buffer(data[:bs], bs)
+    b = ctypes.create_string_buffer(data[bs:2 * bs], bs)
+    safe = ctypes.create_string_buffer(65536)
+    cap = bs + bs // 255 + 16
+    state = ctypes.create_string_buffer(16416 + 8)
+    sp = (_addr(state) + 7) & ~7
+    s = L.LZ4_initStream(sp, 16416)
+    assert s == sp and L.LZ4_initStream(sp, 100) is None
+    c1 = ctypes.create_string_buffer(cap); c2 = ctypes.create_string_buffer(cap)
+    r1 = L.LZ4_compress_fast_continue(s, _addr(a), _addr(c1), bs, cap, 1)
+    assert r1 > 0
+    kept = L.LZ4_saveDict(s, _addr(safe), 65536)
+    assert kept == bs and safe.raw[:bs] == data[:bs]
+    ctypes.memset(a, 0, bs)                                  # the first block's memory is gone
+    r2 = L.LZ4_compress_fast_continue(s, _addr(b), _addr(c2), bs, cap, 1)
+    assert r2 > 0
+    out = ctypes.create_string_buffer(bs)
+    lib_d = ref if ref is not None else L
+    assert lib_d.LZ4_decompress_safe_usingDict(_addr(c2), _addr(out), r2, bs, _addr(safe), kept) == bs
+    assert out.raw == data[bs:2 * bs]
+    assert L.LZ4_decoderRingBufferSize(65536) == 65536 + 14 + 65536 and L.LZ4_decoderRingBufferSize(-1) == 0
