@@ -23,7 +23,9 @@
  *  - LZ4F_decompress buffers the frame and decodes it when it is complete; the bytes delivered and
  *    the return convention (0 = frame done, else a hint > 0, errors per LZ4F_isError) are the
  *    reference's, the pacing is not.
- * Not provided: the streaming compression context (LZ4F_compressBegin/Update/End), dictionaries.
+ *  - The streaming compression context (LZ4F_compressBegin / Update / flush / End, lz4frame_stream_api.c) sends
+ *    one block per call to the device; LZ4F_compressFrame sends the whole frame at once.
+ * Not provided: dictionaries (LZ4F_CDict, LZ4F_compressBegin_usingDict).
  */
 #ifndef LZ4_AMD_LZ4FRAME_H
 #define LZ4_AMD_LZ4FRAME_H
@@ -70,6 +72,20 @@ unsigned LZ4F_getVersion(void);                                     /* lz4frame.
 size_t LZ4F_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* preferencesPtr);
 size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
                           const LZ4F_preferences_t* preferencesPtr);
+
+/* streaming compression, lz4frame.h:240-366 */
+typedef struct LZ4F_cctx_s LZ4F_cctx;
+typedef LZ4F_cctx* LZ4F_compressionContext_t;
+typedef struct { unsigned stableSrc; unsigned reserved[3]; } LZ4F_compressOptions_t;                 /* lz4frame.h:262-265 */
+int              LZ4F_compressionLevel_max(void);                                                   /* lz4frame.h:240 */
+LZ4F_errorCode_t LZ4F_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned version);              /* lz4frame.h:274 */
+LZ4F_errorCode_t LZ4F_freeCompressionContext(LZ4F_cctx* cctx);                                      /* lz4frame.h:275 */
+size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* prefsPtr);   /* lz4frame.h:302 */
+size_t LZ4F_compressBound(size_t srcSize, const LZ4F_preferences_t* prefsPtr);                      /* lz4frame.h:321 */
+size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                           const LZ4F_compressOptions_t* cOptPtr);                                  /* lz4frame.h:335 */
+size_t LZ4F_flush(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* cOptPtr);       /* lz4frame.h:349 */
+size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* cOptPtr); /* lz4frame.h:363 */
 
 /* lz4frame.h:366-382 */
 typedef struct LZ4F_dctx_s LZ4F_dctx;

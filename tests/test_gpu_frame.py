@@ -190,3 +190,89 @@ def test_decompress_safe_using_dict(L, golden):
     # the frame's content is datagen -g600000 -P60: compare the prefix through the golden md5 of the whole
     full, _ = decompress_frame(L, frame, 600000)
     assert out == full[:len(out)] and hashlib.md5(full).hexdigest() == golden["frames"]["f_p60_600k_B4_BD_cs"]["src_md5"]
+
+
+class COpts(ctypes.Structure):
+    _fields_ = [("stableSrc", ctypes.c_uint), ("reserved", ctypes.c_uint * 3)]
+
+
+def stream_compress(L, data, rng, level=0, auto_flush=0, flush_every=0, **kw):
+    """LZ4F_compressBegin / Update (arbitrary input pieces) / flush / End, the way lz4io.c and frametest.c drive it."""
+    st, vp = ctypes.c_size_t, ctypes.c_void_p
+    L.LZ4F_createCompressionContext.restype = st
+    L.LZ4F_createCompressionContext.argtypes = [ctypes.POINTER(vp), ctypes.c_uint]
+    L.LZ4F_freeCompressionContext.argtypes = [vp]
+    for name in ("LZ4F_compressBegin",):
+        getattr(L, name).restype = st
+        getattr(L, name).argtypes = [vp, ctypes.c_char_p, st, ctypes.POINTER(Prefs)]
+    L.LZ4F_compressBound.restype = st
+    L.LZ4F_compressBound.argtypes = [st, ctypes.POINTER(Prefs)]
+    L.LZ4F_compressUpdate.restype = st
+    L.LZ4F_compressUpdate.argtypes = [vp, ctypes.c_char_p, st, ctypes.c_char_p, st, vp]
+    for name in ("LZ4F_flush", "LZ4F_compressEnd"):
+        getattr(L, name).restype = st
+        getattr(L, name).argtypes = [vp, ctypes.c_char_p, st, vp]
+    p = Prefs()
+    p.compressionLevel = level
+    p.autoFlush = auto_flush
+    for k, v in kw.items():
+        setattr(p.frameInfo, k, v)
+    c = vp()
+    assert L.LZ4F_createCompressionContext(ctypes.byref(c), 100) == 0
+    out = bytearray()
+    hdr = ctypes.create_string_buffer(32)
+    n = L.LZ4F_compressBegin(c, hdr, 32, ctypes.byref(p))
+    assert not L.LZ4F_isError(n), L.LZ4F_getErrorName(n)
+    out += hdr.raw[:n]
+    pos, calls = 0, 0
+    while pos < len(data):
+        take = min(len(data) - pos, rng.choice((1, 7, 1000, 65536, 65537, 300000, 1 << 20)))
+        cap = L.LZ4F_compressBound(take, ctypes.byref(p))
+        dst = ctypes.create_string_buffer(cap + 8)
+        n = L.LZ4F_compressUpdate(c, dst, cap, data[pos:pos + take], take, None)
+        assert not L.LZ4F_isError(n), L.LZ4F_getErrorName(n)
+        assert dst.raw[cap:] == b"\0" * 8
+        out += dst.raw[:n]
+        pos += take
+        calls += 1
+        if flush_every and calls % flush_every == 0:
+            cap = L.LZ4F_compressBound(0, ctypes.byref(p))
+            dst = ctypes.create_string_buffer(cap)
+            n = L.LZ4F_flush(c, dst, cap, None)
+            assert not L.LZ4F_isError(n)
+            out += dst.raw[:n]
+    cap = L.LZ4F_compressBound(0, ctypes.byref(p))
+    dst = ctypes.create_string_buffer(cap)
+    n = L.LZ4F_compressEnd(c, dst, cap, None)
+    assert not L.LZ4F_isError(n), L.LZ4F_getErrorName(n)
+    out += dst.raw[:n]
+    # too small a destination is refused, a context without compressBegin too
+    assert L.LZ4F_isError(L.LZ4F_compressUpdate(c, dst, cap, b"x" * 10, 10, None))
+    L.LZ4F_freeCompressionContext(c)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(blockSizeID=5, contentChecksumFlag=1, blockChecksumFlag=1), dict(blockSizeID=4, blockMode=1, contentChecksumFlag=1),
+    dict(blockSizeID=6, contentChecksumFlag=1, auto_flush=1), dict(blockSizeID=5, level=9, contentChecksumFlag=1),
+    dict(blockSizeID=4, flush_every=3, blockChecksumFlag=1)])
+def test_streaming_compression_context(L, oracle, datagen, kw):
+    rng = random.Random(17)
+    for n, pct in ((0, 50), (5, 50), (70000, 50), (1500000, 60)):
+        data = datagen(n, pct, n % 5)
+        frame = stream_compress(L, data, rng, **kw)
+        assert frame[:4] == bytes.fromhex("04224d18")
+        out = ctypes.create_string_buffer(n + 1)
+        used = ctypes.c_size_t()
+        r = oracle.lz4o_frame_decompress(out, n, frame, len(frame), ctypes.byref(used))
+        assert r == n and used.value == len(frame) and out.raw[:n] == data, (kw, n)
+        got, pos = decompress_frame(L, frame, n)
+        assert got == data and pos == len(frame)
+    # a declared content size must be honoured (lz4frame.c:1242-1245)
+    data = datagen(100000, 50, 1)
+    assert stream_compress(L, data, rng, contentSize=100000)[4] & 8
+    with pytest.raises(AssertionError):
+        stream_compress(L, data, rng, contentSize=99999)
+    # linked streaming frames use the history: smaller than the same content in independent blocks
+    data = datagen(1 << 20, 60, 3)
+    assert len(stream_compress(L, data, rng, blockSizeID=4)) < len(stream_compress(L, data, rng, blockSizeID=4, blockMode=1))
