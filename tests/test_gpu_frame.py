@@ -276,3 +276,28 @@ def test_streaming_compression_context(L, oracle, datagen, kw):
     # linked streaming frames use the history: smaller than the same content in independent blocks
     data = datagen(1 << 20, 60, 3)
     assert len(stream_compress(L, data, rng, blockSizeID=4)) < len(stream_compress(L, data, rng, blockSizeID=4, blockMode=1))
+
+
+def test_reference_cli_accepts_our_frames(L, datagen, tmp_path):
+    """ours LZ4F_compressFrame / streaming context -> the reference CLI (`lz4 -t`, `lz4 -dc | cmp`).
+    Needs the reference binary built into oracle/_ref (it travels with the snapshot)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "lz4")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lz4 not shipped")
+    rng = random.Random(5)
+    data = datagen(2500000, 60, 8)
+    frames = {
+        "one_shot_linked_cs": compress_frame(L, data, blockSizeID=5, contentChecksumFlag=1),
+        "one_shot_indep_bx": compress_frame(L, data, blockSizeID=4, blockMode=1, blockChecksumFlag=1, contentSize=1),
+        "one_shot_hc9": compress_frame(L, data, level=9, blockSizeID=6, contentChecksumFlag=1),
+        "stream_linked": stream_compress(L, data, rng, blockSizeID=4, contentChecksumFlag=1),
+        "stream_hc_flush": stream_compress(L, data, rng, level=9, blockSizeID=5, flush_every=2, blockChecksumFlag=1),
+    }
+    for name, frame in frames.items():
+        f = tmp_path / (name + ".lz4")
+        f.write_bytes(frame)
+        t = subprocess.run([exe, "-t", str(f)], capture_output=True, text=True)
+        assert t.returncode == 0, (name, t.stderr)
+        d = subprocess.run([exe, "-dc", str(f)], capture_output=True)
+        assert d.returncode == 0 and d.stdout == data, name
