@@ -99,7 +99,9 @@ enum : uint32_t {
     kOffSegExit = kOffPhase,
     kOffRecStage = kOffSegExit + kPreLanes * 4,              // SeqRec[4][kPreLanes]: records wait here to leave four at a time
     kPreEnd = kOffRecStage + 4 * kPreLanes * 16,
+    kOffCStage = kOffRecStage,                               // the compressed block itself, when it fits (then the records need no staging)
     kDecLdsBytes = kStreamEnd > kPreEnd ? kStreamEnd : kPreEnd,
+    kCStageMax = kDecLdsBytes - kOffCStage - 32,             // largest compressed block the pre-parse walks out of LDS
 };
 enum : uint32_t { M_BLOCK = 0, M_ERR = 1, M_CARRY = 2, M_HEAD = 3, M_EMIT = 4, M_FIRSTBAD = 5 };   // M_CARRY unused
 
@@ -109,18 +111,28 @@ __host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize) {
     return ((uint64_t)max_csize / 3 + 4) * sizeof(SeqRec);
 }
 
-// The compressed stream as the pre-parse walkers see it: global memory, served by the CU's L1.
-// (Few lanes walk long stretches - see preparse_block - so their current lines stay L1 resident.)
+// The compressed stream as the pre-parse walkers see it: global memory, served by the CU's L1 (few lanes
+// walk long stretches - see preparse_block - so their current lines stay L1 resident) - or, for a block
+// whose compressed bytes fit beside the pre-parse's own LDS (<= kCStageMax: every block up to 256 KB at
+// ratio >= 1.8), a copy of it in LDS: a walk is a chain of dependent loads, ~2 k cycles each from memory,
+// ~150 from LDS, and for small blocks that chain (the fixed 768-byte warm-up) is most of the decode time.
 struct CView {
     lz4amd_gsrc g;
+    const uint8_t* l;           // LDS copy of the block, or nullptr
     uint32_t csize;
-    __device__ __forceinline__ uint32_t u8(uint32_t p) const { return (uint32_t)g[p]; }
+    __device__ __forceinline__ uint32_t u8(uint32_t p) const { return l ? (uint32_t)l[p] : (uint32_t)g[p]; }
     __device__ __forceinline__ uint32_t u16(uint32_t p) const { return u8(p) | (u8(p + 1) << 8); }
     __device__ __forceinline__ bool in(uint32_t p) const { return p < csize; }
     __device__ __forceinline__ bool has8(uint32_t p) const { return p < csize && csize - p >= 8; }
     __device__ __forceinline__ uint64_t ld8_if(uint32_t p, bool ok) const {
         uint64_t v = 0;
-        if (ok) __builtin_memcpy(&v, g + p, 8);
+        if (ok) {
+            if (l) {            // three aligned dwords + two v_alignbyte (the copy is padded past csize)
+                const uint32_t* w = (const uint32_t*)(l + (p & ~3u));
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = p & 3u;
+                v = (uint64_t)align_bytes(w1, w0, sh) | ((uint64_t)align_bytes(w2, w1, sh) << 32);
+            } else __builtin_memcpy(&v, g + p, 8);
+        }
         return v;
     }
 };
@@ -214,6 +226,7 @@ __device__ __forceinline__ WalkOut walk_chain(const CView& V, uint32_t csize, ui
     const uint32_t seq0 = seq;
     uint32_t nbuf = 0;
     auto put = [&](const SeqRec& rec) {
+        if (stage == nullptr) { recs[seq0 + nbuf] = rec; nbuf++; return; }         // (loads come from LDS: nothing queues behind the store)
         stage[(nbuf & 3) * kPreLanes] = rec;
         nbuf++;
         if ((nbuf & 3) == 0) {
@@ -277,7 +290,7 @@ __device__ __forceinline__ WalkOut walk_chain(const CView& V, uint32_t csize, ui
         r.n++; r.ob += s.ll + ml; o += s.ll + ml; seq++;
         p = s.nx;
     }
-    if (EMIT) { for (uint32_t i = 0; i < (nbuf & 3); i++) recs[seq0 + (nbuf & ~3u) + i] = stage[i * kPreLanes]; }
+    if (EMIT && stage != nullptr) { for (uint32_t i = 0; i < (nbuf & 3); i++) recs[seq0 + (nbuf & ~3u) + i] = stage[i * kPreLanes]; }
     r.exit = p;
     return r;
 }
@@ -407,7 +420,14 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     if (G < kSeg) G = kSeg;
     const uint32_t nst = (csize + G - 1) / G;               // <= kPreLanes
     const uint32_t recap = 64 + G / 8;                       // trips an unconfirmed re-walk may take
-    CView V; V.g = src; V.csize = csize;
+    CView V; V.g = src; V.csize = csize; V.l = nullptr;
+    const bool staged = csize <= kCStageMax;
+    if (staged) {
+        uint8_t* const cs = (uint8_t*)(smem + kOffCStage);
+        for (uint32_t P = 16 * tid; P < csize + 16; P += 16 * kDecThreads) *(U32x4*)(cs + P) = load_granule(src, csize, P);
+        V.l = cs;
+        __syncthreads();
+    }
     const bool has_seg = tid < nst;
     const uint32_t s = tid * G;
     uint32_t e = s + G; if (e > csize || e < s) e = csize;
@@ -464,7 +484,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     // -- 4. the records, at their final place in the block's table
     if (has_seg && w.n) {
         const WalkOut w2 = walk_chain<true>(V, csize, my_entry, e, rectab, ea, (uint32_t)eb + kBias, cap + kBias, kBias - prefix,
-                                            (SeqRec*)(smem + kOffRecStage) + tid);
+                                            staged ? nullptr : (SeqRec*)(smem + kOffRecStage) + tid);
         if (w2.err) { atomicMin(&misc[M_ERR], w2.err - 1); bad = 1; }
     }
     if (tid == 0) { SeqRec rec; rec.outpos = (uint32_t)tb + kBias; rec.litpos = csize; rec.ll = 0; rec.off = 0; rectab[ta] = rec; }

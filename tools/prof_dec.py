@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, lz4_amd
 from bench import gen_data
-nb, bs = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 4 << 20
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4 << 20
 ctx = lz4_amd.Context(0)
 data = torch.from_numpy(gen_data(nb * bs, 60, 0)).cuda()
 comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs)
