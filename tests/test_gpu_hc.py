@@ -141,3 +141,21 @@ def test_hc_boundary_sizes(ctx, ocodec, datagen):
             assert 0 < r <= ocodec.bound(len(d))
             ro, o = ocodec.decompress(c, len(d))
             assert ro == len(d) and o == d, (lvl, len(d))
+
+
+def test_hc_large_and_degenerate_blocks(ctx, datagen):
+    """Blocks far larger than the window (many tiles and bands, 4 K sequence records per strip and more), all
+    zeros (one match per strip), incompressible noise (no match at all): round trip through the GPU decoder."""
+    import lz4_amd
+    blocks = [datagen(12 << 20, 60, 11), bytes(16 << 20), os.urandom(6 << 20), b"0123456789abcdef" * (1 << 19),
+              datagen(5 << 20, 95, 2)]
+    for d in blocks:
+        t = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        comp, cs, _ = lz4_amd.compress_blocks(ctx, t, len(d), hc_level=9)
+        assert 0 < cs[0] <= lz4_amd.compress_bound(len(d))
+        out, res, _ = lz4_amd.decompress_blocks(ctx, comp, cs, len(d), len(d))
+        assert res == [len(d)] and torch.equal(out, t)
+    # sizes: zeros and the 16-byte pattern collapse, noise does not grow beyond the bound
+    t = torch.zeros(16 << 20, dtype=torch.uint8, device="cuda")
+    _, cs, _ = lz4_amd.compress_blocks(ctx, t, 16 << 20, hc_level=9)
+    assert cs[0] < (16 << 20) // 200
