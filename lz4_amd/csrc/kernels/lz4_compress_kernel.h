@@ -406,22 +406,25 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             const bool mine = lane < nstrips;
             const uint32_t nk = mine ? strip_k[S_N * kCmpWaves + lane] : 0, en = mine ? strip_k[S_ENC * kCmpWaves + lane] : 0;
             const uint32_t l0 = mine ? strip_k[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip_k[S_TAIL * kCmpWaves + lane] : 0;
-            uint32_t out = misc[CM_OUT], carry = misc[CM_CARRY], fail = misc[CM_FAIL];
-            uint32_t my_out = 0, my_carry = 0;
-            for (uint32_t k = 0; k < nstrips; k++) {
-                const uint32_t nk_k = wave_readlane(nk, k), tail_k = wave_readlane(tl, k);
-                if (nk_k) {
-                    const uint32_t ll0 = wave_readlane(l0, k);
-                    const uint32_t sz = wave_readlane(en, k) + carry + lit_hdr_ext(ll0 + carry) - lit_hdr_ext(ll0);
-                    // a strip is only written if it fits (the block then fails as a whole, lz4.c:1116)
-                    if ((uint64_t)out + sz > cap) fail = 1;
-                    if (lane == k) { my_out = out; my_carry = carry; }
-                    if (!fail) out += sz;
-                    carry = tail_k;
-                } else {
-                    carry += tail_k;
-                }
-            }
+            // all strips at once: the literals carried into a strip that has sequences are the tails of the strips
+            // since the last one that had any (or since the previous tile); sizes then scan to offsets
+            const uint32_t out0 = misc[CM_OUT], carry0 = misc[CM_CARRY];
+            uint32_t fail = misc[CM_FAIL];
+            const unsigned long long ne = __ballot(mine && nk != 0);                 // strips with sequences
+            const uint32_t t_incl = wave_incl_sum(tl), t_excl = t_incl - tl;
+            const unsigned long long before = ne & ((1ull << lane) - 1);
+            const uint32_t prev = before ? 63u - (uint32_t)__clzll(before) : 0u;       // the last such strip before me
+            const uint32_t t_prev = (uint32_t)__shfl((int)t_excl, (int)prev);
+            const uint32_t my_carry = before ? t_excl - t_prev : carry0 + t_excl;
+            const uint32_t sz = nk ? en + my_carry + lit_hdr_ext(l0 + my_carry) - lit_hdr_ext(l0) : 0u;
+            const uint32_t o_incl = wave_incl_sum(sz);
+            const uint32_t my_out = out0 + o_incl - sz;
+            // a strip is only written if it fits (the block then fails as a whole, lz4.c:1116)
+            if (__ballot(nk != 0 && (uint64_t)out0 + o_incl > cap)) fail = 1;
+            const uint32_t total = wave_readlane(o_incl, 63), t_total = wave_readlane(t_incl, 63);
+            const uint32_t last = ne ? 63u - (uint32_t)__clzll(ne) : 0u;
+            const uint32_t out = fail ? out0 : out0 + total;
+            const uint32_t carry = ne ? t_total - wave_readlane(t_excl, last) : carry0 + t_total;
             if (mine) { strip_k[S_OUT * kCmpWaves + lane] = my_out; strip_k[S_CARRY * kCmpWaves + lane] = my_carry; }
             if (lane == 0) { misc[CM_OUT] = out; misc[CM_CARRY] = carry; misc[CM_FAIL] = fail; }
         }
