@@ -429,19 +429,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             if (lane == 0) { misc[CM_OUT] = out; misc[CM_CARRY] = carry; misc[CM_FAIL] = fail; }
         }
         // -- ... while everybody inserts the tile into the table (positions that may start a match):
-        //    16 consecutive positions per thread, hashed out of three aligned 8-byte words
+        //    8 consecutive positions per thread, hashed out of four aligned dwords
         if (n >= kMfLimit + 1) {
             const uint32_t last_q = n - kMfLimit;
-            // (the upper half of the workgroup first: wave 0 is busy with the offsets)
-            const uint32_t q0 = t0 + 16 * ((tid + kCmpThreads / 2) & (kCmpThreads - 1));      // t0 is a multiple of 1024
+            const uint32_t q0 = t0 + 8 * tid;                       // t0 is a multiple of 1024; tiles are at most 8 * kCmpThreads long
             if (q0 < t1 && q0 <= last_q) {
-                const uint32_t o = src_ring_off(q0);                // multiple of 16: o + 24 <= ring + pad
+                const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
                 const uint32_t* a = (const uint32_t*)(ring + o);
-                uint32_t dw[6];
+                uint32_t dw[4];
 #pragma unroll
-                for (uint32_t i = 0; i < 6; i++) dw[i] = a[i];
+                for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
 #pragma unroll
-                for (uint32_t i = 0; i < 16; i++) {
+                for (uint32_t i = 0; i < 8; i++) {
                     const uint32_t q = q0 + i;
                     const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
                     if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos32(lo, hi, small)], q);
