@@ -57,6 +57,7 @@ enum : uint32_t {
     kHashBits = 13,
     kRecsPerStrip = 64,                // matches a strip may take (the rest of it becomes literals)
     kLaneLenCap = 24,                  // match bytes a lane measures on its own
+    kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
 };
@@ -311,12 +312,22 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
             p[0] = (uint8_t)off; p[1] = (uint8_t)(off >> 8); p += 2;
             if (mlm4 >= 15) p = put_len_ext(p, mlm4 - 15);
         }
-        // literal runs, one sequence at a time, all lanes copying
-        const uint32_t cnt = nk - base < 64 ? nk - base : 64;
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t jl = wave_readlane(tl, j);
-            if (jl == 0) continue;
-            copy_literals(dst, wave_readlane(lit_dst, j), src, ring, wave_readlane(my_i, j), jl, ring_lo);
+        // literal runs: the short ones (nearly all) byte by byte by the lane that owns the sequence, all lanes at
+        // once; the long ones one sequence at a time with the whole wave copying
+        const bool shortrun = have && tl <= kShortRun;
+        if (shortrun && tl) {
+            if (my_i >= ring_lo) {
+                const uint32_t o = src_ring_off(my_i);
+                for (uint32_t i = 0; i < tl; i++) dst[lit_dst + i] = ring[ring_fwd(o, i)];
+            } else {
+                for (uint32_t i = 0; i < tl; i++) dst[lit_dst + i] = src[my_i + i];
+            }
+        }
+        unsigned long long longm = __ballot(have && tl > kShortRun);
+        while (longm) {
+            const uint32_t j = (uint32_t)__ffsll((long long)longm) - 1;
+            longm &= longm - 1;
+            copy_literals(dst, wave_readlane(lit_dst, j), src, ring, wave_readlane(my_i, j), wave_readlane(tl, j), ring_lo);
         }
         opos += wave_readlane(e_incl, 63);
         ipos += wave_readlane(a_incl, 63);
