@@ -334,6 +334,37 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
     }
 }
 
+// ------------------------------------------------------------------------------ offsets (one wave)
+// Output offset and carried-in literals of every strip of a tile, from the strips' summaries (lane k holds
+// strip k).  All strips at once: the literals carried into a strip that has sequences are the tails of the
+// strips since the last one that had any (or since the previous tile); the sizes then scan to offsets.
+struct StripTotals { uint32_t out, carry, fail; };
+__device__ __forceinline__ StripTotals strip_offsets(uint32_t* strip, uint32_t nstrips, uint32_t out0, uint32_t carry0,
+                                                     uint32_t fail, uint32_t cap) {
+    const uint32_t lane = lane_id();
+    const bool mine = lane < nstrips;
+    const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, en = mine ? strip[S_ENC * kCmpWaves + lane] : 0;
+    const uint32_t l0 = mine ? strip[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip[S_TAIL * kCmpWaves + lane] : 0;
+    const unsigned long long ne = __ballot(mine && nk != 0);                 // strips with sequences
+    const uint32_t t_incl = wave_incl_sum(tl), t_excl = t_incl - tl;
+    const unsigned long long before = ne & ((1ull << lane) - 1);
+    const uint32_t prev = before ? 63u - (uint32_t)__clzll(before) : 0u;       // the last such strip before me
+    const uint32_t t_prev = (uint32_t)__shfl((int)t_excl, (int)prev);
+    const uint32_t my_carry = before ? t_excl - t_prev : carry0 + t_excl;
+    const uint32_t sz = nk ? en + my_carry + lit_hdr_ext(l0 + my_carry) - lit_hdr_ext(l0) : 0u;
+    const uint32_t o_incl = wave_incl_sum(sz);
+    // a strip is only written if it fits (the block then fails as a whole, lz4.c:1116)
+    if (__ballot(nk != 0 && (uint64_t)out0 + o_incl > cap)) fail = 1;
+    const uint32_t total = wave_readlane(o_incl, 63), t_total = wave_readlane(t_incl, 63);
+    const uint32_t last = ne ? 63u - (uint32_t)__clzll(ne) : 0u;
+    if (mine) { strip[S_OUT * kCmpWaves + lane] = out0 + o_incl - sz; strip[S_CARRY * kCmpWaves + lane] = my_carry; }
+    StripTotals r;
+    r.out = fail ? out0 : out0 + total;
+    r.carry = ne ? t_total - wave_readlane(t_excl, last) : carry0 + t_total;
+    r.fail = fail;
+    return r;
+}
+
 // ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t b, char* smem) {
     const uint32_t tid = threadIdx.x, w = wave_id();
@@ -411,33 +442,10 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
-        // -- B: offsets (wave 0: lane k holds strip k; the carry chain runs through readlane) ...
+        // -- B: offsets (wave 0) ...
         if (w == 0 && parse) {
-            const uint32_t lane = lane_id();
-            const bool mine = lane < nstrips;
-            const uint32_t nk = mine ? strip_k[S_N * kCmpWaves + lane] : 0, en = mine ? strip_k[S_ENC * kCmpWaves + lane] : 0;
-            const uint32_t l0 = mine ? strip_k[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip_k[S_TAIL * kCmpWaves + lane] : 0;
-            // all strips at once: the literals carried into a strip that has sequences are the tails of the strips
-            // since the last one that had any (or since the previous tile); sizes then scan to offsets
-            const uint32_t out0 = misc[CM_OUT], carry0 = misc[CM_CARRY];
-            uint32_t fail = misc[CM_FAIL];
-            const unsigned long long ne = __ballot(mine && nk != 0);                 // strips with sequences
-            const uint32_t t_incl = wave_incl_sum(tl), t_excl = t_incl - tl;
-            const unsigned long long before = ne & ((1ull << lane) - 1);
-            const uint32_t prev = before ? 63u - (uint32_t)__clzll(before) : 0u;       // the last such strip before me
-            const uint32_t t_prev = (uint32_t)__shfl((int)t_excl, (int)prev);
-            const uint32_t my_carry = before ? t_excl - t_prev : carry0 + t_excl;
-            const uint32_t sz = nk ? en + my_carry + lit_hdr_ext(l0 + my_carry) - lit_hdr_ext(l0) : 0u;
-            const uint32_t o_incl = wave_incl_sum(sz);
-            const uint32_t my_out = out0 + o_incl - sz;
-            // a strip is only written if it fits (the block then fails as a whole, lz4.c:1116)
-            if (__ballot(nk != 0 && (uint64_t)out0 + o_incl > cap)) fail = 1;
-            const uint32_t total = wave_readlane(o_incl, 63), t_total = wave_readlane(t_incl, 63);
-            const uint32_t last = ne ? 63u - (uint32_t)__clzll(ne) : 0u;
-            const uint32_t out = fail ? out0 : out0 + total;
-            const uint32_t carry = ne ? t_total - wave_readlane(t_excl, last) : carry0 + t_total;
-            if (mine) { strip_k[S_OUT * kCmpWaves + lane] = my_out; strip_k[S_CARRY * kCmpWaves + lane] = my_carry; }
-            if (lane == 0) { misc[CM_OUT] = out; misc[CM_CARRY] = carry; misc[CM_FAIL] = fail; }
+            const StripTotals t = strip_offsets(strip_k, nstrips, misc[CM_OUT], misc[CM_CARRY], misc[CM_FAIL], cap);
+            if (lane_id() == 0) { misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; }
         }
         // -- ... while everybody inserts the tile into the table (positions that may start a match):
         //    8 consecutive positions per thread, hashed out of four aligned dwords

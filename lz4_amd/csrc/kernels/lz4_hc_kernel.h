@@ -567,28 +567,10 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         }
         __syncthreads();
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[4] += t - tq; tq = t; }
-        // -- offsets: lane k of wave 0 holds strip k; the literal carry runs through readlane
+        // -- offsets (wave 0; limitedOutput: a block that does not fit fails as a whole, lz4hc.c:297-300)
         if (w == 0) {
-            const uint32_t lane = lane_id();
-            const bool mine = lane < nstrips;
-            const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, en = mine ? strip[S_ENC * kCmpWaves + lane] : 0;
-            const uint32_t l0 = mine ? strip[S_LL0 * kCmpWaves + lane] : 0, tl = mine ? strip[S_TAIL * kCmpWaves + lane] : 0;
-            uint32_t out = 0, carry = 0, fail = 0, my_out = 0, my_carry = 0;
-            for (uint32_t k = 0; k < nstrips; k++) {
-                const uint32_t nk_k = wave_readlane(nk, k), tail_k = wave_readlane(tl, k);
-                if (nk_k) {
-                    const uint32_t ll0 = wave_readlane(l0, k);
-                    const uint32_t sz = wave_readlane(en, k) + carry + lit_hdr_ext(ll0 + carry) - lit_hdr_ext(ll0);
-                    if ((uint64_t)out + sz > cap) fail = 1;              // limitedOutput: the block fails as a whole (lz4hc.c:297-300)
-                    if (lane == k) { my_out = out; my_carry = carry; }
-                    if (!fail) out += sz;
-                    carry = tail_k;
-                } else {
-                    carry += tail_k;
-                }
-            }
-            if (mine) { strip[S_OUT * kCmpWaves + lane] = my_out; strip[S_CARRY * kCmpWaves + lane] = my_carry; }
-            if (lane == 0) { misc[HM_OUT] = out; misc[HM_CARRY] = carry; misc[HM_FAIL] = fail; }
+            const StripTotals t = strip_offsets(strip, nstrips, 0, 0, 0, cap);
+            if (lane_id() == 0) { misc[HM_OUT] = t.out; misc[HM_CARRY] = t.carry; misc[HM_FAIL] = t.fail; }
         }
         __syncthreads();
         // -- emit
