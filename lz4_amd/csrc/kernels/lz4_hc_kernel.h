@@ -62,6 +62,7 @@ enum : uint32_t {
     kHcBandStep = kHcRing - kHcAhead,   // how much further back the next band starts
     kHcBands = 3,                       // 3 x 32496 >= 65535 + kHcTile + kHcAhead: the whole LZ4 window, for every position
     kHcMinStrip = 1024,
+    kHcListCap = 3584,                  // if more walks than this go on in a tile, all its positions are handed out instead
     kHcChunk = 1024,                    // positions of search results a parsing wave stages in LDS at a time
 #ifndef LZ4AMD_HC_BATCH
 #define LZ4AMD_HC_BATCH 4
@@ -89,7 +90,8 @@ enum : uint32_t {
     kHcMineBytes = kHcTile + kHcAhead + 48,           // 36-byte reads at up to kHcLenCap bytes past the tile's last position
     kHOffRes0 = kHOffMine + kHcMineBytes,           //          u32[kHcTile] per-position state, word 0
     kHOffRes1 = kHOffRes0 + 4 * kHcTile,            //          u16[kHcTile] per-position state, word 1
-    kHcSearchEnd = kHOffRes1 + 2 * kHcTile,
+    kHOffList = kHOffRes1 + 2 * kHcTile,            //          u16[kHcListCap] positions of the tile whose walks go on (farther bands)
+    kHcSearchEnd = kHOffList + 2 * kHcListCap,
     kHOffWtab = kHOffBody + (4u << kHcHashLog),     // phase 1: u32[kHcWaves][256] duplicate detection, one table per wave
     kHOffParse = kHOffBody,                         // phase 3: u32[kHcWaves][2 * kHcChunk]
     kHcLdsBytes = kHcSearchEnd,
@@ -99,7 +101,7 @@ static_assert(kHOffParse + kHcWaves * 2 * kHcChunk * 4 <= kHcLdsBytes, "parse st
 static_assert(kHcLdsBytes <= 160 * 1024, "one CU's LDS");
 static_assert(kHcBands * kHcBandStep >= 65535 + kHcTile + kHcAhead, "bands must cover the LZ4 window");
 static_assert(kHOffMine % 16 == 0 && kHOffRes0 % 16 == 0 && kHOffRes1 % 16 == 0 && kHOffChain % 16 == 0, "16-byte LDS accesses");
-enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5 };
+enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5, HM_NLIST = 6 };
 
 // scratch layout of one workgroup, for blocks of at most n bytes
 __host__ __device__ inline uint64_t hc_chain_bytes(uint32_t n) { return ((uint64_t)2 * (n + 64) + 255) & ~255ull; }
@@ -260,6 +262,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
     uint8_t* mine = (uint8_t*)(smem + kHOffMine);
     uint32_t* res0 = (uint32_t*)(smem + kHOffRes0);
     uint16_t* res1 = (uint16_t*)(smem + kHOffRes1);
+    uint16_t* plist = (uint16_t*)(smem + kHOffList);
     uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
     const uint32_t n64 = (n + 63) & ~63u;
     const int32_t last_q = (int32_t)n - (int32_t)kMfLimit;            // last position that may start a match
@@ -295,8 +298,32 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
             *(U32x4*)(res0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads));
             *(U32x4*)(res1 + 8 * tid) = *(const U32x4*)(st1_g + t0 + 8 * tid);
         }
-        if (tid == 0) misc[HM_POOL] = 0;
+        if (tid == 0) { misc[HM_POOL] = 0; misc[HM_NLIST] = 0; }
         __syncthreads();
+        // -- farther bands: most walks are over already.  The positions whose walk goes on are listed and only
+        //    those are handed out (one by one); the others are settled here, eight per thread
+        uint32_t nlist = 0;
+        bool listed = false;
+        if (band != 0) {
+            uint32_t over = 0;                                          // my positions whose walk is over
+#pragma unroll
+            for (uint32_t k = 0; k < kHcPosPerThread; k++) {
+                const uint32_t q = k * kHcThreads + tid;
+                if ((res0[q] >> 16) != 0) { const uint32_t i = atomicAdd(&misc[HM_NLIST], 1u); if (i < kHcListCap) plist[i] = (uint16_t)q; }
+                else over |= 1u << k;
+            }
+            __syncthreads();
+            nlist = misc[HM_NLIST];
+            listed = nlist <= kHcListCap;
+            if (listed && final_band) {                                 // (only entries no walker will touch: see `over`)
+#pragma unroll
+                for (uint32_t k = 0; k < kHcPosPerThread; k++) {
+                    const uint32_t q = k * kHcThreads + tid;
+                    if (over & (1u << k)) res0[q] = (res1[q] & 0xFFu) | ((res0[q] & 0xFFFFu) << 8);
+                }
+            }
+        }
+        const uint32_t nunits = listed ? nlist : kHcRunsPerTile;        // work units of the tile: listed positions, or runs
         // -- the walks.  The tile is a pool of runs of kHcRun consecutive positions; idle lanes of any wave take
         //    the next runs (which lane walks a run does not change its result).  The loop is wave-synchronous
         //    and predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
@@ -321,8 +348,11 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
                     if (lane == (uint32_t)__ffsll((long long)idle) - 1) base = atomicAdd(&misc[HM_POOL], nidle);
                     base = wave_readlane(base, (uint32_t)__ffsll((long long)idle) - 1);
                     const uint32_t mine_i = base + lanes_below(idle);
-                    if (base + nidle >= kHcRunsPerTile) pool_dry = true;
-                    if (want && mine_i < kHcRunsPerTile) { pp = mine_i * kHcRun - 1; run_left = kHcRun; inh_len = 0; }
+                    if (base + nidle >= nunits) pool_dry = true;
+                    if (want && mine_i < nunits) {
+                        if (listed) { pp = (uint32_t)plist[mine_i] - 1; run_left = 1; } else { pp = mine_i * kHcRun - 1; run_left = kHcRun; }
+                        inh_len = 0;
+                    }
                 }
                 // ---- next position of my run.  In the nearest band it starts from what its predecessor found:
                 //      a match of length L at p is a match of length L - 1 at p + 1 (same offset), so inside a long
