@@ -66,3 +66,39 @@ def test_product_does_not_link_oracle(libpath):
     assert "lz4o_" not in out
     ldd = subprocess.run(["ldd", libpath], capture_output=True, text=True).stdout
     assert "oracle" not in ldd and "liblz4_ref" not in ldd
+
+
+def test_bounds_match_the_reference(libpath, reflib):
+    """Pure arithmetic entry points against the real reference (oracle/_ref): LZ4F_compressBound (lz4frame.c:379-424),
+    LZ4F_compressFrameBound (406-416), LZ4_compressBound, LZ4_decoderRingBufferSize (lz4.c:2622-2628)."""
+    import itertools
+
+    class FrameInfo(ctypes.Structure):
+        _fields_ = [("blockSizeID", ctypes.c_int), ("blockMode", ctypes.c_int), ("contentChecksumFlag", ctypes.c_int),
+                    ("frameType", ctypes.c_int), ("contentSize", ctypes.c_ulonglong), ("dictID", ctypes.c_uint),
+                    ("blockChecksumFlag", ctypes.c_int)]
+
+    class Prefs(ctypes.Structure):
+        _fields_ = [("frameInfo", FrameInfo), ("compressionLevel", ctypes.c_int), ("autoFlush", ctypes.c_uint),
+                    ("favorDecSpeed", ctypes.c_uint), ("reserved", ctypes.c_uint * 3)]
+
+    L = ctypes.CDLL(libpath)
+    for lib in (L, reflib):
+        for name in ("LZ4F_compressBound", "LZ4F_compressFrameBound"):
+            getattr(lib, name).restype = ctypes.c_size_t
+            getattr(lib, name).argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+    sizes = (0, 1, 65535, 65536, 65537, 262144, 1000000, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, 50000000)
+    for n in sizes:
+        assert L.LZ4F_compressBound(n, None) == reflib.LZ4F_compressBound(n, None), n
+        assert L.LZ4F_compressFrameBound(n, None) == reflib.LZ4F_compressFrameBound(n, None), n
+    for bsid, bx, cs, af, n in itertools.product((0, 4, 5, 6, 7), (0, 1), (0, 1), (0, 1), sizes):
+        p = Prefs()
+        p.frameInfo.blockSizeID, p.frameInfo.blockChecksumFlag, p.frameInfo.contentChecksumFlag, p.autoFlush = bsid, bx, cs, af
+        assert L.LZ4F_compressBound(n, ctypes.byref(p)) == reflib.LZ4F_compressBound(n, ctypes.byref(p)), (bsid, bx, cs, af, n)
+        assert L.LZ4F_compressFrameBound(n, ctypes.byref(p)) == reflib.LZ4F_compressFrameBound(n, ctypes.byref(p)), (bsid, bx, cs, af, n)
+    for n in (-1, 0, 1, 15, 16, 17, 65536, 4 << 20, 0x7E000000, 0x7E000001):
+        assert L.LZ4_compressBound(n) == reflib.LZ4_compressBound(n)
+        assert L.LZ4_decoderRingBufferSize(n) == reflib.LZ4_decoderRingBufferSize(n), n
+    assert L.LZ4F_compressionLevel_max() == reflib.LZ4F_compressionLevel_max() == 12
+    assert L.LZ4_sizeofStateHC() == reflib.LZ4_sizeofStateHC()
+    assert L.LZ4_sizeofState() == reflib.LZ4_sizeofState()
