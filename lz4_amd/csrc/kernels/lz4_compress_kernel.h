@@ -215,18 +215,27 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                     }
                 }
             }
-            unsigned long long m = __ballot(f);
+            // Which matches are taken is a serial question (a match starts where the previous one ended) but a
+            // cheap one: the walk below only follows "first candidate at or after the end of the last one" and
+            // tells every taken lane where its predecessor ended.  Everything per match - backward extension over
+            // the pending literals, record, encoded size - is then done by the taken lanes side by side.
+            uint32_t e = q + len;                                  // where my match ends (no lane-side length beyond the cap)
+            if (e > mlimit) e = mlimit;
+            uint32_t prev_end = 0;                                 // end of the match taken before mine (taken lanes only)
+            unsigned long long m = __ballot(f && q + kMinMatch <= mlimit);
+            unsigned long long taken = 0;
+            uint32_t ntaken = 0, wend = anchor;                    // wend: end of the last match taken so far
             while (m) {
+                // candidates that start inside what is already covered are out
+                if (cur > p) { const uint32_t k = (cur - p + sh) >> sh; if (k >= 64) break; m &= ~0ull << k; if (!m) break; }
                 const uint32_t l = (uint32_t)__ffsll((long long)m) - 1;
                 m &= m - 1;
-                uint32_t qm = p + (l << sh);
-                if (qm < cur) continue;
-                if (qm + kMinMatch > mlimit) break;            // nothing later in the window fits either
-                uint32_t cm = wave_readlane(c, l);
+                uint32_t el = wave_readlane(e, l);
+                const uint32_t qm = p + (l << sh);
                 uint32_t ml = wave_readlane(len, l);
-                uint32_t bk = wave_readlane(back, l);
                 if (ml >= kLaneLenCap && qm + ml < mlimit) {
                     // long match: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
+                    const uint32_t cm = wave_readlane(c, l);
                     const uint32_t qmo = ring_fwd(cs_off, qm - cs), cmo = ring_back(qmo, qm - cm);
                     for (;;) {
                         const uint32_t a = qm + ml + 8 * lane;
@@ -243,19 +252,31 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                         }
                         ml += 512;
                     }
+                    el = qm + ml; if (el > mlimit) el = mlimit;
+                    e = lane == l ? el : e;
                 }
-                if (qm + ml > mlimit) ml = mlimit - qm;
-                if (bk > qm - anchor) bk = qm - anchor;
-                qm -= bk; cm -= bk; ml += bk;
-                const uint32_t ll = qm - anchor;
-                if (lane == 0) { MatchRec r; r.ll = ll; r.mo = (qm - cm) | ((ml - kMinMatch) << 16); recs[nseq] = r; }
-                if (nseq == 0) ll0 = ll;
-                enc += enc_size(ll, ml - kMinMatch);
-                nseq++;
-                anchor = cur = qm + ml;
-                if (nseq >= kRecsPerStrip) break;
-                if (cur - p >= span) break;
-                m &= ~0ull << ((cur - p + sh) >> sh);          // lanes inside the match
+                prev_end = lane == l ? wend : prev_end;
+                taken |= 1ull << l;
+                ntaken++;
+                wend = cur = el;
+                if (nseq + ntaken >= kRecsPerStrip) break;
+            }
+            if (taken) {
+                const bool mine = (taken >> lane) & 1;
+                uint32_t my_enc = 0, my_ll = 0;
+                if (mine) {
+                    uint32_t bk = back; if (bk > q - prev_end) bk = q - prev_end;     // lz4.c:1105-1109 over the pending literals
+                    const uint32_t qs = q - bk;
+                    my_ll = qs - prev_end;
+                    const uint32_t mlen = e - qs;
+                    MatchRec r; r.ll = my_ll; r.mo = (q - c) | ((mlen - kMinMatch) << 16);
+                    recs[nseq + lanes_below(taken)] = r;
+                    my_enc = enc_size(my_ll, mlen - kMinMatch);
+                }
+                if (nseq == 0) ll0 = wave_readlane(my_ll, (uint32_t)__ffsll((long long)taken) - 1);
+                enc += wave_readlane(wave_incl_sum(my_enc), 63);
+                nseq += ntaken;
+                anchor = wend;
             }
             p = cur > p + span ? (cur + sh) & ~sh : p + span;
         }
