@@ -67,6 +67,11 @@ int  lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
 int  lz4amd_plan_create_compress_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                         const void* const* d_src, const int* src_sizes,
                                         void* const* d_dst, const int* dst_caps, const int* prefix_sizes);
+/* LZ4AMD_OP_COMPRESS_HC with history (LZ4_compress_HC_continue in prefix mode, lz4hc.c:1666-1700; lz4frame linked
+ * blocks at HC levels): the largest multiple of 64 bytes up to 64 KB of prefix_sizes[i] is used. */
+int  lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                                           const void* const* d_src, const int* src_sizes,
+                                           void* const* d_dst, const int* dst_caps, const int* prefix_sizes, int level);
 void lz4amd_plan_destroy(lz4amd_plan* plan);
 /* enqueue the whole table on `stream` (asynchronous) */
 int  lz4amd_plan_launch(lz4amd_plan* plan, void* stream);

@@ -17,9 +17,8 @@
  *    too (the history of a block is source data); they are DECODED block after block, since a
  *    block needs the previous one's output (lz4frame.c:1901-1915) - ask for LZ4F_blockIndependent
  *    when decode speed matters.
- *  - compressionLevel >= 2 selects the HC kernel (lz4frame.c:943-958), lower values the fast one.  HC blocks of a
- *    linked frame are compressed without history (valid, slightly larger); negative "acceleration" levels
- *    are served by the fast kernel as level 0.
+ *  - compressionLevel >= 2 selects the HC kernel (lz4frame.c:943-958), lower values the fast one; negative
+ *    "acceleration" levels are served by the fast kernel as level 0.
  *  - LZ4F_decompress buffers the frame and decodes it when it is complete; the bytes delivered and
  *    the return convention (0 = frame done, else a hint > 0, errors per LZ4F_isError) are the
  *    reference's, the pacing is not.

@@ -8,9 +8,11 @@
  * the bytes differ from the CPU library's, decode identically with any LZ4 decoder, and the size at
  * level 9 stays within the +-3 % window of the reference's (tests/test_gpu_hc.py).
  *
- * Not provided (SURVEY.md section 8f "next"): the streaming HC contexts (LZ4_createStreamHC,
- * LZ4_compress_HC_continue, LZ4_loadDictHC, ...), LZ4_compress_HC_destSize, and the optimal parser
- * of levels 10-12 (those levels run the level-9 search).
+ * The streaming HC context (lz4hc.h:98-180) tracks where the previous data is and ships its last 64 KB with
+ * every block as history (lz4hc_api.c).
+ *
+ * Not provided (SURVEY.md section 8f "next"): LZ4_compress_HC_destSize, LZ4_attach_HC_dictionary, and the
+ * optimal parser of levels 10-12 (those levels run the level-9 search).
  */
 #ifndef LZ4_AMD_LZ4HC_H
 #define LZ4_AMD_LZ4HC_H
@@ -39,6 +41,22 @@ int LZ4_sizeofStateHC(void);                                                    
  * live in LDS / device scratch); it is accepted for ABI compatibility and must be non-NULL and
  * 8-byte aligned as in the reference (lz4hc.c:1506). */
 int LZ4_compress_HC_extStateHC(void* stateHC, const char* src, char* dst, int srcSize, int maxDstSize, int compressionLevel);
+
+/* ---- streaming (reference lz4hc.h:98-180, 275, 356-389) */
+typedef union LZ4_streamHC_u {
+    char minStateSize[LZ4_STREAMHC_MINSIZE];                /* lz4hc.h:252-256: the size is ABI */
+    struct { const char* dictionary; unsigned dictSize; int compressionLevel; } internal_donotuse;
+} LZ4_streamHC_t;
+LZ4_streamHC_t* LZ4_createStreamHC(void);                                          /* lz4hc.h:109 */
+int             LZ4_freeStreamHC(LZ4_streamHC_t* streamHCPtr);                     /* lz4hc.h:110 */
+LZ4_streamHC_t* LZ4_initStreamHC(void* buffer, size_t size);                       /* lz4hc.h:275 */
+void            LZ4_resetStreamHC_fast(LZ4_streamHC_t* streamHCPtr, int compressionLevel);   /* lz4hc.h:157 */
+void            LZ4_resetStreamHC(LZ4_streamHC_t* streamHCPtr, int compressionLevel);        /* lz4hc.h:322 */
+void            LZ4_setCompressionLevel(LZ4_streamHC_t* streamHCPtr, int compressionLevel);  /* lz4hc.h:356 */
+int             LZ4_loadDictHC(LZ4_streamHC_t* streamHCPtr, const char* dictionary, int dictSize);   /* lz4hc.h:158 */
+int             LZ4_compress_HC_continue(LZ4_streamHC_t* streamHCPtr, const char* src, char* dst,
+                                         int srcSize, int maxDstSize);             /* lz4hc.h:160 */
+int             LZ4_saveDictHC(LZ4_streamHC_t* streamHCPtr, char* safeBuffer, int maxDictSize);      /* lz4hc.h:178 */
 
 #ifdef __cplusplus
 }

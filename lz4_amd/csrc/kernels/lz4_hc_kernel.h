@@ -254,7 +254,7 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
     return l > lim ? lim : l;
 }
 
-__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
+__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
                                                uint32_t band, uint32_t attempts, char* smem) {
     const uint32_t tid = threadIdx.x;
     uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
@@ -362,7 +362,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, cons
                     p = (int32_t)(t0 + pp);
                     bool walk = true, kept = false;
                     if (band == 0) {
-                        if (p > last_q) { res0[pp] = 0; res1[pp] = 3; walk = false; }     // also the slots past the block's end
+                        if (p > last_q || (uint32_t)p < first) { res0[pp] = 0; res1[pp] = 3; walk = false; }     // the history, and the slots past the block's end
                         else { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
                     } else {
                         const uint32_t s0 = res0[pp], s1 = res1[pp];
@@ -556,7 +556,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     const uint32_t tid = threadIdx.x, w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
     uint32_t* strip = (uint32_t*)(smem + kHOffStrip);
-    const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
+    const lz4amd_gsrc src0 = LZ4AMD_TO_GSRC(P.src[b]);
     const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
     const int32_t n_i = P.src_size[b];
     const int32_t cap_i = P.dst_cap[b];
@@ -565,7 +565,14 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         return;
     }
     if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }
-    const uint32_t n = (uint32_t)n_i, cap = (uint32_t)cap_i;
+    // history (linked blocks / LZ4_compress_HC_continue in prefix mode, lz4hc.c:1666-1700): the `first` bytes right
+    // before the block are linked into the chains like the block itself, but neither searched nor emitted.  From
+    // here on positions count from the start of the history.  (A multiple of 64 keeps every per-position array aligned.)
+    uint32_t first = P.prefix ? (uint32_t)P.prefix[b] : 0u;
+    if (first > kMaxDistance + 1) first = kMaxDistance + 1;
+    first &= ~63u;
+    const lz4amd_gsrc src = src0 - first;
+    const uint32_t n = (uint32_t)n_i + first, cap = (uint32_t)cap_i;
     uint8_t* scratch = P.scratch + (uint64_t)blockIdx.x * P.scratch_stride;
     uint16_t* chain_g = (uint16_t*)scratch;
     uint32_t* st0_g = (uint32_t*)(scratch + hc_chain_bytes(P.max_src));
@@ -576,22 +583,23 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
 
     uint32_t nstrips = 0, strip_len = 0;
     if (tid == 0) { misc[HM_OUT] = 0; misc[HM_CARRY] = 0; misc[HM_FAIL] = 0; }
-    if (n >= kMfLimit + 1) {
+    if ((uint32_t)n_i >= kMfLimit + 1) {
         hc_build_chain(src, n, chain_g, smem);
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[0] += t - tq; tq = t; }
         const uint32_t attempts = hc_attempts(P.level);
 
         for (uint32_t band = 0; band < kHcBands; band++) {
-            hc_search_band(src, n, chain_g, st0_g, st1_g, band, attempts, smem);
+            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, smem);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         }
-        // -- parse: one wave per strip
-        nstrips = (n + kHcMinStrip - 1) / kHcMinStrip; if (nstrips > kHcWaves) nstrips = kHcWaves;
-        strip_len = (((n + nstrips - 1) / nstrips) + 63) & ~63u;
-        nstrips = (n + strip_len - 1) / strip_len;
+        // -- parse: one wave per strip of the block proper
+        const uint32_t own = n - first;
+        nstrips = (own + kHcMinStrip - 1) / kHcMinStrip; if (nstrips > kHcWaves) nstrips = kHcWaves;
+        strip_len = (((own + nstrips - 1) / nstrips) + 63) & ~63u;
+        nstrips = (own + strip_len - 1) / strip_len;
         const uint32_t rec_cap = strip_len / 4 + 4;
         if (w < nstrips) {
-            const uint32_t cs = w * strip_len;
+            const uint32_t cs = first + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > n) ce = n;
             hc_parse_strip(src, n, st0_g, recs_g + (uint64_t)w * rec_cap, strip, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce);
         }
@@ -605,12 +613,12 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         __syncthreads();
         // -- emit
         if (w < nstrips && !misc[HM_FAIL] && strip[S_N * kCmpWaves + w])
-            emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap, strip, w, src, dst, w * strip_len, 0xFFFFFFFFu);
+            emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap, strip, w, src, dst, first + w * strip_len, 0xFFFFFFFFu);
         __syncthreads();
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[5] += t - tq; tq = t; }
     } else {
         __syncthreads();
-        if (tid == 0) misc[HM_CARRY] = n;
+        if (tid == 0) misc[HM_CARRY] = (uint32_t)n_i;
         __syncthreads();
     }
     // -- final literal run (lz4hc.c:1336-1357)

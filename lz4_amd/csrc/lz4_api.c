@@ -150,8 +150,8 @@ done:
 /* One block with up to 64 KB of history (the bytes a streaming compressor may reference, lz4.c:1707
  * LZ4_compress_fast_continue): history and block are staged back to back in device memory and the block
  * is compressed with the history as its prefix (include/lz4amd.h lz4amd_plan_create_compress_prefix). */
-int lz4amd_compress_with_history(const char* hist, int histSize, const char* src, char* dst, int srcSize, int dstCapacity)
-{
+int lz4amd_compress_with_history(const char* hist, int histSize, const char* src, char* dst, int srcSize, int dstCapacity, int hc_level)
+{   /* hc_level 0: LZ4_compress_default semantics; > 0: LZ4_compress_HC at that level */
     lz4amd_ctx* ctx;
     lz4amd_plan* plan = NULL;
     int result = 0, pre;
@@ -159,7 +159,8 @@ int lz4amd_compress_with_history(const char* hist, int histSize, const char* src
     size_t in_bytes, out_bytes;
     if (srcSize < 0 || (unsigned)srcSize > (unsigned)LZ4_MAX_INPUT_SIZE || dst == NULL || dstCapacity <= 0) return 0;
     if (src == NULL && srcSize != 0) return 0;
-    if (hist == NULL || histSize <= 0) return lz4amd_run_one(LZ4AMD_OP_COMPRESS, src, dst, srcSize, dstCapacity, 0, 0);
+    if (hist == NULL || histSize <= 0)
+        return lz4amd_run_one(hc_level > 0 ? LZ4AMD_OP_COMPRESS_HC : LZ4AMD_OP_COMPRESS, src, dst, srcSize, dstCapacity, hc_level, 0);
     pre = histSize > 65536 ? 65536 : histSize;
     in_bytes = (size_t)srcSize; out_bytes = (size_t)dstCapacity;
     pthread_mutex_lock(&g_lock);
@@ -170,7 +171,8 @@ int lz4amd_compress_with_history(const char* hist, int histSize, const char* src
     if (lz4amd_hip_h2d((char*)g_stage_in + (65536 - pre), hist + (histSize - pre), (size_t)pre, NULL)) goto done;
     if (in_bytes && lz4amd_hip_h2d((char*)g_stage_in + 65536, src, in_bytes, NULL)) goto done;
     dsrc = (char*)g_stage_in + 65536; ddst = g_stage_out;
-    if (lz4amd_plan_create_compress_prefix(ctx, &plan, 1, &dsrc, &srcSize, &ddst, &dstCapacity, &pre)) goto done;
+    if (hc_level > 0 ? lz4amd_plan_create_compress_hc_prefix(ctx, &plan, 1, &dsrc, &srcSize, &ddst, &dstCapacity, &pre, hc_level)
+                     : lz4amd_plan_create_compress_prefix(ctx, &plan, 1, &dsrc, &srcSize, &ddst, &dstCapacity, &pre)) goto done;
     if (lz4amd_plan_launch(plan, NULL) || lz4amd_plan_results(plan, &result, NULL)) { result = 0; goto done; }
     if (result > 0 && (size_t)result <= out_bytes) {
         if (lz4amd_hip_d2h(dst, g_stage_out, (size_t)result, NULL) || lz4amd_hip_sync(NULL)) result = 0;

@@ -58,7 +58,7 @@ int LZ4_compress_fast_continue(LZ4_stream_t* s, const char* src, char* dst, int 
         if (srcEnd >= hist + hsz) { hist = NULL; hsz = 0; }
         else { hsz = (unsigned)((hist + hsz) - srcEnd); hist = srcEnd; if (hsz < 4) { hist = NULL; hsz = 0; } }
     }
-    r = lz4amd_compress_with_history(hist, (int)hsz, src, dst, srcSize, dstCapacity);
+    r = lz4amd_compress_with_history(hist, (int)hsz, src, dst, srcSize, dstCapacity, 0);
     /* what the next call may reference: the block, plus what precedes it if it is contiguous (prefix
      * mode, lz4.c:1750-1757); otherwise only the block (lz4.c:1776-1779) */
     if (hist && hist + hsz == src) {

@@ -150,8 +150,9 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
-        q->level = level; q->max_src = max_n;
-        q->scratch_stride = (lz4amd_hip_hc_scratch_bytes(max_n) + 255) & ~(uint64_t)255;
+        q->level = level; q->max_src = max_n + 65536;           /* room for a block's history (lz4amd_plan_create_compress_hc_prefix) */
+        q->prefix = NULL;
+        q->scratch_stride = (lz4amd_hip_hc_scratch_bytes(q->max_src) + 255) & ~(uint64_t)255;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {
             q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
@@ -181,9 +182,9 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
 
 static int plan_create_with_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
                                    const void* const* d_src, const int* src_sizes,
-                                   void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
+                                   void* const* d_dst, const int* dst_caps, const int* prefix_sizes, int level)
 {
-    int rc = lz4amd_plan_create(ctx, out, op, n, d_src, src_sizes, d_dst, dst_caps, 0);
+    int rc = lz4amd_plan_create(ctx, out, op, n, d_src, src_sizes, d_dst, dst_caps, level);
     int err = 0, i;
     if (rc || !prefix_sizes || n <= 0) return rc;
     for (i = 0; i < LZ4AMD_PLAN_MAX_BUFS && (*out)->bufs[i]; i++) {}
@@ -192,17 +193,22 @@ static int plan_create_with_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op
     if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
     if (err) { lz4amd_plan_destroy(*out); *out = NULL; return err; }
     if (op == LZ4AMD_OP_DECOMPRESS) (*out)->dec.prefix = (const int32_t*)(*out)->bufs[i];
+    else if (op == LZ4AMD_OP_COMPRESS_HC) (*out)->hc.prefix = (const int32_t*)(*out)->bufs[i];
     else (*out)->comp.prefix = (const int32_t*)(*out)->bufs[i];
     return LZ4AMD_OK;
 }
 int lz4amd_plan_create_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                               const void* const* d_src, const int* src_sizes,
                               void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
-{ return plan_create_with_prefix(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes); }
+{ return plan_create_with_prefix(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes, 0); }
 int lz4amd_plan_create_compress_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                        const void* const* d_src, const int* src_sizes,
                                        void* const* d_dst, const int* dst_caps, const int* prefix_sizes)
-{ return plan_create_with_prefix(ctx, out, LZ4AMD_OP_COMPRESS, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes); }
+{ return plan_create_with_prefix(ctx, out, LZ4AMD_OP_COMPRESS, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes, 0); }
+int lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                                          const void* const* d_src, const int* src_sizes,
+                                          void* const* d_dst, const int* dst_caps, const int* prefix_sizes, int level)
+{ return plan_create_with_prefix(ctx, out, LZ4AMD_OP_COMPRESS_HC, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes, level); }
 
 static int launch_stage(lz4amd_plan* p, int stage, void* stream)
 {

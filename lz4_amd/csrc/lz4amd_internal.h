@@ -33,7 +33,7 @@ lz4amd_ctx* lz4amd_default_ctx(void);
 
 /* one host block through the device (lz4_api.c): upload, one-row plan, download; `fail` is returned
  * when the device path cannot run */
-int lz4amd_compress_with_history(const char* hist, int histSize, const char* src, char* dst, int srcSize, int dstCapacity);
+int lz4amd_compress_with_history(const char* hist, int histSize, const char* src, char* dst, int srcSize, int dstCapacity, int hc_level);
 int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail);
 
 #endif

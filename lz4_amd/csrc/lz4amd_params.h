@@ -42,6 +42,7 @@ typedef struct lz4amd_hc_params {
     uint64_t scratch_stride;
     uint32_t max_src;               /* largest src_size of the table (fixes the scratch layout) */
     int32_t level;                  /* LZ4_compress_HC compressionLevel (lz4hc.h:66) */
+    const int32_t* prefix;          /* [n_blocks] or NULL: bytes of history right before src (<= 64 KB used, rounded down to 64) */
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase cycle counts */
 } lz4amd_hc_params;
 

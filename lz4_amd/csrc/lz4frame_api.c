@@ -169,10 +169,8 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
         pres[i] = linked ? (int)(i * bs < 65536 ? i * bs : 65536) : 0;     /* the history is the source itself */
     }
     if (p.compressionLevel >= 2) {
-        /* lz4frame.c:943-958 LZ4F_selectCompression: levels >= LZ4HC_CLEVEL_MIN take the HC compressor.  The HC
-         * kernel has no history input yet, so the blocks of a linked frame are compressed without references to
-         * their predecessors (legal in a linked frame; costs a little ratio at block starts) */
-        if (lz4amd_plan_create(ctx, &cplan, LZ4AMD_OP_COMPRESS_HC, (int)nb, d_src, sizes, d_dst, caps, p.compressionLevel)) goto done;
+        /* lz4frame.c:943-958 LZ4F_selectCompression: levels >= LZ4HC_CLEVEL_MIN take the HC compressor */
+        if (lz4amd_plan_create_compress_hc_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL, p.compressionLevel)) goto done;
     } else
     if (lz4amd_plan_create_compress_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL)) goto done;
     if (lz4amd_plan_launch(cplan, NULL)) goto done;

@@ -158,11 +158,10 @@ static size_t put_block(LZ4F_cctx* c, uint8_t* op)
     const int linked = c->prefs.frameInfo.blockMode == LZ4F_blockLinked;
     uint8_t* const start = op;
     int cs;
-    if (c->prefs.compressionLevel >= LZ4HC_CLEVEL_MIN)           /* lz4frame.c:943-958; no history in HC blocks (see lz4frame.h) */
-        cs = LZ4_compress_HC((const char*)blk, (char*)op + BH, (int)n, (int)n - 1, c->prefs.compressionLevel);
-    else
-        cs = lz4amd_compress_with_history(linked && c->hist ? (const char*)blk - c->hist : NULL, (int)c->hist,
-                                          (const char*)blk, (char*)op + BH, (int)n, (int)n - 1);
+    /* lz4frame.c:943-958: levels >= LZ4HC_CLEVEL_MIN take the HC compressor; linked blocks see the 64 KB before them */
+    cs = lz4amd_compress_with_history(linked && c->hist ? (const char*)blk - c->hist : NULL, (int)c->hist,
+                                      (const char*)blk, (char*)op + BH, (int)n, (int)n - 1,
+                                      c->prefs.compressionLevel >= LZ4HC_CLEVEL_MIN ? c->prefs.compressionLevel : 0);
     if (cs <= 0 || (size_t)cs >= n) {                            /* lz4frame.c:896-899: stored raw */
         wr32(op, (uint32_t)n | 0x80000000u); memcpy(op + BH, blk, n); cs = (int)n;
     } else wr32(op, (uint32_t)cs);

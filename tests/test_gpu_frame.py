@@ -132,6 +132,8 @@ def test_hc_levels_in_frames(L, oracle, datagen):
         assert r == len(data) and used.value == len(hc) and out.raw[:len(data)] == data
         got, pos = decompress_frame(L, hc, len(data))
         assert got == data and pos == len(hc)
+    # linked HC blocks see the 64 KB before them: smaller than the same blocks compressed independently
+    assert len(compress_frame(L, data, level=9, blockSizeID=4)) < len(compress_frame(L, data, level=9, blockSizeID=4, blockMode=1))
 
 
 def test_frame_header_known_answers(L, datagen):

@@ -174,3 +174,69 @@ def test_save_dict_and_state_api(L, ref, datagen):
     assert lib_d.LZ4_decompress_safe_usingDict(_addr(c2), _addr(out), r2, bs, _addr(safe), kept) == bs
     assert out.raw == data[bs:2 * bs]
     assert L.LZ4_decoderRingBufferSize(65536) == 65536 + 14 + 65536 and L.LZ4_decoderRingBufferSize(-1) == 0
+
+
+def test_hc_streaming_context(L, ref, oracle, datagen):
+    """LZ4_streamHC_t: LZ4_compress_HC_continue in prefix mode, LZ4_loadDictHC, LZ4_saveDictHC (lz4hc.h:98-180).
+    Our dependent HC blocks decode with the oracle's prefix decoder and the reference's streaming decoder; the
+    reference's HC stream decodes here; dependent blocks are smaller than independent ones."""
+    L.LZ4_createStreamHC.restype = vp
+    L.LZ4_freeStreamHC.argtypes = [vp]
+    L.LZ4_resetStreamHC_fast.argtypes = [vp, ci]
+    L.LZ4_loadDictHC.argtypes = [vp, vp, ci]
+    L.LZ4_compress_HC_continue.argtypes = [vp, vp, vp, ci, ci]
+    L.LZ4_saveDictHC.argtypes = [vp, vp, ci]
+    L.LZ4_compress_HC.argtypes = [vp, vp, ci, ci, ci]
+    total, bs = 500000, 40000
+    data = datagen(total, 60, 6)
+    src = ctypes.create_string_buffer(data, total)
+    cap = bs + bs // 255 + 16
+
+    def hc_stream(lib):
+        s = lib.LZ4_createStreamHC()
+        lib.LZ4_resetStreamHC_fast(s, 9)
+        out = []
+        for o in range(0, total, bs):
+            n = min(bs, total - o)
+            dst = ctypes.create_string_buffer(cap)
+            r = lib.LZ4_compress_HC_continue(s, _addr(src, o), _addr(dst), n, cap)
+            assert 0 < r <= cap
+            out.append(dst.raw[:r])
+        lib.LZ4_freeStreamHC(s)
+        return out
+
+    blocks = hc_stream(L)
+    dst = ctypes.create_string_buffer(cap)
+    alone = sum(L.LZ4_compress_HC(_addr(src, o), _addr(dst), min(bs, total - o), cap, 9) for o in range(0, total, bs))
+    assert sum(map(len, blocks)) < 0.97 * alone
+    assert decompress_stream(L, blocks, total, bs) == data
+    out = ctypes.create_string_buffer(total + 8)
+    oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, vp, ci, ci, ctypes.c_size_t]
+    pos = 0
+    for b in blocks:
+        r = oracle.lz4o_decompress_safe_prefix(b, _addr(out, pos), len(b), min(bs, total - pos), min(pos, 65536))
+        assert r > 0
+        pos += r
+    assert pos == total and out.raw[:total] == data
+    if ref is not None:
+        ref.LZ4_createStreamHC.restype = vp
+        ref.LZ4_freeStreamHC.argtypes = [vp]
+        ref.LZ4_resetStreamHC_fast.argtypes = [vp, ci]
+        ref.LZ4_compress_HC_continue.argtypes = [vp, vp, vp, ci, ci]
+        assert decompress_stream(ref, blocks, total, bs) == data
+        rblocks = hc_stream(ref)
+        assert decompress_stream(L, rblocks, total, bs) == data
+        assert abs(sum(map(len, blocks)) - sum(map(len, rblocks))) / sum(map(len, rblocks)) < 0.03     # the +-3 % window holds for dependent blocks too
+    # dictionary + saveDict
+    s = L.LZ4_createStreamHC()
+    L.LZ4_resetStreamHC_fast(s, 9)
+    assert L.LZ4_loadDictHC(s, _addr(src), 70000) == 65536
+    c1 = ctypes.create_string_buffer(cap)
+    r1 = L.LZ4_compress_HC_continue(s, _addr(src, 70000), _addr(c1), bs, cap)          # contiguous with the dictionary
+    assert 0 < r1 < L.LZ4_compress_HC(_addr(src, 70000), _addr(dst), bs, cap, 9)
+    safe = ctypes.create_string_buffer(65536)
+    assert L.LZ4_saveDictHC(s, _addr(safe), 65536) == 65536
+    assert safe.raw == data[70000 + bs - 65536:70000 + bs]
+    o = ctypes.create_string_buffer(bs)
+    assert L.LZ4_decompress_safe_usingDict(_addr(c1), _addr(o), r1, bs, _addr(src, 4464), 65536) == bs and o.raw == data[70000:70000 + bs]
+    L.LZ4_freeStreamHC(s)

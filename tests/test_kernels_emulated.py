@@ -350,3 +350,26 @@ def test_hc_sizes_around_tile_band_and_strip_boundaries(emu, ocodec, datagen):
     for d, (r, c) in zip(datas[:20], emu_compress_hc(emu, datas[:20], level=3)):
         ro, o = ocodec.decompress(c, len(d))
         assert ro == len(d) and o == d, len(d)
+
+
+def test_hc_with_history_decodes_with_prefix_oracle(emu, oracle, datagen):
+    """LZ4_compress_HC with history (linked HC blocks, LZ4_compress_HC_continue in prefix mode): the block may
+    reference the bytes before it; the oracle's prefix decoder restores it, and the history pays."""
+    data = datagen(400000, 60, 7)
+    emu.emu_compress_hc_batch_prefix.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+    buf = ctypes.create_string_buffer(data, len(data))
+    for pre, n in ((65536, 200000), (65536, 5000), (1000, 100000), (64, 70000), (30000, 13), (70000, 262144)):
+        cap = n + n // 255 + 16
+        dst = ctypes.create_string_buffer(cap + 32)
+        sp = (ctypes.c_void_p * 1)(ctypes.addressof(buf) + pre); dp = (ctypes.c_void_p * 1)(ctypes.addressof(dst))
+        ss = (ctypes.c_int32 * 1)(n); dc = (ctypes.c_int32 * 1)(cap); res = (ctypes.c_int32 * 1)(); pr = (ctypes.c_int32 * 1)(pre)
+        emu.emu_compress_hc_batch_prefix(sp, ss, dp, dc, res, 1, 1, 9, pr)
+        assert res[0] > 0
+        (r0, _), = emu_compress_hc(emu, [data[pre:pre + n]])
+        if pre >= 1000 and n >= 5000:
+            assert res[0] < r0, (pre, n)                       # the history pays
+        used = min(pre, 65536)
+        out = ctypes.create_string_buffer(data[pre - used:pre], used + n)
+        r = oracle.lz4o_decompress_safe_prefix(dst.raw[:res[0]], ctypes.addressof(out) + used, res[0], n, used)
+        assert r == n and out.raw[used:used + n] == data[pre:pre + n], (pre, n)
