@@ -1,502 +1,141 @@
-// lz4_decompress_kernel.h -- batched LZ4 block decompression for gfx950 (MI355X).
+// lz4_decompress_kernel.h -- batched LZ4 block decompression for gfx950 (MI355X), streaming design.
 //
-// Replaces, for a whole batch of independent blocks resident in HBM, what the reference does
-// per block in LZ4_decompress_safe (lib/lz4.c:2451 -> LZ4_decompress_generic lz4.c:2023-2445;
-// length fields: read_variable_length lz4.c:1979-2014; end-of-block rules lz4.c:2276-2330,
-// 2421-2429).  Accepts ANY legal LZ4 block (reference-produced included), rejects what the
-// reference's safe loop rejects, never reads outside src[0,csize) nor writes outside
-// dst[0,cap).  This is not a port: the reference decoder is one serial token chain per block.
-// Here ONE 1024-thread workgroup (16 waves, one CU, ~155 KB of its LDS) decodes a block in two
-// stages:
+// Replaces, for a whole batch of independent blocks resident in HBM, what the reference does per
+// block in LZ4_decompress_safe (lib/lz4.c:2451 -> LZ4_decompress_generic lz4.c:2023-2445; length
+// fields: read_variable_length lz4.c:1979-2014; end-of-block rules lz4.c:2276-2330, 2421-2429).
+// Accepts ANY legal LZ4 block, rejects what the reference's safe loop rejects, never reads outside
+// src[0,csize) nor writes outside dst[0,cap).  Not a port: the reference decoder is one serial
+// token chain per block.  Here ONE 1024-thread workgroup (16 waves, one CU, all of its 160 KB LDS)
+// decodes a block as a three-role pipeline; the roles talk through LDS rings and counters only -
+// no workgroup barrier between the first and the last byte of a block, no scratch in HBM:
 //
-//   A PRE-PARSE  turns the serial token chain into a table of sequence records (output position,
-//       literal source, literal length, offset; 16 B each) in the workgroup's scratch (L2/HBM).
-//       The compressed stream is cut in 1024 SEGMENTS; every thread follows the chain of its own
-//       segment, starting 768 bytes EARLY at an arbitrary byte and relying on LZ4 chains
-//       self-synchronising (a wrong start merges with the true chain after a few hundred bytes).
-//       A fix-point pass then makes it exact: segment j is right iff it started where segment
-//       j-1 exited; threads whose guess was wrong re-walk from the true entry (segment 0 starts at
-//       byte 0, so by induction the result is the true chain for every input; 1-3 rounds on real
-//       data).  An accounting walk counts sequences and output bytes and applies the input-side
-//       format rules, block-wide prefix sums give every segment its first sequence number and
-//       output position, and a last walk writes the records (output-side rules applied) - so a
-//       malformed block is rejected before a byte of output is written.  The warm-up walk runs
-//       mostly over literal bytes misread as tokens (a step per ~6.5 bytes), so it is a
-//       position-only loop with one byte load per trip; rarer token shapes are parked and handled
-//       every fourth trip.
+//   LOADER (wave 15)   streams the compressed block into a 48 KB LDS ring (coalesced 16-byte
+//       loads, the next 4 KB in flight while the last is written).  The block is read from HBM
+//       exactly once; everything below reads LDS.
 //
-//   B STREAM     iterates over the block; every iteration
-//       LOAD   refills a 32 KB window of the compressed stream and up to 1023 rows of a record
-//              ring in LDS (the global loads are issued before the previous iteration's copy and
-//              committed after it),
-//       INDEX  notes, for every 1 KB REGION of output the records cover, the record that holds
-//              its first byte,
-//       COPY   is output-stationary and barrier-free: wave w owns regions w, w+16, ... and lane
-//              k owns the 16-byte CHUNK k of the region.  A lane composes its chunk in four
-//              VGPRs: literal pieces are unaligned 16-byte reads from the compressed window in
-//              LDS (HBM only for literal runs too long to be resident), match pieces are
-//              unaligned 16-byte reads from a 96 KB LDS ring that always holds the 64 KB LZ4
-//              window; finished chunks go to the ring and to HBM (one 16-byte store per lane,
-//              1 KB contiguous per wave).  Match sources that are not final yet are waited for
-//              through per-chunk done bits and per-wave completed-region counters in LDS -
-//              pure dataflow between the 16 waves.  Dependencies always point to lower output
-//              positions and every wave walks its regions in increasing order, so the lowest
-//              unfinished region can always finish: no deadlock.
+//   PARSER (wave 14)   turns the serial token chain into sequence records {output position,
+//       literal source, literal length, offset} in a 1024-row LDS ring, a TILE of 16 KB of the
+//       stream at a time: the tile is cut in 64 segments of 256 B, one per lane.
+//         P1  every lane walks the chain of its segment from the segment's first byte (lane 0:
+//             from the tile's true entry), marking the token positions it visits in a bitmap.
+//             A wrong start walks over literal bytes misread as tokens (~6.5 B per step) and
+//             merges with the true chain after a few hundred bytes (LZ4 chains self-synchronise).
+//         P2  every lane walks on from its exit (the "bridge") until it steps on a position a
+//             later lane marked, the tile ends, or 48 steps have passed.
+//         P3  the true chain is stitched by induction: lane 0 is true from the entry; where its
+//             bridge merges into lane k's marks, lane k's marks are true from there on, and so on
+//             (<= 64 hops, scalar).  A lane that never merged ends the tile early at its last
+//             (true) position - never a wrong answer, only a shorter tile.
+//         P4  marks before a lane's merge point and of skipped lanes are dropped, the bridges of
+//             the lanes on the true path are added: the bitmap now holds exactly the true tokens.
+//         P5  64 tokens at a time, a lane decodes one sequence completely (both length fields,
+//             offset), a wave scan gives the output positions, the reference's input- and
+//             output-side rules are applied, and the records are published.
+//       Tokens whose fields leave the tile (+1 KB look-ahead), length fields longer than 32
+//       bytes and the block's last sequence go through a wave-cooperative SLOW PATH that takes
+//       one token at a time (any length, records split at 8 KB, flow control inside).
 //
-// HBM/L2 traffic per block: compressed bytes read ~2.4x (pre-parse walks, stream window), the
-// record table written and read once (16 B per sequence), output written once; matches and
-// (except for giant runs) literals never touch HBM during the copy.  No MFMA: byte shuffling.
+//   COPY (waves 0-13)  output-stationary in 1 KB REGIONS, wave w owns regions w, w+14, ... .
+//       A region is composed in its slot of an 80 KB LDS ring that always holds the 64 KB LZ4
+//       window, from PIECES (the literal run or the match of a record, cut at 16-byte chunk
+//       borders) in two lane-uniform rounds: round A, lane = chunk, writes the piece that covers
+//       the chunk's first byte; round B, lane = piece, ORs in the head of every piece that starts
+//       inside a chunk.  Literals are unaligned 16-byte reads from the compressed ring, matches
+//       from the output ring (a match that overlaps itself reads any earlier period - the
+//       farthest the window holds - so long runs do not serialise).  Sources still in flight on
+//       another wave are waited for through per-chunk done bits; finished regions go to HBM
+//       with one 16-byte store per lane (1 KB contiguous per wave).
+//
+// HBM traffic per block: compressed bytes read once, output written once.  No MFMA: byte moves.
 #pragma once
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
+
+#ifdef LZ4AMD_TRACE
+#define DTRACE(...) do { if (lane_id() == 0) { fprintf(stderr, "[w%u] ", wave_id()); fprintf(stderr, __VA_ARGS__); } } while (0)
+#else
+#define DTRACE(...) do {} while (0)
+#endif
 
 namespace lz4amd {
 
 using DecBatch = ::lz4amd_dec_params;     // argument block (lz4amd_params.h)
 
 struct alignas(16) SeqRec { uint32_t outpos, litpos, ll, off; };
+struct alignas(16) DoneEnt { uint64_t mask; uint32_t tag, pad; };
 
 enum : uint32_t {
     kDecThreads = 1024,
     kDecWaves = kDecThreads / 64,
-    kSegShift = 8,
-    kSeg = 1u << kSegShift,                     // compressed bytes per pre-parse segment
-    kChunk = 16,                                // output bytes owned by one lane per region
+    kCopyWaves = 14,
+    kParseWave = 14,
+    kLoadWave = 15,
+    kChunk = 16,                                // output bytes composed at a time
     kRegionShift = 10,
-    kRegion = 1u << kRegionShift,               // 64 lanes x 16 bytes
-    kSlots = 96,                                // output ring slots (regions)
+    kRegion = 1u << kRegionShift,               // 64 chunks
+    kSlots = 80,                                // output ring slots (regions): 64 KB window + regions in flight
     kRingBytes = kSlots * kRegion,
     kRingPad = 32,                              // mirror of the first bytes: reads never wrap
-    kMaxLead = 31,                              // a wave may lead the slowest by this many regions
-    kCrBytes = 32u << 10,                       // compressed window (direct mapped by position)
-    kCrMask = kCrBytes - 1,
+    kMaxLead = kSlots - 64 - 1,                 // a wave may lead the first unfinished region by this many
+    kCrBytes = 48u << 10,                       // compressed ring (direct mapped: position mod 48 K)
+    kCrPad = 32,
+    kLoadBatch = 4096,                          // bytes the loader moves per step
     kRecCap = 1024,                             // sequence-record ring
     kRecMask = kRecCap - 1,
-    kIdxCap = 256,                              // regions handled per stream iteration (max)
-    kIdxRing = 512,
+    kIdxRing = 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
-    kPreLanes = 1024,                           // pre-parse lanes per block (segments)
-    kPreWarm = 768,                             // speculative warm-up distance
+    kOutAhead = 480,                            // records are published at most this many regions ahead of the copy
+    kSegShift = 8,
+    kSeg = 1u << kSegShift,                     // parser segment (bytes of the stream per lane)
+    kTile = 64 * kSeg,
+    kLook = 1024,                               // fields of a tile's tokens may reach this far past the tile
+    kBridgeCap = 48,
+    kTokCap = 2048,                             // tokens decoded per tile (a longer tile is cut there)
+    kExtMax = 32,                               // longer length fields take the slow path
+    kSlowSpan = 8192,                           // slow-path records cover at most this many output bytes
+    kMaxTrips = 10,                             // round-B trips per region (32 records each)
     kBias = 65536,                              // output positions are biased: [kBias - prefix, kBias) is the history before dst
+    kFirstRegion = kBias >> kRegionShift,
     kNone = 0xFFFFFFFFu,
 };
 
 // LDS carve-up (bytes)
 enum : uint32_t {
-    kOffScan = 0,                                            // u32[64] (3 per wave needed)
-    kOffMisc = kOffScan + 64 * 4,                            // u32[32]
-    kOffPhase = kOffMisc + 32 * 4,
-    // stage B
-    kOffRing = kOffPhase,
-    kOffCr = kOffRing + kRingBytes + kRingPad,
-    kOffRecs = kOffCr + kCrBytes,
-    kOffIdx = kOffRecs + kRecCap * 16,                       // u32[kIdxRing]
-    kOffFirst = kOffIdx + kIdxRing * 4,                      // u32[kDecWaves][64]
-    kOffBits = kOffFirst + kDecWaves * 64 * 4,               // DoneEnt[kSlots] per-chunk done bits
-    kOffFin = kOffBits + kSlots * 16,                        // u32[kDecWaves] regions completed
-    kStreamEnd = kOffFin + kDecWaves * 4,
-    // stage A (overlays stage B's arrays; not live at the same time)
-    kOffSegExit = kOffPhase,
-    kOffRecStage = kOffSegExit + kPreLanes * 4,              // SeqRec[4][kPreLanes]: records wait here to leave four at a time
-    kPreEnd = kOffRecStage + 4 * kPreLanes * 16,
-    kOffCStage = kOffRecStage,                               // the compressed block itself, when it fits (then the records need no staging)
-    kDecLdsBytes = kStreamEnd > kPreEnd ? kStreamEnd : kPreEnd,
-    kCStageMax = kDecLdsBytes - kOffCStage - 32,             // largest compressed block the pre-parse walks out of LDS
+    kOffMisc = 0,                                            // u32[64] control words
+    kOffFin = kOffMisc + 64 * 4,                             // u32[16] regions completed per copy wave
+    kOffBits = kOffFin + 16 * 4,                             // DoneEnt[kSlots]
+    kOffIdx = kOffBits + kSlots * 16,                        // u16[kIdxRing]
+    kOffPend = kOffIdx + kIdxRing * 2,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
+    kOffSBits = kOffPend + kCopyWaves * (kMaxTrips + 2) * 8, // u32[kTile / 32] parser bitmap
+    kOffBridge = kOffSBits + kTile / 8,                      // u16[kBridgeCap][64]
+    kOffTok = kOffBridge + kBridgeCap * 64 * 2,              // u16[kTokCap]
+    kOffRecs = kOffTok + kTokCap * 2,                        // SeqRec[kRecCap]
+    kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
+    kOffRing = kOffCr + kCrBytes + kCrPad,                   // output ring + pad
+    kDecLdsBytes = kOffRing + kRingBytes + kRingPad,
 };
-enum : uint32_t { M_BLOCK = 0, M_ERR = 1, M_CARRY = 2, M_HEAD = 3, M_EMIT = 4, M_FIRSTBAD = 5 };   // M_CARRY unused
+static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
+static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0, "LDS alignment");
 
-// scratch of one workgroup: the sequence-record table of the block it is decoding.  Every sequence
-// but the last takes >= 3 compressed bytes; +1 last, +1 sentinel.
-__host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize) {
-    return ((uint64_t)max_csize / 3 + 4) * sizeof(SeqRec);
+enum : uint32_t { M_BLOCK = 0, M_ERR, M_ABORT, M_FIN, M_CHI, M_CLO, M_EMIT, M_HEAD, M_TOKX };
+
+// (the round-1 decoder kept a record table in HBM; this one needs no scratch)
+__host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t) { return 256; }
+
+// ------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// position in the compressed ring
+__device__ __forceinline__ uint32_t mod_cr(uint32_t x) {            // x mod 48 K, x < 2^31
+    return x - (uint32_t)(((uint64_t)(x >> 14) * 0xAAAAAAABull) >> 33) * kCrBytes;
 }
+__device__ __forceinline__ uint32_t cr_fold(uint32_t a) { return umin32(a, a - kCrBytes); }        // [0, 2*48K) -> [0, 48K)
+__device__ __forceinline__ uint32_t ring_fold(uint32_t a) { return umin32(a, a - kRingBytes); }
+// a control word every lane of the wave agrees on
+__device__ __forceinline__ uint32_t uload(const uint32_t* w) { return __builtin_amdgcn_readfirstlane(lds_load_acquire(w)); }
 
-// The compressed stream as the pre-parse walkers see it: global memory, served by the CU's L1 (few lanes
-// walk long stretches - see preparse_block - so their current lines stay L1 resident) - or, for a block
-// whose compressed bytes fit beside the pre-parse's own LDS (<= kCStageMax: every block up to 256 KB at
-// ratio >= 1.8), a copy of it in LDS: a walk is a chain of dependent loads, ~2 k cycles each from memory,
-// ~150 from LDS, and for small blocks that chain (the fixed 768-byte warm-up) is most of the decode time.
-struct CView {
-    lz4amd_gsrc g;
-    const uint8_t* l;           // LDS copy of the block, or nullptr
-    uint32_t csize;
-    __device__ __forceinline__ uint32_t u8(uint32_t p) const { return l ? (uint32_t)l[p] : (uint32_t)g[p]; }
-    __device__ __forceinline__ uint32_t u16(uint32_t p) const { return u8(p) | (u8(p + 1) << 8); }
-    __device__ __forceinline__ bool in(uint32_t p) const { return p < csize; }
-    __device__ __forceinline__ bool has8(uint32_t p) const { return p < csize && csize - p >= 8; }
-    __device__ __forceinline__ uint64_t ld8_if(uint32_t p, bool ok) const {
-        uint64_t v = 0;
-        if (ok) {
-            if (l) {            // three aligned dwords + two v_alignbyte (the copy is padded past csize)
-                const uint32_t* w = (const uint32_t*)(l + (p & ~3u));
-                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = p & 3u;
-                v = (uint64_t)align_bytes(w1, w0, sh) | ((uint64_t)align_bytes(w2, w1, sh) << 32);
-            } else __builtin_memcpy(&v, g + p, 8);
-        }
-        return v;
-    }
-};
-
-struct WalkOut { uint32_t exit, n, ob, err; };
-
-// Literal-length field of the token at p (lz4.c:1979-2014, limit iend-15).  q = first literal byte.
-// Fast path: token and up to 6 extension bytes in one 8-byte LDS read.
-__device__ __forceinline__ bool read_litlen(const CView& V, uint32_t csize, uint32_t p, uint32_t& t,
-                                            uint32_t& ll, uint32_t& q) {
-    uint64_t w = 0;
-    const bool fast = V.has8(p);
-    if (fast) { w = V.ld8_if(p, true); t = (uint32_t)w & 0xFFu; } else t = V.u8(p);
-    ll = t >> 4; q = p + 1;
-    if (ll != 15) return true;
-    if (fast) {
-        const uint64_t x = w >> 8, inv = ~x & 0x00FFFFFFFFFFFFFFull;     // 7 extension bytes
-        const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 7u;
-        if (k < 7) {
-            if (q + k + 15 >= csize) return false;                   // the last byte read is q + k
-            ll = 15 + 255 * k + ((uint32_t)(x >> (8 * k)) & 0xFFu);
-            q += k + 1;
-            return true;
-        }
-    }
-    uint32_t b;
-    do {
-        if (q + 15 >= csize) return false;
-        b = V.u8(q); q++; ll += b;
-        if (ll > csize) return false;
-    } while (b == 255);
-    return true;
-}
-// Offset and match-length field at m (limit iend-LASTLITERALS+1).  nx = next token.
-__device__ __forceinline__ bool read_match(const CView& V, uint32_t csize, uint32_t m, uint32_t t,
-                                           uint32_t& off, uint32_t& ml, uint32_t& nx) {
-    uint64_t y = 0;
-    const bool fast = V.has8(m);
-    if (fast) { y = V.ld8_if(m, true); off = (uint32_t)y & 0xFFFFu; } else off = V.u16(m);
-    ml = t & 15; nx = m + 2;
-    if (ml != 15) return true;
-    if (fast) {
-        const uint64_t z = y >> 16, inv = ~z & 0x0000FFFFFFFFFFFFull;     // 6 extension bytes
-        const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 6u;
-        if (k < 6) {
-            nx += k + 1;
-            if (nx + 4 > csize) return false;
-            ml = 15 + 255 * k + ((uint32_t)(z >> (8 * k)) & 0xFFu);
-            return true;
-        }
-    }
-    uint32_t b;
-    do {
-        b = V.u8(nx); nx++; ml += b;
-        if (nx + 4 > csize || ml > 0x7FFFFFF0u) return false;
-    } while (b == 255);
-    return true;
-}
-
-// One sequence of the chain, as the walkers need it.
-struct SeqStep { uint32_t ll, q, off, ml, nx; bool last, bad; };
-
-// Generic (byte-wise) decode of the sequence at p: any field length, window misses allowed.
-__device__ __forceinline__ SeqStep seq_step_slow(const CView& V, uint32_t csize, uint32_t p, uint32_t out_room, bool emit) {
-    SeqStep s; s.off = 0; s.ml = 0; s.nx = 0; s.last = false; s.bad = true;
-    uint32_t t;
-    if (!read_litlen(V, csize, p, t, s.ll, s.q)) return s;
-    const uint32_t rem = csize - s.q;
-    s.last = (rem < s.ll + 8) || (emit && out_room < s.ll + kMfLimit);
-    if (s.last) { s.bad = false; return s; }
-    if (!read_match(V, csize, s.q + s.ll, t, s.off, s.ml, s.nx)) return s;
-    s.bad = false;
-    return s;
-}
-
-// Follow the token chain from p while p < e (e <= csize).  err != 0 => malformed at err-1.
-// EMIT: also write SeqRec's (ring, from sequence number `seq`, output position `o`) and apply the
-// output-side rules (needs cap).  The input-side rules are those of the reference's safe loop
-// (lz4.c:1979-2014 length fields, lz4.c:2279 last-literals test).  The common case - both length
-// fields and the offset inside two 8-byte LDS reads - is straight-line code with selects; anything
-// else (fields longer than 6 extension bytes, bytes outside the LDS window) takes the byte-wise
-// path above.
-// Records leave through a small LDS staging area, four at a time (64 contiguous bytes per lane): a store
-// after every sequence would sit in the same in-order memory queue as the next sequence's loads, and the
-// walk would wait for the write latency at every step (measured: 0.8 M of the 1.6 M cycles of this pass).
-template <bool EMIT>
-__device__ __forceinline__ WalkOut walk_chain(const CView& V, uint32_t csize, uint32_t p, uint32_t e,
-                                              SeqRec* recs, uint32_t seq, uint32_t o, uint32_t cap, uint32_t low,
-                                              SeqRec* stage = nullptr) {
-    WalkOut r; r.n = 0; r.ob = 0; r.err = 0;
-    const uint32_t seq0 = seq;
-    uint32_t nbuf = 0;
-    auto put = [&](const SeqRec& rec) {
-        if (stage == nullptr) { recs[seq0 + nbuf] = rec; nbuf++; return; }         // (loads come from LDS: nothing queues behind the store)
-        stage[(nbuf & 3) * kPreLanes] = rec;
-        nbuf++;
-        if ((nbuf & 3) == 0) {
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) recs[seq0 + nbuf - 4 + i] = stage[i * kPreLanes];
-        }
-    };
-    while (p < e) {
-        SeqStep s;
-        const uint32_t room = EMIT ? cap - o : 0u;
-        // ---- token + literal length
-        bool slow = !V.has8(p);
-        const uint64_t w = V.ld8_if(p, !slow);
-        const uint32_t t = (uint32_t)w & 0xFFu, nib = t >> 4;
-        const uint64_t x = w >> 8, inv = ~x & 0x00FFFFFFFFFFFFFFull;
-        const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 7u;
-        const bool l15 = nib == 15;
-        slow = slow || (l15 && k >= 7);
-        s.ll = l15 ? 15 + 255 * k + ((uint32_t)(x >> (8 * (k & 7))) & 0xFFu) : nib;
-        s.q = p + 1 + (l15 ? k + 1 : 0);
-        s.bad = l15 && (p + k + 16 >= csize);                    // extension byte i is read only if q0+i+15 < csize
-        const uint32_t rem = csize - s.q;
-        s.last = (rem < s.ll + 8) || (EMIT && room < s.ll + kMfLimit);
-        // ---- offset + match length
-        const uint32_t m = s.q + s.ll;
-        const bool need2 = !slow && !s.bad && !s.last;
-        const bool ok2 = need2 && V.has8(m);
-        slow = slow || (need2 && !ok2);
-        const uint64_t y = V.ld8_if(m, ok2);
-        s.off = (uint32_t)y & 0xFFFFu;
-        const uint64_t z = y >> 16, invz = ~z & 0x0000FFFFFFFFFFFFull;
-        const uint32_t km = invz ? ((uint32_t)__ffsll((long long)invz) - 1) >> 3 : 6u;
-        const uint32_t mnib = t & 15;
-        const bool m15 = mnib == 15;
-        slow = slow || (ok2 && m15 && km >= 6);
-        s.ml = m15 ? 15 + 255 * km + ((uint32_t)(z >> (8 * (km & 7))) & 0xFFu) : mnib;
-        s.nx = m + 2 + (m15 ? km + 1 : 0);
-        if (ok2 && m15 && s.nx + 4 > csize) s.bad = true;
-        if (slow) s = seq_step_slow(V, csize, p, room, EMIT);
-        if (s.bad) { r.err = p + 1; break; }
-        if (s.last) {
-            if (csize - s.q != s.ll) { r.err = p + 1; break; }    // must end the input exactly
-            if (EMIT) {
-                if (room < s.ll) { r.err = p + 1; break; }
-                SeqRec rec; rec.outpos = o; rec.litpos = s.q; rec.ll = s.ll; rec.off = 0;
-                put(rec);
-            }
-            r.n++; r.ob += s.ll; o += s.ll; seq++;
-            p = csize;
-            break;
-        }
-        const uint32_t ml = s.ml + kMinMatch;
-        if (EMIT) {
-            const uint32_t ms = o + s.ll;        // match start in the output
-            if (s.off == 0 || s.off > ms - low) { r.err = p + 1; break; } // lz4.c:2356 (low = first position with history)
-            if (cap - ms < ml + kLastLiterals) { r.err = p + 1; break; } // lz4.c:2423
-            SeqRec rec; rec.outpos = o; rec.litpos = s.q; rec.ll = s.ll; rec.off = s.off;
-            put(rec);
-        }
-        if (r.ob + s.ll + ml < r.ob) { r.err = p + 1; break; }           // u32 overflow
-        r.n++; r.ob += s.ll + ml; o += s.ll + ml; seq++;
-        p = s.nx;
-    }
-    if (EMIT && stage != nullptr) { for (uint32_t i = 0; i < (nbuf & 3); i++) recs[seq0 + (nbuf & ~3u) + i] = stage[i * kPreLanes]; }
-    r.exit = p;
-    return r;
-}
-
-// Position-only generic step: next token position after the sequence at p (csize at the end of
-// the block or on any violation - the accounting walk over the true chain reports those).
-__device__ __forceinline__ uint32_t next_pos_slow(const CView& V, uint32_t csize, uint32_t p) {
-    const SeqStep s = seq_step_slow(V, csize, p, 0, false);
-    return (s.bad || s.last) ? csize : s.nx;
-}
-// Position-only walk from p to the first chain position >= e (e <= csize), at most max_trips loop
-// trips (kNone if it did not get there).  This is what the speculative warm-up runs on, mostly over
-// literal bytes misread as tokens (one step per ~6.5 bytes), so a trip is a single LDS byte read
-// and a handful of VALU instructions: tokens with both nibbles < 15 are stepped over directly;
-// anything else (length extensions, window edge, end of block) parks the lane until the next
-// multiple-of-4 trip, where all parked lanes take the generic step together.
-__device__ __forceinline__ uint32_t walk_pos(const CView& V, uint32_t csize, uint32_t p, uint32_t e, uint32_t max_trips) {
-    bool parked = false;
-    uint32_t trip = 0;
-    while (p < e) {
-        if (trip >= max_trips) { p = kNone; break; }
-        if (!parked) {
-            const bool inwin = V.in(p);
-            const uint32_t b = inwin ? V.u8(p) : 0u;
-            const uint32_t ll = b >> 4, ml = b & 15;
-            if (inwin && ll != 15 && ml != 15 && p + ll + 9 <= csize) p += 3 + ll;
-            else parked = true;
-        }
-        trip++;
-        if ((trip & 3) == 0 && parked) { p = next_pos_slow(V, csize, p); parked = false; }
-    }
-    return p;
-}
-
-// The pre-parse walker: positions, sequence count and output bytes only (no offsets, no records).
-// Most of its steps are speculative warm-up over literal bytes misread as tokens (about one step
-// per 6.5 bytes on datagen data), so a step must be cheap: ONE 8-byte LDS read per loop trip.  A
-// lane is either at a token (mode 0: decodes token + literal length, and is done with the sequence
-// unless the match length nibble is 15) or at the offset field of a long match (mode 1: decodes the
-// match-length extension).  Same input-side rules as walk_chain<false>.
-__device__ __forceinline__ WalkOut walk_count(const CView& V, uint32_t csize, uint32_t p, uint32_t e, uint32_t max_trips) {
-    WalkOut r; r.n = 0; r.ob = 0; r.err = 0;
-    uint32_t rp = p, pend = 0;          // read position; literal length of the sequence in mode 1
-    uint32_t trips = 0;
-    bool mode1 = false;
-    while (p < e) {
-        if (trips++ >= max_trips) { p = kNone; break; }           // gave up (unconfirmed re-walk)
-        bool slow = !V.has8(rp);
-        const uint64_t w = V.ld8_if(rp, !slow);
-        uint32_t add_ob = 0, next_p = p, next_rp = rp;
-        bool bad = false, last = false, next_mode1 = false, complete = false;
-        uint32_t last_ll = 0, last_q = 0;
-        if (!mode1) {
-            const uint32_t t = (uint32_t)w & 0xFFu, nib = t >> 4;
-            const uint64_t x = w >> 8, inv = ~x & 0x00FFFFFFFFFFFFFFull;
-            const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 7u;
-            const bool l15 = nib == 15;
-            slow = slow || (l15 && k >= 7);
-            const uint32_t ll = l15 ? 15 + 255 * k + ((uint32_t)(x >> (8 * (k & 7))) & 0xFFu) : nib;
-            const uint32_t q = p + 1 + (l15 ? k + 1 : 0);
-            bad = l15 && (p + k + 16 >= csize);
-            last = !bad && (csize - q < ll + 8);
-            last_ll = ll; last_q = q;
-            const uint32_t m = q + ll, mnib = t & 15;
-            if (mnib == 15) { next_mode1 = true; next_rp = m; pend = ll; }
-            else { complete = true; add_ob = ll + mnib + kMinMatch; next_p = next_rp = m + 2; }
-        } else {
-            const uint64_t z = w >> 16, invz = ~z & 0x0000FFFFFFFFFFFFull;
-            const uint32_t km = invz ? ((uint32_t)__ffsll((long long)invz) - 1) >> 3 : 6u;
-            slow = slow || km >= 6;
-            const uint32_t nx = rp + 2 + km + 1;
-            bad = nx + 4 > csize;
-            complete = true;
-            add_ob = pend + 15 + 255 * km + ((uint32_t)(z >> (8 * (km & 7))) & 0xFFu) + kMinMatch;
-            next_p = next_rp = nx;
-        }
-        if (slow) {                                     // byte-wise redo of the whole sequence at p
-            const SeqStep s = seq_step_slow(V, csize, p, 0, false);
-            bad = s.bad; last = !s.bad && s.last; last_ll = s.ll; last_q = s.q;
-            complete = true; next_mode1 = false;
-            add_ob = s.ll + s.ml + kMinMatch; next_p = next_rp = s.nx;
-        }
-        if (bad) { r.err = p + 1; break; }
-        if (last) {
-            if (csize - last_q != last_ll) { r.err = p + 1; break; }
-            r.n++; r.ob += last_ll; p = csize;
-            break;
-        }
-        if (complete) {
-            if (r.ob + add_ob < r.ob) { r.err = p + 1; break; }          // u32 overflow
-            r.n++; r.ob += add_ob;
-        }
-        p = next_p; rp = next_rp; mode1 = next_mode1;
-    }
-    r.exit = p;
-    return r;
-}
-
-__device__ __forceinline__ void chunk_set_byte(U32x4& a, uint32_t i, uint32_t b);
-// 16 bytes of the compressed stream at position P (tail of the block zero padded)
-__device__ __forceinline__ U32x4 load_granule(lz4amd_gsrc src, uint32_t csize, uint32_t P) {
-    if (P + 16 <= csize) return ld_global16(src + P);
-    U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
-#pragma nounroll
-    for (uint32_t i = 0; i < 16 && P + i < csize; i++) chunk_set_byte(v, i, (uint32_t)src[P + i]);
-    return v;
-}
-
-// ------------------------------------------------------------------------------ stage A
-// The whole block at once: kPreLanes lanes, each owning one SEGMENT of G = csize/kPreLanes bytes
-// (rounded up to 256).  Long segments are the point: the speculative warm-up is a fixed price per
-// lane (~120 slow steps over literals misread as tokens), the true chain inside the segment costs
-// one step per ~40 bytes, and with few lanes every lane's current cache line stays in the CU's L1.
-// Returns false (uniformly) when the block is malformed; nseq_out / total_out otherwise.
-__device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix,
-                                               SeqRec* rectab, char* smem,
-                                               uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof) {
-    uint64_t pt_walk = 0, pt_fix = 0, pt_iters = 0, pt0 = 0;
-    const uint32_t tid = threadIdx.x;
-    uint32_t* scan = (uint32_t*)(smem + kOffScan);
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    uint32_t* seg_exit = (uint32_t*)(smem + kOffSegExit);
-    if (tid == 0) misc[M_ERR] = kNone;
-    if (prof) pt0 = clock_ticks();
-
-    uint32_t G = ((csize + kPreLanes - 1) / kPreLanes + kSeg - 1) & ~(kSeg - 1);
-    if (G < kSeg) G = kSeg;
-    const uint32_t nst = (csize + G - 1) / G;               // <= kPreLanes
-    const uint32_t recap = 64 + G / 8;                       // trips an unconfirmed re-walk may take
-    CView V; V.g = src; V.csize = csize; V.l = nullptr;
-    const bool staged = csize <= kCStageMax;
-    if (staged) {
-        uint8_t* const cs = (uint8_t*)(smem + kOffCStage);
-        for (uint32_t P = 16 * tid; P < csize + 16; P += 16 * kDecThreads) *(U32x4*)(cs + P) = load_granule(src, csize, P);
-        V.l = cs;
-        __syncthreads();
-    }
-    const bool has_seg = tid < nst;
-    const uint32_t s = tid * G;
-    uint32_t e = s + G; if (e > csize || e < s) e = csize;
-    // -- 1. positions: speculative entry (warm-up) and exit of every segment
-    //    (the segment itself is walked with the accounting walker: sequences, output bytes and format
-    //    errors of the LAST walk of a segment are the ones that count, and that walk starts at the true entry)
-    uint32_t my_entry = kNone;
-    WalkOut w; w.exit = 0; w.n = 0; w.ob = 0; w.err = 0;
-    if (has_seg) {
-        my_entry = s > 0 ? walk_pos(V, csize, s > kPreWarm ? s - kPreWarm : 0, s, kNone) : 0u;
-        w = walk_count(V, csize, my_entry, e, kNone);
-        seg_exit[tid] = w.err ? csize : w.exit;               // a malformed chain ends the block
-    }
-    // -- 2. fix-point: segment j is right iff it started where segment j-1 exited.  F = first
-    //    segment that is not; everything before it is the true chain, so X = exit of segment F-1 is
-    //    a true chain position: segments the chain jumps over completely (long literal runs) and
-    //    the segment X falls into are settled at once; the others re-walk from their predecessor's
-    //    current exit, for a bounded number of trips (that exit may still be garbage, and garbage
-    //    is slow to walk: they try again once it has settled).  F grows every round.
-    bool first_iter = true;
-    for (;;) {
-        __syncthreads();
-        if (prof) { const uint64_t t1 = clock_ticks(); if (first_iter) pt_walk += t1 - pt0; else { pt_fix += t1 - pt0; pt_iters++; } pt0 = t1; first_iter = false; }
-        if (tid == 0) misc[M_FIRSTBAD] = nst;
-        uint32_t want = kNone;
-        if (has_seg) want = (tid == 0) ? 0u : seg_exit[tid - 1];
-        __syncthreads();
-        if (has_seg && (want != my_entry || want == kNone)) atomicMin(&misc[M_FIRSTBAD], tid);
-        __syncthreads();
-        const uint32_t F = misc[M_FIRSTBAD];
-        if (F >= nst) break;
-        const uint32_t X = (F == 0) ? 0u : seg_exit[F - 1];       // != kNone: segment F-1 is right
-        __syncthreads();
-        if (has_seg && tid >= F) {
-            if (X >= e) { my_entry = X; seg_exit[tid] = X; w.n = 0; w.ob = 0; w.err = 0; }   // the chain jumps over this segment
-            else if (X >= s) { my_entry = X; w = walk_count(V, csize, X, e, kNone); seg_exit[tid] = w.err ? csize : w.exit; }   // ... enters it at X
-            else if (want != kNone && want != my_entry) {
-                w = walk_count(V, csize, want, e, recap);
-                seg_exit[tid] = w.exit == kNone ? kNone : (w.err ? csize : w.exit);
-                my_entry = (w.exit == kNone) ? kNone : want;             // gave up: not resolved yet
-            }
-        }
-    }
-    // -- 3. sequence numbers and output positions of the segments
-    if (!has_seg) { w.n = 0; w.ob = 0; w.err = 0; }
-    uint32_t ea, ta; uint64_t eb, tb;
-    block_excl_sum2(w.n, (uint64_t)w.ob, scan, ea, eb, ta, tb);
-    int bad = 0;
-    if (w.err) { atomicMin(&misc[M_ERR], w.err - 1); bad = 1; }
-    // output positions beyond the capacity are errors (this also keeps them inside u32)
-    if (has_seg && eb + w.ob > cap) { atomicMin(&misc[M_ERR], my_entry < csize ? my_entry : csize - 1); bad = 1; }
-    if (__syncthreads_or(bad)) return false;
-    if (prof) { const uint64_t t1 = clock_ticks(); if (tid == 0) prof[5] = t1 - pt0; pt0 = t1; }
-    // -- 4. the records, at their final place in the block's table
-    if (has_seg && w.n) {
-        const WalkOut w2 = walk_chain<true>(V, csize, my_entry, e, rectab, ea, (uint32_t)eb + kBias, cap + kBias, kBias - prefix,
-                                            staged ? nullptr : (SeqRec*)(smem + kOffRecStage) + tid);
-        if (w2.err) { atomicMin(&misc[M_ERR], w2.err - 1); bad = 1; }
-    }
-    if (tid == 0) { SeqRec rec; rec.outpos = (uint32_t)tb + kBias; rec.litpos = csize; rec.ll = 0; rec.off = 0; rectab[ta] = rec; }
-    if (__syncthreads_or(bad)) return false;
-    nseq_out = ta; total_out = (uint32_t)tb;
-    if (prof && tid == 0) { prof[6] = pt_walk; prof[7] = pt_fix | (pt_iters << 48); }
-    return true;
-}
-
-// ------------------------------------------------------------------------------ stage B: COPY
 // 16 bytes as four dwords; byte i of the chunk is byte (i & 3) of dword (i >> 2).
-// (written with selects on whole dwords: indexing the struct dynamically would send it to scratch)
+// (written with selects on whole dwords: indexing the vector dynamically would send it to scratch)
 __device__ __forceinline__ uint32_t chunk_byte(const U32x4& a, uint32_t i) {
     const uint32_t lo = (i & 4) ? a[1] : a[0], hi = (i & 4) ? a[3] : a[2];
     const uint32_t d = (i & 8) ? hi : lo;
@@ -510,17 +149,21 @@ __device__ __forceinline__ void chunk_set_byte(U32x4& a, uint32_t i, uint32_t b)
     a[2] = (k == 2) ? ((a[2] & ~m) | v) : a[2];
     a[3] = (k == 3) ? ((a[3] & ~m) | v) : a[3];
 }
-// bytes [lo, 16) of the result come from v, bytes [0, lo) from a
-__device__ __forceinline__ U32x4 chunk_merge_from(const U32x4& a, const U32x4& v, uint32_t lo) {
-    const uint64_t m0 = lo < 8 ? (~0ull << (lo * 8)) : 0ull;
-    const uint64_t m1 = lo <= 8 ? ~0ull : (~0ull << ((lo - 8) * 8));
-    const uint64_t a0 = (uint64_t)a[0] | ((uint64_t)a[1] << 32), a1 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
-    const uint64_t v0 = (uint64_t)v[0] | ((uint64_t)v[1] << 32), v1 = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
-    const uint64_t r0 = (a0 & ~m0) | (v0 & m0), r1 = (a1 & ~m1) | (v1 & m1);
-    U32x4 r; r[0] = (uint32_t)r0; r[1] = (uint32_t)(r0 >> 32); r[2] = (uint32_t)r1; r[3] = (uint32_t)(r1 >> 32);
+// dword k of the 16-byte mask that selects bytes [0, n), n in 0..16
+__device__ __forceinline__ uint32_t low_bytes_mask(uint32_t n, uint32_t k) {
+    const int32_t r = (int32_t)n - 4 * (int32_t)k;
+    return r >= 4 ? 0xFFFFFFFFu : (r <= 0 ? 0u : ((1u << (8 * r)) - 1u));
+}
+// v restricted to bytes [lo, hi)
+__device__ __forceinline__ U32x4 keep_bytes(const U32x4& v, uint32_t lo, uint32_t hi) {
+    U32x4 r;
+    r[0] = v[0] & low_bytes_mask(hi, 0) & ~low_bytes_mask(lo, 0);
+    r[1] = v[1] & low_bytes_mask(hi, 1) & ~low_bytes_mask(lo, 1);
+    r[2] = v[2] & low_bytes_mask(hi, 2) & ~low_bytes_mask(lo, 2);
+    r[3] = v[3] & low_bytes_mask(hi, 3) & ~low_bytes_mask(lo, 3);
     return r;
 }
-// 16 bytes starting at ANY byte of an LDS array of dwords (the caller guarantees b+20 in range)
+// 16 bytes starting at ANY byte a of an LDS array of dwords (the arrays are padded: a + 20 is in range)
 __device__ __forceinline__ U32x4 lds_read16_at(const uint8_t* base, uint32_t a) {
     const uint32_t* r32 = (const uint32_t*)(base + (a & ~3u));
     const uint32_t sh = a & 3u;
@@ -530,311 +173,791 @@ __device__ __forceinline__ U32x4 lds_read16_at(const uint8_t* base, uint32_t a) 
     v[2] = align_bytes(d3, d2, sh); v[3] = align_bytes(d4, d3, sh);
     return v;
 }
-// ring address of output position pos
-__device__ __forceinline__ uint32_t ring_addr(uint32_t pos) {
-    return (((pos >> kRegionShift) % kSlots) << kRegionShift) | (pos & (kRegion - 1));
-}
-// 16 ring bytes of which byte `lo` is output position s0 (bytes below lo are don't-care and may
-// lie before the ring's start: step back with wrap-around; the pad mirrors the ring's first bytes)
-__device__ __forceinline__ U32x4 ring_read16(const uint8_t* ring, uint32_t s0, uint32_t lo) {
-    uint32_t a = ring_addr(s0);
-    a = a >= lo ? a - lo : a + kRingBytes - lo;
-    return lds_read16_at(ring, a);
+// 16 bytes of the compressed stream at position P (tail of the block zero padded; never reads past csize)
+__device__ __forceinline__ U32x4 load_granule(lz4amd_gsrc src, uint32_t csize, uint32_t P) {
+    if (P + 16 <= csize) return ld_global16(src + P);
+    U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
+#pragma nounroll
+    for (uint32_t i = 0; i < 16 && P + i < csize; i++) chunk_set_byte(v, i, (uint32_t)src[P + i]);
+    return v;
 }
 
-// Done tracking: one 16-byte entry per ring slot = {u64 mask of finished chunks, u32 tag, pad}.
-// tag = region number + kSlots of the region the mask belongs to (so a slot that was never used
-// carries tag = slot index = "region slot-kSlots").  Single writer (lane 0 of the owning wave);
-// readers take the entry with one 16-byte LDS read.
-struct alignas(16) DoneEnt { uint64_t mask; uint32_t tag, pad; };
-
-// Is output chunk c (global chunk index = output position / 16) final in the ring?
-// g = a lower bound of the first unfinished region (everything below it is final).
-__device__ __forceinline__ bool chunk_final(uint32_t c, uint32_t g, const DoneEnt* ents) {
-    const uint32_t r = c >> 6;
-    if (r < g) return true;
-    const DoneEnt e = lds_load_ent(&ents[r % kSlots]);
-    const uint32_t want = r + kSlots;
-    // tag > want: the slot already serves a later region, so r was finished long ago
-    return e.tag > want || (e.tag == want && ((e.mask >> (c & 63)) & 1));
+// First region some copy wave has not completed: every region below it is final.
+__device__ __forceinline__ uint32_t first_open_region(const char* smem) {
+    const uint32_t* fin = (const uint32_t*)(smem + kOffFin);
+    const uint32_t l16 = lane_id() & 15u;
+    const uint32_t f = lds_load_acquire(&fin[l16]);
+    const uint32_t r = l16 < kCopyWaves ? kFirstRegion + l16 + kCopyWaves * f : kNone;
+    return __builtin_amdgcn_readfirstlane(row16_min_u32(r));
 }
-// both chunks ca <= cb (cb - ca <= 1)
-__device__ __forceinline__ bool chunks_final(uint32_t ca, uint32_t cb, uint32_t g, const DoneEnt* ents) {
-    if ((cb >> 6) < g) return true;
-    if ((ca >> 6) == (cb >> 6)) {
-        const uint32_t r = ca >> 6;
-        const DoneEnt e = lds_load_ent(&ents[r % kSlots]);
-        const uint32_t want = r + kSlots;
-        const uint64_t need = (1ull << (ca & 63)) | (1ull << (cb & 63));
-        return e.tag > want || (e.tag == want && (e.mask & need) == need);
+
+// ------------------------------------------------------------------------------ LOADER
+__device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, char* smem) {
+    uint8_t* cr = (uint8_t*)(smem + kOffCr);
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    const uint32_t lane = lane_id();
+    U32x4 cur[4], nxt[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) { const uint32_t P = 16 * (lane + 64 * i); if (P < csize) cur[i] = load_granule(src, csize, P); }
+    uint32_t L = 0;
+    while (L < csize) {
+        // bytes [L, L + batch) may be written once nobody needs the bytes 48 K below them
+        for (;;) {
+            const uint32_t clo = uload(&misc[M_CLO]);
+            if (L + kLoadBatch <= clo + kCrBytes) break;
+            if (uload(&misc[M_ABORT])) return;
+            spin_pause_long();
+        }
+        const uint32_t nL = L + kLoadBatch;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) { const uint32_t P = nL + 16 * (lane + 64 * i); if (P < csize) nxt[i] = load_granule(src, csize, P); }
+        const uint32_t a0 = mod_cr(L);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t o = 16 * (lane + 64 * i);
+            if (L + o < csize) {
+                const uint32_t a = cr_fold(a0 + o);
+                *(U32x4*)(cr + a) = cur[i];
+                if (a < kCrPad) *(U32x4*)(cr + kCrBytes + a) = cur[i];
+            }
+        }
+        wave_lds_fence();
+        if (lane == 0) lds_store_release(&misc[M_CHI], nL < csize ? nL : csize);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) cur[i] = nxt[i];
+        L = nL;
     }
-    return chunk_final(ca, g, ents) && chunk_final(cb, g, ents);
 }
 
-struct CopyCtx {
-    lz4amd_gsrc src; uint32_t csize; lz4amd_gdst dst;
-    uint32_t out_emit;          // output position covered by the records in the ring
-    uint32_t rec_head;          // number of records emitted so far (the ring holds a sentinel there)
-    uint32_t cr_lo, cr_hi;      // compressed bytes resident in the LDS window
-    uint32_t r_ready;           // regions below this one can be composed in this iteration
+// ------------------------------------------------------------------------------ PARSER
+struct ParserS {
+    uint32_t csize, capB, low;      // capB = capacity + kBias; low = first output position that exists (kBias - prefix)
+    uint32_t e;                     // next token of the true chain
+    uint32_t obase;                 // output position of the next sequence (= everything published so far)
+    uint32_t head;                  // records published
+    uint32_t ppos;                  // lowest compressed position the parser still needs
+    uint32_t g, tail;               // first open region / first record still in use (last refresh)
+    uint64_t t_wait, t_walk, t_stitch, t_decode, t_slow;   // developer profile (cycles)
+    uint32_t n_trips1, n_trips2;
 };
 
-// One wave composes its regions R, R+16, ... below C.r_ready.  R / myfin persist across iterations.
-__device__ __forceinline__ void copy_regions(const CopyCtx& C, char* smem, uint32_t& R, uint32_t& myfin) {
-    uint8_t* ring = (uint8_t*)(smem + kOffRing);
-    const SeqRec* tab = (const SeqRec*)(smem + kOffRecs);
-    const uint32_t* idx = (const uint32_t*)(smem + kOffIdx);
-    const uint32_t lane = lane_id(), w = wave_id();
-    uint32_t* first = (uint32_t*)(smem + kOffFirst) + w * 64;
-    DoneEnt* ents = (DoneEnt*)(smem + kOffBits);
-    uint32_t* fin = (uint32_t*)(smem + kOffFin);
-    const lz4amd_gsrc src = C.src;
-    const lz4amd_gdst dst = C.dst;
-    const uint32_t csize = C.csize, cr_lo = C.cr_lo, cr_hi = C.cr_hi, cr_span = C.cr_hi - C.cr_lo;
-    for (; R < C.r_ready; R += kDecWaves, myfin++) {
-        const uint32_t x0 = R << kRegionShift;
-        uint32_t x1 = x0 + kRegion; if (x1 > C.out_emit) x1 = C.out_emit;     // only the block's last region is short
-        // -- flow control: region R overwrites the ring slot of region R-96, which waves working
-        //    on regions <= R-32 may still read.  g = first region not known to be complete.
-        uint32_t g;
-        for (;;) {
-            uint32_t f = lds_load_acquire(&fin[lane & (kDecWaves - 1)]) * kDecWaves + (lane & (kDecWaves - 1));
-            g = __builtin_amdgcn_readfirstlane(row16_min_u32(f));   // one value for the whole wave
-            if (g + kMaxLead >= R) break;
-            spin_pause();
-        }
-        const uint32_t slot = R % kSlots;
-        // the slot is mine now: no chunk of region R is done (mask first, then the tag)
-        if (lane == 0) { lds_store_release64(&ents[slot].mask, 0ull); lds_store_release(&ents[slot].tag, R + kSlots); }
-        // -- which sequence covers the first byte of each chunk?  (records j0..jl overlap the region)
-        const uint32_t j0 = idx[R & kIdxMask];
-        const uint32_t jl = (x1 < C.out_emit) ? idx[(R + 1) & kIdxMask] : C.rec_head - 1;
-        first[lane] = 0;
-        wave_lds_fence();
-        for (uint32_t base = 1; base <= jl - j0; base += 64) {
-            const uint32_t r = base + lane;
-            if (r <= jl - j0) {
-                const uint32_t o = tab[(j0 + r) & kRecMask].outpos;  // > x0
-                const uint32_t s = (o - x0 + kChunk - 1) / kChunk;
-                if (s < 64) atomicMax(&first[s], r);
-            }
-        }
-        wave_lds_fence();
-        uint32_t j = j0 + wave_incl_max(first[lane]);
-
-        const uint32_t c0 = x0 + kChunk * lane;
-        uint32_t c1 = c0 + kChunk; if (c1 > x1) c1 = x1;
-        const bool active = c0 < x1;
-        const uint32_t mychunk = c0 / kChunk;
-        uint32_t pos = c0;
-        U32x4 acc; acc[0] = acc[1] = acc[2] = acc[3] = 0;
-        SeqRec rec, nrec;
-        rec.outpos = rec.litpos = rec.ll = rec.off = 0; nrec = rec;
-        if (active) { rec = tab[j & kRecMask]; nrec = tab[(j + 1) & kRecMask]; }
-        bool done = !active;
-        uint64_t donemask = __ballot(!active);
-        const uint32_t my_ring = (slot << kRegionShift) + kChunk * lane;
-        for (;;) {
-            bool newly = false;
-            if (!done) {
-                while (pos < c1) {
-                    // one PIECE per trip: the part of a literal run or of a match inside my chunk
-                    const uint32_t lit_end = rec.outpos + rec.ll;
-                    const uint32_t lo = pos - c0;
-                    const bool is_lit = pos < lit_end;
-                    const uint32_t pend = is_lit ? lit_end : nrec.outpos;
-                    uint32_t stop = pend < c1 ? pend : c1;
-                    // kind 0: 16 bytes from LDS at `a` (literals in the window / final long match);
-                    // 1: wait; 2: literals from HBM; 3: short or overlapping match
-                    uint32_t kind, a = 0;
-                    const uint32_t A = rec.litpos + c0 - rec.outpos;     // compressed index of chunk byte 0 (may wrap below 0)
-                    const uint32_t off = rec.off, ms = lit_end;
-                    if (is_lit) {
-                        const bool inwin = (A - cr_lo < cr_span) && (A + 16 <= cr_hi) && ((A & kCrMask) + 20 <= kCrBytes);
-                        kind = inwin ? 0u : 2u;
-                        a = kOffCr + (A & kCrMask);
-                    } else if (off >= kChunk && off >= nrec.outpos - ms) {
-                        const uint32_t s0 = pos - off;
-                        kind = chunks_final(s0 / kChunk, (s0 + (stop - pos) - 1) / kChunk, g, ents) ? 0u : 1u;
-                        uint32_t ra = ring_addr(s0);
-                        ra = ra >= lo ? ra - lo : ra + kRingBytes - lo;
-                        a = kOffRing + ra;
-                    } else kind = 3;
-                    if (kind == 0) {
-                        acc = chunk_merge_from(acc, lds_read16_at((const uint8_t*)smem, a), lo);
-                    } else if (kind == 1) {
-                        break;
-                    } else if (kind == 2) {
-                        if (A < csize && A + 16 <= csize) acc = chunk_merge_from(acc, ld_global16(src + A), lo);
-                        else {                                       // block edges: byte by byte
-#pragma nounroll
-                            for (uint32_t i = lo; i < stop - c0; i++) chunk_set_byte(acc, i, (uint32_t)src[A + i]);
-                        }
-                    } else {
-                        const uint32_t ml = nrec.outpos - ms;
-                        if (off >= kChunk) {                       // overlapping, period >= 16: at most one wrap inside a piece
-                            const uint32_t d = (pos - ms) % off;
-                            const uint32_t s0 = ms - off + d;
-                            if (d + (stop - pos) > off) stop = pos + (off - d);
-                            if (!chunks_final(s0 / kChunk, (s0 + (stop - pos) - 1) / kChunk, g, ents)) break;
-                            acc = chunk_merge_from(acc, ring_read16(ring, s0, lo), lo);
-                        } else {
-                            // short offset (< 16): sources lie in [ms-off, ms) (period `off` if overlapping),
-                            // possibly inside this very chunk (still in registers)
-                            (void)ml;
-                            const uint32_t p0 = ms - off;
-                            bool ok = true;
-                            if (p0 / kChunk < mychunk) ok = chunk_final(p0 / kChunk, g, ents);
-                            if (ok && (ms - 1) / kChunk < mychunk && (ms - 1) / kChunk != p0 / kChunk) ok = chunk_final((ms - 1) / kChunk, g, ents);
-                            if (!ok) break;
-                            uint32_t d = (pos - ms) % off;
-#pragma nounroll
-                            for (uint32_t i = lo; i < stop - c0; i++) {
-                                const uint32_t sp = p0 + d;
-                                const uint32_t b = sp >= c0 ? chunk_byte(acc, sp - c0) : (uint32_t)ring[ring_addr(sp)];
-                                chunk_set_byte(acc, i, b);
-                                if (++d == off) d = 0;
-                            }
-                        }
-                    }
-                    pos = stop;
-                    if (pos < c1 && pos >= nrec.outpos) { j++; rec = nrec; nrec = tab[(j + 1) & kRecMask]; }
-                }
-                if (pos >= c1) {
-                    *(U32x4*)(ring + my_ring) = acc;
-                    if (my_ring < kRingPad) *(U32x4*)(ring + kRingBytes + my_ring) = acc;   // mirror
-                    if (c1 - c0 == kChunk) st_global16(dst + (c0 - kBias), acc);
-                    else {
-#pragma nounroll
-                        for (uint32_t i = 0; i < c1 - c0; i++) dst[c0 - kBias + i] = (uint8_t)chunk_byte(acc, i);
-                    }
-                    done = true; newly = true;
-                }
-            }
-            const uint64_t m = __ballot(newly);
-            if (m) {
-                donemask |= m;
-                wave_lds_fence();                       // chunk data before the done bits
-                if (lane == 0) lds_store_release64(&ents[slot].mask, donemask);
-            }
-            if (__all(done)) break;
-            spin_pause();
-        }
-        // region complete
-        wave_lds_fence();
-        if (lane == 0) lds_store_release(&fin[w], myfin + 1);
-    }
-}
-
-// ------------------------------------------------------------------------------ stage B driver
-__device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, uint32_t prefix,
-                                             const SeqRec* rectab, uint32_t nseq, uint32_t total_real,
-                                             char* smem, uint64_t* prof) {
-    const uint32_t tid = threadIdx.x;
+// Look at the copy waves' progress: first open region, first record still needed, and tell the loader
+// which compressed bytes are free (everything below the literals of that region and below the parser).
+__device__ __forceinline__ void parser_refresh(ParserS& S, char* smem) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    uint8_t* cr = (uint8_t*)(smem + kOffCr);
-    SeqRec* recs = (SeqRec*)(smem + kOffRecs);
-    uint32_t* idx = (uint32_t*)(smem + kOffIdx);
-    const uint32_t total = total_real + kBias;            // positions are biased by kBias from here on
-    const uint32_t nreg = (uint32_t)(((uint64_t)total + kRegion - 1) >> kRegionShift);
-
-    // uniform state (every thread computes the same values)
-    uint32_t rec_head = 0, rec_tail = 0, out_emit = kBias, r_next = kBias >> kRegionShift;
-    uint32_t cr_lo = 0, cr_hi = 0;
-    uint32_t myfin = (kBias >> kRegionShift) / kDecWaves;                  // the history regions count as done
-    uint32_t R = wave_id() + myfin * kDecWaves;           // per-wave copy cursor
-    uint64_t t_emit = 0, t_copy = 0, t0 = 0;
-
-    if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = tid; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
-    if (tid < kDecWaves) ((uint32_t*)(smem + kOffFin))[tid] = myfin;
-    // history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
-    {
-        uint8_t* ring = (uint8_t*)(smem + kOffRing);
-        const uint32_t lo = kBias - prefix;
-        for (uint32_t v = (lo & ~15u) + 16 * tid; v < kBias; v += 16 * kDecThreads) {
-            U32x4 g; g[0] = g[1] = g[2] = g[3] = 0;
-#pragma nounroll
-            for (uint32_t i = 0; i < 16; i++) if (v + i >= lo) chunk_set_byte(g, i, (uint32_t)(dst - (kBias - (v + i)))[0]);
-            const uint32_t a = ring_addr(v);
-            *(U32x4*)(ring + a) = g;
-            if (a < kRingPad) *(U32x4*)(ring + kRingBytes + a) = g;
-        }
+    const uint16_t* idx = (const uint16_t*)(smem + kOffIdx);
+    const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
+    const uint32_t g = first_open_region(smem);
+    const uint32_t x = g << kRegionShift;
+    uint32_t tail = S.head, need = S.ppos;
+    if (x < S.obase) {                                       // region g is covered by published records
+        const uint32_t t16 = idx[g & kIdxMask];
+        tail = S.head - ((S.head - t16) & 0xFFFFu);
+        const SeqRec r = recs[tail & kRecMask];
+        uint32_t d = x - r.outpos; if (d > r.ll) d = r.ll;
+        need = r.litpos + d;
     }
-    // what the prefetch registers hold: window granules [pf_lo, pf_hi) and table records rec_head+tid
-    uint32_t cr_lo_n = 0, cr_hi_n = csize < kCrBytes ? csize : kCrBytes;
-    uint32_t pf_lo = 0, pf_hi = cr_hi_n;
-    uint32_t ncand = nseq + 1 < kRecCap - 1 ? nseq + 1 : kRecCap - 1;      // table rows [rec_head, rec_head+ncand), incl. a sentinel
-    U32x4 pf0, pf1; pf0[0] = pf0[1] = pf0[2] = pf0[3] = 0; pf1 = pf0;
-    SeqRec prec; prec.outpos = prec.litpos = prec.ll = prec.off = 0;
-    {
-        const uint32_t P0 = pf_lo + 16 * tid, P1 = P0 + 16 * kDecThreads;
-        if (P0 < pf_hi) pf0 = load_granule(src, csize, P0);
-        if (P1 < pf_hi) pf1 = load_granule(src, csize, P1);
-        if (tid < ncand) prec = rectab[tid];
+    S.g = g; S.tail = tail;
+    const uint32_t clo = umin32(need, S.ppos);
+    if (lane_id() == 0) lds_store_release(&misc[M_CLO], clo);
+}
+__device__ __forceinline__ void parser_wait_data(ParserS& S, char* smem, uint32_t need) {
+    const uint32_t* misc = (const uint32_t*)(smem + kOffMisc);
+    if (need > S.csize) need = S.csize;
+    if (uload(&misc[M_CHI]) >= need) return;
+    const uint64_t t0 = clock_ticks();
+    for (;;) {
+        parser_refresh(S, smem);
+        if (uload(&misc[M_CHI]) >= need) break;
+        spin_pause();
     }
-    while (r_next < nreg) {
-        if (prof && tid == 0) t0 = clock_ticks();
-        // ---- commit the prefetched window granules; the slots of [old cr_lo, new cr_lo) are free
-        {
-            const uint32_t P0 = pf_lo + 16 * tid, P1 = P0 + 16 * kDecThreads;
-            if (P0 < pf_hi) *(U32x4*)(cr + (P0 & kCrMask)) = pf0;
-            if (P1 < pf_hi) *(U32x4*)(cr + (P1 & kCrMask)) = pf1;
-        }
-        cr_lo = cr_lo_n; cr_hi = cr_hi_n;
-        // ---- commit the prefetched records whose literals lie inside the window (litpos grows with the
-        //      sequence number, so a prefix passes); the first one always goes (HBM literals if need be)
-        const bool mine = tid < ncand && rec_head + tid < nseq;          // a real record, not the sentinel
-        const int ok = mine && tid + 1 < ncand && (tid == 0 || prec.litpos + prec.ll <= cr_hi);   // row ncand-1 can only be the sentinel
-        const uint32_t nacc = (uint32_t)__syncthreads_count(ok);
-        if (tid <= nacc && tid < ncand) recs[(rec_head + tid) & kRecMask] = prec;      // row nacc = sentinel (real record later)
-        if (tid == nacc && tid < ncand) misc[M_EMIT] = prec.outpos;
-        __syncthreads();
-        if (ncand) { rec_head += nacc; out_emit = misc[M_EMIT]; }
-        // ---- INDEX: first record of every region the ring covers
-        for (uint32_t j = rec_tail + tid; j < rec_head; j += kDecThreads) {
-            const uint32_t o = recs[j & kRecMask].outpos, on = recs[(j + 1) & kRecMask].outpos;
-            uint32_t g = (o + kRegion - 1) >> kRegionShift;
-            if (g < r_next) g = r_next;
-            for (; g <= r_next + kIdxCap && ((uint64_t)g << kRegionShift) < on; g++) idx[g & kIdxMask] = j;
-        }
-        uint32_t r_ready = rec_head >= nseq ? nreg : (out_emit >> kRegionShift);
-        if (r_ready > r_next + kIdxCap) r_ready = r_next + kIdxCap;
-        __syncthreads();
-        // ---- plan the next iteration and issue its global loads (committed after the copy)
-        const uint32_t x = r_ready << kRegionShift;
-        const uint32_t rec_tail_n = (r_ready < nreg && x < out_emit) ? idx[r_ready & kIdxMask] : rec_head;
-        uint32_t need;
-        {
-            const SeqRec r = recs[rec_tail_n & kRecMask];            // rec_tail_n == rec_head: the sentinel row = next record
-            uint32_t d = (rec_tail_n < rec_head && x > r.outpos) ? x - r.outpos : 0; if (d > r.ll) d = r.ll;
-            need = r.litpos + d; if (need > csize) need = csize;
-        }
-        cr_lo_n = need & ~15u; if (cr_lo_n < cr_lo) cr_lo_n = cr_lo;
-        cr_hi_n = cr_lo_n + kCrBytes; if (cr_hi_n > csize) cr_hi_n = csize;
-        pf_lo = cr_hi > cr_lo_n ? cr_hi : cr_lo_n; pf_hi = cr_hi_n;
-        {
-            const uint32_t room = kRecCap - 1 - (rec_head - rec_tail_n);  // ring rows free after this iteration
-            const uint32_t left = nseq + 1 - rec_head;                     // table rows left, sentinel included
-            ncand = room < left ? room : left; if (ncand > kDecThreads) ncand = kDecThreads;
-            const uint32_t P0 = pf_lo + 16 * tid, P1 = P0 + 16 * kDecThreads;
-            if (P0 < pf_hi) pf0 = load_granule(src, csize, P0);
-            if (P1 < pf_hi) pf1 = load_granule(src, csize, P1);
-            if (tid < ncand) prec = rectab[rec_head + tid];
-        }
-        if (prof && tid == 0) { const uint64_t t1 = clock_ticks(); t_emit += t1 - t0; t0 = t1; }
-        // ---- COPY
-        CopyCtx C; C.src = src; C.csize = csize; C.dst = dst; C.out_emit = out_emit; C.rec_head = rec_head;
-        C.cr_lo = cr_lo; C.cr_hi = cr_hi; C.r_ready = r_ready;
-        copy_regions(C, smem, R, myfin);
-        __syncthreads();
-        if (prof && tid == 0) t_copy += clock_ticks() - t0;
-        r_next = r_ready; rec_tail = rec_tail_n;
-    }
-    if (prof && tid == 0) { prof[2] = t_emit; prof[3] = t_copy; }
+    S.t_wait += clock_ticks() - t0;
+}
+__device__ __forceinline__ void parser_fail(char* smem, uint32_t pos) {
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    if (lane_id() == 0) { lds_store_relaxed(&misc[M_ERR], pos); lds_store_release(&misc[M_ABORT], 1u); }
 }
 
+// the compressed ring as a tile's walkers see it
+struct TileView { const uint8_t* cr; uint32_t t0, crT, tlim, csize; };
+__device__ __forceinline__ uint32_t tv_byte(const TileView& V, uint32_t p) { return (uint32_t)V.cr[cr_fold(V.crT + (p - V.t0))]; }
+
+struct TokInfo { uint32_t ll, q, off, ml, nx, st; };      // st: 0 decoded, 1 not inside the tile's reach (slow path), 2 malformed
+// Decode the sequence whose token is at p (p < tlim).  The walkers (FULL = false) only need nx; the
+// same function with FULL = true is the authority on the fields and on the reference's input-side
+// rules (read_variable_length, lz4.c:1979-2014).
+template <bool FULL>
+__device__ __forceinline__ TokInfo tok_decode(const TileView& V, uint32_t p) {
+    TokInfo r; r.ll = 0; r.q = 0; r.off = 0; r.ml = 0; r.nx = 0; r.st = 1;
+    const uint32_t b = tv_byte(V, p);
+    uint32_t ll = b >> 4, q = p + 1;
+    if (ll == 15) {
+        uint32_t n = 0, x;
+        do {
+            if (q >= V.tlim || n >= kExtMax) return r;
+            if (FULL && q + 15 >= V.csize) { r.st = 2; return r; }
+            x = tv_byte(V, q); q++; n++; ll += x;
+        } while (x == 255);
+    }
+    r.ll = ll; r.q = q;
+    if (V.csize - q < ll + 8) return r;                  // the block's last sequence (or a malformed one): slow path
+    const uint32_t m = q + ll;
+    if (m + 2 > V.tlim) return r;
+    uint32_t nx = m + 2, ml = b & 15;
+    if (ml == 15) {
+        uint32_t n = 0, x;
+        do {
+            if (nx >= V.tlim || n >= kExtMax) return r;
+            x = tv_byte(V, nx); nx++; n++; ml += x;
+            if (FULL && nx + 4 > V.csize) { r.st = 2; return r; }
+        } while (x == 255);
+    }
+    if (FULL) r.off = tv_byte(V, m) | (tv_byte(V, m + 1) << 8);
+    r.ml = ml + kMinMatch; r.nx = nx; r.st = 0;
+    return r;
+}
+// the walkers' common case: both nibbles < 15, fields inside the tile's reach, not the last sequence
+__device__ __forceinline__ bool tok_simple(const TileView& V, uint32_t p, uint32_t b, uint32_t& nx) {
+    const uint32_t ll = b >> 4;
+    nx = p + ll + 3;
+    return ll != 15 && (b & 15) != 15 && p + ll + 9 <= V.csize && nx <= V.tlim;
+}
+
+// Publish the records of lanes [0, nok) of a decoded batch (o / len / rec per lane), waiting for room in
+// the record ring and for the copy to come within kOutAhead regions.  false: aborted.
+__device__ __forceinline__ void publish_batch(ParserS& S, char* smem, uint32_t nok, uint32_t o, uint32_t len, const SeqRec& rec) {
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    uint16_t* idx = (uint16_t*)(smem + kOffIdx);
+    SeqRec* recs = (SeqRec*)(smem + kOffRecs);
+    const uint32_t lane = lane_id();
+    const uint32_t er = (o + len - 1) >> kRegionShift;
+    uint32_t done = 0;
+    while (done < nok) {
+        parser_refresh(S, smem);
+        const unsigned long long okm = __ballot(lane >= done && lane < nok && er < S.g + kOutAhead);
+        const unsigned long long run = ~(okm >> done);
+        uint32_t npub = run ? (uint32_t)__ffsll((long long)run) - 1 : 64u;
+        if (npub > nok - done) npub = nok - done;
+        const uint32_t room = kRecCap - 1 - (S.head - S.tail);               // rows free, one kept for the sentinel
+        if (npub > room) npub = room;
+        if (npub == 0) { spin_pause(); continue; }
+        if (lane >= done && lane < done + npub) {
+            const uint32_t j = S.head + (lane - done);
+            recs[j & kRecMask] = rec;
+            for (uint32_t g1 = (o + kRegion - 1) >> kRegionShift; (g1 << kRegionShift) < o + len; g1++) idx[g1 & kIdxMask] = (uint16_t)j;
+            if (lane == done + npub - 1) recs[(j + 1) & kRecMask].outpos = o + len;     // sentinel: where the next record starts
+        }
+        const uint32_t oend = wave_readlane(o + len, done + npub - 1);
+        wave_lds_fence();
+        if (lane == 0) { lds_store_release(&misc[M_HEAD], S.head + npub); lds_store_release(&misc[M_EMIT], oend); }
+        S.head += npub; S.obase = oend; done += npub;
+    }
+}
+// One record from the slow path (every lane holds the same values).
+__device__ __forceinline__ void publish_one(ParserS& S, char* smem, uint32_t litpos, uint32_t ll, uint32_t off, uint32_t len) {
+    SeqRec rec; rec.outpos = S.obase; rec.litpos = litpos; rec.ll = ll; rec.off = off;
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    uint16_t* idx = (uint16_t*)(smem + kOffIdx);
+    SeqRec* recs = (SeqRec*)(smem + kOffRecs);
+    const uint32_t lane = lane_id(), o = S.obase;
+    for (;;) {
+        parser_refresh(S, smem);
+        if (S.head + 2 - S.tail <= kRecCap && ((o + len) >> kRegionShift) < S.g + kOutAhead) break;
+        spin_pause();
+    }
+    if (lane == 0) { recs[S.head & kRecMask] = rec; recs[(S.head + 1) & kRecMask].outpos = o + len; }
+    const uint32_t g1 = ((o + kRegion - 1) >> kRegionShift) + lane;            // len <= kSlowSpan: at most 9 regions
+    if ((g1 << kRegionShift) < o + len) idx[g1 & kIdxMask] = (uint16_t)S.head;
+    wave_lds_fence();
+    if (lane == 0) { lds_store_release(&misc[M_HEAD], S.head + 1); lds_store_release(&misc[M_EMIT], o + len); }
+    S.head += 1; S.obase = o + len;
+}
+
+// SLOW PATH: the sequence whose token is at S.e, whatever its size; every lane computes the same values,
+// length fields are scanned 64 bytes at a time.  Same rules as the reference's safe loop.
+// Returns 0: go on at S.e, 1: that was the block's last sequence, 2: malformed (reported).
+__device__ __forceinline__ int slow_token(ParserS& S, char* smem) {
+    const uint8_t* cr = (const uint8_t*)(smem + kOffCr);
+    const uint32_t lane = lane_id(), csize = S.csize, p = S.e;
+    DTRACE("slow token p=%u obase=%u\n", p, S.obase);
+    if (p >= csize) { parser_fail(smem, csize ? csize - 1 : 0); return 2; }
+    S.ppos = p;
+    parser_wait_data(S, smem, p + 1);
+    const uint32_t t = cr[mod_cr(p)];
+    uint32_t ll = t >> 4, q = p + 1;
+    if (ll == 15) {
+        for (;;) {
+            parser_wait_data(S, smem, q + 64);
+            const uint32_t pos = q + lane;
+            const bool inb = pos + 15 < csize;                              // lz4.c:1986-2006: a length byte is read only there
+            const uint32_t x = inb ? (uint32_t)cr[mod_cr(pos)] : 0u;
+            const unsigned long long stopm = __ballot(!inb || x != 255);
+            if (!stopm) {
+                ll += 255 * 64; q += 64; S.ppos = q;
+                if (ll > csize) { parser_fail(smem, p); return 2; }
+                continue;
+            }
+            const uint32_t kk = (uint32_t)__ffsll((long long)stopm) - 1;
+            if (!wave_readlane(inb ? 1u : 0u, kk)) { parser_fail(smem, p); return 2; }
+            ll += 255 * kk + wave_readlane(x, kk); q += kk + 1;
+            break;
+        }
+        if (ll > csize) { parser_fail(smem, p); return 2; }
+    }
+    S.ppos = q;                                                             // (the literals are held by the records from here on)
+    const uint32_t rem = csize - q, room = S.capB - S.obase;
+    const bool last = rem < ll + 8 || room < ll + kMfLimit;                 // lz4.c:2279
+    if (last && (rem != ll || room < ll)) { parser_fail(smem, p); return 2; }   // lz4.c:2312-2318
+    // the literal run, in records of at most kSlowSpan bytes (a last sequence always gets a record)
+    if (ll || last) {
+        uint32_t left = ll, lp = q;
+        do {
+            const uint32_t n = left < kSlowSpan ? left : kSlowSpan;
+            publish_one(S, smem, lp, n, 0, n);
+            left -= n; lp += n;
+        } while (left);
+    }
+    if (last) return 1;
+    const uint32_t m = q + ll;                                              // m + 8 <= csize
+    S.ppos = m;
+    parser_wait_data(S, smem, m + 2);
+    const uint32_t off = (uint32_t)cr[mod_cr(m)] | ((uint32_t)cr[mod_cr(m + 1)] << 8);
+    uint32_t ml = t & 15, nx = m + 2;
+    if (ml == 15) {
+        for (;;) {
+            parser_wait_data(S, smem, nx + 64);
+            const uint32_t pos = nx + lane;
+            const uint32_t x = pos < csize ? (uint32_t)cr[mod_cr(pos)] : 0u;
+            const bool badafter = pos + 5 > csize;                          // after a length byte at least 4 more bytes must follow
+            const unsigned long long stopm = __ballot(x != 255 || badafter);
+            if (!stopm) {
+                ml += 255 * 64; nx += 64; S.ppos = nx;
+                if (ml > 0x7FFFFFF0u) { parser_fail(smem, p); return 2; }
+                continue;
+            }
+            const uint32_t kk = (uint32_t)__ffsll((long long)stopm) - 1;
+            ml += 255 * kk + wave_readlane(x, kk); nx += kk + 1;
+            if (wave_readlane(badafter ? 1u : 0u, kk) || ml > 0x7FFFFFF0u) { parser_fail(smem, p); return 2; }
+            break;
+        }
+    }
+    ml += kMinMatch;
+    const uint32_t ms = S.obase;
+    if (off == 0 || off > ms - S.low) { parser_fail(smem, p); return 2; }   // lz4.c:2356
+    if (S.capB - ms < ml + kLastLiterals) { parser_fail(smem, p); return 2; }   // lz4.c:2423
+    {
+        uint32_t left = ml;
+        do {
+            const uint32_t n = left < kSlowSpan ? left : kSlowSpan;
+            publish_one(S, smem, nx, 0, off, n);
+            left -= n;
+        } while (left);
+    }
+    S.e = nx;
+    return 0;
+}
+
+enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_OVER = 4 };
+
+// One tile of the stream.  Returns 0: go on at S.e with another tile, 1: S.e needs the slow path,
+// 2: malformed (reported).
+__device__ __forceinline__ int parse_tile(ParserS& S, char* smem) {
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    uint32_t* sb = (uint32_t*)(smem + kOffSBits);
+    uint16_t* blist = (uint16_t*)(smem + kOffBridge);
+    uint16_t* tl = (uint16_t*)(smem + kOffTok);
+    const uint32_t lane = lane_id(), csize = S.csize;
+    const uint32_t e = S.e;
+    const uint32_t t0 = e & ~(kSeg - 1), t1 = t0 + kTile;
+    TileView V; V.cr = (const uint8_t*)(smem + kOffCr); V.t0 = t0; V.crT = mod_cr(t0); V.csize = csize;
+    V.tlim = t1 + kLook < csize ? t1 + kLook : csize;
+    S.ppos = e;
+    DTRACE("tile e=%u t0=%u tlim=%u\n", e, t0, V.tlim);
+    parser_wait_data(S, smem, V.tlim);
+    DTRACE("tile data ok\n");
+    uint64_t tc = clock_ticks();
+
+    // ---- P1: every lane walks its segment, marking the token positions it visits
+#pragma unroll
+    for (uint32_t w = 0; w < 8; w++) sb[lane * 8 + w] = 0;
+    wave_lds_fence();
+    const uint32_t seg_lo = t0 + lane * kSeg, seg_hi = seg_lo + kSeg;
+    uint32_t p = lane == 0 ? e : seg_lo;
+    bool dead = false, parked = false;
+    for (uint32_t trip = 0;; trip++) {
+        const bool run = !dead && p < seg_hi;
+        if (!__any(run)) break;
+        S.n_trips1++;
+        if (run && !parked) {
+            if (p >= V.tlim) dead = true;                      // ran off the block
+            else {
+                uint32_t nx;
+                if (tok_simple(V, p, tv_byte(V, p), nx)) { atomicOr(&sb[(p - t0) >> 5], 1u << ((p - t0) & 31)); p = nx; }
+                else parked = true;
+            }
+        }
+        if ((trip & 3) == 3 && run && parked) {                // the rarer token shapes, all parked lanes together
+            atomicOr(&sb[(p - t0) >> 5], 1u << ((p - t0) & 31));
+            const TokInfo ti = tok_decode<false>(V, p);
+            if (ti.st) dead = true; else p = ti.nx;
+            parked = false;
+        }
+    }
+    wave_lds_fence();
+    // ---- P2: walk on from the exit until a position a later lane marked
+    uint32_t okind = dead ? OUT_STOP : OUT_NONE, opos = p, nb = 0;
+    parked = false;
+    for (uint32_t trip = 0;; trip++) {
+        const bool run = okind == OUT_NONE;
+        if (!__any(run)) break;
+        S.n_trips2++;
+        if (run && !parked) {
+            if (p >= t1) { okind = OUT_EXIT; opos = p; }
+            else if ((sb[(p - t0) >> 5] >> ((p - t0) & 31)) & 1u) { okind = OUT_MERGE; opos = p; }
+            else if (nb >= kBridgeCap) { okind = OUT_OVER; opos = p; }
+            else if (p >= V.tlim) { okind = OUT_STOP; opos = p; }
+            else {
+                uint32_t nx;
+                if (tok_simple(V, p, tv_byte(V, p), nx)) { blist[nb * 64 + lane] = (uint16_t)(p - t0); nb++; p = nx; }
+                else parked = true;
+            }
+        }
+        if ((trip & 3) == 3 && run && parked && okind == OUT_NONE) {
+            const TokInfo ti = tok_decode<false>(V, p);
+            if (ti.st) { okind = OUT_STOP; opos = p; }
+            else { blist[nb * 64 + lane] = (uint16_t)(p - t0); nb++; p = ti.nx; }
+            parked = false;
+        }
+    }
+    { const uint64_t t = clock_ticks(); S.t_walk += t - tc; tc = t; }
+    // ---- P3: stitch the true chain (lane 0 is true from e; a merge hands the truth to the marking lane)
+    uint32_t myT = kNone, cur = 0, Tcur = e, tend = e;
+    bool stop = true;                                          // (never left like this: cur grows with every merge, lane 63 cannot merge)
+    for (uint32_t it = 0; it < 64; it++) {
+        if (lane == cur) myT = Tcur;
+        const uint32_t kind = wave_readlane(okind, cur), pos = wave_readlane(opos, cur);
+        if (kind == OUT_MERGE) { cur = (pos - t0) >> kSegShift; Tcur = pos; continue; }
+        tend = pos; stop = kind == OUT_STOP;
+        break;
+    }
+    DTRACE("P3 done tend=%u stop=%d\n", tend, (int)stop);
+    // ---- P4: the bitmap of the true tokens in [e, tend)
+    const bool active = myT != kNone;
+#pragma unroll
+    for (uint32_t w = 0; w < 8; w++) {
+        uint32_t v = sb[lane * 8 + w];
+        const uint32_t base = seg_lo + 32 * w;
+        if (!active) v = 0;
+        else if (myT > base) v = (myT - base >= 32) ? 0u : (v & (0xFFFFFFFFu << (myT - base)));
+        if (tend <= base) v = 0; else if (tend - base < 32) v &= (1u << (tend - base)) - 1u;
+        sb[lane * 8 + w] = v;
+    }
+    wave_lds_fence();
+    for (uint32_t n = 0; __any(active && n < nb); n++) {
+        if (active && n < nb) {
+            const uint32_t rel = blist[n * 64 + lane];
+            if (t0 + rel < tend) atomicOr(&sb[rel >> 5], 1u << (rel & 31));
+        }
+    }
+    wave_lds_fence();
+    // ---- the token list
+    uint32_t wv[8], cnt = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 8; w++) { wv[w] = sb[lane * 8 + w]; cnt += (uint32_t)__popc(wv[w]); }
+    const uint32_t incl = wave_incl_sum(cnt);
+    uint32_t N = wave_readlane(incl, 63);
+    {
+        uint32_t k = incl - cnt;
+#pragma unroll
+        for (uint32_t w = 0; w < 8; w++) {
+            uint32_t v = wv[w];
+            while (v) {
+                const uint32_t b = (uint32_t)__ffs((int)v) - 1; v &= v - 1;
+                const uint32_t rel = lane * kSeg + 32 * w + b;
+                if (k < kTokCap) tl[k] = (uint16_t)rel;
+                else if (k == kTokCap) misc[M_TOKX] = t0 + rel;
+                k++;
+            }
+        }
+    }
+    wave_lds_fence();
+    if (N > kTokCap) { N = kTokCap; tend = misc[M_TOKX]; stop = false; }    // cut the tile at token kTokCap (a true position)
+    { const uint64_t t = clock_ticks(); S.t_stitch += t - tc; tc = t; }
+    DTRACE("tokens N=%u\n", N);
+    // ---- P5: decode 64 tokens at a time, place them, check them, publish them
+    for (uint32_t base = 0; base < N; base += 64) {
+        const uint32_t i = base + lane;
+        const bool have = i < N;
+        TokInfo ti; ti.ll = ti.q = ti.off = ti.ml = ti.nx = 0; ti.st = 0;
+        uint32_t tp = 0;
+        if (have) { tp = t0 + tl[i]; ti = tok_decode<true>(V, tp); }
+        const uint32_t len = have && ti.st == 0 ? ti.ll + ti.ml : 0;         // <= 2 * (15 + 255 * 32 + 4)
+        const uint32_t isum = wave_incl_sum(len);
+        const uint32_t o = S.obase + (isum - len);
+        // output-side rules (lz4.c:2279 as an error: a sequence inside the tile is never the last; 2356; 2423)
+        bool bad = false;
+        if (have) {
+            const uint32_t room = S.capB - o;
+            bad = ti.st != 0 || o > S.capB || room < ti.ll + kMfLimit || ti.off == 0 || ti.off > o + ti.ll - S.low
+                  || S.capB - (o + ti.ll) < ti.ml + kLastLiterals;
+        }
+        const unsigned long long badm = __ballot(bad);
+        uint32_t nok = N - base < 64 ? N - base : 64;
+        if (badm) nok = (uint32_t)__ffsll((long long)badm) - 1;
+        SeqRec rec; rec.outpos = o; rec.litpos = ti.q; rec.ll = ti.ll; rec.off = ti.off;
+        publish_batch(S, smem, nok, o, len, rec);
+        if (badm) { parser_fail(smem, wave_readlane(tp, nok)); return 2; }
+    }
+    S.t_decode += clock_ticks() - tc;
+    S.e = tend;
+    return stop ? 1 : 0;
+}
+
+__device__ __forceinline__ void parser_role(uint32_t csize, uint32_t cap, uint32_t prefix, char* smem, uint64_t* prof) {
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    wave_priority_high();
+    ParserS S;
+    S.csize = csize; S.capB = cap + kBias; S.low = kBias - prefix;
+    S.e = 0; S.obase = kBias; S.head = 0; S.ppos = 0; S.g = kFirstRegion; S.tail = 0;
+    S.t_wait = S.t_walk = S.t_stitch = S.t_decode = S.t_slow = 0; S.n_trips1 = S.n_trips2 = 0;
+    int rc = 0;
+    for (;;) {
+        rc = parse_tile(S, smem);
+        if (rc == 1) {
+            const uint64_t t0 = clock_ticks();
+            rc = slow_token(S, smem);
+            S.t_slow += clock_ticks() - t0;
+            if (rc == 1) break;                 // the block's last sequence has been published
+        }
+        if (rc == 2) break;
+    }
+    if (rc == 1) {
+        wave_lds_fence();
+        if (lane_id() == 0) lds_store_release(&misc[M_FIN], 1u);
+        // the loader may still be behind (a long final literal run): keep telling it what the copy has consumed
+        S.ppos = csize;
+        while (uload(&misc[M_CHI]) < csize) { parser_refresh(S, smem); spin_pause(); }
+    }
+    if (prof && lane_id() == 0) { prof[1] = S.t_wait; prof[2] = S.t_walk; prof[3] = S.t_stitch; prof[4] = S.t_decode; prof[5] = S.t_slow | ((uint64_t)S.n_trips1 << 24) | ((uint64_t)S.n_trips2 << 44); }
+}
+
+// ------------------------------------------------------------------------------ COPY
+struct RegionCtx {
+    char* smem;
+    uint32_t R, x0, x1, slot;       // region, its output range, its ring slot
+    uint32_t g;                     // regions below g are final
+    uint32_t chi;                   // compressed bytes resident
+    uint32_t crW, lp0;              // ring address / stream position of the region's first literal source
+    uint32_t ringB;                 // output position of ring address 0 two laps below the region
+    uint32_t j0, nrec;              // records that overlap the region
+    uint64_t mydone;                // chunks of this region that are final
+};
+
+__device__ __forceinline__ bool chunk_is_final(const RegionCtx& C, uint32_t c) {
+    const uint32_t r = c >> 6;
+    if (r < C.g) return true;
+    if (r == C.R) return (C.mydone >> (c & 63)) & 1ull;
+    int32_t s = (int32_t)C.slot - (int32_t)(C.R - r); if (s < 0) s += kSlots;
+    const DoneEnt* e = (const DoneEnt*)(C.smem + kOffBits) + s;
+    uint32_t tag; uint64_t mask;
+    lds_load_tag_mask(&e->tag, &e->mask, tag, mask);         // the tag first: tag == want means the mask is this region's
+    const uint32_t want = r + kSlots;
+    return tag > want || (tag == want && ((mask >> (c & 63)) & 1ull));
+}
+// output bytes [sa, sb] final?  (sb - sa < 16)
+__device__ __forceinline__ bool range_is_final(const RegionCtx& C, uint32_t sa, uint32_t sb) {
+    if ((sb >> kRegionShift) < C.g) return true;
+    bool ok = chunk_is_final(C, sa >> 4);
+    if ((sb >> 4) != (sa >> 4)) ok = ok && chunk_is_final(C, sb >> 4);
+    return ok;
+}
+__device__ __forceinline__ U32x4 ring_read16(const RegionCtx& C, uint32_t pos) {
+    return lds_read16_at((const uint8_t*)(C.smem + kOffRing), ring_fold(pos - C.ringB));
+}
+
+// Bytes [lo, lo + n) of v := output bytes [d, d + n) of the piece (literal run or match of rec; ms = where
+// the match starts).  false: a source is not final yet.  own_ok: every lower piece of d's own chunk is done
+// (only a match with a period < 16 that starts inside a chunk reads its own chunk).
+__device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint32_t d, uint32_t lo, uint32_t n,
+                                           const SeqRec& rec, uint32_t ms, bool own_ok, U32x4& v) {
+    if (is_lit) {
+        const uint32_t A = rec.litpos + (d - rec.outpos);
+        if (A + n > C.chi) return false;
+        uint32_t a = C.crW + (A - C.lp0) - lo + kCrBytes;
+        a = cr_fold(cr_fold(a));
+        v = lds_read16_at((const uint8_t*)(C.smem + kOffCr), a);
+        return true;
+    }
+    uint32_t dist = rec.off;
+    const uint32_t into = d - ms;
+    if (into >= dist) {
+        // the source lies inside this very match (it overlaps itself): every earlier period holds the same
+        // bytes; read the farthest one the 64 KB window holds, long final, instead of the bytes just written
+        uint32_t k = into / dist + 1;
+        const uint32_t kmax = kMaxDistance / dist;
+        if (k > kmax) k = kmax;
+        dist *= k;
+    }
+    const uint32_t s = d - dist;
+    // sources below my chunk must be final; sources inside my own chunk (a match that starts inside a chunk,
+    // offset < 16 + lo) are in once every lower piece of the chunk is
+    const uint32_t cstart = d - lo;
+    const uint32_t se = n <= dist ? s + n - 1 : d - 1;                       // last source byte
+    if (s < cstart && !range_is_final(C, s, se < cstart ? se : cstart - 1)) return false;
+    if (se >= cstart && !own_ok) return false;
+    if (n <= dist) {
+        v = ring_read16(C, s - lo);
+        return true;
+    }
+    // period < n <= 16: bytes [s, d) are the pattern
+    const U32x4 pat = ring_read16(C, s);
+    v[0] = v[1] = v[2] = v[3] = 0;
+    uint32_t k = 0;
+#pragma nounroll
+    for (uint32_t i = 0; i < n; i++) { chunk_set_byte(v, lo + i, chunk_byte(pat, k)); if (++k == dist) k = 0; }
+    return true;
+}
+
+__device__ __forceinline__ void lds_or16(char* smem, uint32_t off, const U32x4& v) {
+    unsigned long long* q = (unsigned long long*)(smem + off);
+    atomicOr(&q[0], (unsigned long long)v[0] | ((unsigned long long)v[1] << 32));
+    atomicOr(&q[1], (unsigned long long)v[2] | ((unsigned long long)v[3] << 32));
+}
+
+// chunk c of the region's slot |= v (the ring's pad mirrors chunks 0-1 of slot 0 at all times, so that a 16-byte
+// read that starts in the ring's last bytes runs on into valid data)
+__device__ __forceinline__ void slot_or16(const RegionCtx& C, uint32_t c, const U32x4& v) {
+    lds_or16(C.smem, kOffRing + (C.slot << kRegionShift) + (c << 4), v);
+    if (C.slot == 0 && c < kRingPad / kChunk) lds_or16(C.smem, kOffRing + kRingBytes + (c << 4), v);
+}
+__device__ __forceinline__ void slot_write16(const RegionCtx& C, uint32_t c, const U32x4& v) {
+    *(U32x4*)(C.smem + kOffRing + (C.slot << kRegionShift) + (c << 4)) = v;
+    if (C.slot == 0 && c < kRingPad / kChunk) *(U32x4*)(C.smem + kOffRing + kRingBytes + (c << 4)) = v;
+}
+
+// round-B item of lane l in trip t: the head of a piece that starts inside a chunk
+struct BItem { SeqRec rec; uint32_t ms, d, lo, n, chunk; bool is_lit, valid; };
+__device__ __forceinline__ BItem b_item(const RegionCtx& C, uint32_t t) {
+    const SeqRec* recs = (const SeqRec*)(C.smem + kOffRecs);
+    const uint32_t l = lane_id(), r = 32 * t + (l >> 1);
+    BItem it; it.valid = false; it.is_lit = !(l & 1);
+    it.rec.outpos = it.rec.litpos = it.rec.ll = it.rec.off = 0; it.ms = it.d = it.lo = it.n = it.chunk = 0;
+    if (r < C.nrec) {
+        it.rec = recs[(C.j0 + r) & kRecMask];
+        const uint32_t nout = recs[(C.j0 + r + 1) & kRecMask].outpos;
+        it.ms = it.rec.outpos + it.rec.ll;
+        it.d = it.is_lit ? it.rec.outpos : it.ms;
+        const uint32_t pe = it.is_lit ? it.ms : nout;
+        it.lo = it.d & 15u;
+        it.valid = it.d >= C.x0 && it.d < C.x1 && it.lo != 0 && pe > it.d;
+        const uint32_t n = pe - it.d;
+        it.n = n < 16 - it.lo ? n : 16 - it.lo;
+        it.chunk = (it.d - C.x0) >> 4;
+    }
+    return it;
+}
+
+// Compose region C.R in its ring slot and store it.
+__device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint32_t w, uint64_t& t_retry) {
+    char* smem = C.smem;
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
+    DoneEnt* ents = (DoneEnt*)(smem + kOffBits);
+    unsigned long long* pend = (unsigned long long*)(smem + kOffPend) + w * (kMaxTrips + 2);     // [0] scratch, [1..] trips
+    const uint32_t lane = lane_id();
+    const uint32_t slot_off = kOffRing + (C.slot << kRegionShift);
+    // the slot is mine now: no chunk of region R is done (mask first, then the tag)
+    if (lane == 0) { lds_store_release64(&ents[C.slot].mask, 0ull); lds_store_release(&ents[C.slot].tag, C.R + kSlots); }
+    C.mydone = 0;
+    C.lp0 = recs[C.j0 & kRecMask].litpos; C.crW = mod_cr(C.lp0);
+    C.ringB = (C.R - C.slot - kSlots) << kRegionShift;
+    // ---- round A: which record covers the first byte of each chunk?  (scratch: the slot itself)
+    uint32_t* fs = (uint32_t*)(smem + slot_off);
+    fs[lane] = 0;
+    wave_lds_fence();
+    for (uint32_t base = 1; base < C.nrec; base += 64) {
+        const uint32_t r = base + lane;
+        if (r < C.nrec) {
+            const uint32_t o = recs[(C.j0 + r) & kRecMask].outpos;        // > x0
+            const uint32_t s = (o - C.x0 + kChunk - 1) / kChunk;
+            if (s < 64) atomicMax(&fs[s], r);
+        }
+    }
+    wave_lds_fence();
+    const uint32_t jr = wave_incl_max(fs[lane]);
+    wave_lds_fence();
+    const uint32_t c0 = C.x0 + kChunk * lane;
+    const bool actA = c0 < C.x1;
+    SeqRec arec; arec.outpos = arec.litpos = arec.ll = arec.off = 0;
+    uint32_t ams = 0, an = 0; bool alit = false;
+    if (actA) {
+        arec = recs[(C.j0 + jr) & kRecMask];
+        const uint32_t nout = recs[(C.j0 + jr + 1) & kRecMask].outpos;
+        ams = arec.outpos + arec.ll;
+        alit = c0 < ams;
+        const uint32_t pe = alit ? ams : nout;
+        an = pe - c0 < 16 ? pe - c0 : 16;
+    }
+    {
+        U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
+        bool ready = false;
+        if (actA) {
+            ready = item_fetch(C, alit, c0, 0, an, arec, ams, true, v);
+            v = ready ? keep_bytes(v, 0, an) : U32x4{0, 0, 0, 0};
+            slot_write16(C, lane, v);
+        }
+        uint64_t pendA = __ballot(actA && !ready);
+        // ---- round B: heads of the pieces that start inside a chunk, 32 records per trip
+        const uint32_t trips = (C.nrec + 31) / 32;
+        bool anyB = false;
+        for (uint32_t t = 0; t < trips; t++) {
+            const BItem it = b_item(C, t);
+            bool rdy = false;
+            if (it.valid) {
+                U32x4 bv;
+                rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, false, bv);
+                if (rdy) slot_or16(C, it.chunk, keep_bytes(bv, it.lo, it.lo + it.n));
+            }
+            const unsigned long long pm = __ballot(it.valid && !rdy);
+            if (lane == 0) pend[1 + t] = pm;
+            anyB = anyB || pm != 0;
+        }
+        // ---- pieces whose sources were still in flight: try again until they are all in
+        if (pendA || anyB) {
+            const uint64_t tr0 = clock_ticks();
+            uint64_t published = 0;
+            const uint64_t actm = __ballot(actA);
+            for (;;) {
+                // chunks without a pending piece are final: tell the other waves
+                wave_lds_fence();
+                if (lane == 0) pend[0] = 0;
+                wave_lds_fence();
+                for (uint32_t t = 0; t < trips; t++) {
+                    const unsigned long long pm = pend[1 + t];
+                    if (pm) { const BItem it = b_item(C, t); if ((pm >> lane) & 1ull) atomicOr(&pend[0], 1ull << it.chunk); }
+                }
+                wave_lds_fence();
+                const uint64_t pendchunks = pendA | pend[0];
+                DTRACE("retry R=%u pendA=%llx pendB0=%llx chunks=%llx g=%u chi=%u\n", C.R, (unsigned long long)pendA, (unsigned long long)pend[1], (unsigned long long)pendchunks, C.g, C.chi);
+                C.mydone = ~pendchunks;
+                const uint64_t pub = ~pendchunks & actm;
+                if (pub != published) { published = pub; if (lane == 0) lds_store_release64(&ents[C.slot].mask, pub); }
+                if (!pendchunks) break;
+                if (uload(&misc[M_ABORT])) return;
+                spin_pause();
+                C.g = first_open_region(smem);
+                C.chi = uload(&misc[M_CHI]);
+                if (pendA) {
+                    const bool mine = (pendA >> lane) & 1ull;
+                    bool rdy = false;
+                    if (mine) {
+                        U32x4 av;
+                        rdy = item_fetch(C, alit, c0, 0, an, arec, ams, true, av);
+                        if (rdy) slot_or16(C, lane, keep_bytes(av, 0, an));
+                    }
+                    pendA &= ~__ballot(rdy);
+                }
+                bool earlier_clear = true;
+                for (uint32_t t = 0; t < trips; t++) {
+                    const unsigned long long pm = pend[1 + t];
+                    if (!pm) continue;
+                    const BItem it = b_item(C, t);
+                    const bool mine = (pm >> lane) & 1ull;
+                    // is every lower piece of my own chunk in? (chunk A, the earlier trips, the lower lanes of this trip)
+                    const unsigned long long lower = pm & ((1ull << lane) - 1ull);
+                    const uint32_t h = lower ? 63u - (uint32_t)__clzll((long long)lower) : 0u;
+                    const uint32_t hc = (uint32_t)__shfl((int)it.chunk, (int)h);
+                    const bool own_ok = earlier_clear && !((pendA >> it.chunk) & 1ull) && (!lower || hc != it.chunk);
+                    bool rdy = false;
+                    if (mine) {
+                        U32x4 bv;
+                        rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, own_ok, bv);
+                        if (rdy) slot_or16(C, it.chunk, keep_bytes(bv, it.lo, it.lo + it.n));
+                    }
+                    const unsigned long long left = pm & ~__ballot(rdy);
+                    wave_lds_fence();
+                    if (lane == 0) pend[1 + t] = left;
+                    wave_lds_fence();
+                    if (left) earlier_clear = false;
+                }
+            }
+            t_retry += clock_ticks() - tr0;
+        }
+    }
+    // ---- the region is complete: to HBM, then tell the other waves
+    wave_lds_fence();
+    if (actA) {
+        const U32x4 v = *(const U32x4*)(smem + slot_off + kChunk * lane);
+        const uint32_t c1 = c0 + kChunk < C.x1 ? c0 + kChunk : C.x1;
+        if (c1 - c0 == kChunk) st_global16(dst + (c0 - kBias), v);
+        else {
+#pragma nounroll
+            for (uint32_t i = 0; i < c1 - c0; i++) dst[c0 - kBias + i] = (uint8_t)chunk_byte(v, i);
+        }
+    }
+    wave_lds_fence();
+    if (lane == 0) lds_store_release64(&ents[C.slot].mask, ~0ull);
+}
+
+__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* smem, uint64_t* prof) {
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    const uint16_t* idx = (const uint16_t*)(smem + kOffIdx);
+    uint32_t* fin = (uint32_t*)(smem + kOffFin);
+    const uint32_t lane = lane_id();
+    uint32_t k = 0, R = kFirstRegion + w, slot = (kFirstRegion + w) % kSlots;
+    uint64_t t_rec = 0, t_lead = 0, t_work = 0, t_retry = 0;
+    for (;; R += kCopyWaves, slot = slot + kCopyWaves >= kSlots ? slot + kCopyWaves - kSlots : slot + kCopyWaves) {
+        RegionCtx C; C.smem = smem; C.R = R; C.slot = slot;
+        C.x0 = R << kRegionShift;
+        // ---- wait until the records cover the region (or the block ends inside / before it)
+        uint64_t ts = clock_ticks();
+        uint32_t oe;
+        for (;;) {
+            oe = uload(&misc[M_EMIT]);
+            if (oe >= C.x0 + kRegion) { C.x1 = C.x0 + kRegion; break; }
+            if (uload(&misc[M_FIN])) {
+                oe = uload(&misc[M_EMIT]);
+                if (C.x0 >= oe) goto out;
+                C.x1 = oe < C.x0 + kRegion ? oe : C.x0 + kRegion;
+                break;
+            }
+            if (uload(&misc[M_ABORT])) goto out;
+            spin_pause_long();
+        }
+        { const uint64_t t = clock_ticks(); t_rec += t - ts; ts = t; }
+        // ---- flow control: region R takes the ring slot of region R-80, which regions up to R-16 may still read
+        for (;;) {
+            C.g = first_open_region(smem);
+            if (C.g + kMaxLead >= R) break;
+            if (uload(&misc[M_ABORT])) goto out;
+            spin_pause();
+        }
+        { const uint64_t t = clock_ticks(); t_lead += t - ts; ts = t; }
+        C.chi = uload(&misc[M_CHI]);
+        C.j0 = idx[R & kIdxMask];
+        {
+            const uint32_t head = uload(&misc[M_HEAD]);
+            const uint32_t jl = (C.x1 < oe) ? (uint32_t)idx[(R + 1) & kIdxMask] : head - 1;
+            uint32_t nrec = ((jl - C.j0) & 0xFFFFu) + 1;
+            if (nrec > 32 * kMaxTrips) nrec = 32 * kMaxTrips;             // (more than 258 records never overlap a region)
+            C.nrec = nrec;
+        }
+        uint64_t tr = 0;
+        DTRACE("region R=%u x0=%u x1=%u j0=%u nrec=%u g=%u\n", R, C.x0, C.x1, C.j0, C.nrec, C.g);
+        copy_region(C, dst, w, tr);
+        DTRACE("region R=%u done\n", R);
+        if (uload(&misc[M_ABORT])) goto out;
+        k++;
+        if (lane == 0) lds_store_release(&fin[w], k);
+        { const uint64_t t = clock_ticks(); t_work += t - ts - tr; t_retry += tr; }
+    }
+out:
+    if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); }
+}
+
+// ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, char* smem) {
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
 
     const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
@@ -850,22 +973,41 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     }
     if (csize_i <= 0) { if (tid == 0) P.result[b] = -1; return; }
     const uint32_t csize = (uint32_t)csize_i, cap = (uint32_t)cap_i;
-
-    SeqRec* rectab = (SeqRec*)(P.scratch + (uint64_t)blockIdx.x * P.scratch_stride);
-    uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
-    if (prof && tid == 0) prof[0] = clock_ticks();
-
-    uint32_t nseq = 0, total = 0;
     uint32_t prefix = P.prefix ? (uint32_t)P.prefix[b] : 0u; if (prefix > kBias) prefix = kBias;
-    if (!preparse_block(src, csize, cap, prefix, rectab, smem, nseq, total, prof)) {
-        if (tid == 0) P.result[b] = err_at(misc[M_ERR]);
-        return;
+
+    uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
+    uint64_t tstart = 0;
+    if (prof && tid == 0) tstart = clock_ticks();
+
+    // -- control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
+    if (tid == 0) {
+        misc[M_ERR] = kNone; misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_CLO] = 0;
+        misc[M_EMIT] = kBias; misc[M_HEAD] = 0;
     }
-    if (prof && tid == 0) prof[1] = clock_ticks();
-    __syncthreads();            // record table visible to the whole workgroup; stage A's LDS is dead
-    stream_block(src, csize, dst, prefix, rectab, nseq, total, smem, prof);
-    if (tid == 0) P.result[b] = (int32_t)total;
-    if (prof && tid == 0) prof[4] = clock_ticks();
+    if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
+    if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
+    if (prefix) {
+        uint8_t* ring = (uint8_t*)(smem + kOffRing);
+        const uint32_t lo = kBias - prefix;
+        for (uint32_t v = (lo & ~15u) + 16 * tid; v < kBias; v += 16 * kDecThreads) {
+            U32x4 g; g[0] = g[1] = g[2] = g[3] = 0;
+#pragma nounroll
+            for (uint32_t i = 0; i < 16; i++) if (v + i >= lo) chunk_set_byte(g, i, (uint32_t)(dst - (kBias - (v + i)))[0]);
+            *(U32x4*)(ring + v) = g;                         // positions below kBias sit at ring address = position
+            if (v < kRingPad) *(U32x4*)(ring + kRingBytes + v) = g;
+        }
+    }
+    __syncthreads();
+
+    if (w == kLoadWave) loader_role(src, csize, smem);
+    else if (w == kParseWave) parser_role(csize, cap, prefix, smem, prof);
+    else copy_role(w, dst, smem, prof);
+
+    __syncthreads();
+    if (tid == 0) {
+        P.result[b] = misc[M_ABORT] ? err_at(misc[M_ERR]) : (int32_t)(misc[M_EMIT] - kBias);
+        if (prof) prof[0] = clock_ticks() - tstart;
+    }
 }
 
 // Workgroups pull blocks from a device-wide ticket counter (load balance for ragged batches).

@@ -43,6 +43,14 @@ template <class E> __device__ __forceinline__ E lds_load_ent(const E* p) {
     const lz4amd_u32x4 v = *(const volatile lz4amd_u32x4*)p; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     E e; __builtin_memcpy(&e, &v, sizeof(E)); return e;
 }
+// {tag, mask} of a done entry, the tag FIRST: two LDS reads issued back to back are serviced in that order,
+// so a tag that matches proves the mask was already reset for that tag's region (the writer resets the
+// mask before it stores the tag)
+__device__ __forceinline__ void lds_load_tag_mask(const uint32_t* tagp, const uint64_t* maskp, uint32_t& tag, uint64_t& mask) {
+    tag = *(const volatile __attribute__((address_space(3))) uint32_t*)tagp;
+    mask = *(const volatile __attribute__((address_space(3))) uint64_t*)maskp;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // LDS operations of one wave are issued and serviced in program order; this only keeps the
 // compiler from moving LDS accesses of the wave across the point (the CPU interpreter used by the
 // unit tests needs a real rendezvous here, because its lanes do not run in lockstep).
@@ -65,6 +73,9 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+__device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8); }
+// issue priority of this wave among the waves of its SIMD (0..3)
+__device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
 
 // {hi,lo} >> (8 * (sh & 3)), low 32 bits (v_alignbyte_b32)
 __device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {

@@ -15,11 +15,16 @@ static inline uint64_t lds_load_acquire64(const uint64_t* w) { return *(volatile
 static inline void lds_store_release(uint32_t* w, uint32_t v) { *(volatile uint32_t*)w = v; }
 static inline void lds_store_release64(uint64_t* w, uint64_t v) { *(volatile uint64_t*)w = v; }
 template <class E> static inline E lds_load_ent(const E* p) { E e; memcpy(&e, (const void*)p, sizeof(E)); return e; }
+static inline void lds_load_tag_mask(const uint32_t* tagp, const uint64_t* maskp, uint32_t& tag, uint64_t& mask) {
+    tag = *(const volatile uint32_t*)tagp; mask = *(const volatile uint64_t*)maskp;
+}
 static inline void wave_lds_fence() { (void)__ballot(1); }
 static inline void wave_lds_order() { (void)__ballot(1); }
 static inline void lds_store_relaxed(uint32_t* w, uint32_t v) { *(volatile uint32_t*)w = v; }
 static inline uint32_t lanes_below(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << (simt::cur()->tid & 63u)) - 1)); }
 static inline void spin_pause() { simt::yield_to_sched(); }
+static inline void spin_pause_long() { simt::yield_to_sched(); }
+static inline void wave_priority_high() {}
 static inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
 }

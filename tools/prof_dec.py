@@ -1,5 +1,6 @@
-"""Developer aid: phase breakdown of the decompress kernel (LZ4AMD_PROF stamps). GPU only."""
-import ctypes, os, sys
+"""Developer aid: role breakdown of the streaming decompress kernel (LZ4AMD_PROF stamps). GPU only.
+usage: prof_dec.py [n_blocks] [block_bytes] [P] [hc_level]"""
+import ctypes, os, sys, statistics
 os.environ["LZ4AMD_PROF"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,23 +8,30 @@ import torch, lz4_amd
 from bench import gen_data
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4 << 20
+pct = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+hc = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = lz4_amd.Context(0)
-data = torch.from_numpy(gen_data(nb * bs, 60, 0)).cuda()
-comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs)
+data = torch.from_numpy(gen_data(nb * bs, pct, 0)).cuda()
+comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs, hc_level=(hc or None))
 out, res, plan = lz4_amd.decompress_blocks(ctx, comp, csizes, bs, nb * bs)
-for _ in range(3):
+best = 1e9
+for _ in range(5):
     km, tot = plan.launch_timed(torch.cuda.current_stream().cuda_stream)
-print("decompress kernel ms", km[0], "GB/s out", nb * bs / km[0] / 1e6)
-L = lz4_amd.lib()
-w = (ctypes.c_ulonglong * (256 * 8))()
-n = L.lz4amd_plan_profile(plan._h, w, len(w))
-import statistics
-nw = n // 8
-pre = [w[i * 8 + 1] - w[i * 8 + 0] for i in range(nw)]
-emit = [w[i * 8 + 2] for i in range(nw)]
-copy = [w[i * 8 + 3] for i in range(nw)]
-tot = [w[i * 8 + 4] - w[i * 8 + 0] for i in range(nw)]
-for name, d in (("preparse", pre), ("stream.emit+load+index", emit), ("stream.copy", copy), ("total", tot)):
-    print(name, "cycles median", statistics.median(d), "max", max(d))
-print("preparse: count+scan", statistics.median([w[i*8+5] for i in range(nw)]), "walk", statistics.median([w[i*8+6] for i in range(nw)]), "fix", statistics.median([w[i*8+7] & ((1<<48)-1) for i in range(nw)]), "fix iterations", statistics.median([w[i*8+7] >> 48 for i in range(nw)]))
-assert torch.equal(out, data)
+    best = min(best, km[0])
+U, C = nb * bs, sum(csizes)
+print("decoder %s: %d x %d B P%d%s  kernel ms %.3f  GB/s out %.1f  (U+C)/t %.1f GB/s = %.3f of 8 TB/s" % (
+    os.environ.get("LZ4AMD_DEC", "v1"), nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
+assert torch.equal(out, data), "decode mismatch"
+if os.environ.get("LZ4AMD_DEC", "v1") != "v1":
+    L = lz4_amd.lib()
+    w = (ctypes.c_ulonglong * (256 * 8))()
+    n = L.lz4amd_plan_profile(plan._h, w, len(w))
+    nw = n // 8
+    med = lambda f: statistics.median([f(i) for i in range(nw)])
+    print("cycles per workgroup pass (median over %d workgroups; last block each):" % nw)
+    print("  block total        %10d" % med(lambda i: w[i * 8]))
+    print("  parser: wait data  %10d  walk P1+P2 %d  stitch P3+P4 %d  decode+publish P5 %d  slow path %d" % (
+        med(lambda i: w[i * 8 + 1]), med(lambda i: w[i * 8 + 2]), med(lambda i: w[i * 8 + 3]), med(lambda i: w[i * 8 + 4]), med(lambda i: w[i * 8 + 5] & 0xFFFFFF)))
+    print("  parser trips: P1 %d  P2 %d" % (med(lambda i: (w[i * 8 + 5] >> 24) & 0xFFFFF), med(lambda i: w[i * 8 + 5] >> 44)))
+    print("  copy wave 0: wait records %d  wait lead %d  work %d  retry (sources in flight) %d" % (
+        med(lambda i: w[i * 8 + 6] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 6] >> 32), med(lambda i: w[i * 8 + 7] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 7] >> 32)))
