@@ -9,44 +9,51 @@
 // decodes a block as a three-role pipeline; the roles talk through LDS rings and counters only -
 // no workgroup barrier between the first and the last byte of a block, no scratch in HBM:
 //
-//   LOADER (wave 15)   streams the compressed block into a 48 KB LDS ring (coalesced 16-byte
-//       loads, the next 4 KB in flight while the last is written).  The block is read from HBM
-//       exactly once; everything below reads LDS.
+//   LOADER (wave 15)   streams the compressed block into a 48 KB LDS ring for the parsers
+//       (coalesced 16-byte loads, the next 4 KB in flight while the last is written).
 //
-//   PARSER (wave 14)   turns the serial token chain into sequence records {output position,
-//       literal source, literal length, offset} in a 1024-row LDS ring, a TILE of 16 KB of the
-//       stream at a time: the tile is cut in 64 segments of 256 B, one per lane.
-//         P1  every lane walks the chain of its segment from the segment's first byte (lane 0:
-//             from the tile's true entry), marking the token positions it visits in a bitmap.
-//             A wrong start walks over literal bytes misread as tokens (~6.5 B per step) and
-//             merges with the true chain after a few hundred bytes (LZ4 chains self-synchronise).
+//   PARSERS (4 waves)  turn the serial token chain into sequence records {output position,
+//       literal source, literal length, offset} in a 1024-row LDS ring.  The stream is cut in
+//       TILES of 8 KB on a fixed grid, tile i belongs to parser wave i mod 4; a tile is cut in
+//       64 segments of 128 B, one per lane.
+//         P1  every lane walks the chain of its segment from the segment's first byte, marking
+//             the token positions it visits in a bitmap.  A wrong start walks over literal bytes
+//             misread as tokens (~6.5 B per step) and merges with the true chain after a few
+//             hundred bytes (LZ4 chains self-synchronise).
 //         P2  every lane walks on from its exit (the "bridge") until it steps on a position a
-//             later lane marked, the tile ends, or 48 steps have passed.
-//         P3  the true chain is stitched by induction: lane 0 is true from the entry; where its
-//             bridge merges into lane k's marks, lane k's marks are true from there on, and so on
-//             (<= 64 hops, scalar).  A lane that never merged ends the tile early at its last
-//             (true) position - never a wrong answer, only a shorter tile.
+//             later lane marked, or the tile ends.
+//         (P1 + P2 need nothing from the earlier tiles: the four owners walk side by side.)
+//         P3  once the previous tile's owner has handed over the ENTRY - the first true token at
+//             or after the tile's start - a short walk from it finds the first marked position;
+//             the lane that marked it is true from there on, and where a true lane's bridge
+//             merged into lane k's marks, lane k is true from there on (<= 64 hops).  A bridge
+//             that never merged ends the stitch early at its last (true) position - never a
+//             wrong answer: the owner walks the rest of the tile again from that position.
 //         P4  marks before a lane's merge point and of skipped lanes are dropped, the bridges of
-//             the lanes on the true path are added: the bitmap now holds exactly the true tokens.
+//             the true lanes are added: the bitmap now holds exactly the true tokens.
 //         P5  64 tokens at a time, a lane decodes one sequence completely (both length fields,
-//             offset), a wave scan gives the output positions, the reference's input- and
-//             output-side rules are applied, and the records are published.
+//             offset) and checks that it starts where its predecessor ended - the decoder, not
+//             the walk, is the authority on the chain; wave scans place the sequences relative
+//             to the tile.  Then, when it is the owner's TURN (output positions are a running
+//             sum over all earlier sequences), the reference's output-side rules are applied
+//             and the records are published.
 //       Tokens whose fields leave the tile (+1 KB look-ahead), length fields longer than 32
 //       bytes and the block's last sequence go through a wave-cooperative SLOW PATH that takes
 //       one token at a time (any length, records split at 8 KB, flow control inside).
 //
-//   COPY (waves 0-13)  output-stationary in 1 KB REGIONS, wave w owns regions w, w+14, ... .
+//   COPY (waves 0-10)  output-stationary in 1 KB REGIONS, wave w owns regions w, w+11, ... .
 //       A region is composed in its slot of an 80 KB LDS ring that always holds the 64 KB LZ4
 //       window, from PIECES (the literal run or the match of a record, cut at 16-byte chunk
 //       borders) in two lane-uniform rounds: round A, lane = chunk, writes the piece that covers
 //       the chunk's first byte; round B, lane = piece, ORs in the head of every piece that starts
-//       inside a chunk.  Literals are unaligned 16-byte reads from the compressed ring, matches
-//       from the output ring (a match that overlaps itself reads any earlier period - the
+//       inside a chunk.  Literals are unaligned 16-byte loads from the block itself (the L2 still
+//       holds what the loader fetched), matches unaligned 16-byte reads from the output ring (a match that overlaps itself reads any earlier period - the
 //       farthest the window holds - so long runs do not serialise).  Sources still in flight on
 //       another wave are waited for through per-chunk done bits; finished regions go to HBM
 //       with one 16-byte store per lane (1 KB contiguous per wave).
 //
-// HBM traffic per block: compressed bytes read once, output written once.  No MFMA: byte moves.
+// HBM traffic per block: compressed bytes read once (the literal loads hit the L2), output written
+// once.  No MFMA: byte moves.
 #pragma once
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
@@ -67,9 +74,9 @@ struct alignas(16) DoneEnt { uint64_t mask; uint32_t tag, pad; };
 enum : uint32_t {
     kDecThreads = 1024,
     kDecWaves = kDecThreads / 64,
-    kCopyWaves = 14,
-    kParseWave = 14,
-    kLoadWave = 15,
+    kParseWaves = 4,                            // tile owners
+    kLoadWave = kDecWaves - 1,
+    kCopyWaves = kDecWaves - 1 - kParseWaves,   // waves 0 .. kCopyWaves-1
     kChunk = 16,                                // output bytes composed at a time
     kRegionShift = 10,
     kRegion = 1u << kRegionShift,               // 64 chunks
@@ -77,7 +84,7 @@ enum : uint32_t {
     kRingBytes = kSlots * kRegion,
     kRingPad = 32,                              // mirror of the first bytes: reads never wrap
     kMaxLead = kSlots - 64 - 1,                 // a wave may lead the first unfinished region by this many
-    kCrBytes = 48u << 10,                       // compressed ring (direct mapped: position mod 48 K)
+    kCrBytes = 48u << 10,                       // compressed ring (direct mapped: position mod 48 K), read by the parsers only
     kCrPad = 32,
     kLoadBatch = 4096,                          // bytes the loader moves per step
     kRecCap = 1024,                             // sequence-record ring
@@ -85,12 +92,13 @@ enum : uint32_t {
     kIdxRing = 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
     kOutAhead = 480,                            // records are published at most this many regions ahead of the copy
-    kSegShift = 8,
+    kSegShift = 7,
     kSeg = 1u << kSegShift,                     // parser segment (bytes of the stream per lane)
     kTile = 64 * kSeg,
     kLook = 1024,                               // fields of a tile's tokens may reach this far past the tile
-    kBridgeCap = 48,
-    kTokCap = 2048,                             // tokens decoded per tile (a longer tile is cut there)
+    kBridgeTrips = 40,                          // lockstep trips of the bridge walk
+    kEntrySteps = 64,                           // steps of the serial walk from a tile's entry to the first mark
+    kTokRound = 512,                            // tokens listed per round
     kExtMax = 32,                               // longer length fields take the slow path
     kSlowSpan = 8192,                           // slow-path records cover at most this many output bytes
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
@@ -98,6 +106,7 @@ enum : uint32_t {
     kFirstRegion = kBias >> kRegionShift,
     kNone = 0xFFFFFFFFu,
 };
+static_assert(kParseWaves * kTile + kLook + kLoadBatch <= kCrBytes, "the tiles in flight must fit the compressed ring");
 
 // LDS carve-up (bytes)
 enum : uint32_t {
@@ -106,18 +115,17 @@ enum : uint32_t {
     kOffBits = kOffFin + 16 * 4,                             // DoneEnt[kSlots]
     kOffIdx = kOffBits + kSlots * 16,                        // u16[kIdxRing]
     kOffPend = kOffIdx + kIdxRing * 2,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
-    kOffSBits = kOffPend + kCopyWaves * (kMaxTrips + 2) * 8, // u32[kTile / 32] parser bitmap
-    kOffBridge = kOffSBits + kTile / 8,                      // u16[kBridgeCap][64]
-    kOffTok = kOffBridge + kBridgeCap * 64 * 2,              // u16[kTokCap]
-    kOffRecs = kOffTok + kTokCap * 2,                        // SeqRec[kRecCap]
+    kOffPar = kOffPend + kCopyWaves * (kMaxTrips + 2) * 8,   // per parser wave: token bitmap of its tile, token list
+    kParBytes = kTile / 8 + kTokRound * 2,
+    kOffRecs = (kOffPar + kParseWaves * kParBytes + 15) & ~15u,   // SeqRec[kRecCap]
     kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
     kOffRing = kOffCr + kCrBytes + kCrPad,                   // output ring + pad
     kDecLdsBytes = kOffRing + kRingBytes + kRingPad,
 };
 static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
-static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0, "LDS alignment");
+static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0 && (kOffPar % 4) == 0, "LDS alignment");
 
-enum : uint32_t { M_BLOCK = 0, M_ERR, M_ABORT, M_FIN, M_CHI, M_CLO, M_EMIT, M_HEAD, M_TOKX };
+enum : uint32_t { M_BLOCK = 0, M_ERR, M_ABORT, M_FIN, M_CHI, M_CLO, M_EMIT, M_HEAD, M_ENT_SEQ, M_ENT_POS, M_TURN };
 
 // (the round-1 decoder kept a record table in HBM; this one needs no scratch)
 __host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t) { return 256; }
@@ -190,6 +198,10 @@ __device__ __forceinline__ uint32_t first_open_region(const char* smem) {
     const uint32_t r = l16 < kCopyWaves ? kFirstRegion + l16 + kCopyWaves * f : kNone;
     return __builtin_amdgcn_readfirstlane(row16_min_u32(r));
 }
+__device__ __forceinline__ bool block_over(const char* smem) {        // finished or failed: nothing left to wait for
+    const uint32_t* misc = (const uint32_t*)(smem + kOffMisc);
+    return (uload(&misc[M_FIN]) | uload(&misc[M_ABORT])) != 0;
+}
 
 // ------------------------------------------------------------------------------ LOADER
 __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, char* smem) {
@@ -201,11 +213,11 @@ __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, cha
     for (uint32_t i = 0; i < 4; i++) { const uint32_t P = 16 * (lane + 64 * i); if (P < csize) cur[i] = load_granule(src, csize, P); }
     uint32_t L = 0;
     while (L < csize) {
-        // bytes [L, L + batch) may be written once nobody needs the bytes 48 K below them
+        // bytes [L, L + batch) may be written once no parser needs the bytes 48 K below them
         for (;;) {
             const uint32_t clo = uload(&misc[M_CLO]);
             if (L + kLoadBatch <= clo + kCrBytes) break;
-            if (uload(&misc[M_ABORT])) return;
+            if (block_over(smem)) return;
             spin_pause_long();
         }
         const uint32_t nL = L + kLoadBatch;
@@ -230,48 +242,50 @@ __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, cha
 }
 
 // ------------------------------------------------------------------------------ PARSER
+// The stream is cut in TILES of kTile bytes on a fixed grid; tile i belongs to parser wave i mod kParseWaves.
+// What a tile's owner can do before it knows where the true chain enters the tile (the speculative walk) runs
+// in parallel with the other owners; two short hand-offs are serial from tile to tile: the ENTRY (the first
+// true token at or after the tile's start, known once the previous tile is stitched) and the TURN to publish
+// records (output positions are a running sum over all earlier sequences).
 struct ParserS {
     uint32_t csize, capB, low;      // capB = capacity + kBias; low = first output position that exists (kBias - prefix)
-    uint32_t e;                     // next token of the true chain
-    uint32_t obase;                 // output position of the next sequence (= everything published so far)
-    uint32_t head;                  // records published
-    uint32_t ppos;                  // lowest compressed position the parser still needs
+    uint32_t e;                     // slow path: token to decode / next token after it
+    uint32_t obase, head;           // output position of the next sequence / records published (valid while holding the turn)
+    uint32_t ppos;                  // slow path: lowest compressed position still needed
     uint32_t g, tail;               // first open region / first record still in use (last refresh)
-    uint64_t t_wait, t_walk, t_stitch, t_decode, t_slow;   // developer profile (cycles)
-    uint32_t n_trips1, n_trips2;
+    uint64_t t_wait, t_walk, t_stitch, t_decode, t_turn, t_slow;   // developer profile (cycles)
+    uint32_t n_trips;
 };
 
-// Look at the copy waves' progress: first open region, first record still needed, and tell the loader
-// which compressed bytes are free (everything below the literals of that region and below the parser).
+// Look at the copy waves' progress: first open region and first record still needed.
 __device__ __forceinline__ void parser_refresh(ParserS& S, char* smem) {
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const uint16_t* idx = (const uint16_t*)(smem + kOffIdx);
-    const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
     const uint32_t g = first_open_region(smem);
-    const uint32_t x = g << kRegionShift;
-    uint32_t tail = S.head, need = S.ppos;
-    if (x < S.obase) {                                       // region g is covered by published records
+    uint32_t tail = S.head;
+    if ((g << kRegionShift) < S.obase) {                     // region g is covered by published records
         const uint32_t t16 = idx[g & kIdxMask];
         tail = S.head - ((S.head - t16) & 0xFFFFu);
-        const SeqRec r = recs[tail & kRecMask];
-        uint32_t d = x - r.outpos; if (d > r.ll) d = r.ll;
-        need = r.litpos + d;
     }
     S.g = g; S.tail = tail;
-    const uint32_t clo = umin32(need, S.ppos);
-    if (lane_id() == 0) lds_store_release(&misc[M_CLO], clo);
 }
-__device__ __forceinline__ void parser_wait_data(ParserS& S, char* smem, uint32_t need) {
+__device__ __forceinline__ void set_clo(char* smem, uint32_t pos) {            // (turn holder only; never moves back)
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    if (lane_id() == 0 && pos > misc[M_CLO]) lds_store_release(&misc[M_CLO], pos);
+}
+// wait until the stream is resident up to `need`; false: the block is over
+__device__ __forceinline__ bool parser_wait_data(ParserS& S, char* smem, uint32_t need) {
     const uint32_t* misc = (const uint32_t*)(smem + kOffMisc);
     if (need > S.csize) need = S.csize;
-    if (uload(&misc[M_CHI]) >= need) return;
+    if (uload(&misc[M_CHI]) >= need) return true;
     const uint64_t t0 = clock_ticks();
+    bool ok = true;
     for (;;) {
-        parser_refresh(S, smem);
         if (uload(&misc[M_CHI]) >= need) break;
+        if (block_over(smem)) { ok = false; break; }
         spin_pause();
     }
     S.t_wait += clock_ticks() - t0;
+    return ok;
 }
 __device__ __forceinline__ void parser_fail(char* smem, uint32_t pos) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
@@ -316,15 +330,44 @@ __device__ __forceinline__ TokInfo tok_decode(const TileView& V, uint32_t p) {
     r.ml = ml + kMinMatch; r.nx = nx; r.st = 0;
     return r;
 }
-// the walkers' common case: both nibbles < 15, fields inside the tile's reach, not the last sequence
-__device__ __forceinline__ bool tok_simple(const TileView& V, uint32_t p, uint32_t b, uint32_t& nx) {
-    const uint32_t ll = b >> 4;
-    nx = p + ll + 3;
-    return ll != 15 && (b & 15) != 15 && p + ll + 9 <= V.csize && nx <= V.tlim;
+
+// 8 stream bytes at position p of the tile view (any alignment; the ring is padded, bytes past tlim are garbage, not faults)
+__device__ __forceinline__ uint64_t tv_read8(const TileView& V, uint32_t p) {
+    const uint32_t a = cr_fold(V.crT + (p - V.t0));
+    const uint32_t* w = (const uint32_t*)(V.cr + (a & ~3u));
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = a & 3u;
+    return (uint64_t)align_bytes(w1, w0, sh) | ((uint64_t)align_bytes(w2, w1, sh) << 32);
+}
+// tok_decode<true> for the common shapes - both length fields at most 5 bytes, everything well inside the tile's reach
+// and the block - with two 8-byte reads; any other token goes through tok_decode<true> itself (same answers).
+__device__ __forceinline__ TokInfo tok_decode_fast(const TileView& V, uint32_t p) {
+    TokInfo r; r.st = 0;
+    bool easy = p + 8 <= V.tlim;
+    const uint64_t w = tv_read8(V, p);
+    const uint32_t t = (uint32_t)w & 0xFFu, lnib = t >> 4, mnib = t & 15u;
+    const uint64_t x = w >> 8, invx = ~x & 0x00FFFFFFFFFFFFFFull;                     // 7 bytes after the token
+    const uint32_t k = invx ? ((uint32_t)__ffsll((long long)invx) - 1) >> 3 : 7u;    // leading 255s
+    const bool l15 = lnib == 15;
+    easy = easy && (!l15 || k <= 5);
+    const uint32_t ll = l15 ? 15 + 255 * k + ((uint32_t)(x >> (8 * (k & 7))) & 0xFFu) : lnib;
+    const uint32_t q = p + 1 + (l15 ? k + 1 : 0);
+    easy = easy && q + 15 < V.csize;                                                 // every length byte was readable (lz4.c:1986-2006)
+    const uint32_t m = q + ll;
+    easy = easy && m + 8 <= V.tlim && m + 16 <= V.csize;                             // not the last sequence; the match fields are resident
+    const uint64_t y = easy ? tv_read8(V, m) : 0ull;
+    const uint64_t z = y >> 16, invz = ~z & 0x0000FFFFFFFFFFFFull;                     // 6 bytes after the offset
+    const uint32_t km = invz ? ((uint32_t)__ffsll((long long)invz) - 1) >> 3 : 6u;
+    const bool m15 = mnib == 15;
+    easy = easy && (!m15 || km <= 4);
+    r.ll = ll; r.q = q; r.off = (uint32_t)y & 0xFFFFu;
+    r.ml = (m15 ? 15 + 255 * km + ((uint32_t)(z >> (8 * (km & 7))) & 0xFFu) : mnib) + kMinMatch;
+    r.nx = m + 2 + (m15 ? km + 1 : 0);
+    if (!easy) r = tok_decode<true>(V, p);
+    return r;
 }
 
 // Publish the records of lanes [0, nok) of a decoded batch (o / len / rec per lane), waiting for room in
-// the record ring and for the copy to come within kOutAhead regions.  false: aborted.
+// the record ring and for the copy to come within kOutAhead regions.  Turn holder only.
 __device__ __forceinline__ void publish_batch(ParserS& S, char* smem, uint32_t nok, uint32_t o, uint32_t len, const SeqRec& rec) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     uint16_t* idx = (uint16_t*)(smem + kOffIdx);
@@ -332,15 +375,17 @@ __device__ __forceinline__ void publish_batch(ParserS& S, char* smem, uint32_t n
     const uint32_t lane = lane_id();
     const uint32_t er = (o + len - 1) >> kRegionShift;
     uint32_t done = 0;
+    bool fresh = false;                                   // the cached view of the copy's progress is good enough most of the time
     while (done < nok) {
-        parser_refresh(S, smem);
+        if (fresh) parser_refresh(S, smem);
+        fresh = true;
         const unsigned long long okm = __ballot(lane >= done && lane < nok && er < S.g + kOutAhead);
         const unsigned long long run = ~(okm >> done);
         uint32_t npub = run ? (uint32_t)__ffsll((long long)run) - 1 : 64u;
         if (npub > nok - done) npub = nok - done;
         const uint32_t room = kRecCap - 1 - (S.head - S.tail);               // rows free, one kept for the sentinel
         if (npub > room) npub = room;
-        if (npub == 0) { spin_pause(); continue; }
+        if (npub == 0) { if (uload(&misc[M_ABORT])) return; spin_pause(); continue; }
         if (lane >= done && lane < done + npub) {
             const uint32_t j = S.head + (lane - done);
             recs[j & kRecMask] = rec;
@@ -363,6 +408,7 @@ __device__ __forceinline__ void publish_one(ParserS& S, char* smem, uint32_t lit
     for (;;) {
         parser_refresh(S, smem);
         if (S.head + 2 - S.tail <= kRecCap && ((o + len) >> kRegionShift) < S.g + kOutAhead) break;
+        if (uload(&misc[M_ABORT])) return;
         spin_pause();
     }
     if (lane == 0) { recs[S.head & kRecMask] = rec; recs[(S.head + 1) & kRecMask].outpos = o + len; }
@@ -373,27 +419,26 @@ __device__ __forceinline__ void publish_one(ParserS& S, char* smem, uint32_t lit
     S.head += 1; S.obase = o + len;
 }
 
-// SLOW PATH: the sequence whose token is at S.e, whatever its size; every lane computes the same values,
-// length fields are scanned 64 bytes at a time.  Same rules as the reference's safe loop.
-// Returns 0: go on at S.e, 1: that was the block's last sequence, 2: malformed (reported).
-__device__ __forceinline__ int slow_token(ParserS& S, char* smem) {
+// SLOW PATH (turn holder only): the sequence whose token is at S.e, whatever its size; every lane computes the
+// same values, length fields are scanned 64 bytes at a time.  Same rules as the reference's safe loop.
+// Returns 0: go on at S.e, 1: that was the block's last sequence, 2: malformed (reported) or the block is over.
+__device__ __noinline__ int slow_token(ParserS& S, char* smem) {
     const uint8_t* cr = (const uint8_t*)(smem + kOffCr);
     const uint32_t lane = lane_id(), csize = S.csize, p = S.e;
-    DTRACE("slow token p=%u obase=%u\n", p, S.obase);
     if (p >= csize) { parser_fail(smem, csize ? csize - 1 : 0); return 2; }
-    S.ppos = p;
-    parser_wait_data(S, smem, p + 1);
+    S.ppos = p; set_clo(smem, p);
+    if (!parser_wait_data(S, smem, p + 1)) return 2;
     const uint32_t t = cr[mod_cr(p)];
     uint32_t ll = t >> 4, q = p + 1;
     if (ll == 15) {
         for (;;) {
-            parser_wait_data(S, smem, q + 64);
+            if (!parser_wait_data(S, smem, q + 64)) return 2;
             const uint32_t pos = q + lane;
             const bool inb = pos + 15 < csize;                              // lz4.c:1986-2006: a length byte is read only there
             const uint32_t x = inb ? (uint32_t)cr[mod_cr(pos)] : 0u;
             const unsigned long long stopm = __ballot(!inb || x != 255);
             if (!stopm) {
-                ll += 255 * 64; q += 64; S.ppos = q;
+                ll += 255 * 64; q += 64; S.ppos = q; set_clo(smem, q);
                 if (ll > csize) { parser_fail(smem, p); return 2; }
                 continue;
             }
@@ -404,7 +449,6 @@ __device__ __forceinline__ int slow_token(ParserS& S, char* smem) {
         }
         if (ll > csize) { parser_fail(smem, p); return 2; }
     }
-    S.ppos = q;                                                             // (the literals are held by the records from here on)
     const uint32_t rem = csize - q, room = S.capB - S.obase;
     const bool last = rem < ll + 8 || room < ll + kMfLimit;                 // lz4.c:2279
     if (last && (rem != ll || room < ll)) { parser_fail(smem, p); return 2; }   // lz4.c:2312-2318
@@ -419,19 +463,19 @@ __device__ __forceinline__ int slow_token(ParserS& S, char* smem) {
     }
     if (last) return 1;
     const uint32_t m = q + ll;                                              // m + 8 <= csize
-    S.ppos = m;
-    parser_wait_data(S, smem, m + 2);
+    S.ppos = m; set_clo(smem, m);                                           // (the copy reads literals from memory, not from the ring)
+    if (!parser_wait_data(S, smem, m + 2)) return 2;
     const uint32_t off = (uint32_t)cr[mod_cr(m)] | ((uint32_t)cr[mod_cr(m + 1)] << 8);
     uint32_t ml = t & 15, nx = m + 2;
     if (ml == 15) {
         for (;;) {
-            parser_wait_data(S, smem, nx + 64);
+            if (!parser_wait_data(S, smem, nx + 64)) return 2;
             const uint32_t pos = nx + lane;
             const uint32_t x = pos < csize ? (uint32_t)cr[mod_cr(pos)] : 0u;
             const bool badafter = pos + 5 > csize;                          // after a length byte at least 4 more bytes must follow
             const unsigned long long stopm = __ballot(x != 255 || badafter);
             if (!stopm) {
-                ml += 255 * 64; nx += 64; S.ppos = nx;
+                ml += 255 * 64; nx += 64; S.ppos = nx; set_clo(smem, nx);
                 if (ml > 0x7FFFFFF0u) { parser_fail(smem, p); return 2; }
                 continue;
             }
@@ -459,186 +503,315 @@ __device__ __forceinline__ int slow_token(ParserS& S, char* smem) {
 
 enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_OVER = 4 };
 
-// One tile of the stream.  Returns 0: go on at S.e with another tile, 1: S.e needs the slow path,
-// 2: malformed (reported).
-__device__ __forceinline__ int parse_tile(ParserS& S, char* smem) {
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    uint32_t* sb = (uint32_t*)(smem + kOffSBits);
-    uint16_t* blist = (uint16_t*)(smem + kOffBridge);
-    uint16_t* tl = (uint16_t*)(smem + kOffTok);
-    const uint32_t lane = lane_id(), csize = S.csize;
-    const uint32_t e = S.e;
-    const uint32_t t0 = e & ~(kSeg - 1), t1 = t0 + kTile;
-    TileView V; V.cr = (const uint8_t*)(smem + kOffCr); V.t0 = t0; V.crT = mod_cr(t0); V.csize = csize;
-    V.tlim = t1 + kLook < csize ? t1 + kLook : csize;
-    S.ppos = e;
-    DTRACE("tile e=%u t0=%u tlim=%u\n", e, t0, V.tlim);
-    parser_wait_data(S, smem, V.tlim);
-    DTRACE("tile data ok\n");
-    uint64_t tc = clock_ticks();
-
-    // ---- P1: every lane walks its segment, marking the token positions it visits
-#pragma unroll
-    for (uint32_t w = 0; w < 8; w++) sb[lane * 8 + w] = 0;
-    wave_lds_fence();
-    const uint32_t seg_lo = t0 + lane * kSeg, seg_hi = seg_lo + kSeg;
-    uint32_t p = lane == 0 ? e : seg_lo;
-    bool dead = false, parked = false;
-    for (uint32_t trip = 0;; trip++) {
-        const bool run = !dead && p < seg_hi;
-        if (!__any(run)) break;
-        S.n_trips1++;
-        if (run && !parked) {
-            if (p >= V.tlim) dead = true;                      // ran off the block
-            else {
-                uint32_t nx;
-                if (tok_simple(V, p, tv_byte(V, p), nx)) { atomicOr(&sb[(p - t0) >> 5], 1u << ((p - t0) & 31)); p = nx; }
-                else parked = true;
-            }
-        }
-        if ((trip & 3) == 3 && run && parked) {                // the rarer token shapes, all parked lanes together
-            atomicOr(&sb[(p - t0) >> 5], 1u << ((p - t0) & 31));
-            const TokInfo ti = tok_decode<false>(V, p);
-            if (ti.st) dead = true; else p = ti.nx;
-            parked = false;
-        }
-    }
-    wave_lds_fence();
-    // ---- P2: walk on from the exit until a position a later lane marked
-    uint32_t okind = dead ? OUT_STOP : OUT_NONE, opos = p, nb = 0;
-    parked = false;
-    for (uint32_t trip = 0;; trip++) {
-        const bool run = okind == OUT_NONE;
-        if (!__any(run)) break;
-        S.n_trips2++;
-        if (run && !parked) {
-            if (p >= t1) { okind = OUT_EXIT; opos = p; }
-            else if ((sb[(p - t0) >> 5] >> ((p - t0) & 31)) & 1u) { okind = OUT_MERGE; opos = p; }
-            else if (nb >= kBridgeCap) { okind = OUT_OVER; opos = p; }
-            else if (p >= V.tlim) { okind = OUT_STOP; opos = p; }
-            else {
-                uint32_t nx;
-                if (tok_simple(V, p, tv_byte(V, p), nx)) { blist[nb * 64 + lane] = (uint16_t)(p - t0); nb++; p = nx; }
-                else parked = true;
-            }
-        }
-        if ((trip & 3) == 3 && run && parked && okind == OUT_NONE) {
-            const TokInfo ti = tok_decode<false>(V, p);
-            if (ti.st) { okind = OUT_STOP; opos = p; }
-            else { blist[nb * 64 + lane] = (uint16_t)(p - t0); nb++; p = ti.nx; }
-            parked = false;
-        }
-    }
-    { const uint64_t t = clock_ticks(); S.t_walk += t - tc; tc = t; }
-    // ---- P3: stitch the true chain (lane 0 is true from e; a merge hands the truth to the marking lane)
-    uint32_t myT = kNone, cur = 0, Tcur = e, tend = e;
-    bool stop = true;                                          // (never left like this: cur grows with every merge, lane 63 cannot merge)
-    for (uint32_t it = 0; it < 64; it++) {
-        if (lane == cur) myT = Tcur;
-        const uint32_t kind = wave_readlane(okind, cur), pos = wave_readlane(opos, cur);
-        if (kind == OUT_MERGE) { cur = (pos - t0) >> kSegShift; Tcur = pos; continue; }
-        tend = pos; stop = kind == OUT_STOP;
-        break;
-    }
-    DTRACE("P3 done tend=%u stop=%d\n", tend, (int)stop);
-    // ---- P4: the bitmap of the true tokens in [e, tend)
-    const bool active = myT != kNone;
-#pragma unroll
-    for (uint32_t w = 0; w < 8; w++) {
-        uint32_t v = sb[lane * 8 + w];
-        const uint32_t base = seg_lo + 32 * w;
-        if (!active) v = 0;
-        else if (myT > base) v = (myT - base >= 32) ? 0u : (v & (0xFFFFFFFFu << (myT - base)));
-        if (tend <= base) v = 0; else if (tend - base < 32) v &= (1u << (tend - base)) - 1u;
-        sb[lane * 8 + w] = v;
-    }
-    wave_lds_fence();
-    for (uint32_t n = 0; __any(active && n < nb); n++) {
-        if (active && n < nb) {
-            const uint32_t rel = blist[n * 64 + lane];
-            if (t0 + rel < tend) atomicOr(&sb[rel >> 5], 1u << (rel & 31));
-        }
-    }
-    wave_lds_fence();
-    // ---- the token list
-    uint32_t wv[8], cnt = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 8; w++) { wv[w] = sb[lane * 8 + w]; cnt += (uint32_t)__popc(wv[w]); }
-    const uint32_t incl = wave_incl_sum(cnt);
-    uint32_t N = wave_readlane(incl, 63);
-    {
-        uint32_t k = incl - cnt;
-#pragma unroll
-        for (uint32_t w = 0; w < 8; w++) {
-            uint32_t v = wv[w];
-            while (v) {
-                const uint32_t b = (uint32_t)__ffs((int)v) - 1; v &= v - 1;
-                const uint32_t rel = lane * kSeg + 32 * w + b;
-                if (k < kTokCap) tl[k] = (uint16_t)rel;
-                else if (k == kTokCap) misc[M_TOKX] = t0 + rel;
-                k++;
-            }
-        }
-    }
-    wave_lds_fence();
-    if (N > kTokCap) { N = kTokCap; tend = misc[M_TOKX]; stop = false; }    // cut the tile at token kTokCap (a true position)
-    { const uint64_t t = clock_ticks(); S.t_stitch += t - tc; tc = t; }
-    DTRACE("tokens N=%u\n", N);
-    // ---- P5: decode 64 tokens at a time, place them, check them, publish them
-    for (uint32_t base = 0; base < N; base += 64) {
-        const uint32_t i = base + lane;
-        const bool have = i < N;
-        TokInfo ti; ti.ll = ti.q = ti.off = ti.ml = ti.nx = 0; ti.st = 0;
-        uint32_t tp = 0;
-        if (have) { tp = t0 + tl[i]; ti = tok_decode<true>(V, tp); }
-        const uint32_t len = have && ti.st == 0 ? ti.ll + ti.ml : 0;         // <= 2 * (15 + 255 * 32 + 4)
-        const uint32_t isum = wave_incl_sum(len);
-        const uint32_t o = S.obase + (isum - len);
-        // output-side rules (lz4.c:2279 as an error: a sequence inside the tile is never the last; 2356; 2423)
-        bool bad = false;
-        if (have) {
-            const uint32_t room = S.capB - o;
-            bad = ti.st != 0 || o > S.capB || room < ti.ll + kMfLimit || ti.off == 0 || ti.off > o + ti.ll - S.low
-                  || S.capB - (o + ti.ll) < ti.ml + kLastLiterals;
-        }
-        const unsigned long long badm = __ballot(bad);
-        uint32_t nok = N - base < 64 ? N - base : 64;
-        if (badm) nok = (uint32_t)__ffsll((long long)badm) - 1;
-        SeqRec rec; rec.outpos = o; rec.litpos = ti.q; rec.ll = ti.ll; rec.off = ti.off;
-        publish_batch(S, smem, nok, o, len, rec);
-        if (badm) { parser_fail(smem, wave_readlane(tp, nok)); return 2; }
-    }
-    S.t_decode += clock_ticks() - tc;
-    S.e = tend;
-    return stop ? 1 : 0;
+// The walkers' view of the chain: one stream byte per trip, no branches.  A lane is at a token (mode 0), inside a
+// literal-length field (mode 1) or inside a match-length field (mode 2).  It stops (dead, at the token `tok`) exactly
+// where tok_decode says "not inside the tile's reach": those tokens belong to the slow path.
+struct WalkState { uint32_t p, tok, acc, mode, cnt; bool mlf, dead; };
+__device__ __forceinline__ void walk_init(WalkState& s, uint32_t p) { s.p = p; s.tok = p; s.acc = 0; s.mode = 0; s.cnt = 0; s.mlf = false; s.dead = false; }
+// consume byte b = stream[s.p] (the caller checked s.p < tlim)
+__device__ __forceinline__ void walk_step(WalkState& s, uint32_t b, const TileView& V) {
+    const bool m0 = s.mode == 0, m1 = s.mode == 1, m2 = s.mode == 2;
+    const bool is255 = b == 255;
+    const uint32_t ll0 = b >> 4;
+    const bool ext0 = ll0 == 15;
+    const bool litdone = (m0 && !ext0) || (m1 && !is255);                  // the literal length is complete with this byte
+    const uint32_t ll = m0 ? ll0 : s.acc + b;
+    const uint32_t m = s.p + 1 + ll;                                        // first byte after the literals
+    const bool mlf = m0 ? (b & 15) == 15 : s.mlf;
+    const bool cont = (m0 && ext0) || ((m1 || m2) && is255);               // the length field goes on
+    const uint32_t cnt = m0 ? 0u : s.cnt + 1;
+    const bool stop = (litdone && (m + 8 > V.csize || m + 2 > V.tlim)) || (cont && cnt >= kExtMax);
+    s.tok = m0 ? s.p : s.tok;
+    s.dead = stop;
+    s.acc = m0 ? 15u : s.acc + b;
+    s.mlf = mlf;
+    s.cnt = litdone ? 0u : cnt;
+    s.mode = litdone ? (mlf ? 2u : 0u) : (cont ? (m2 ? 2u : 1u) : 0u);
+    s.p = litdone ? m + 2 : s.p + 1;
 }
 
-__device__ __forceinline__ void parser_role(uint32_t csize, uint32_t cap, uint32_t prefix, char* smem, uint64_t* prof) {
+// what a lane knows after the speculative walk of its segment
+struct LaneWalk { uint32_t x; uint32_t okind, opos, nb; };
+
+__device__ __forceinline__ void sb_mark(uint32_t* sb, uint32_t rel) { atomicOr(&sb[rel >> 5], 1u << (rel & 31)); }
+__device__ __forceinline__ bool sb_test(const uint32_t* sb, uint32_t rel) { return (sb[rel >> 5] >> (rel & 31)) & 1u; }
+
+// P1 + P2.  Every lane walks the token chain of its segment from the segment's first byte - or, when the tile is
+// (re)entered at a known true token `ent`, the lane of that segment from `ent` and the lanes below it not at all -
+// marking the token positions it visits (P1); then walks on ("bridge") until it steps on a position a later lane
+// marked, leaves the tile, or kBridgeTrips trips have passed (P2).  A wrong start walks over literal bytes misread
+// as tokens (~6.5 B per step) and merges with the true chain after a few hundred bytes.
+__device__ __forceinline__ LaneWalk walk_tile(const TileView& V, uint32_t* sb, uint32_t ent, uint32_t& trips) {
+    const uint32_t lane = lane_id(), t0 = V.t0, t1 = t0 + kTile;
+#pragma unroll
+    for (uint32_t w = 0; w < kSeg / 32; w++) sb[lane * (kSeg / 32) + w] = 0;
+    wave_lds_fence();
+    const uint32_t seg_lo = t0 + lane * kSeg, seg_hi = seg_lo + kSeg;
+    WalkState s; walk_init(s, seg_lo);
+    bool idle = false;
+    if (ent != kNone) { if (ent >= seg_hi) idle = true; else if (ent > seg_lo) walk_init(s, ent); }
+    for (;;) {
+        const bool run = !idle && !s.dead && !(s.mode == 0 && s.p >= seg_hi);
+        if (!__any(run)) break;
+        trips++;
+        if (run) {
+            if (s.p >= V.tlim) { s.tok = s.mode == 0 ? s.p : s.tok; s.dead = true; }      // ran off the block
+            else {
+                if (s.mode == 0) sb_mark(sb, s.p - t0);
+                walk_step(s, tv_byte(V, s.p), V);
+            }
+        }
+    }
+    wave_lds_fence();
+    LaneWalk L; L.x = s.p; L.okind = idle ? OUT_OVER : (s.dead ? OUT_STOP : OUT_NONE); L.opos = s.dead ? s.tok : s.p; L.nb = 0;
+    for (uint32_t trip = 0;; trip++) {
+        const bool run = L.okind == OUT_NONE;
+        if (!__any(run)) break;
+        trips++;
+        if (run) {
+            const bool at_tok = s.mode == 0;
+            if (at_tok && s.p >= t1) { L.okind = OUT_EXIT; L.opos = s.p; }
+            else if (at_tok && sb_test(sb, s.p - t0)) { L.okind = OUT_MERGE; L.opos = s.p; }
+            else if (trip >= kBridgeTrips) { L.okind = OUT_OVER; L.opos = at_tok ? s.p : s.tok; }   // (a token either way)
+            else if (s.p >= V.tlim) { L.okind = OUT_STOP; L.opos = at_tok ? s.p : s.tok; }
+            else {
+                L.nb += at_tok ? 1u : 0u;
+                walk_step(s, tv_byte(V, s.p), V);
+                if (s.dead) { L.okind = OUT_STOP; L.opos = s.tok; }
+            }
+        }
+    }
+    return L;
+}
+
+// P3 + P4: stitch the true chain through the walked tile and leave exactly its tokens in [cur, tend) in the bitmap.
+//   spec == true : the tile was walked before its entry was known; the chain comes in at `cur` (any token of the tile):
+//                  a serial walk from cur finds the first marked position, the lane that marked it is true from there on.
+//   spec == false: the tile was walked from `cur` (walk_tile's ent): that lane is true from cur.
+// A true lane's marks are true up to its exit; where its bridge merged into lane k's marks, lane k is true from there
+// (<= 64 hops).  A bridge that did not merge ends the stitch at its last (true) token - never a wrong answer, only
+// a shorter stretch.  stop: the token at tend needs the slow path.  stitch_chain is the serial part (the next tile's
+// entry is known after it), stitch_marks the rest.
+struct Stitch { uint32_t tend; bool stop; uint32_t myT, epos, ne; };
+__device__ __forceinline__ Stitch stitch_chain(const TileView& V, const uint32_t* sb, const LaneWalk& L, uint32_t cur, bool spec, uint32_t& trips) {
+    const uint32_t lane = lane_id(), t0 = V.t0, t1 = t0 + kTile;
+    Stitch R; R.tend = cur; R.stop = true; R.myT = kNone; R.epos = kNone; R.ne = 0;
+    uint32_t k = kNone, Tk = 0;
+    bool chain = false;
+    if (spec) {
+        WalkState s; walk_init(s, cur);                      // every lane walks the same walk
+        for (;;) {
+            if (s.mode == 0) {
+                if (s.p >= t1) { R.tend = s.p; R.stop = false; break; }
+                if (sb_test(sb, s.p - t0)) { k = (s.p - t0) >> kSegShift; Tk = s.p; chain = true; break; }
+                if (R.ne >= kEntrySteps) { R.tend = s.p; R.stop = false; break; }   // (a true token: the caller walks the rest of the tile from it)
+                if (lane == R.ne) R.epos = s.p;
+                R.ne++;
+            }
+            if (s.p >= V.tlim) { R.tend = s.mode == 0 ? s.p : s.tok; R.stop = true; break; }
+            walk_step(s, tv_byte(V, s.p), V);
+            trips++;
+            if (s.dead) { R.tend = s.tok; R.stop = true; break; }
+        }
+    } else { k = (cur - t0) >> kSegShift; Tk = cur; chain = true; }
+    if (chain) {
+        for (uint32_t it = 0; it < 64; it++) {
+            if (lane == k) R.myT = Tk;
+            const uint32_t kind = wave_readlane(L.okind, k), pos = wave_readlane(L.opos, k);
+            if (kind == OUT_MERGE) { k = (pos - t0) >> kSegShift; Tk = pos; continue; }
+            R.tend = pos; R.stop = kind == OUT_STOP;
+            break;
+        }
+    }
+    return R;
+}
+__device__ __forceinline__ void stitch_marks(const TileView& V, uint32_t* sb, const LaneWalk& L, const Stitch& R, uint32_t& trips) {
+    const uint32_t lane = lane_id(), t0 = V.t0, t1 = t0 + kTile, tend = R.tend;
+    // ---- P4: drop the marks of the lanes the chain skipped and the marks before a lane's entry ...
+    const bool active = R.myT != kNone;
+    const uint32_t seg_lo = t0 + lane * kSeg;
+#pragma unroll
+    for (uint32_t w = 0; w < kSeg / 32; w++) {
+        uint32_t v = sb[lane * (kSeg / 32) + w];
+        const uint32_t base = seg_lo + 32 * w;
+        if (!active) v = 0;
+        else if (R.myT > base) v = (R.myT - base >= 32) ? 0u : (v & (0xFFFFFFFFu << (R.myT - base)));
+        if (tend <= base) v = 0; else if (tend - base < 32) v &= (1u << (tend - base)) - 1u;
+        sb[lane * (kSeg / 32) + w] = v;
+    }
+    wave_lds_fence();
+    // ... add the bridges of the true lanes (walked again: they were not kept) ...
+    {
+        WalkState s; walk_init(s, L.x);
+        uint32_t left = active ? L.nb : 0;
+        while (__any(left != 0)) {
+            trips++;
+            if (left) {
+                if (s.mode == 0) { if (s.p < tend && s.p < t1) sb_mark(sb, s.p - t0); left--; }
+                if (left) walk_step(s, tv_byte(V, s.p), V);
+            }
+        }
+    }
+    // ... and the tokens of the entry walk
+    if (lane < R.ne && R.epos < tend && R.epos < t1) sb_mark(sb, R.epos - t0);
+    wave_lds_fence();
+}
+
+// Token list of a round: tokens [first, first + kTokRound) of the bitmap, in order.  Returns the tile's token count.
+__device__ __forceinline__ uint32_t list_tokens(const uint32_t* sb, uint16_t* tl, uint32_t first) {
+    const uint32_t lane = lane_id();
+    uint32_t wv[kSeg / 32], cnt = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kSeg / 32; w++) { wv[w] = sb[lane * (kSeg / 32) + w]; cnt += (uint32_t)__popc(wv[w]); }
+    const uint32_t incl = wave_incl_sum(cnt);
+    const uint32_t N = wave_readlane(incl, 63);
+    uint32_t k = incl - cnt;
+#pragma unroll
+    for (uint32_t w = 0; w < kSeg / 32; w++) {
+        uint32_t v = wv[w];
+        while (v) {
+            const uint32_t b = (uint32_t)__ffs((int)v) - 1; v &= v - 1;
+            if (k >= first && k - first < kTokRound) tl[k - first] = (uint16_t)(lane * kSeg + 32 * w + b);
+            k++;
+        }
+    }
+    wave_lds_fence();
+    return N;
+}
+
+// hand-offs between tile owners
+__device__ __forceinline__ void publish_entry(char* smem, uint32_t next_tile, uint32_t pos) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    if (lane_id() == 0) { lds_store_relaxed(&misc[M_ENT_POS], pos); lds_store_release(&misc[M_ENT_SEQ], next_tile); }
+}
+__device__ __forceinline__ bool wait_word(ParserS& S, char* smem, uint32_t word, uint32_t value) {
+    const uint32_t* misc = (const uint32_t*)(smem + kOffMisc);
+    if (uload(&misc[word]) == value) return true;
+    const uint64_t t0 = clock_ticks();
+    bool ok = true;
+    for (;;) {
+        if (uload(&misc[word]) == value) break;
+        if (block_over(smem)) { ok = false; break; }
+        spin_pause();
+    }
+    S.t_turn += clock_ticks() - t0;
+    return ok;
+}
+
+// One tile.  Returns 0: done, go on with the owner's next tile; 1: the block is over (finished, failed, or somebody
+// else's business).
+__device__ __forceinline__ int parse_tile(ParserS& S, char* smem, uint32_t pw, uint32_t tile) {
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    uint32_t* sb = (uint32_t*)(smem + kOffPar + pw * kParBytes);
+    uint16_t* tl = (uint16_t*)(smem + kOffPar + pw * kParBytes + kTile / 8);
+    const uint32_t lane = lane_id(), csize = S.csize;
+    const uint32_t t0 = tile * kTile, t1 = t0 + kTile;
+    TileView V; V.cr = (const uint8_t*)(smem + kOffCr); V.t0 = t0; V.crT = mod_cr(t0); V.csize = csize;
+    V.tlim = t1 + kLook < csize ? t1 + kLook : csize;
+    if (!parser_wait_data(S, smem, V.tlim)) return 1;
+    uint64_t tc = clock_ticks();
+    bool have_turn = false, entry_sent = false, spec = true;
+    uint32_t cur = kNone;                              // the true token the tile is (re)entered at; unknown during the first walk
+    for (;;) {
+        // ---- the walk: before the entry is known the first time, from a true token after a stop inside the tile
+        const LaneWalk L = walk_tile(V, sb, cur, S.n_trips);
+        { const uint64_t t = clock_ticks(); S.t_walk += t - tc; tc = t; }
+        if (spec) {
+            if (!wait_word(S, smem, M_ENT_SEQ, tile)) return 1;
+            cur = uload(&misc[M_ENT_POS]);
+            tc = clock_ticks();
+            if (cur >= t1) break;                      // the chain jumps over this tile (a long literal run)
+        }
+        const Stitch St = stitch_chain(V, sb, L, cur, spec, S.n_trips);
+        uint32_t tend = St.tend; bool stop = St.stop;
+        // the next tile's owner can start stitching as soon as this tile's exit is known
+        if (!entry_sent && !stop && tend >= t1) { publish_entry(smem, tile + 1, tend); entry_sent = true; }
+        stitch_marks(V, sb, L, St, S.n_trips);
+        spec = false;
+        { const uint64_t t = clock_ticks(); S.t_stitch += t - tc; tc = t; }
+        if (!have_turn) {
+            if (!wait_word(S, smem, M_TURN, tile)) return 1;
+            have_turn = true;
+            S.obase = uload(&misc[M_EMIT]); S.head = uload(&misc[M_HEAD]);
+            parser_refresh(S, smem);                   // (publish_batch trusts this view until it runs out of room)
+            tc = clock_ticks();
+        }
+        // ---- P5: 64 tokens at a time - decode (the decoder, not the walk, is the authority: every sequence must start
+        //      where its predecessor ended), place, apply the output-side rules (lz4.c:2279 as an error - a sequence
+        //      inside a tile is never the last; 2356; 2423), publish
+        uint32_t expect = cur;
+        bool failed = false; uint32_t failpos = 0;
+        for (uint32_t first = 0; !failed; first += kTokRound) {
+            const uint32_t N = list_tokens(sb, tl, first);
+            if (first >= N) break;
+            const uint32_t nround = N - first < kTokRound ? N - first : kTokRound;
+            bool cut = false;
+            for (uint32_t base = 0; base < nround && !failed && !cut; base += 64) {
+                const uint32_t i = base + lane;
+                const bool have = i < nround;
+                TokInfo ti; ti.ll = ti.q = ti.off = ti.ml = ti.nx = 0; ti.st = 0;
+                uint32_t tp = 0;
+                if (have) { tp = t0 + tl[i]; ti = tok_decode_fast(V, tp); }
+                const uint32_t pnx = __shfl_up(ti.nx, 1u);
+                const uint32_t want = lane ? pnx : expect;
+                const uint32_t len = ti.ll + ti.ml;
+                const uint32_t isum = wave_incl_sum(have ? len : 0u);
+                const uint32_t o = S.obase + (isum - len);
+                const bool chainbad = have && (ti.st != 0 || tp != want);
+                const bool outbad = have && (o > S.capB || S.capB - o < ti.ll + kMfLimit || ti.off == 0 || ti.off > o + ti.ll - S.low
+                                             || S.capB - (o + ti.ll) < ti.ml + kLastLiterals);
+                const unsigned long long badm = __ballot(chainbad || outbad);
+                uint32_t nok = nround - base < 64 ? nround - base : 64;
+                if (badm) {
+                    const uint32_t l = (uint32_t)__ffsll((long long)badm) - 1;
+                    const uint32_t wl = wave_readlane(want, l), tpl = wave_readlane(tp, l), stl = wave_readlane(ti.st, l);
+                    const bool cb = wave_readlane(chainbad ? 1u : 0u, l) != 0;
+                    nok = l;
+                    if (cb && !(tpl == wl && stl == 2)) {
+                        // the list does not continue the chain here (or the token needs the slow path after all): the slow path takes the token the chain expects
+                        cut = true; tend = wl; stop = true;
+                        if (entry_sent) { failed = true; failpos = wl; }          // (cannot happen: the exit was already handed on)
+                    } else { failed = true; failpos = tpl; }
+                }
+                SeqRec rec; rec.outpos = o; rec.litpos = ti.q; rec.ll = ti.ll; rec.off = ti.off;
+                publish_batch(S, smem, nok, o, len, rec);
+                if (nok) expect = wave_readlane(ti.nx, nok - 1);
+            }
+            if (cut) break;
+        }
+        { const uint64_t t = clock_ticks(); S.t_decode += t - tc; tc = t; }
+        if (failed) { parser_fail(smem, failpos); return 1; }
+        if (stop) {
+            S.e = tend;
+            const int rc = slow_token(S, smem);
+            { const uint64_t t = clock_ticks(); S.t_slow += t - tc; tc = t; }
+            if (rc == 1) { wave_lds_fence(); if (lane == 0) lds_store_release(&misc[M_FIN], 1u); return 1; }
+            if (rc == 2) return 1;
+            cur = S.e;
+        } else cur = tend;
+        if (cur >= t1) break;
+    }
+    // ---- the tile is done: entry of the next tile, turn, the stream below the next tile is free
+    if (!entry_sent) publish_entry(smem, tile + 1, cur);
+    if (!have_turn && !wait_word(S, smem, M_TURN, tile)) return 1;
+    set_clo(smem, t1);
+    wave_lds_fence();
+    if (lane == 0) lds_store_release(&misc[M_TURN], tile + 1);
+    return 0;
+}
+
+__device__ __forceinline__ void parser_role(uint32_t pw, uint32_t csize, uint32_t cap, uint32_t prefix, char* smem, uint64_t* prof) {
     wave_priority_high();
     ParserS S;
     S.csize = csize; S.capB = cap + kBias; S.low = kBias - prefix;
     S.e = 0; S.obase = kBias; S.head = 0; S.ppos = 0; S.g = kFirstRegion; S.tail = 0;
-    S.t_wait = S.t_walk = S.t_stitch = S.t_decode = S.t_slow = 0; S.n_trips1 = S.n_trips2 = 0;
-    int rc = 0;
-    for (;;) {
-        rc = parse_tile(S, smem);
-        if (rc == 1) {
-            const uint64_t t0 = clock_ticks();
-            rc = slow_token(S, smem);
-            S.t_slow += clock_ticks() - t0;
-            if (rc == 1) break;                 // the block's last sequence has been published
-        }
-        if (rc == 2) break;
+    S.t_wait = S.t_walk = S.t_stitch = S.t_decode = S.t_turn = S.t_slow = 0; S.n_trips = 0;
+    for (uint32_t tile = pw; (uint64_t)tile * kTile < csize; tile += kParseWaves)
+        if (parse_tile(S, smem, pw, tile)) break;
+    if (prof && pw == 0 && lane_id() == 0) {
+        prof[1] = S.t_wait | (S.t_turn << 32); prof[2] = S.t_walk; prof[3] = S.t_stitch; prof[4] = S.t_decode;
+        prof[5] = S.t_slow | ((uint64_t)S.n_trips << 32);
     }
-    if (rc == 1) {
-        wave_lds_fence();
-        if (lane_id() == 0) lds_store_release(&misc[M_FIN], 1u);
-        // the loader may still be behind (a long final literal run): keep telling it what the copy has consumed
-        S.ppos = csize;
-        while (uload(&misc[M_CHI]) < csize) { parser_refresh(S, smem); spin_pause(); }
-    }
-    if (prof && lane_id() == 0) { prof[1] = S.t_wait; prof[2] = S.t_walk; prof[3] = S.t_stitch; prof[4] = S.t_decode; prof[5] = S.t_slow | ((uint64_t)S.n_trips1 << 24) | ((uint64_t)S.n_trips2 << 44); }
 }
 
 // ------------------------------------------------------------------------------ COPY
@@ -646,8 +819,7 @@ struct RegionCtx {
     char* smem;
     uint32_t R, x0, x1, slot;       // region, its output range, its ring slot
     uint32_t g;                     // regions below g are final
-    uint32_t chi;                   // compressed bytes resident
-    uint32_t crW, lp0;              // ring address / stream position of the region's first literal source
+    lz4amd_gsrc src; uint32_t csize;   // the compressed block (literals are read from memory: the L2 still holds what the loader fetched)
     uint32_t ringB;                 // output position of ring address 0 two laps below the region
     uint32_t j0, nrec;              // records that overlap the region
     uint64_t mydone;                // chunks of this region that are final
@@ -681,11 +853,13 @@ __device__ __forceinline__ U32x4 ring_read16(const RegionCtx& C, uint32_t pos) {
 __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint32_t d, uint32_t lo, uint32_t n,
                                            const SeqRec& rec, uint32_t ms, bool own_ok, U32x4& v) {
     if (is_lit) {
-        const uint32_t A = rec.litpos + (d - rec.outpos);
-        if (A + n > C.chi) return false;
-        uint32_t a = C.crW + (A - C.lp0) - lo + kCrBytes;
-        a = cr_fold(cr_fold(a));
-        v = lds_read16_at((const uint8_t*)(C.smem + kOffCr), a);
+        const uint32_t A = rec.litpos + (d - rec.outpos);                  // stream position of output byte d; [A, A + n) is inside the block
+        if (A >= lo && A - lo + 16 <= C.csize) v = ld_global16(C.src + (A - lo));
+        else {                                                              // the block's first / last bytes: never read outside src[0, csize)
+            v[0] = v[1] = v[2] = v[3] = 0;
+#pragma nounroll
+            for (uint32_t i = 0; i < n; i++) chunk_set_byte(v, lo + i, (uint32_t)C.src[A + i]);
+        }
         return true;
     }
     uint32_t dist = rec.off;
@@ -769,7 +943,6 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     // the slot is mine now: no chunk of region R is done (mask first, then the tag)
     if (lane == 0) { lds_store_release64(&ents[C.slot].mask, 0ull); lds_store_release(&ents[C.slot].tag, C.R + kSlots); }
     C.mydone = 0;
-    C.lp0 = recs[C.j0 & kRecMask].litpos; C.crW = mod_cr(C.lp0);
     C.ringB = (C.R - C.slot - kSlots) << kRegionShift;
     // ---- round A: which record covers the first byte of each chunk?  (scratch: the slot itself)
     uint32_t* fs = (uint32_t*)(smem + slot_off);
@@ -846,7 +1019,6 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                 if (uload(&misc[M_ABORT])) return;
                 spin_pause();
                 C.g = first_open_region(smem);
-                C.chi = uload(&misc[M_CHI]);
                 if (pendA) {
                     const bool mine = (pendA >> lane) & 1ull;
                     bool rdy = false;
@@ -899,7 +1071,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     if (lane == 0) lds_store_release64(&ents[C.slot].mask, ~0ull);
 }
 
-__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* smem, uint64_t* prof) {
+__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, char* smem, uint64_t* prof) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const uint16_t* idx = (const uint16_t*)(smem + kOffIdx);
     uint32_t* fin = (uint32_t*)(smem + kOffFin);
@@ -907,7 +1079,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
     uint32_t k = 0, R = kFirstRegion + w, slot = (kFirstRegion + w) % kSlots;
     uint64_t t_rec = 0, t_lead = 0, t_work = 0, t_retry = 0;
     for (;; R += kCopyWaves, slot = slot + kCopyWaves >= kSlots ? slot + kCopyWaves - kSlots : slot + kCopyWaves) {
-        RegionCtx C; C.smem = smem; C.R = R; C.slot = slot;
+        RegionCtx C; C.smem = smem; C.R = R; C.slot = slot; C.src = src; C.csize = csize;
         C.x0 = R << kRegionShift;
         // ---- wait until the records cover the region (or the block ends inside / before it)
         uint64_t ts = clock_ticks();
@@ -933,7 +1105,6 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
             spin_pause();
         }
         { const uint64_t t = clock_ticks(); t_lead += t - ts; ts = t; }
-        C.chi = uload(&misc[M_CHI]);
         C.j0 = idx[R & kIdxMask];
         {
             const uint32_t head = uload(&misc[M_HEAD]);
@@ -982,7 +1153,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     // -- control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
     if (tid == 0) {
         misc[M_ERR] = kNone; misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_CLO] = 0;
-        misc[M_EMIT] = kBias; misc[M_HEAD] = 0;
+        misc[M_EMIT] = kBias; misc[M_HEAD] = 0; misc[M_ENT_SEQ] = 0; misc[M_ENT_POS] = 0; misc[M_TURN] = 0;
     }
     if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
     if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
@@ -1000,8 +1171,8 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     __syncthreads();
 
     if (w == kLoadWave) loader_role(src, csize, smem);
-    else if (w == kParseWave) parser_role(csize, cap, prefix, smem, prof);
-    else copy_role(w, dst, smem, prof);
+    else if (w >= kCopyWaves) parser_role(w - kCopyWaves, csize, cap, prefix, smem, prof);
+    else copy_role(w, src, csize, dst, smem, prof);
 
     __syncthreads();
     if (tid == 0) {

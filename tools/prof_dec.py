@@ -30,8 +30,8 @@ if os.environ.get("LZ4AMD_DEC", "v1") != "v1":
     med = lambda f: statistics.median([f(i) for i in range(nw)])
     print("cycles per workgroup pass (median over %d workgroups; last block each):" % nw)
     print("  block total        %10d" % med(lambda i: w[i * 8]))
-    print("  parser: wait data  %10d  walk P1+P2 %d  stitch P3+P4 %d  decode+publish P5 %d  slow path %d" % (
-        med(lambda i: w[i * 8 + 1]), med(lambda i: w[i * 8 + 2]), med(lambda i: w[i * 8 + 3]), med(lambda i: w[i * 8 + 4]), med(lambda i: w[i * 8 + 5] & 0xFFFFFF)))
-    print("  parser trips: P1 %d  P2 %d" % (med(lambda i: (w[i * 8 + 5] >> 24) & 0xFFFFF), med(lambda i: w[i * 8 + 5] >> 44)))
+    print("  parser 0: wait data %d  wait entry/turn %d  walk P1+P2 %d  stitch+list %d  decode+publish %d  slow path %d  trips %d" % (
+        med(lambda i: w[i * 8 + 1] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 1] >> 32), med(lambda i: w[i * 8 + 2]), med(lambda i: w[i * 8 + 3]),
+        med(lambda i: w[i * 8 + 4]), med(lambda i: w[i * 8 + 5] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 5] >> 32)))
     print("  copy wave 0: wait records %d  wait lead %d  work %d  retry (sources in flight) %d" % (
         med(lambda i: w[i * 8 + 6] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 6] >> 32), med(lambda i: w[i * 8 + 7] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 7] >> 32)))
