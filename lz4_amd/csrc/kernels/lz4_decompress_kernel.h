@@ -1,62 +1,44 @@
-// lz4_decompress_kernel.h -- batched LZ4 block decompression for gfx950 (MI355X), streaming design.
+// lz4_decompress_kernel.h -- batched LZ4 block decompression for gfx950 (MI355X).
 //
 // Replaces, for a whole batch of independent blocks resident in HBM, what the reference does per
 // block in LZ4_decompress_safe (lib/lz4.c:2451 -> LZ4_decompress_generic lz4.c:2023-2445; length
 // fields: read_variable_length lz4.c:1979-2014; end-of-block rules lz4.c:2276-2330, 2421-2429).
 // Accepts ANY legal LZ4 block, rejects what the reference's safe loop rejects, never reads outside
 // src[0,csize) nor writes outside dst[0,cap).  Not a port: the reference decoder is one serial
-// token chain per block.  Here ONE 1024-thread workgroup (16 waves, one CU, all of its 160 KB LDS)
-// decodes a block as a three-role pipeline; the roles talk through LDS rings and counters only -
-// no workgroup barrier between the first and the last byte of a block, no scratch in HBM:
+// token chain per block.  Here ONE 1024-thread workgroup (16 waves, one CU, ~150 KB of its LDS)
+// decodes a block in two stages:
 //
-//   LOADER (wave 15)   streams the compressed block into a 48 KB LDS ring for the parsers
-//       (coalesced 16-byte loads, the next 4 KB in flight while the last is written).
+//   A PRE-PARSE  (all 16 waves, lz4_preparse_kernel.h) turns the serial token chain into a table of
+//       sequence records {output position, literal source, literal length, offset} in the
+//       workgroup's scratch, applying every format rule on the way: a malformed block is rejected
+//       before a byte of output is written.
 //
-//   PARSERS (4 waves)  turn the serial token chain into sequence records {output position,
-//       literal source, literal length, offset} in a 1024-row LDS ring.  The stream is cut in
-//       TILES of 8 KB on a fixed grid, tile i belongs to parser wave i mod 4; a tile is cut in
-//       64 segments of 128 B, one per lane.
-//         P1  every lane walks the chain of its segment from the segment's first byte, marking
-//             the token positions it visits in a bitmap.  A wrong start walks over literal bytes
-//             misread as tokens (~6.5 B per step) and merges with the true chain after a few
-//             hundred bytes (LZ4 chains self-synchronise).
-//         P2  every lane walks on from its exit (the "bridge") until it steps on a position a
-//             later lane marked, or the tile ends.
-//         (P1 + P2 need nothing from the earlier tiles: the four owners walk side by side.)
-//         P3  once the previous tile's owner has handed over the ENTRY - the first true token at
-//             or after the tile's start - a short walk from it finds the first marked position;
-//             the lane that marked it is true from there on, and where a true lane's bridge
-//             merged into lane k's marks, lane k is true from there on (<= 64 hops).  A bridge
-//             that never merged ends the stitch early at its last (true) position - never a
-//             wrong answer: the owner walks the rest of the tile again from that position.
-//         P4  marks before a lane's merge point and of skipped lanes are dropped, the bridges of
-//             the true lanes are added: the bitmap now holds exactly the true tokens.
-//         P5  64 tokens at a time, a lane decodes one sequence completely (both length fields,
-//             offset) and checks that it starts where its predecessor ended - the decoder, not
-//             the walk, is the authority on the chain; wave scans place the sequences relative
-//             to the tile.  Then, when it is the owner's TURN (output positions are a running
-//             sum over all earlier sequences), the reference's output-side rules are applied
-//             and the records are published.
-//       Tokens whose fields leave the tile (+1 KB look-ahead), length fields longer than 32
-//       bytes and the block's last sequence go through a wave-cooperative SLOW PATH that takes
-//       one token at a time (any length, records split at 8 KB, flow control inside).
+//   B STREAM     a dataflow pipeline through LDS rings and counters only - no workgroup barrier
+//       between the first and the last byte of the block:
+//       LOADER (wave 14)  streams the compressed block into a 32 KB LDS ring (coalesced 16-byte
+//           loads, the next 4 KB in flight while the last is written).
+//       FEEDER (wave 15)  streams the record table into a 1024-row LDS ring, 64 records at a
+//           time, noting for every 1 KB REGION of output the record that holds its first byte;
+//           records longer than 16 KB of output are cut in pieces.
+//       (both run as far ahead as the rings allow)
+//       COPY (waves 0-13)  output-stationary: wave w owns regions w, w+14, ... .  A region is
+//           composed in its slot of a 96 KB LDS ring that always holds the 64 KB LZ4 window, from
+//           PIECES (the literal run or the match of a record, cut at 16-byte chunk borders) in two
+//           lane-uniform rounds: round A, lane = chunk, writes the piece that covers the chunk's
+//           first byte; round B, lane = piece, ORs in the head of every piece that starts inside a
+//           chunk.  Literals are unaligned 16-byte reads from the compressed ring, matches from
+//           the output ring (a match that overlaps itself reads any earlier period - the farthest
+//           the window holds - so long runs do not serialise and never read a recycled slot).
+//           Sources still in flight on another wave are waited for through per-chunk done bits;
+//           finished regions go to HBM with one 16-byte store per lane (1 KB contiguous per wave).
 //
-//   COPY (waves 0-10)  output-stationary in 1 KB REGIONS, wave w owns regions w, w+11, ... .
-//       A region is composed in its slot of an 80 KB LDS ring that always holds the 64 KB LZ4
-//       window, from PIECES (the literal run or the match of a record, cut at 16-byte chunk
-//       borders) in two lane-uniform rounds: round A, lane = chunk, writes the piece that covers
-//       the chunk's first byte; round B, lane = piece, ORs in the head of every piece that starts
-//       inside a chunk.  Literals are unaligned 16-byte loads from the block itself (the L2 still
-//       holds what the loader fetched), matches unaligned 16-byte reads from the output ring (a match that overlaps itself reads any earlier period - the
-//       farthest the window holds - so long runs do not serialise).  Sources still in flight on
-//       another wave are waited for through per-chunk done bits; finished regions go to HBM
-//       with one 16-byte store per lane (1 KB contiguous per wave).
-//
-// HBM traffic per block: compressed bytes read once (the literal loads hit the L2), output written
-// once.  No MFMA: byte moves.
+// HBM/L2 traffic per block: compressed bytes read by the pre-parse and once more by the feeder,
+// the record table written and read once (16 B per sequence), output written once; matches and
+// literals never touch HBM during the copy.  No MFMA: byte moves.
 #pragma once
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
+#include "lz4_preparse_kernel.h"
 
 #ifdef LZ4AMD_TRACE
 #define DTRACE(...) do { if (lane_id() == 0) { fprintf(stderr, "[w%u] ", wave_id()); fprintf(stderr, __VA_ARGS__); } } while (0)
@@ -68,95 +50,73 @@ namespace lz4amd {
 
 using DecBatch = ::lz4amd_dec_params;     // argument block (lz4amd_params.h)
 
-struct alignas(16) SeqRec { uint32_t outpos, litpos, ll, off; };
+using SeqRec = pre::SeqRec;               // { outpos, litpos, ll, off }, output positions biased by kBias
 struct alignas(16) DoneEnt { uint64_t mask; uint32_t tag, pad; };
 
 enum : uint32_t {
     kDecThreads = 1024,
     kDecWaves = kDecThreads / 64,
-    kParseWaves = 4,                            // tile owners
-    kLoadWave = kDecWaves - 1,
-    kCopyWaves = kDecWaves - 1 - kParseWaves,   // waves 0 .. kCopyWaves-1
+    kFeedWave = kDecWaves - 1,                  // sequence records -> LDS
+    kLoadWave = kDecWaves - 2,                  // compressed stream -> LDS
+    kCopyWaves = kDecWaves - 2,                 // waves 0 .. kCopyWaves-1
     kChunk = 16,                                // output bytes composed at a time
     kRegionShift = 10,
     kRegion = 1u << kRegionShift,               // 64 chunks
-    kSlots = 80,                                // output ring slots (regions): 64 KB window + regions in flight
+    kSlots = 96,                                // output ring slots (regions): 64 KB window + regions in flight
     kRingBytes = kSlots * kRegion,
     kRingPad = 32,                              // mirror of the first bytes: reads never wrap
     kMaxLead = kSlots - 64 - 1,                 // a wave may lead the first unfinished region by this many
-    kCrBytes = 48u << 10,                       // compressed ring (direct mapped: position mod 48 K), read by the parsers only
+    kCrBytes = 32u << 10,                       // compressed ring (direct mapped: position mod 32 K)
     kCrPad = 32,
-    kLoadBatch = 4096,                          // bytes the loader moves per step
+    kLoadBatch = 4096,                          // bytes the feeder moves per step
     kRecCap = 1024,                             // sequence-record ring
     kRecMask = kRecCap - 1,
     kIdxRing = 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
     kOutAhead = 480,                            // records are published at most this many regions ahead of the copy
-    kSegShift = 7,
-    kSeg = 1u << kSegShift,                     // parser segment (bytes of the stream per lane)
-    kTile = 64 * kSeg,
-    kLook = 1024,                               // fields of a tile's tokens may reach this far past the tile
-    kBridgeTrips = 40,                          // lockstep trips of the bridge walk
-    kEntrySteps = 64,                           // steps of the serial walk from a tile's entry to the first mark
-    kTokRound = 512,                            // tokens listed per round
-    kExtMax = 32,                               // longer length fields take the slow path
-    kSlowSpan = 8192,                           // slow-path records cover at most this many output bytes
+    kPieceSpan = 8192,                          // records of more than 2 * kPieceSpan output bytes are fed in pieces of this size
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
-    kBias = 65536,                              // output positions are biased: [kBias - prefix, kBias) is the history before dst
+    kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kFirstRegion = kBias >> kRegionShift,
     kNone = 0xFFFFFFFFu,
 };
-static_assert(kParseWaves * kTile + kLook + kLoadBatch <= kCrBytes, "the tiles in flight must fit the compressed ring");
+static_assert(kMaxLead + 1 >= kCopyWaves, "every copy wave must be able to work at once");
+static_assert(kSlots == 96, "slot = region mod 96 is computed with a multiply");
 
-// LDS carve-up (bytes)
+// LDS carve-up of stage B (bytes); stage A uses the same memory before (lz4_preparse_kernel.h)
 enum : uint32_t {
     kOffMisc = 0,                                            // u32[64] control words
     kOffFin = kOffMisc + 64 * 4,                             // u32[16] regions completed per copy wave
     kOffBits = kOffFin + 16 * 4,                             // DoneEnt[kSlots]
     kOffIdx = kOffBits + kSlots * 16,                        // u16[kIdxRing]
     kOffPend = kOffIdx + kIdxRing * 2,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
-    kOffPar = kOffPend + kCopyWaves * (kMaxTrips + 2) * 8,   // per parser wave: token bitmap of its tile, token list
-    kParBytes = kTile / 8 + kTokRound * 2,
-    kOffRecs = (kOffPar + kParseWaves * kParBytes + 15) & ~15u,   // SeqRec[kRecCap]
+    kOffRecs = (kOffPend + kCopyWaves * (kMaxTrips + 2) * 8 + 15) & ~15u,   // SeqRec[kRecCap]
     kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
     kOffRing = kOffCr + kCrBytes + kCrPad,                   // output ring + pad
-    kDecLdsBytes = kOffRing + kRingBytes + kRingPad,
+    kStreamLdsBytes = kOffRing + kRingBytes + kRingPad,
+    kDecLdsBytes = kStreamLdsBytes > pre::kPreLdsBytes ? kStreamLdsBytes : pre::kPreLdsBytes,
 };
 static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
-static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0 && (kOffPar % 4) == 0, "LDS alignment");
+static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0, "LDS alignment");
 
-enum : uint32_t { M_BLOCK = 0, M_ERR, M_ABORT, M_FIN, M_CHI, M_CLO, M_EMIT, M_HEAD, M_ENT_SEQ, M_ENT_POS, M_TURN };
+enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_FIN, M_CHI, M_EMIT, M_HEAD, M_CLO, M_NEXT, M_OPEN };      // (word 1 is the pre-parse's error word)
 
-// (the round-1 decoder kept a record table in HBM; this one needs no scratch)
-__host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t) { return 256; }
+// scratch of one workgroup: the sequence-record table of the block it is decoding
+__host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize) { return pre::scratch_bytes(max_csize); }
 
 // ------------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 // position in the compressed ring
-__device__ __forceinline__ uint32_t mod_cr(uint32_t x) {            // x mod 48 K, x < 2^31
-    return x - (uint32_t)(((uint64_t)(x >> 14) * 0xAAAAAAABull) >> 33) * kCrBytes;
-}
-__device__ __forceinline__ uint32_t cr_fold(uint32_t a) { return umin32(a, a - kCrBytes); }        // [0, 2*48K) -> [0, 48K)
+__device__ __forceinline__ uint32_t mod_cr(uint32_t x) { return x & (kCrBytes - 1); }
+static_assert((kCrBytes & (kCrBytes - 1)) == 0, "ring size");
+__device__ __forceinline__ uint32_t cr_fold(uint32_t a) { return umin32(a, a - kCrBytes); }        // [0, 2*32K) -> [0, 32K)
 __device__ __forceinline__ uint32_t ring_fold(uint32_t a) { return umin32(a, a - kRingBytes); }
 // a control word every lane of the wave agrees on
 __device__ __forceinline__ uint32_t uload(const uint32_t* w) { return __builtin_amdgcn_readfirstlane(lds_load_acquire(w)); }
 
-// 16 bytes as four dwords; byte i of the chunk is byte (i & 3) of dword (i >> 2).
-// (written with selects on whole dwords: indexing the vector dynamically would send it to scratch)
-__device__ __forceinline__ uint32_t chunk_byte(const U32x4& a, uint32_t i) {
-    const uint32_t lo = (i & 4) ? a[1] : a[0], hi = (i & 4) ? a[3] : a[2];
-    const uint32_t d = (i & 8) ? hi : lo;
-    return (d >> ((i & 3) * 8)) & 0xFFu;
-}
-__device__ __forceinline__ void chunk_set_byte(U32x4& a, uint32_t i, uint32_t b) {
-    const uint32_t sh = (i & 3) * 8, m = 0xFFu << sh, v = (b & 0xFFu) << sh;
-    const uint32_t k = i >> 2;
-    a[0] = (k == 0) ? ((a[0] & ~m) | v) : a[0];
-    a[1] = (k == 1) ? ((a[1] & ~m) | v) : a[1];
-    a[2] = (k == 2) ? ((a[2] & ~m) | v) : a[2];
-    a[3] = (k == 3) ? ((a[3] & ~m) | v) : a[3];
-}
+using pre::chunk_byte;
+using pre::chunk_set_byte;
+using pre::load_granule;
 // dword k of the 16-byte mask that selects bytes [0, n), n in 0..16
 __device__ __forceinline__ uint32_t low_bytes_mask(uint32_t n, uint32_t k) {
     const int32_t r = (int32_t)n - 4 * (int32_t)k;
@@ -181,29 +141,32 @@ __device__ __forceinline__ U32x4 lds_read16_at(const uint8_t* base, uint32_t a) 
     v[2] = align_bytes(d3, d2, sh); v[3] = align_bytes(d4, d3, sh);
     return v;
 }
-// 16 bytes of the compressed stream at position P (tail of the block zero padded; never reads past csize)
-__device__ __forceinline__ U32x4 load_granule(lz4amd_gsrc src, uint32_t csize, uint32_t P) {
-    if (P + 16 <= csize) return ld_global16(src + P);
-    U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
-#pragma nounroll
-    for (uint32_t i = 0; i < 16 && P + i < csize; i++) chunk_set_byte(v, i, (uint32_t)src[P + i]);
-    return v;
-}
 
-// First region some copy wave has not completed: every region below it is final.
-__device__ __forceinline__ uint32_t first_open_region(const char* smem) {
-    const uint32_t* fin = (const uint32_t*)(smem + kOffFin);
-    const uint32_t l16 = lane_id() & 15u;
-    const uint32_t f = lds_load_acquire(&fin[l16]);
-    const uint32_t r = l16 < kCopyWaves ? kFirstRegion + l16 + kCopyWaves * f : kNone;
-    return __builtin_amdgcn_readfirstlane(row16_min_u32(r));
+// The control words M_ABORT .. M_OPEN (8 consecutive dwords) in one look: two 16-byte LDS reads issued together, so a
+// wave pays one LDS round trip instead of one per word.
+struct Ctl { uint32_t abort_, fin, chi, emit, head, clo, next, open; };
+__device__ __forceinline__ Ctl ctl_snapshot(const char* smem) {
+    const U32x4* w = (const U32x4*)(smem + kOffMisc + 4 * M_ABORT);
+    U32x4 a, b;
+    lds_load_pair16(w, a, b);
+    Ctl c;
+    c.abort_ = __builtin_amdgcn_readfirstlane(a[0]); c.fin = __builtin_amdgcn_readfirstlane(a[1]);
+    c.chi = __builtin_amdgcn_readfirstlane(a[2]); c.emit = __builtin_amdgcn_readfirstlane(a[3]);
+    c.head = __builtin_amdgcn_readfirstlane(b[0]); c.clo = __builtin_amdgcn_readfirstlane(b[1]);
+    c.next = __builtin_amdgcn_readfirstlane(b[2]); c.open = __builtin_amdgcn_readfirstlane(b[3]);
+    return c;
 }
-__device__ __forceinline__ bool block_over(const char* smem) {        // finished or failed: nothing left to wait for
-    const uint32_t* misc = (const uint32_t*)(smem + kOffMisc);
-    return (uload(&misc[M_FIN]) | uload(&misc[M_ABORT])) != 0;
+static_assert(M_OPEN == M_ABORT + 7 && (kOffMisc + 4 * M_ABORT) % 16 == 0, "control word layout");
+
+// First region that is not complete: every region below it is final.  (Kept by the copy waves: whoever completes a
+// region moves the word over every complete region in front of it.)
+__device__ __forceinline__ uint32_t first_open_region(const char* smem) {
+    return uload((const uint32_t*)(smem + kOffMisc) + M_OPEN);
 }
 
 // ------------------------------------------------------------------------------ LOADER
+// The compressed block -> the 32 KB LDS ring the copy reads its literals from (coalesced 16-byte loads, the next
+// 4 KB in flight while the last is written); it runs as far ahead as the ring allows.
 __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, char* smem) {
     uint8_t* cr = (uint8_t*)(smem + kOffCr);
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
@@ -213,12 +176,11 @@ __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, cha
     for (uint32_t i = 0; i < 4; i++) { const uint32_t P = 16 * (lane + 64 * i); if (P < csize) cur[i] = load_granule(src, csize, P); }
     uint32_t L = 0;
     while (L < csize) {
-        // bytes [L, L + batch) may be written once no parser needs the bytes 48 K below them
+        // bytes [L, L + batch) may be written once nobody needs the bytes 32 K below them
         for (;;) {
             const uint32_t clo = uload(&misc[M_CLO]);
             if (L + kLoadBatch <= clo + kCrBytes) break;
-            if (block_over(smem)) return;
-            spin_pause_long();
+            spin_pause();
         }
         const uint32_t nL = L + kLoadBatch;
 #pragma unroll
@@ -241,576 +203,103 @@ __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, cha
     }
 }
 
-// ------------------------------------------------------------------------------ PARSER
-// The stream is cut in TILES of kTile bytes on a fixed grid; tile i belongs to parser wave i mod kParseWaves.
-// What a tile's owner can do before it knows where the true chain enters the tile (the speculative walk) runs
-// in parallel with the other owners; two short hand-offs are serial from tile to tile: the ENTRY (the first
-// true token at or after the tile's start, known once the previous tile is stitched) and the TURN to publish
-// records (output positions are a running sum over all earlier sequences).
-struct ParserS {
-    uint32_t csize, capB, low;      // capB = capacity + kBias; low = first output position that exists (kBias - prefix)
-    uint32_t e;                     // slow path: token to decode / next token after it
-    uint32_t obase, head;           // output position of the next sequence / records published (valid while holding the turn)
-    uint32_t ppos;                  // slow path: lowest compressed position still needed
-    uint32_t g, tail;               // first open region / first record still in use (last refresh)
-    uint64_t t_wait, t_walk, t_stitch, t_decode, t_turn, t_slow;   // developer profile (cycles)
-    uint32_t n_trips;
-};
-
-// Look at the copy waves' progress: first open region and first record still needed.
-__device__ __forceinline__ void parser_refresh(ParserS& S, char* smem) {
-    const uint16_t* idx = (const uint16_t*)(smem + kOffIdx);
-    const uint32_t g = first_open_region(smem);
-    uint32_t tail = S.head;
-    if ((g << kRegionShift) < S.obase) {                     // region g is covered by published records
-        const uint32_t t16 = idx[g & kIdxMask];
-        tail = S.head - ((S.head - t16) & 0xFFFFu);
-    }
-    S.g = g; S.tail = tail;
-}
-__device__ __forceinline__ void set_clo(char* smem, uint32_t pos) {            // (turn holder only; never moves back)
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    if (lane_id() == 0 && pos > misc[M_CLO]) lds_store_release(&misc[M_CLO], pos);
-}
-// wait until the stream is resident up to `need`; false: the block is over
-__device__ __forceinline__ bool parser_wait_data(ParserS& S, char* smem, uint32_t need) {
-    const uint32_t* misc = (const uint32_t*)(smem + kOffMisc);
-    if (need > S.csize) need = S.csize;
-    if (uload(&misc[M_CHI]) >= need) return true;
-    const uint64_t t0 = clock_ticks();
-    bool ok = true;
-    for (;;) {
-        if (uload(&misc[M_CHI]) >= need) break;
-        if (block_over(smem)) { ok = false; break; }
-        spin_pause();
-    }
-    S.t_wait += clock_ticks() - t0;
-    return ok;
-}
-__device__ __forceinline__ void parser_fail(char* smem, uint32_t pos) {
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    if (lane_id() == 0) { lds_store_relaxed(&misc[M_ERR], pos); lds_store_release(&misc[M_ABORT], 1u); }
-}
-
-// the compressed ring as a tile's walkers see it
-struct TileView { const uint8_t* cr; uint32_t t0, crT, tlim, csize; };
-__device__ __forceinline__ uint32_t tv_byte(const TileView& V, uint32_t p) { return (uint32_t)V.cr[cr_fold(V.crT + (p - V.t0))]; }
-
-struct TokInfo { uint32_t ll, q, off, ml, nx, st; };      // st: 0 decoded, 1 not inside the tile's reach (slow path), 2 malformed
-// Decode the sequence whose token is at p (p < tlim).  The walkers (FULL = false) only need nx; the
-// same function with FULL = true is the authority on the fields and on the reference's input-side
-// rules (read_variable_length, lz4.c:1979-2014).
-template <bool FULL>
-__device__ __forceinline__ TokInfo tok_decode(const TileView& V, uint32_t p) {
-    TokInfo r; r.ll = 0; r.q = 0; r.off = 0; r.ml = 0; r.nx = 0; r.st = 1;
-    const uint32_t b = tv_byte(V, p);
-    uint32_t ll = b >> 4, q = p + 1;
-    if (ll == 15) {
-        uint32_t n = 0, x;
-        do {
-            if (q >= V.tlim || n >= kExtMax) return r;
-            if (FULL && q + 15 >= V.csize) { r.st = 2; return r; }
-            x = tv_byte(V, q); q++; n++; ll += x;
-        } while (x == 255);
-    }
-    r.ll = ll; r.q = q;
-    if (V.csize - q < ll + 8) return r;                  // the block's last sequence (or a malformed one): slow path
-    const uint32_t m = q + ll;
-    if (m + 2 > V.tlim) return r;
-    uint32_t nx = m + 2, ml = b & 15;
-    if (ml == 15) {
-        uint32_t n = 0, x;
-        do {
-            if (nx >= V.tlim || n >= kExtMax) return r;
-            x = tv_byte(V, nx); nx++; n++; ml += x;
-            if (FULL && nx + 4 > V.csize) { r.st = 2; return r; }
-        } while (x == 255);
-    }
-    if (FULL) r.off = tv_byte(V, m) | (tv_byte(V, m + 1) << 8);
-    r.ml = ml + kMinMatch; r.nx = nx; r.st = 0;
-    return r;
-}
-
-// 8 stream bytes at position p of the tile view (any alignment; the ring is padded, bytes past tlim are garbage, not faults)
-__device__ __forceinline__ uint64_t tv_read8(const TileView& V, uint32_t p) {
-    const uint32_t a = cr_fold(V.crT + (p - V.t0));
-    const uint32_t* w = (const uint32_t*)(V.cr + (a & ~3u));
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = a & 3u;
-    return (uint64_t)align_bytes(w1, w0, sh) | ((uint64_t)align_bytes(w2, w1, sh) << 32);
-}
-// tok_decode<true> for the common shapes - both length fields at most 5 bytes, everything well inside the tile's reach
-// and the block - with two 8-byte reads; any other token goes through tok_decode<true> itself (same answers).
-__device__ __forceinline__ TokInfo tok_decode_fast(const TileView& V, uint32_t p) {
-    TokInfo r; r.st = 0;
-    bool easy = p + 8 <= V.tlim;
-    const uint64_t w = tv_read8(V, p);
-    const uint32_t t = (uint32_t)w & 0xFFu, lnib = t >> 4, mnib = t & 15u;
-    const uint64_t x = w >> 8, invx = ~x & 0x00FFFFFFFFFFFFFFull;                     // 7 bytes after the token
-    const uint32_t k = invx ? ((uint32_t)__ffsll((long long)invx) - 1) >> 3 : 7u;    // leading 255s
-    const bool l15 = lnib == 15;
-    easy = easy && (!l15 || k <= 5);
-    const uint32_t ll = l15 ? 15 + 255 * k + ((uint32_t)(x >> (8 * (k & 7))) & 0xFFu) : lnib;
-    const uint32_t q = p + 1 + (l15 ? k + 1 : 0);
-    easy = easy && q + 15 < V.csize;                                                 // every length byte was readable (lz4.c:1986-2006)
-    const uint32_t m = q + ll;
-    easy = easy && m + 8 <= V.tlim && m + 16 <= V.csize;                             // not the last sequence; the match fields are resident
-    const uint64_t y = easy ? tv_read8(V, m) : 0ull;
-    const uint64_t z = y >> 16, invz = ~z & 0x0000FFFFFFFFFFFFull;                     // 6 bytes after the offset
-    const uint32_t km = invz ? ((uint32_t)__ffsll((long long)invz) - 1) >> 3 : 6u;
-    const bool m15 = mnib == 15;
-    easy = easy && (!m15 || km <= 4);
-    r.ll = ll; r.q = q; r.off = (uint32_t)y & 0xFFFFu;
-    r.ml = (m15 ? 15 + 255 * km + ((uint32_t)(z >> (8 * (km & 7))) & 0xFFu) : mnib) + kMinMatch;
-    r.nx = m + 2 + (m15 ? km + 1 : 0);
-    if (!easy) r = tok_decode<true>(V, p);
-    return r;
-}
-
-// Publish the records of lanes [0, nok) of a decoded batch (o / len / rec per lane), waiting for room in
-// the record ring and for the copy to come within kOutAhead regions.  Turn holder only.
-__device__ __forceinline__ void publish_batch(ParserS& S, char* smem, uint32_t nok, uint32_t o, uint32_t len, const SeqRec& rec) {
+// ------------------------------------------------------------------------------ FEEDER
+// The record table -> the 1024-row LDS ring, 64 records at a time (the next batch is on its way from memory while
+// one is published), with the first record of every region noted; it also tells the loader which stream bytes the
+// copy has left behind.  Nothing here blocks on the copy: whatever does not fit now is tried again on the next trip.
+__device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab, uint32_t nseq, char* smem) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     uint16_t* idx = (uint16_t*)(smem + kOffIdx);
     SeqRec* recs = (SeqRec*)(smem + kOffRecs);
     const uint32_t lane = lane_id();
-    const uint32_t er = (o + len - 1) >> kRegionShift;
-    uint32_t done = 0;
-    bool fresh = false;                                   // the cached view of the copy's progress is good enough most of the time
-    while (done < nok) {
-        if (fresh) parser_refresh(S, smem);
-        fresh = true;
-        const unsigned long long okm = __ballot(lane >= done && lane < nok && er < S.g + kOutAhead);
-        const unsigned long long run = ~(okm >> done);
-        uint32_t npub = run ? (uint32_t)__ffsll((long long)run) - 1 : 64u;
-        if (npub > nok - done) npub = nok - done;
-        const uint32_t room = kRecCap - 1 - (S.head - S.tail);               // rows free, one kept for the sentinel
-        if (npub > room) npub = room;
-        if (npub == 0) { if (uload(&misc[M_ABORT])) return; spin_pause(); continue; }
-        if (lane >= done && lane < done + npub) {
-            const uint32_t j = S.head + (lane - done);
-            recs[j & kRecMask] = rec;
-            for (uint32_t g1 = (o + kRegion - 1) >> kRegionShift; (g1 << kRegionShift) < o + len; g1++) idx[g1 & kIdxMask] = (uint16_t)j;
-            if (lane == done + npub - 1) recs[(j + 1) & kRecMask].outpos = o + len;     // sentinel: where the next record starts
-        }
-        const uint32_t oend = wave_readlane(o + len, done + npub - 1);
-        wave_lds_fence();
-        if (lane == 0) { lds_store_release(&misc[M_HEAD], S.head + npub); lds_store_release(&misc[M_EMIT], oend); }
-        S.head += npub; S.obase = oend; done += npub;
-    }
-}
-// One record from the slow path (every lane holds the same values).
-__device__ __forceinline__ void publish_one(ParserS& S, char* smem, uint32_t litpos, uint32_t ll, uint32_t off, uint32_t len) {
-    SeqRec rec; rec.outpos = S.obase; rec.litpos = litpos; rec.ll = ll; rec.off = off;
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    uint16_t* idx = (uint16_t*)(smem + kOffIdx);
-    SeqRec* recs = (SeqRec*)(smem + kOffRecs);
-    const uint32_t lane = lane_id(), o = S.obase;
+    wave_priority_high();                              // fifteen waves wait for what this one produces
+    // ---- record state: the batch in registers (lane i: record rix + i), how much of it is published
+    uint32_t rix = 0, bn = 0, bdone = 0, head = 0, obase = kBias;
+    SeqRec brec; brec.outpos = brec.litpos = brec.ll = brec.off = 0;
+    uint32_t blen = 0;
+    // the batch after it, on its way from the table (lane i: record rix + bn + i)
+    SeqRec prec; prec.outpos = prec.litpos = prec.ll = prec.off = 0;
+    uint32_t plen = 0, pn = nseq < 64 ? nseq : 64;
+    if (lane < pn) { prec = rectab[lane]; plen = rectab[lane + 1].outpos - prec.outpos; }
+    uint32_t pc_off = 0;                               // a long record is fed in pieces: output bytes of it already fed
+    bool fin_sent = false;
+    uint32_t clo_sent = 0;
     for (;;) {
-        parser_refresh(S, smem);
-        if (S.head + 2 - S.tail <= kRecCap && ((o + len) >> kRegionShift) < S.g + kOutAhead) break;
-        if (uload(&misc[M_ABORT])) return;
-        spin_pause();
-    }
-    if (lane == 0) { recs[S.head & kRecMask] = rec; recs[(S.head + 1) & kRecMask].outpos = o + len; }
-    const uint32_t g1 = ((o + kRegion - 1) >> kRegionShift) + lane;            // len <= kSlowSpan: at most 9 regions
-    if ((g1 << kRegionShift) < o + len) idx[g1 & kIdxMask] = (uint16_t)S.head;
-    wave_lds_fence();
-    if (lane == 0) { lds_store_release(&misc[M_HEAD], S.head + 1); lds_store_release(&misc[M_EMIT], o + len); }
-    S.head += 1; S.obase = o + len;
-}
-
-// SLOW PATH (turn holder only): the sequence whose token is at S.e, whatever its size; every lane computes the
-// same values, length fields are scanned 64 bytes at a time.  Same rules as the reference's safe loop.
-// Returns 0: go on at S.e, 1: that was the block's last sequence, 2: malformed (reported) or the block is over.
-__device__ __noinline__ int slow_token(ParserS& S, char* smem) {
-    const uint8_t* cr = (const uint8_t*)(smem + kOffCr);
-    const uint32_t lane = lane_id(), csize = S.csize, p = S.e;
-    if (p >= csize) { parser_fail(smem, csize ? csize - 1 : 0); return 2; }
-    S.ppos = p; set_clo(smem, p);
-    if (!parser_wait_data(S, smem, p + 1)) return 2;
-    const uint32_t t = cr[mod_cr(p)];
-    uint32_t ll = t >> 4, q = p + 1;
-    if (ll == 15) {
-        for (;;) {
-            if (!parser_wait_data(S, smem, q + 64)) return 2;
-            const uint32_t pos = q + lane;
-            const bool inb = pos + 15 < csize;                              // lz4.c:1986-2006: a length byte is read only there
-            const uint32_t x = inb ? (uint32_t)cr[mod_cr(pos)] : 0u;
-            const unsigned long long stopm = __ballot(!inb || x != 255);
-            if (!stopm) {
-                ll += 255 * 64; q += 64; S.ppos = q; set_clo(smem, q);
-                if (ll > csize) { parser_fail(smem, p); return 2; }
-                continue;
-            }
-            const uint32_t kk = (uint32_t)__ffsll((long long)stopm) - 1;
-            if (!wave_readlane(inb ? 1u : 0u, kk)) { parser_fail(smem, p); return 2; }
-            ll += 255 * kk + wave_readlane(x, kk); q += kk + 1;
-            break;
+        bool progress = false;
+        // ---- the next batch of the record table, when the last one is out (it was requested a batch ago)
+        if (bdone == bn && pn) {
+            brec = prec; blen = plen; bn = pn; bdone = 0; pc_off = 0;
+            rix += bn;
+            pn = nseq - rix < 64 ? nseq - rix : 64;
+            if (lane < pn) {
+                prec = rectab[rix + lane];
+                plen = rectab[rix + lane + 1].outpos - prec.outpos;      // (the table ends with a sentinel row)
+            } else { prec.outpos = prec.litpos = prec.ll = prec.off = 0; plen = 0; }
+            progress = true;
         }
-        if (ll > csize) { parser_fail(smem, p); return 2; }
-    }
-    const uint32_t rem = csize - q, room = S.capB - S.obase;
-    const bool last = rem < ll + 8 || room < ll + kMfLimit;                 // lz4.c:2279
-    if (last && (rem != ll || room < ll)) { parser_fail(smem, p); return 2; }   // lz4.c:2312-2318
-    // the literal run, in records of at most kSlowSpan bytes (a last sequence always gets a record)
-    if (ll || last) {
-        uint32_t left = ll, lp = q;
-        do {
-            const uint32_t n = left < kSlowSpan ? left : kSlowSpan;
-            publish_one(S, smem, lp, n, 0, n);
-            left -= n; lp += n;
-        } while (left);
-    }
-    if (last) return 1;
-    const uint32_t m = q + ll;                                              // m + 8 <= csize
-    S.ppos = m; set_clo(smem, m);                                           // (the copy reads literals from memory, not from the ring)
-    if (!parser_wait_data(S, smem, m + 2)) return 2;
-    const uint32_t off = (uint32_t)cr[mod_cr(m)] | ((uint32_t)cr[mod_cr(m + 1)] << 8);
-    uint32_t ml = t & 15, nx = m + 2;
-    if (ml == 15) {
-        for (;;) {
-            if (!parser_wait_data(S, smem, nx + 64)) return 2;
-            const uint32_t pos = nx + lane;
-            const uint32_t x = pos < csize ? (uint32_t)cr[mod_cr(pos)] : 0u;
-            const bool badafter = pos + 5 > csize;                          // after a length byte at least 4 more bytes must follow
-            const unsigned long long stopm = __ballot(x != 255 || badafter);
-            if (!stopm) {
-                ml += 255 * 64; nx += 64; S.ppos = nx; set_clo(smem, nx);
-                if (ml > 0x7FFFFFF0u) { parser_fail(smem, p); return 2; }
-                continue;
-            }
-            const uint32_t kk = (uint32_t)__ffsll((long long)stopm) - 1;
-            ml += 255 * kk + wave_readlane(x, kk); nx += kk + 1;
-            if (wave_readlane(badafter ? 1u : 0u, kk) || ml > 0x7FFFFFF0u) { parser_fail(smem, p); return 2; }
-            break;
-        }
-    }
-    ml += kMinMatch;
-    const uint32_t ms = S.obase;
-    if (off == 0 || off > ms - S.low) { parser_fail(smem, p); return 2; }   // lz4.c:2356
-    if (S.capB - ms < ml + kLastLiterals) { parser_fail(smem, p); return 2; }   // lz4.c:2423
-    {
-        uint32_t left = ml;
-        do {
-            const uint32_t n = left < kSlowSpan ? left : kSlowSpan;
-            publish_one(S, smem, nx, 0, off, n);
-            left -= n;
-        } while (left);
-    }
-    S.e = nx;
-    return 0;
-}
-
-enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_OVER = 4 };
-
-// The walkers' view of the chain: one stream byte per trip, no branches.  A lane is at a token (mode 0), inside a
-// literal-length field (mode 1) or inside a match-length field (mode 2).  It stops (dead, at the token `tok`) exactly
-// where tok_decode says "not inside the tile's reach": those tokens belong to the slow path.
-struct WalkState { uint32_t p, tok, acc, mode, cnt; bool mlf, dead; };
-__device__ __forceinline__ void walk_init(WalkState& s, uint32_t p) { s.p = p; s.tok = p; s.acc = 0; s.mode = 0; s.cnt = 0; s.mlf = false; s.dead = false; }
-// consume byte b = stream[s.p] (the caller checked s.p < tlim)
-__device__ __forceinline__ void walk_step(WalkState& s, uint32_t b, const TileView& V) {
-    const bool m0 = s.mode == 0, m1 = s.mode == 1, m2 = s.mode == 2;
-    const bool is255 = b == 255;
-    const uint32_t ll0 = b >> 4;
-    const bool ext0 = ll0 == 15;
-    const bool litdone = (m0 && !ext0) || (m1 && !is255);                  // the literal length is complete with this byte
-    const uint32_t ll = m0 ? ll0 : s.acc + b;
-    const uint32_t m = s.p + 1 + ll;                                        // first byte after the literals
-    const bool mlf = m0 ? (b & 15) == 15 : s.mlf;
-    const bool cont = (m0 && ext0) || ((m1 || m2) && is255);               // the length field goes on
-    const uint32_t cnt = m0 ? 0u : s.cnt + 1;
-    const bool stop = (litdone && (m + 8 > V.csize || m + 2 > V.tlim)) || (cont && cnt >= kExtMax);
-    s.tok = m0 ? s.p : s.tok;
-    s.dead = stop;
-    s.acc = m0 ? 15u : s.acc + b;
-    s.mlf = mlf;
-    s.cnt = litdone ? 0u : cnt;
-    s.mode = litdone ? (mlf ? 2u : 0u) : (cont ? (m2 ? 2u : 1u) : 0u);
-    s.p = litdone ? m + 2 : s.p + 1;
-}
-
-// what a lane knows after the speculative walk of its segment
-struct LaneWalk { uint32_t x; uint32_t okind, opos, nb; };
-
-__device__ __forceinline__ void sb_mark(uint32_t* sb, uint32_t rel) { atomicOr(&sb[rel >> 5], 1u << (rel & 31)); }
-__device__ __forceinline__ bool sb_test(const uint32_t* sb, uint32_t rel) { return (sb[rel >> 5] >> (rel & 31)) & 1u; }
-
-// P1 + P2.  Every lane walks the token chain of its segment from the segment's first byte - or, when the tile is
-// (re)entered at a known true token `ent`, the lane of that segment from `ent` and the lanes below it not at all -
-// marking the token positions it visits (P1); then walks on ("bridge") until it steps on a position a later lane
-// marked, leaves the tile, or kBridgeTrips trips have passed (P2).  A wrong start walks over literal bytes misread
-// as tokens (~6.5 B per step) and merges with the true chain after a few hundred bytes.
-__device__ __forceinline__ LaneWalk walk_tile(const TileView& V, uint32_t* sb, uint32_t ent, uint32_t& trips) {
-    const uint32_t lane = lane_id(), t0 = V.t0, t1 = t0 + kTile;
-#pragma unroll
-    for (uint32_t w = 0; w < kSeg / 32; w++) sb[lane * (kSeg / 32) + w] = 0;
-    wave_lds_fence();
-    const uint32_t seg_lo = t0 + lane * kSeg, seg_hi = seg_lo + kSeg;
-    WalkState s; walk_init(s, seg_lo);
-    bool idle = false;
-    if (ent != kNone) { if (ent >= seg_hi) idle = true; else if (ent > seg_lo) walk_init(s, ent); }
-    for (;;) {
-        const bool run = !idle && !s.dead && !(s.mode == 0 && s.p >= seg_hi);
-        if (!__any(run)) break;
-        trips++;
-        if (run) {
-            if (s.p >= V.tlim) { s.tok = s.mode == 0 ? s.p : s.tok; s.dead = true; }      // ran off the block
-            else {
-                if (s.mode == 0) sb_mark(sb, s.p - t0);
-                walk_step(s, tv_byte(V, s.p), V);
-            }
-        }
-    }
-    wave_lds_fence();
-    LaneWalk L; L.x = s.p; L.okind = idle ? OUT_OVER : (s.dead ? OUT_STOP : OUT_NONE); L.opos = s.dead ? s.tok : s.p; L.nb = 0;
-    for (uint32_t trip = 0;; trip++) {
-        const bool run = L.okind == OUT_NONE;
-        if (!__any(run)) break;
-        trips++;
-        if (run) {
-            const bool at_tok = s.mode == 0;
-            if (at_tok && s.p >= t1) { L.okind = OUT_EXIT; L.opos = s.p; }
-            else if (at_tok && sb_test(sb, s.p - t0)) { L.okind = OUT_MERGE; L.opos = s.p; }
-            else if (trip >= kBridgeTrips) { L.okind = OUT_OVER; L.opos = at_tok ? s.p : s.tok; }   // (a token either way)
-            else if (s.p >= V.tlim) { L.okind = OUT_STOP; L.opos = at_tok ? s.p : s.tok; }
-            else {
-                L.nb += at_tok ? 1u : 0u;
-                walk_step(s, tv_byte(V, s.p), V);
-                if (s.dead) { L.okind = OUT_STOP; L.opos = s.tok; }
-            }
-        }
-    }
-    return L;
-}
-
-// P3 + P4: stitch the true chain through the walked tile and leave exactly its tokens in [cur, tend) in the bitmap.
-//   spec == true : the tile was walked before its entry was known; the chain comes in at `cur` (any token of the tile):
-//                  a serial walk from cur finds the first marked position, the lane that marked it is true from there on.
-//   spec == false: the tile was walked from `cur` (walk_tile's ent): that lane is true from cur.
-// A true lane's marks are true up to its exit; where its bridge merged into lane k's marks, lane k is true from there
-// (<= 64 hops).  A bridge that did not merge ends the stitch at its last (true) token - never a wrong answer, only
-// a shorter stretch.  stop: the token at tend needs the slow path.  stitch_chain is the serial part (the next tile's
-// entry is known after it), stitch_marks the rest.
-struct Stitch { uint32_t tend; bool stop; uint32_t myT, epos, ne; };
-__device__ __forceinline__ Stitch stitch_chain(const TileView& V, const uint32_t* sb, const LaneWalk& L, uint32_t cur, bool spec, uint32_t& trips) {
-    const uint32_t lane = lane_id(), t0 = V.t0, t1 = t0 + kTile;
-    Stitch R; R.tend = cur; R.stop = true; R.myT = kNone; R.epos = kNone; R.ne = 0;
-    uint32_t k = kNone, Tk = 0;
-    bool chain = false;
-    if (spec) {
-        WalkState s; walk_init(s, cur);                      // every lane walks the same walk
-        for (;;) {
-            if (s.mode == 0) {
-                if (s.p >= t1) { R.tend = s.p; R.stop = false; break; }
-                if (sb_test(sb, s.p - t0)) { k = (s.p - t0) >> kSegShift; Tk = s.p; chain = true; break; }
-                if (R.ne >= kEntrySteps) { R.tend = s.p; R.stop = false; break; }   // (a true token: the caller walks the rest of the tile from it)
-                if (lane == R.ne) R.epos = s.p;
-                R.ne++;
-            }
-            if (s.p >= V.tlim) { R.tend = s.mode == 0 ? s.p : s.tok; R.stop = true; break; }
-            walk_step(s, tv_byte(V, s.p), V);
-            trips++;
-            if (s.dead) { R.tend = s.tok; R.stop = true; break; }
-        }
-    } else { k = (cur - t0) >> kSegShift; Tk = cur; chain = true; }
-    if (chain) {
-        for (uint32_t it = 0; it < 64; it++) {
-            if (lane == k) R.myT = Tk;
-            const uint32_t kind = wave_readlane(L.okind, k), pos = wave_readlane(L.opos, k);
-            if (kind == OUT_MERGE) { k = (pos - t0) >> kSegShift; Tk = pos; continue; }
-            R.tend = pos; R.stop = kind == OUT_STOP;
-            break;
-        }
-    }
-    return R;
-}
-__device__ __forceinline__ void stitch_marks(const TileView& V, uint32_t* sb, const LaneWalk& L, const Stitch& R, uint32_t& trips) {
-    const uint32_t lane = lane_id(), t0 = V.t0, t1 = t0 + kTile, tend = R.tend;
-    // ---- P4: drop the marks of the lanes the chain skipped and the marks before a lane's entry ...
-    const bool active = R.myT != kNone;
-    const uint32_t seg_lo = t0 + lane * kSeg;
-#pragma unroll
-    for (uint32_t w = 0; w < kSeg / 32; w++) {
-        uint32_t v = sb[lane * (kSeg / 32) + w];
-        const uint32_t base = seg_lo + 32 * w;
-        if (!active) v = 0;
-        else if (R.myT > base) v = (R.myT - base >= 32) ? 0u : (v & (0xFFFFFFFFu << (R.myT - base)));
-        if (tend <= base) v = 0; else if (tend - base < 32) v &= (1u << (tend - base)) - 1u;
-        sb[lane * (kSeg / 32) + w] = v;
-    }
-    wave_lds_fence();
-    // ... add the bridges of the true lanes (walked again: they were not kept) ...
-    {
-        WalkState s; walk_init(s, L.x);
-        uint32_t left = active ? L.nb : 0;
-        while (__any(left != 0)) {
-            trips++;
-            if (left) {
-                if (s.mode == 0) { if (s.p < tend && s.p < t1) sb_mark(sb, s.p - t0); left--; }
-                if (left) walk_step(s, tv_byte(V, s.p), V);
-            }
-        }
-    }
-    // ... and the tokens of the entry walk
-    if (lane < R.ne && R.epos < tend && R.epos < t1) sb_mark(sb, R.epos - t0);
-    wave_lds_fence();
-}
-
-// Token list of a round: tokens [first, first + kTokRound) of the bitmap, in order.  Returns the tile's token count.
-__device__ __forceinline__ uint32_t list_tokens(const uint32_t* sb, uint16_t* tl, uint32_t first) {
-    const uint32_t lane = lane_id();
-    uint32_t wv[kSeg / 32], cnt = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kSeg / 32; w++) { wv[w] = sb[lane * (kSeg / 32) + w]; cnt += (uint32_t)__popc(wv[w]); }
-    const uint32_t incl = wave_incl_sum(cnt);
-    const uint32_t N = wave_readlane(incl, 63);
-    uint32_t k = incl - cnt;
-#pragma unroll
-    for (uint32_t w = 0; w < kSeg / 32; w++) {
-        uint32_t v = wv[w];
-        while (v) {
-            const uint32_t b = (uint32_t)__ffs((int)v) - 1; v &= v - 1;
-            if (k >= first && k - first < kTokRound) tl[k - first] = (uint16_t)(lane * kSeg + 32 * w + b);
-            k++;
-        }
-    }
-    wave_lds_fence();
-    return N;
-}
-
-// hand-offs between tile owners
-__device__ __forceinline__ void publish_entry(char* smem, uint32_t next_tile, uint32_t pos) {
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    if (lane_id() == 0) { lds_store_relaxed(&misc[M_ENT_POS], pos); lds_store_release(&misc[M_ENT_SEQ], next_tile); }
-}
-__device__ __forceinline__ bool wait_word(ParserS& S, char* smem, uint32_t word, uint32_t value) {
-    const uint32_t* misc = (const uint32_t*)(smem + kOffMisc);
-    if (uload(&misc[word]) == value) return true;
-    const uint64_t t0 = clock_ticks();
-    bool ok = true;
-    for (;;) {
-        if (uload(&misc[word]) == value) break;
-        if (block_over(smem)) { ok = false; break; }
-        spin_pause();
-    }
-    S.t_turn += clock_ticks() - t0;
-    return ok;
-}
-
-// One tile.  Returns 0: done, go on with the owner's next tile; 1: the block is over (finished, failed, or somebody
-// else's business).
-__device__ __forceinline__ int parse_tile(ParserS& S, char* smem, uint32_t pw, uint32_t tile) {
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    uint32_t* sb = (uint32_t*)(smem + kOffPar + pw * kParBytes);
-    uint16_t* tl = (uint16_t*)(smem + kOffPar + pw * kParBytes + kTile / 8);
-    const uint32_t lane = lane_id(), csize = S.csize;
-    const uint32_t t0 = tile * kTile, t1 = t0 + kTile;
-    TileView V; V.cr = (const uint8_t*)(smem + kOffCr); V.t0 = t0; V.crT = mod_cr(t0); V.csize = csize;
-    V.tlim = t1 + kLook < csize ? t1 + kLook : csize;
-    if (!parser_wait_data(S, smem, V.tlim)) return 1;
-    uint64_t tc = clock_ticks();
-    bool have_turn = false, entry_sent = false, spec = true;
-    uint32_t cur = kNone;                              // the true token the tile is (re)entered at; unknown during the first walk
-    for (;;) {
-        // ---- the walk: before the entry is known the first time, from a true token after a stop inside the tile
-        const LaneWalk L = walk_tile(V, sb, cur, S.n_trips);
-        { const uint64_t t = clock_ticks(); S.t_walk += t - tc; tc = t; }
-        if (spec) {
-            if (!wait_word(S, smem, M_ENT_SEQ, tile)) return 1;
-            cur = uload(&misc[M_ENT_POS]);
-            tc = clock_ticks();
-            if (cur >= t1) break;                      // the chain jumps over this tile (a long literal run)
-        }
-        const Stitch St = stitch_chain(V, sb, L, cur, spec, S.n_trips);
-        uint32_t tend = St.tend; bool stop = St.stop;
-        // the next tile's owner can start stitching as soon as this tile's exit is known
-        if (!entry_sent && !stop && tend >= t1) { publish_entry(smem, tile + 1, tend); entry_sent = true; }
-        stitch_marks(V, sb, L, St, S.n_trips);
-        spec = false;
-        { const uint64_t t = clock_ticks(); S.t_stitch += t - tc; tc = t; }
-        if (!have_turn) {
-            if (!wait_word(S, smem, M_TURN, tile)) return 1;
-            have_turn = true;
-            S.obase = uload(&misc[M_EMIT]); S.head = uload(&misc[M_HEAD]);
-            parser_refresh(S, smem);                   // (publish_batch trusts this view until it runs out of room)
-            tc = clock_ticks();
-        }
-        // ---- P5: 64 tokens at a time - decode (the decoder, not the walk, is the authority: every sequence must start
-        //      where its predecessor ended), place, apply the output-side rules (lz4.c:2279 as an error - a sequence
-        //      inside a tile is never the last; 2356; 2423), publish
-        uint32_t expect = cur;
-        bool failed = false; uint32_t failpos = 0;
-        for (uint32_t first = 0; !failed; first += kTokRound) {
-            const uint32_t N = list_tokens(sb, tl, first);
-            if (first >= N) break;
-            const uint32_t nround = N - first < kTokRound ? N - first : kTokRound;
-            bool cut = false;
-            for (uint32_t base = 0; base < nround && !failed && !cut; base += 64) {
-                const uint32_t i = base + lane;
-                const bool have = i < nround;
-                TokInfo ti; ti.ll = ti.q = ti.off = ti.ml = ti.nx = 0; ti.st = 0;
-                uint32_t tp = 0;
-                if (have) { tp = t0 + tl[i]; ti = tok_decode_fast(V, tp); }
-                const uint32_t pnx = __shfl_up(ti.nx, 1u);
-                const uint32_t want = lane ? pnx : expect;
-                const uint32_t len = ti.ll + ti.ml;
-                const uint32_t isum = wave_incl_sum(have ? len : 0u);
-                const uint32_t o = S.obase + (isum - len);
-                const bool chainbad = have && (ti.st != 0 || tp != want);
-                const bool outbad = have && (o > S.capB || S.capB - o < ti.ll + kMfLimit || ti.off == 0 || ti.off > o + ti.ll - S.low
-                                             || S.capB - (o + ti.ll) < ti.ml + kLastLiterals);
-                const unsigned long long badm = __ballot(chainbad || outbad);
-                uint32_t nok = nround - base < 64 ? nround - base : 64;
-                if (badm) {
-                    const uint32_t l = (uint32_t)__ffsll((long long)badm) - 1;
-                    const uint32_t wl = wave_readlane(want, l), tpl = wave_readlane(tp, l), stl = wave_readlane(ti.st, l);
-                    const bool cb = wave_readlane(chainbad ? 1u : 0u, l) != 0;
-                    nok = l;
-                    if (cb && !(tpl == wl && stl == 2)) {
-                        // the list does not continue the chain here (or the token needs the slow path after all): the slow path takes the token the chain expects
-                        cut = true; tend = wl; stop = true;
-                        if (entry_sent) { failed = true; failpos = wl; }          // (cannot happen: the exit was already handed on)
-                    } else { failed = true; failpos = tpl; }
+        // ---- what the copy still needs: first open region g, first record in use, first literal byte in use
+        const uint32_t g = first_open_region(smem);
+        uint32_t tail = head, need;
+        if ((g << kRegionShift) < obase) {
+            const uint32_t t16 = idx[g & kIdxMask];
+            tail = head - ((head - t16) & 0xFFFFu);
+            const SeqRec r = recs[tail & kRecMask];
+            uint32_t d = (g << kRegionShift) - r.outpos; if (d > r.ll) d = r.ll;
+            need = r.litpos + d;
+        } else need = bdone < bn ? wave_readlane(brec.litpos, bdone) : csize;   // nothing published is in use
+        if (need != clo_sent) { clo_sent = need; if (lane == 0) lds_store_release(&misc[M_CLO], need); }   // what the loader may overwrite
+        if (bdone < bn) {
+            const uint32_t room = kRecCap - 1 - (head - tail);           // rows free, one kept for the sentinel
+            const bool islong = blen > 2 * kPieceSpan;
+            if (wave_readlane(islong ? 1u : 0u, bdone)) {
+                // one piece of a long record: literals first ({position, source, n, 0}), then the match ({position, -, 0, offset})
+                const uint32_t o0 = wave_readlane(brec.outpos, bdone), ll = wave_readlane(brec.ll, bdone), len = wave_readlane(blen, bdone);
+                const uint32_t lp = wave_readlane(brec.litpos, bdone), off = wave_readlane(brec.off, bdone);
+                const bool inlit = pc_off < ll;
+                const uint32_t left = inlit ? ll - pc_off : len - pc_off;
+                const uint32_t n = left < kPieceSpan ? left : kPieceSpan;
+                const uint32_t o = o0 + pc_off;
+                if (room >= 1 && ((o + n) >> kRegionShift) < g + kOutAhead) {
+                    SeqRec rec; rec.outpos = o; rec.litpos = inlit ? lp + pc_off : lp + ll; rec.ll = inlit ? n : 0u; rec.off = inlit ? 0u : off;
+                    // (a match piece points at the end of its record's literals: literal sources never go back)
+                    if (lane == 0) { recs[head & kRecMask] = rec; recs[(head + 1) & kRecMask].outpos = o + n; }
+                    const uint32_t g1 = ((o + kRegion - 1) >> kRegionShift) + lane;
+                    if ((g1 << kRegionShift) < o + n) idx[g1 & kIdxMask] = (uint16_t)head;
+                    wave_lds_fence();
+                    if (lane == 0) { lds_store_release(&misc[M_HEAD], head + 1); lds_store_release(&misc[M_EMIT], o + n); }
+                    head += 1; obase = o + n; pc_off += n;
+                    if (pc_off >= len) { bdone++; pc_off = 0; }
+                    progress = true;
                 }
-                SeqRec rec; rec.outpos = o; rec.litpos = ti.q; rec.ll = ti.ll; rec.off = ti.off;
-                publish_batch(S, smem, nok, o, len, rec);
-                if (nok) expect = wave_readlane(ti.nx, nok - 1);
+            } else {
+                const uint32_t o = brec.outpos, er = (o + blen - 1) >> kRegionShift;
+                const unsigned long long okm = __ballot(lane >= bdone && lane < bn && !islong && (blen == 0 || er < g + kOutAhead));
+                const unsigned long long run = ~(okm >> bdone);
+                uint32_t npub = run ? (uint32_t)__ffsll((long long)run) - 1 : 64u;
+                if (npub > bn - bdone) npub = bn - bdone;
+                if (npub > room) npub = room;
+                if (npub) {
+                    if (lane >= bdone && lane < bdone + npub) {
+                        const uint32_t j = head + (lane - bdone);
+                        recs[j & kRecMask] = brec;
+                        for (uint32_t g1 = (o + kRegion - 1) >> kRegionShift; (g1 << kRegionShift) < o + blen; g1++) idx[g1 & kIdxMask] = (uint16_t)j;
+                        if (lane == bdone + npub - 1) recs[(j + 1) & kRecMask].outpos = o + blen;      // sentinel: where the next record starts
+                    }
+                    const uint32_t oend = wave_readlane(o + blen, bdone + npub - 1);
+                    wave_lds_fence();
+                    if (lane == 0) { lds_store_release(&misc[M_HEAD], head + npub); lds_store_release(&misc[M_EMIT], oend); }
+                    head += npub; obase = oend; bdone += npub;
+                    progress = true;
+                }
             }
-            if (cut) break;
         }
-        { const uint64_t t = clock_ticks(); S.t_decode += t - tc; tc = t; }
-        if (failed) { parser_fail(smem, failpos); return 1; }
-        if (stop) {
-            S.e = tend;
-            const int rc = slow_token(S, smem);
-            { const uint64_t t = clock_ticks(); S.t_slow += t - tc; tc = t; }
-            if (rc == 1) { wave_lds_fence(); if (lane == 0) lds_store_release(&misc[M_FIN], 1u); return 1; }
-            if (rc == 2) return 1;
-            cur = S.e;
-        } else cur = tend;
-        if (cur >= t1) break;
-    }
-    // ---- the tile is done: entry of the next tile, turn, the stream below the next tile is free
-    if (!entry_sent) publish_entry(smem, tile + 1, cur);
-    if (!have_turn && !wait_word(S, smem, M_TURN, tile)) return 1;
-    set_clo(smem, t1);
-    wave_lds_fence();
-    if (lane == 0) lds_store_release(&misc[M_TURN], tile + 1);
-    return 0;
-}
-
-__device__ __forceinline__ void parser_role(uint32_t pw, uint32_t csize, uint32_t cap, uint32_t prefix, char* smem, uint64_t* prof) {
-    wave_priority_high();
-    ParserS S;
-    S.csize = csize; S.capB = cap + kBias; S.low = kBias - prefix;
-    S.e = 0; S.obase = kBias; S.head = 0; S.ppos = 0; S.g = kFirstRegion; S.tail = 0;
-    S.t_wait = S.t_walk = S.t_stitch = S.t_decode = S.t_turn = S.t_slow = 0; S.n_trips = 0;
-    for (uint32_t tile = pw; (uint64_t)tile * kTile < csize; tile += kParseWaves)
-        if (parse_tile(S, smem, pw, tile)) break;
-    if (prof && pw == 0 && lane_id() == 0) {
-        prof[1] = S.t_wait | (S.t_turn << 32); prof[2] = S.t_walk; prof[3] = S.t_stitch; prof[4] = S.t_decode;
-        prof[5] = S.t_slow | ((uint64_t)S.n_trips << 32);
+        if (!fin_sent && pn == 0 && bdone == bn) {            // every record is out: the copy may run to the end
+            wave_lds_fence();
+            if (lane == 0) lds_store_release(&misc[M_FIN], 1u);
+            fin_sent = true;
+        }
+        if (fin_sent && uload(&misc[M_CHI]) >= csize) break;     // (the loader may still be behind: keep telling it what the copy has consumed)
+        if (!progress) spin_pause();
     }
 }
 
@@ -819,7 +308,8 @@ struct RegionCtx {
     char* smem;
     uint32_t R, x0, x1, slot;       // region, its output range, its ring slot
     uint32_t g;                     // regions below g are final
-    lz4amd_gsrc src; uint32_t csize;   // the compressed block (literals are read from memory: the L2 still holds what the loader fetched)
+    uint32_t chi;                   // compressed bytes resident
+    uint32_t crW, lp0;              // ring address / stream position of the region's first literal source
     uint32_t ringB;                 // output position of ring address 0 two laps below the region
     uint32_t j0, nrec;              // records that overlap the region
     uint64_t mydone;                // chunks of this region that are final
@@ -850,20 +340,26 @@ __device__ __forceinline__ U32x4 ring_read16(const RegionCtx& C, uint32_t pos) {
 // Bytes [lo, lo + n) of v := output bytes [d, d + n) of the piece (literal run or match of rec; ms = where
 // the match starts).  false: a source is not final yet.  own_ok: every lower piece of d's own chunk is done
 // (only a match with a period < 16 that starts inside a chunk reads its own chunk).
+// key: a piece that is not ready for the most common reason - a plain match whose source bytes [key, key + n) lie in
+// other chunks that are still in flight - reports where its source starts: it can be finished later with one poll of
+// those chunks' done bits and one ring read.  kKeyAlways: only a full attempt can tell.
+enum : uint32_t { kKeyAlways = 0xFFFFFFFFu };
 __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint32_t d, uint32_t lo, uint32_t n,
-                                           const SeqRec& rec, uint32_t ms, bool own_ok, U32x4& v) {
+                                           const SeqRec& rec, uint32_t ms, bool own_ok, U32x4& v, uint32_t& key) {
+    key = kKeyAlways;
     if (is_lit) {
-        const uint32_t A = rec.litpos + (d - rec.outpos);                  // stream position of output byte d; [A, A + n) is inside the block
-        if (A >= lo && A - lo + 16 <= C.csize) v = ld_global16(C.src + (A - lo));
-        else {                                                              // the block's first / last bytes: never read outside src[0, csize)
-            v[0] = v[1] = v[2] = v[3] = 0;
-#pragma nounroll
-            for (uint32_t i = 0; i < n; i++) chunk_set_byte(v, lo + i, (uint32_t)C.src[A + i]);
-        }
+        const uint32_t A = rec.litpos + (d - rec.outpos);
+        if (A + n > C.chi) return false;
+        uint32_t a = C.crW + (A - C.lp0) - lo + kCrBytes;
+        a = cr_fold(cr_fold(a));
+        v = lds_read16_at((const uint8_t*)(C.smem + kOffCr), a);
         return true;
     }
     uint32_t dist = rec.off;
     const uint32_t into = d - ms;
+#ifdef LZ4AMD_TRACE
+    if (dist == 0) { fprintf(stderr, "ZERO OFFSET item: R=%u d=%u lo=%u n=%u rec{%u,%u,%u,%u} ms=%u j0=%u nrec=%u\n", C.R, d, lo, n, rec.outpos, rec.litpos, rec.ll, rec.off, ms, C.j0, C.nrec); return false; }
+#endif
     if (into >= dist) {
         // the source lies inside this very match (it overlaps itself): every earlier period holds the same
         // bytes; read the farthest one the 64 KB window holds, long final, instead of the bytes just written
@@ -877,7 +373,7 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     // offset < 16 + lo) are in once every lower piece of the chunk is
     const uint32_t cstart = d - lo;
     const uint32_t se = n <= dist ? s + n - 1 : d - 1;                       // last source byte
-    if (s < cstart && !range_is_final(C, s, se < cstart ? se : cstart - 1)) return false;
+    if (s < cstart && !range_is_final(C, s, se < cstart ? se : cstart - 1)) { if (n <= dist && se < cstart) key = s; return false; }
     if (se >= cstart && !own_ok) return false;
     if (n <= dist) {
         v = ring_read16(C, s - lo);
@@ -909,6 +405,16 @@ __device__ __forceinline__ void slot_write16(const RegionCtx& C, uint32_t c, con
     if (C.slot == 0 && c < kRingPad / kChunk) *(U32x4*)(C.smem + kOffRing + kRingBytes + (c << 4)) = v;
 }
 
+// chunks that still have a pending piece: OR of 1 << chunk over the lanes of pm (few lanes: a scalar loop)
+__device__ __forceinline__ uint64_t chunks_of(unsigned long long pm, uint32_t chunk) {
+    uint64_t m = 0;
+    while (pm) {
+        const uint32_t l = (uint32_t)__ffsll((long long)pm) - 1; pm &= pm - 1;
+        m |= 1ull << wave_readlane(chunk, l);
+    }
+    return m;
+}
+
 // round-B item of lane l in trip t: the head of a piece that starts inside a chunk
 struct BItem { SeqRec rec; uint32_t ms, d, lo, n, chunk; bool is_lit, valid; };
 __device__ __forceinline__ BItem b_item(const RegionCtx& C, uint32_t t) {
@@ -932,7 +438,7 @@ __device__ __forceinline__ BItem b_item(const RegionCtx& C, uint32_t t) {
 }
 
 // Compose region C.R in its ring slot and store it.
-__device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint32_t w, uint64_t& t_retry) {
+__device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint32_t w, uint64_t& t_retry, uint32_t& n_iter) {
     char* smem = C.smem;
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
@@ -943,6 +449,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     // the slot is mine now: no chunk of region R is done (mask first, then the tag)
     if (lane == 0) { lds_store_release64(&ents[C.slot].mask, 0ull); lds_store_release(&ents[C.slot].tag, C.R + kSlots); }
     C.mydone = 0;
+    C.lp0 = recs[C.j0 & kRecMask].litpos; C.crW = mod_cr(C.lp0);
     C.ringB = (C.R - C.slot - kSlots) << kRegionShift;
     // ---- round A: which record covers the first byte of each chunk?  (scratch: the slot itself)
     uint32_t* fs = (uint32_t*)(smem + slot_off);
@@ -974,57 +481,84 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     {
         U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
         bool ready = false;
+        uint32_t keyA = kKeyAlways, keyB0 = kKeyAlways, packB0 = 0;    // what my pending pieces wait for (round A; round B, first trip: + lo / n / chunk)
         if (actA) {
-            ready = item_fetch(C, alit, c0, 0, an, arec, ams, true, v);
+            ready = item_fetch(C, alit, c0, 0, an, arec, ams, true, v, keyA);
             v = ready ? keep_bytes(v, 0, an) : U32x4{0, 0, 0, 0};
             slot_write16(C, lane, v);
         }
         uint64_t pendA = __ballot(actA && !ready);
         // ---- round B: heads of the pieces that start inside a chunk, 32 records per trip
         const uint32_t trips = (C.nrec + 31) / 32;
-        bool anyB = false;
+        uint64_t pendBc = 0;                           // chunks with a pending round-B piece
         for (uint32_t t = 0; t < trips; t++) {
             const BItem it = b_item(C, t);
             bool rdy = false;
             if (it.valid) {
                 U32x4 bv;
-                rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, false, bv);
+                uint32_t kb;
+                rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, false, bv, kb);
                 if (rdy) slot_or16(C, it.chunk, keep_bytes(bv, it.lo, it.lo + it.n));
+                else if (t == 0) { keyB0 = kb; packB0 = it.lo | (it.n << 4) | (it.chunk << 9); }
             }
             const unsigned long long pm = __ballot(it.valid && !rdy);
             if (lane == 0) pend[1 + t] = pm;
-            anyB = anyB || pm != 0;
+            if (pm) pendBc |= chunks_of(pm, it.chunk);
         }
         // ---- pieces whose sources were still in flight: try again until they are all in
-        if (pendA || anyB) {
+        if (pendA || pendBc) {
             const uint64_t tr0 = clock_ticks();
             uint64_t published = 0;
             const uint64_t actm = __ballot(actA);
             for (;;) {
                 // chunks without a pending piece are final: tell the other waves
-                wave_lds_fence();
-                if (lane == 0) pend[0] = 0;
-                wave_lds_fence();
-                for (uint32_t t = 0; t < trips; t++) {
-                    const unsigned long long pm = pend[1 + t];
-                    if (pm) { const BItem it = b_item(C, t); if ((pm >> lane) & 1ull) atomicOr(&pend[0], 1ull << it.chunk); }
-                }
-                wave_lds_fence();
-                const uint64_t pendchunks = pendA | pend[0];
-                DTRACE("retry R=%u pendA=%llx pendB0=%llx chunks=%llx g=%u chi=%u\n", C.R, (unsigned long long)pendA, (unsigned long long)pend[1], (unsigned long long)pendchunks, C.g, C.chi);
+                const uint64_t pendchunks = pendA | pendBc;
                 C.mydone = ~pendchunks;
                 const uint64_t pub = ~pendchunks & actm;
                 if (pub != published) { published = pub; if (lane == 0) lds_store_release64(&ents[C.slot].mask, pub); }
                 if (!pendchunks) break;
-                if (uload(&misc[M_ABORT])) return;
-                spin_pause();
+                n_iter++;
+                {
+                    const uint32_t ab = lds_load_acquire(&misc[M_ABORT]), chi = lds_load_acquire(&misc[M_CHI]);
+                    if (__builtin_amdgcn_readfirstlane(ab)) return;
+                    C.chi = __builtin_amdgcn_readfirstlane(chi);
+                }
                 C.g = first_open_region(smem);
+                wave_lds_fence();                      // (pend[] of the last pass)
+                {
+                    // the cheap way first: plain matches that only waited for their source chunks (one poll, one ring read)
+                    const unsigned long long pb0 = pend[1];
+                    const bool sa_ = ((pendA >> lane) & 1ull) && keyA != kKeyAlways;
+                    bool rdyA = false;
+                    if (sa_ && range_is_final(C, keyA, keyA + an - 1)) { slot_or16(C, lane, keep_bytes(ring_read16(C, keyA), 0, an)); rdyA = true; }
+                    const unsigned long long doneA = __ballot(rdyA);
+                    const bool sb_ = ((pb0 >> lane) & 1ull) && keyB0 != kKeyAlways;
+                    bool rdyB = false;
+                    if (sb_) {
+                        const uint32_t blo = packB0 & 15u, bn = (packB0 >> 4) & 31u, bch = packB0 >> 9;
+                        if (range_is_final(C, keyB0, keyB0 + bn - 1)) { slot_or16(C, bch, keep_bytes(ring_read16(C, keyB0 - blo), blo, blo + bn)); rdyB = true; }
+                    }
+                    const unsigned long long doneB = __ballot(rdyB);
+                    pendA &= ~doneA;
+                    const unsigned long long left0 = pb0 & ~doneB;
+                    if (doneB) { if (lane == 0) pend[1] = left0; wave_lds_fence(); }
+                    // is anything left that needs the full attempt?  (other waits, later trips)
+                    bool later = false;
+                    for (uint32_t t = 1; t < trips; t++) later = later || pend[1 + t] != 0;
+                    const bool hard = __any((((pendA >> lane) & 1ull) && keyA == kKeyAlways) || (((left0 >> lane) & 1ull) && keyB0 == kKeyAlways));
+                    if (!hard && !later) {
+                        pendBc = left0 ? chunks_of(left0, packB0 >> 9) : 0;
+                        if (!(doneA | doneB)) spin_pause();
+                        continue;
+                    }
+                }
+                pendBc = 0;
                 if (pendA) {
                     const bool mine = (pendA >> lane) & 1ull;
                     bool rdy = false;
                     if (mine) {
                         U32x4 av;
-                        rdy = item_fetch(C, alit, c0, 0, an, arec, ams, true, av);
+                        rdy = item_fetch(C, alit, c0, 0, an, arec, ams, true, av, keyA);
                         if (rdy) slot_or16(C, lane, keep_bytes(av, 0, an));
                     }
                     pendA &= ~__ballot(rdy);
@@ -1043,14 +577,14 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                     bool rdy = false;
                     if (mine) {
                         U32x4 bv;
-                        rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, own_ok, bv);
+                        uint32_t kb;
+                        rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, own_ok, bv, kb);
+                        if (!rdy && t == 0) { keyB0 = kb; packB0 = it.lo | (it.n << 4) | (it.chunk << 9); }
                         if (rdy) slot_or16(C, it.chunk, keep_bytes(bv, it.lo, it.lo + it.n));
                     }
                     const unsigned long long left = pm & ~__ballot(rdy);
-                    wave_lds_fence();
                     if (lane == 0) pend[1 + t] = left;
-                    wave_lds_fence();
-                    if (left) earlier_clear = false;
+                    if (left) { earlier_clear = false; pendBc |= chunks_of(left, it.chunk); }
                 }
             }
             t_retry += clock_ticks() - tr0;
@@ -1071,59 +605,70 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     if (lane == 0) lds_store_release64(&ents[C.slot].mask, ~0ull);
 }
 
-__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, char* smem, uint64_t* prof) {
+__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* smem, uint64_t* prof) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const uint16_t* idx = (const uint16_t*)(smem + kOffIdx);
-    uint32_t* fin = (uint32_t*)(smem + kOffFin);
+    const DoneEnt* ents = (const DoneEnt*)(smem + kOffBits);
     const uint32_t lane = lane_id();
-    uint32_t k = 0, R = kFirstRegion + w, slot = (kFirstRegion + w) % kSlots;
+    uint32_t k = 0;
     uint64_t t_rec = 0, t_lead = 0, t_work = 0, t_retry = 0;
-    for (;; R += kCopyWaves, slot = slot + kCopyWaves >= kSlots ? slot + kCopyWaves - kSlots : slot + kCopyWaves) {
-        RegionCtx C; C.smem = smem; C.R = R; C.slot = slot; C.src = src; C.csize = csize;
+    uint32_t n_iters = 0, n_retried = 0;
+    for (;;) {
+        // regions are handed out in order to whichever wave is free: a slow region does not hold up its wave's next ones
+        uint32_t R = 0;
+        if (lane == 0) R = atomicAdd(&misc[M_NEXT], 1u);
+        R = __builtin_amdgcn_readfirstlane(R);
+        const uint32_t slot = R - (uint32_t)(((uint64_t)R * 0xAAAAAAABull) >> 38) * kSlots;          // R mod 96
+        RegionCtx C; C.smem = smem; C.R = R; C.slot = slot;
         C.x0 = R << kRegionShift;
-        // ---- wait until the records cover the region (or the block ends inside / before it)
+        // ---- wait until the records cover the region (or the block ends inside / before it) and its ring slot is free:
+        //      region R takes the slot of region R-96, which regions up to R-32 may still read
         uint64_t ts = clock_ticks();
-        uint32_t oe;
+        uint32_t oe, head;
         for (;;) {
-            oe = uload(&misc[M_EMIT]);
-            if (oe >= C.x0 + kRegion) { C.x1 = C.x0 + kRegion; break; }
-            if (uload(&misc[M_FIN])) {
-                oe = uload(&misc[M_EMIT]);
+            const Ctl c = ctl_snapshot(smem);
+            oe = c.emit; head = c.head; C.g = c.open; C.chi = c.chi;
+            if (c.abort_) goto out;
+            bool covered = oe >= C.x0 + kRegion;
+            C.x1 = C.x0 + kRegion;
+            if (!covered && c.fin) {
                 if (C.x0 >= oe) goto out;
                 C.x1 = oe < C.x0 + kRegion ? oe : C.x0 + kRegion;
-                break;
+                covered = true;
             }
-            if (uload(&misc[M_ABORT])) goto out;
-            spin_pause_long();
-        }
-        { const uint64_t t = clock_ticks(); t_rec += t - ts; ts = t; }
-        // ---- flow control: region R takes the ring slot of region R-80, which regions up to R-16 may still read
-        for (;;) {
-            C.g = first_open_region(smem);
-            if (C.g + kMaxLead >= R) break;
-            if (uload(&misc[M_ABORT])) goto out;
+            if (covered && C.g + kMaxLead >= R) break;
             spin_pause();
         }
-        { const uint64_t t = clock_ticks(); t_lead += t - ts; ts = t; }
-        C.j0 = idx[R & kIdxMask];
+        { const uint64_t t = clock_ticks(); t_rec += t - ts; ts = t; }
         {
-            const uint32_t head = uload(&misc[M_HEAD]);
-            const uint32_t jl = (C.x1 < oe) ? (uint32_t)idx[(R + 1) & kIdxMask] : head - 1;
+            const uint32_t i0 = idx[R & kIdxMask], i1 = idx[(R + 1) & kIdxMask];
+            C.j0 = i0;
+            const uint32_t jl = (C.x1 < oe) ? i1 : head - 1;
             uint32_t nrec = ((jl - C.j0) & 0xFFFFu) + 1;
             if (nrec > 32 * kMaxTrips) nrec = 32 * kMaxTrips;             // (more than 258 records never overlap a region)
             C.nrec = nrec;
         }
-        uint64_t tr = 0;
+        uint64_t tr = 0; uint32_t ni = 0;
         DTRACE("region R=%u x0=%u x1=%u j0=%u nrec=%u g=%u\n", R, C.x0, C.x1, C.j0, C.nrec, C.g);
-        copy_region(C, dst, w, tr);
+        copy_region(C, dst, w, tr, ni);
+        n_iters += ni; n_retried += ni ? 1u : 0u;
         DTRACE("region R=%u done\n", R);
         if (uload(&misc[M_ABORT])) goto out;
         k++;
-        if (lane == 0) lds_store_release(&fin[w], k);
+        // move the first-open-region word over every complete region in front of it (mine included)
+        for (;;) {
+            const uint32_t g = uload(&misc[M_OPEN]);
+            const uint32_t gs = g - (uint32_t)(((uint64_t)g * 0xAAAAAAABull) >> 38) * kSlots;
+            uint32_t tag; uint64_t mask;
+            lds_load_tag_mask(&ents[gs].tag, &ents[gs].mask, tag, mask);
+            const bool complete = tag == g + kSlots && mask == ~0ull;
+            if (!__builtin_amdgcn_readfirstlane(complete ? 1u : 0u)) break;
+            if (lane == 0) atomicCAS(&misc[M_OPEN], g, g + 1);
+        }
         { const uint64_t t = clock_ticks(); t_work += t - ts - tr; t_retry += tr; }
     }
 out:
-    if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); }
+    if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[2] = n_iters | ((uint64_t)n_retried << 32); prof[3] = k; }
 }
 
 // ------------------------------------------------------------------------------ one block
@@ -1146,15 +691,22 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     const uint32_t csize = (uint32_t)csize_i, cap = (uint32_t)cap_i;
     uint32_t prefix = P.prefix ? (uint32_t)P.prefix[b] : 0u; if (prefix > kBias) prefix = kBias;
 
+    SeqRec* rectab = (SeqRec*)(P.scratch + (uint64_t)blockIdx.x * P.scratch_stride);
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tstart = 0;
     if (prof && tid == 0) tstart = clock_ticks();
 
-    // -- control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
-    if (tid == 0) {
-        misc[M_ERR] = kNone; misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_CLO] = 0;
-        misc[M_EMIT] = kBias; misc[M_HEAD] = 0; misc[M_ENT_SEQ] = 0; misc[M_ENT_POS] = 0; misc[M_TURN] = 0;
+    // ---- stage A: the record table (a malformed block ends here, nothing written)
+    uint32_t nseq = 0, total = 0;
+    if (!pre::preparse_block(src, csize, cap, prefix, rectab, smem, nseq, total, nullptr)) {
+        if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]);
+        return;
     }
+    if (prof && tid == 0) prof[1] = clock_ticks() - tstart;
+    __syncthreads();            // record table visible to the whole workgroup; stage A's LDS is dead
+
+    // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
+    if (tid == 0) { misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_EMIT] = kBias; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
     if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
     if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
     if (prefix) {
@@ -1170,13 +722,13 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     }
     __syncthreads();
 
-    if (w == kLoadWave) loader_role(src, csize, smem);
-    else if (w >= kCopyWaves) parser_role(w - kCopyWaves, csize, cap, prefix, smem, prof);
-    else copy_role(w, src, csize, dst, smem, prof);
+    if (w == kFeedWave) feeder_role(csize, rectab, nseq, smem);
+    else if (w == kLoadWave) loader_role(src, csize, smem);
+    else copy_role(w, dst, smem, prof);
 
     __syncthreads();
     if (tid == 0) {
-        P.result[b] = misc[M_ABORT] ? err_at(misc[M_ERR]) : (int32_t)(misc[M_EMIT] - kBias);
+        P.result[b] = (int32_t)total;
         if (prof) prof[0] = clock_ticks() - tstart;
     }
 }

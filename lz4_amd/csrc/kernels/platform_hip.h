@@ -51,6 +51,12 @@ __device__ __forceinline__ void lds_load_tag_mask(const uint32_t* tagp, const ui
     mask = *(const volatile __attribute__((address_space(3))) uint64_t*)maskp;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// two consecutive 16-byte LDS reads issued back to back (one wait for both)
+__device__ __forceinline__ void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b) {
+    const volatile __attribute__((address_space(3))) lz4amd_u32x4* q = (const volatile __attribute__((address_space(3))) lz4amd_u32x4*)p;
+    a = q[0]; b = q[1];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // LDS operations of one wave are issued and serviced in program order; this only keeps the
 // compiler from moving LDS accesses of the wave across the point (the CPU interpreter used by the
 // unit tests needs a real rendezvous here, because its lanes do not run in lockstep).

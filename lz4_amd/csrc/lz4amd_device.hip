@@ -81,8 +81,8 @@ extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
     return ms;
 }
 
-// which decoder runs: the streaming one is opt-in (LZ4AMD_DEC=v2) until it beats the round-1 kernel
-static bool dec_use_v1() { const char* e = getenv("LZ4AMD_DEC"); return !(e && e[0] == 'v' && e[1] == '2'); }
+// which decoder runs: LZ4AMD_DEC=v1 selects the round-1 kernel (A/B timing)
+static bool dec_use_v1() { const char* e = getenv("LZ4AMD_DEC"); return e && e[0] == 'v' && e[1] == '1'; }
 extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return dec_use_v1() ? (size_t)v1::dec_scratch_bytes(max_csize) : (size_t)dec_scratch_bytes(max_csize); }
 extern "C" size_t lz4amd_hip_hc_scratch_bytes(unsigned max_src) { return (size_t)hc_scratch_bytes(max_src); }
 extern "C" int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned grid, void* s) {

@@ -29,6 +29,7 @@ static inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
 }
 typedef uint32_t lz4amd_u32x4 __attribute__((vector_size(16)));
+static inline void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b) { memcpy(&a, (const void*)p, 16); memcpy(&b, (const void*)(p + 1), 16); }
 static inline lz4amd_u32x4 ld_global16_raw(const uint8_t* p) { lz4amd_u32x4 v; memcpy(&v, p, 16); return v; }
 static inline void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { memcpy(p, &v, 16); }
 static inline uint64_t clock_ticks() { return 0; }

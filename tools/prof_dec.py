@@ -20,9 +20,9 @@ for _ in range(5):
     best = min(best, km[0])
 U, C = nb * bs, sum(csizes)
 print("decoder %s: %d x %d B P%d%s  kernel ms %.3f  GB/s out %.1f  (U+C)/t %.1f GB/s = %.3f of 8 TB/s" % (
-    os.environ.get("LZ4AMD_DEC", "v1"), nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
+    os.environ.get("LZ4AMD_DEC", "v2"), nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
 assert torch.equal(out, data), "decode mismatch"
-if os.environ.get("LZ4AMD_DEC", "v1") != "v1":
+if os.environ.get("LZ4AMD_DEC", "v2") != "v1":
     L = lz4_amd.lib()
     w = (ctypes.c_ulonglong * (256 * 8))()
     n = L.lz4amd_plan_profile(plan._h, w, len(w))
@@ -30,8 +30,7 @@ if os.environ.get("LZ4AMD_DEC", "v1") != "v1":
     med = lambda f: statistics.median([f(i) for i in range(nw)])
     print("cycles per workgroup pass (median over %d workgroups; last block each):" % nw)
     print("  block total        %10d" % med(lambda i: w[i * 8]))
-    print("  parser 0: wait data %d  wait entry/turn %d  walk P1+P2 %d  stitch+list %d  decode+publish %d  slow path %d  trips %d" % (
-        med(lambda i: w[i * 8 + 1] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 1] >> 32), med(lambda i: w[i * 8 + 2]), med(lambda i: w[i * 8 + 3]),
-        med(lambda i: w[i * 8 + 4]), med(lambda i: w[i * 8 + 5] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 5] >> 32)))
+    print("  pre-parse %d" % med(lambda i: w[i * 8 + 1]))
+    print("  copy wave 0: regions %d, with retry %d, retry iterations %d" % (med(lambda i: w[i * 8 + 3]), med(lambda i: w[i * 8 + 2] >> 32), med(lambda i: w[i * 8 + 2] & 0xFFFFFFFF)))
     print("  copy wave 0: wait records %d  wait lead %d  work %d  retry (sources in flight) %d" % (
         med(lambda i: w[i * 8 + 6] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 6] >> 32), med(lambda i: w[i * 8 + 7] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 7] >> 32)))
