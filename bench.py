@@ -8,20 +8,27 @@ Workload (BASELINE.json configs[1]): per GPU, 1 GiB of independent 4 MiB blocks 
 batch: LZ4 block compression of every block (LZ4_compress_default semantics) followed by
 decompression of every block (LZ4_decompress_safe semantics), through the C ABI of
 include/lz4amd.h.  GB/s counts UNCOMPRESSED bytes per second (programs/bench.c:500-503,
-564-568).  Blocks shard across ranks with no data-path collective (weak scaling).
+564-568).  Blocks shard across ranks; the codec itself has no collective (weak scaling).
 
 Prints ONE JSON line on rank 0:
   value            whole-job round-trip throughput: ranks * 1 GiB * K / max-over-ranks time
   compress_GBps / decompress_GBps   the two halves, from HIP events around their kernels
-  roofline         dominant kernel: algorithmic bytes (U + C per block) / HIP-event time
+  roofline         dominant kernel: algorithmic bytes (U + C per block) / HIP-event time; `peak` is the
+                   8 TB/s spec, `frac_of_measured_copy` the same rate against this box's own stream-copy kernel
   kernels          the same for every kernel of the step
-  cpu_baseline     the reference lib/lz4.c (oracle/_ref, kind "reference") or the oracle port,
-                   timed on this box's host cores on a bounded sample of the same workload
-  hc               (N=1) BASELINE configs[3] beside it: LZ4_compress_HC level 9 on 256 KiB blocks of the
-                   same GiB, with its own roofline and the reference lz4hc.c on the host cores
+  cpu_baseline     the reference lib/lz4.c (oracle/_ref, kind "reference") or the oracle port, timed on this box's
+                   host cores (1 thread, one per physical core, one per logical CPU; >= 4 blocks per thread,
+                   loops of >= 1 s, best of 3) on a bounded sample of the same workload
+  hc               (N=1) BASELINE configs[3]: LZ4_compress_HC level 9 on 256 KiB blocks of the same GiB
+  shape_2048       (N=1) the per-GPU shape of configs[4]: 2048 x 4 MiB blocks (8 GiB), blocks queue 8 deep per CU
+  frame            (N=1) configs[2]: the GiB as ONE frame, 4 MB linked blocks + content checksum, through the
+                   host-pointer API LZ4F_compressFrame / LZ4F_decompress (PCIe inclusive)
+  data_path        (N>1) configs[4]'s movement over RCCL: scatter of the input from rank 0, all-gather of the
+                   compressed sizes, gather of the payloads; reported beside the kernel-only `value`
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import subprocess
@@ -31,7 +38,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a float4 copy reaches ~6300
 
 
 def shard_plan(total_blocks_per_rank, rank, world):
@@ -43,7 +50,7 @@ def shard_plan(total_blocks_per_rank, rank, world):
 
 
 def aggregate(dist, local_seconds, local_bytes, device=None):
-    """max-over-ranks time and sum-over-ranks bytes (the only collectives of the bench)."""
+    """max-over-ranks time and sum-over-ranks bytes."""
     import torch
     t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
     b = torch.tensor([float(local_bytes)], dtype=torch.float64, device=device)
@@ -65,9 +72,71 @@ def gen_data(nbytes, pct, seed):
     return buf
 
 
-def cpu_baseline(n_blocks, block_bytes, pct, seed):
-    """Reference (or oracle port) on the host cores, bounded sample, best of 3 (bench.c style)."""
-    cores = os.cpu_count() or 1
+def kernel_sources_sha():
+    """Identity of the device code: the traffic file under profiles/ is only quoted when it was measured on these sources."""
+    h = hashlib.sha256()
+    kdir = os.path.join(ROOT, "lz4_amd", "csrc", "kernels")
+    for f in sorted(os.listdir(kdir)) + ["../lz4amd_device.hip"]:
+        with open(os.path.join(kdir, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic():
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); {} when the
+    file was measured on other kernel sources."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return pmc if pmc.get("kernel_sources_sha") == kernel_sources_sha() else {}
+    except Exception:
+        return {}
+
+
+def host_cpus():
+    """(physical cores, logical CPUs) of this box."""
+    logical = os.cpu_count() or 1
+    cores = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except Exception:
+        pass
+    return (len(cores) or logical), logical
+
+
+def _mem_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    return 8 << 30
+
+
+def _refbench(exe, threads, block_bytes, pct, seed, level=0, min_s=1.0, reps=3, unique=64):
+    per_block = 3 * block_bytes + block_bytes // 255 + 16
+    per_thread = 4                                           # >= 4 blocks per thread (VERDICT r1)
+    while per_thread > 1 and threads * per_thread * per_block > _mem_available() // 3:
+        per_thread -= 1
+    nblocks = threads * per_thread
+    r = subprocess.run([exe, str(threads), str(nblocks), str(block_bytes), str(pct), str(seed), str(reps), str(level),
+                        str(min_s), str(min(unique, nblocks))], capture_output=True, text=True, check=True, timeout=900)
+    return json.loads(r.stdout)
+
+
+def cpu_baseline(block_bytes, pct, seed):
+    """Reference (or oracle port) on the host cores: persistent threads, every timed pass bracketed by barriers,
+    passes repeated for >= 1 s, fastest of 3 such loops (bench.c:466-493)."""
+    phys, logical = host_cpus()
     exe, kind = os.path.join(ROOT, "oracle", "_ref", "refbench"), "reference"
     if not os.path.exists(exe):
         exe, kind = os.path.join(ROOT, "oracle", "oraclebench"), "port"
@@ -77,49 +146,68 @@ def cpu_baseline(n_blocks, block_bytes, pct, seed):
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             except Exception:
                 return None
-    sample_blocks = min(n_blocks, 64)                       # 256 MiB of the same stream
     out = {}
     try:
-        for threads in (1, cores):
-            r = subprocess.run([exe, str(threads), str(sample_blocks), str(block_bytes), str(pct), str(seed), "3"],
-                               capture_output=True, text=True, check=True, timeout=600)
-            out[threads] = json.loads(r.stdout)
+        for threads in sorted({1, phys, logical}):
+            out[threads] = _refbench(exe, threads, block_bytes, pct, seed)
     except Exception as e:                                   # never let the baseline kill the bench
         return {"error": str(e)}
-    full = out[cores]
-    return {"value": round(full["roundtrip_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": f"{sample_blocks} x {block_bytes} B blocks of datagen -P{pct} -s{seed} (first "
-                      f"{sample_blocks * block_bytes >> 20} MiB of rank 0's shard), best of 3, static partition over {cores} threads",
+    best_t = max(out, key=lambda t: out[t]["roundtrip_GBps"])
+    full = out[best_t]
+    per = {str(t): {"compress_GBps": round(o["compress_GBps"], 3), "decompress_GBps": round(o["decompress_GBps"], 3),
+                    "roundtrip_GBps": round(o["roundtrip_GBps"], 3), "blocks": o["blocks"]} for t, o in out.items()}
+    return {"value": round(full["roundtrip_GBps"], 3), "unit": "GB/s", "cores": best_t, "kind": kind,
+            "physical_cores": phys, "logical_cpus": logical,
+            "sample": f"{full['blocks']} x {block_bytes} B blocks (the first {full['unique_blocks']} blocks of datagen -P{pct} -s{seed}, repeated), "
+                      f"{full['blocks'] // best_t} per thread, static partition, threads created once, passes repeated >= {full['min_loop_s']:.0f} s, best of 3",
             "compress_GBps": round(full["compress_GBps"], 3), "decompress_GBps": round(full["decompress_GBps"], 3),
-            "single_thread": {"compress_GBps": round(out[1]["compress_GBps"], 3),
-                              "decompress_GBps": round(out[1]["decompress_GBps"], 3),
-                              "roundtrip_GBps": round(out[1]["roundtrip_GBps"], 3)},
-            "ref_comp_bytes": full["comp_bytes"], "ref_src_bytes": full["src_bytes"]}
+            "by_threads": per,
+            "ref_comp_bytes_per_unique": full["comp_bytes"] * full["unique_blocks"] // full["blocks"], "unique_blocks": full["unique_blocks"]}
 
 
 def cpu_baseline_hc(block_bytes, pct, seed, level):
-    """Reference LZ4_compress_HC (oracle/_ref only: the oracle port has no HC) on the host cores,
-    bounded sample of configs[3]'s table."""
-    cores = os.cpu_count() or 1
+    """Reference LZ4_compress_HC (oracle/_ref only: the oracle port has no HC) on the host cores."""
+    phys, logical = host_cpus()
     exe = os.path.join(ROOT, "oracle", "_ref", "refbench")
     if not os.path.exists(exe):
         return None
-    sample_blocks = 2 * cores if cores >= 64 else 128        # ~0.1 s of one-thread work per thread
     try:
-        one = json.loads(subprocess.run([exe, "1", "16", str(block_bytes), str(pct), str(seed), "1", str(level)],
-                                        capture_output=True, text=True, check=True, timeout=300).stdout)
-        full = json.loads(subprocess.run([exe, str(cores), str(sample_blocks), str(block_bytes), str(pct), str(seed), "3", str(level)],
-                                         capture_output=True, text=True, check=True, timeout=600).stdout)
+        one = _refbench(exe, 1, block_bytes, pct, seed, level=level, min_s=1.0, reps=1, unique=16)
+        full = _refbench(exe, logical, block_bytes, pct, seed, level=level, min_s=1.0, reps=3, unique=4 * logical)
     except Exception as e:
         return {"error": str(e)}
-    return {"value": round(full["compress_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": "reference",
-            "sample": f"{sample_blocks} x {block_bytes} B blocks of datagen -P{pct} -s{seed}, LZ4_compress_HC level {level}, best of 3, "
-                      f"static partition over {cores} threads",
+    return {"value": round(full["compress_GBps"], 3), "unit": "GB/s", "cores": logical, "kind": "reference",
+            "sample": f"{full['blocks']} x {block_bytes} B blocks of datagen -P{pct} -s{seed}, LZ4_compress_HC level {level}, "
+                      f"{full['blocks'] // logical} per thread, passes repeated >= 1 s, best of 3",
             "single_thread_GBps": round(one["compress_GBps"], 4),
-            "ref_comp_bytes": full["comp_bytes"], "ref_src_bytes": full["src_bytes"], "sample_blocks": sample_blocks}
+            "ref_comp_bytes": full["comp_bytes"], "ref_src_bytes": full["src_bytes"], "sample_blocks": full["blocks"]}
 
 
-def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, level=9, bs=256 << 10, with_cpu=True):
+def stream_copy_gbps(ctx, lz4_amd, torch, nbytes, stream):
+    """This box's own read+write stream rate: a plain 16-bytes-per-lane copy kernel of the library (2 * bytes / time)."""
+    L = lz4_amd.lib()
+    L.lz4amd_stream_copy_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    a.fill_(7)
+    ms = ctypes.c_float(0)
+    rc = L.lz4amd_stream_copy_ms(ctx._h, b.data_ptr(), a.data_ptr(), nbytes, 10, stream, ctypes.byref(ms))
+    if rc != 0 or ms.value <= 0:
+        return None
+    return 2.0 * nbytes / (ms.value * 1e-3) / 1e9
+
+
+def roofline_obj(kernel, ms, alg_bytes, copy_gbps, traffic):
+    ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 5),
+            "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
+            "frac_of_measured_copy": round(ach / copy_gbps, 5) if copy_gbps else None,
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": round(ms, 4)}
+
+
+def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, copy_gbps, level=9, bs=256 << 10, with_cpu=True):
     """BASELINE configs[3]: LZ4_compress_HC level 9 on 256 KiB blocks of the same GiB, device resident.
     Not part of `value`; reported next to it with its own roofline and CPU baseline."""
     U = data.numel()
@@ -141,25 +229,157 @@ def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, level=9, bs=256 
     ms = min(plan.launch_timed(stream)[0][0] for _ in range(3))
     dms = min(dplan.launch_timed(stream)[0][0] for _ in range(3))
     C = sum(cs)
+    tr = measured_traffic().get("compress_hc", {}).get("hbm_bytes_per_launch") if (nb == 4096 and pct == 60 and level == 9) else None
     res = {"workload": "configs[3]: %d independent %d-byte blocks (%.2f GiB), datagen -P%d, LZ4_compress_HC level %d, device resident"
                        % (nb, bs, U / 2**30, pct, level),
            "compress_GBps": round(U / (ms * 1e-3) / 1e9, 2), "kernel_ms": round(ms, 3),
            "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 2), "ratio": round(U / C, 4), "compressed_bytes": C,
-           "roofline": {"kernel": "compress_hc", "bound": "hbm", "achieved": round((U + C) / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": round((U + C) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
-                        "algorithmic_bytes_per_launch": U + C, "avg_ms": round(ms, 3)}}
-    try:                                                     # HBM bytes per launch from the committed PMC passes
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if nb == 4096 and bs == 256 << 10 and pct == 60 and level == 9:
-            res["roofline"]["traffic"] = pmc["compress_hc"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+           "roofline": roofline_obj("compress_hc", ms, U + C, copy_gbps, tr)}
     if with_cpu:
         cb = cpu_baseline_hc(bs, pct, seed, level)
         res["cpu_baseline"] = cb
         if cb and "ref_comp_bytes" in cb:
-            res["ratio_vs_reference"] = round(cb["ref_comp_bytes"] / sum(cs[:cb["sample_blocks"]]), 4)
+            n_s = cb["sample_blocks"]                        # the CPU sample is the table's first blocks
+            if n_s <= len(cs):
+                res["ratio_vs_reference"] = round(cb["ref_comp_bytes"] / sum(cs[:n_s]), 4)
     return res
+
+
+def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps):
+    """The per-GPU shape of configs[4]: 2048 x 4 MiB blocks (the GiB eight times over), blocks queue on the CUs."""
+    reps = (2048 * bs) // data.numel()
+    big = data.repeat(reps)
+    nb = big.numel() // bs
+    stride = (lz4_amd.compress_bound(bs) + 255) & ~255
+    comp = torch.empty((nb, stride), dtype=torch.uint8, device=data.device)
+    out = torch.empty(big.numel(), dtype=torch.uint8, device=data.device)
+    ctab = lz4_amd.BlockTable([big.data_ptr() + i * bs for i in range(nb)], [bs] * nb,
+                              [comp.data_ptr() + i * stride for i in range(nb)], [stride] * nb)
+    cplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, ctab)
+    cplan.launch(stream)
+    cs = cplan.results(stream)
+    dtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nb)], cs,
+                              [out.data_ptr() + i * bs for i in range(nb)], [bs] * nb)
+    dplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+    dplan.launch(stream)
+    assert dplan.results(stream) == [bs] * nb and torch.equal(out, big), "2048-block round trip is not bit exact"
+    cms = min(cplan.launch_timed(stream)[0][0] for _ in range(2))
+    dms = min(dplan.launch_timed(stream)[0][0] for _ in range(3))
+    U, C = big.numel(), sum(cs)
+    return {"workload": "configs[4] per-GPU shape: %d independent %d-byte blocks (%.0f GiB: the GiB of configs[1] x %d), device resident" % (nb, bs, U / 2**30, reps),
+            "compress_GBps": round(U / (cms * 1e-3) / 1e9, 2), "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 2),
+            "roundtrip_GBps": round(U / ((cms + dms) * 1e-3) / 1e9, 2),
+            "roofline_compress": roofline_obj("compress", cms, U + C, copy_gbps, None),
+            "roofline_decompress": roofline_obj("decompress", dms, U + C, copy_gbps, None)}
+
+
+def bench_frame(lz4_amd, host):
+    """configs[2]: the GiB as one frame (LZ4F_max4MB, blockLinked, content checksum) through the host-pointer API."""
+    class FrameInfo(ctypes.Structure):
+        _fields_ = [("blockSizeID", ctypes.c_int), ("blockMode", ctypes.c_int), ("contentChecksumFlag", ctypes.c_int),
+                    ("frameType", ctypes.c_int), ("contentSize", ctypes.c_ulonglong), ("dictID", ctypes.c_uint),
+                    ("blockChecksumFlag", ctypes.c_int)]
+
+    class Prefs(ctypes.Structure):
+        _fields_ = [("frameInfo", FrameInfo), ("compressionLevel", ctypes.c_int), ("autoFlush", ctypes.c_uint),
+                    ("favorDecSpeed", ctypes.c_uint), ("reserved", ctypes.c_uint * 3)]
+    L = lz4_amd.lib()
+    st, vp = ctypes.c_size_t, ctypes.c_void_p
+    L.LZ4F_compressFrameBound.restype = st
+    L.LZ4F_compressFrameBound.argtypes = [st, ctypes.POINTER(Prefs)]
+    L.LZ4F_compressFrame.restype = st
+    L.LZ4F_compressFrame.argtypes = [vp, st, vp, st, ctypes.POINTER(Prefs)]
+    L.LZ4F_isError.argtypes = [st]
+    L.LZ4F_createDecompressionContext.restype = st
+    L.LZ4F_createDecompressionContext.argtypes = [ctypes.POINTER(vp), ctypes.c_uint]
+    L.LZ4F_freeDecompressionContext.argtypes = [vp]
+    L.LZ4F_decompress.restype = st
+    L.LZ4F_decompress.argtypes = [vp, vp, ctypes.POINTER(st), vp, ctypes.POINTER(st), vp]
+    import numpy as np
+    p = Prefs()
+    p.frameInfo.blockSizeID = 7; p.frameInfo.blockMode = 0; p.frameInfo.contentChecksumFlag = 1      # LZ4F_max4MB, linked
+    n = host.size
+    cap = L.LZ4F_compressFrameBound(n, ctypes.byref(p))
+    dst = np.empty(cap, dtype=np.uint8)
+    t0 = time.perf_counter()
+    fsz = L.LZ4F_compressFrame(dst.ctypes.data, cap, host.ctypes.data, n, ctypes.byref(p))
+    tc = time.perf_counter() - t0
+    if L.LZ4F_isError(fsz):
+        return {"error": "LZ4F_compressFrame failed"}
+    header = bytes(dst[:7]).hex()
+    out = np.empty(n, dtype=np.uint8)
+    d = vp()
+    L.LZ4F_createDecompressionContext(ctypes.byref(d), 100)
+    t0 = time.perf_counter()
+    ipos = opos = 0
+    while ipos < fsz:
+        ss = st(fsz - ipos); ds = st(n - opos)
+        r = L.LZ4F_decompress(d, out.ctypes.data + opos, ctypes.byref(ds), dst.ctypes.data + ipos, ctypes.byref(ss), None)
+        if L.LZ4F_isError(r):
+            L.LZ4F_freeDecompressionContext(d)
+            return {"error": "LZ4F_decompress failed"}
+        ipos += ss.value; opos += ds.value
+        if r == 0:
+            break
+    td = time.perf_counter() - t0
+    L.LZ4F_freeDecompressionContext(d)
+    ok = opos == n and bool((out == host).all())
+    return {"workload": "configs[2]: %.2f GiB as one frame, LZ4F_max4MB, blockLinked, content checksum; host buffers (upload, kernels, download, XXH32 on the host)" % (n / 2**30),
+            "header_hex": header, "frame_bytes": int(fsz), "ratio": round(n / fsz, 4),
+            "compress_GBps": round(n / tc / 1e9, 3), "decompress_GBps": round(n / td / 1e9, 3), "bit_exact": ok,
+            "note": "PCIe inclusive and single-threaded on the host side: a parity path, not the HBM-resident rate"}
+
+
+def _sync(torch, dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def data_path(dist, torch, dev, rank, world, data, comp, csizes):
+    """configs[4]'s movement with torch.distributed collectives (backend nccl = RCCL over xGMI on the GPU
+    box, gloo in the CPU test): scatter of the input shards from rank 0, all-gather of the compressed sizes, gather of
+    the payloads (packed per rank) to rank 0.  Returns seconds per phase and, on rank 0, the gathered payloads
+    re-ordered by (rank, block) with the help of the sizes table."""
+    U = data.numel()
+    recv = torch.empty_like(data)
+    shards = [data] + [data.clone() for _ in range(world - 1)] if rank == 0 else None      # rank 0 holds every shard
+    _sync(torch, dev); dist.barrier()
+    t0 = time.perf_counter()
+    dist.scatter(recv, scatter_list=shards, src=0)
+    _sync(torch, dev); dist.barrier()
+    t_scatter = time.perf_counter() - t0
+    del shards
+    # compressed sizes of every block of every rank
+    mine = torch.tensor(list(csizes), dtype=torch.int32, device=dev)
+    allsz = [torch.empty_like(mine) for _ in range(world)]
+    t0 = time.perf_counter()
+    dist.all_gather(allsz, mine)
+    _sync(torch, dev)
+    t_sizes = time.perf_counter() - t0
+    # payloads: the used part of every slot, packed per rank, gathered on a fixed stride (the largest packed size)
+    totals = [int(t.sum().item()) for t in allsz]
+    slot = max(totals)
+    packed = torch.zeros(slot, dtype=torch.uint8, device=dev)
+    off = 0
+    for i, c in enumerate(csizes):
+        packed[off:off + c] = comp[i, :c]
+        off += c
+    _sync(torch, dev); dist.barrier()
+    t0 = time.perf_counter()
+    gl = [torch.empty(slot, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(packed, gather_list=gl, dst=0)
+    _sync(torch, dev); dist.barrier()
+    t_gather = time.perf_counter() - t0
+    blocks = None
+    if rank == 0:                                            # (rank, block) order from the sizes table
+        blocks = []
+        for r in range(world):
+            o = 0
+            for c in allsz[r].tolist():
+                blocks.append(gl[r][o:o + c])
+                o += c
+    return {"scatter_s": t_scatter, "sizes_s": t_sizes, "gather_s": t_gather, "received": recv,
+            "scatter_bytes": U * (world - 1), "gather_bytes": sum(totals), "blocks": blocks, "sizes": [t.tolist() for t in allsz]}
 
 
 def main():
@@ -172,6 +392,8 @@ def main():
     ap.add_argument("--pct", type=int, default=60, help="datagen -P compressibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hc", action="store_true", help="skip the LZ4_compress_HC (configs[3]) side measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 2048-block shape and the configs[2] frame object")
+    ap.add_argument("--no-data-path", action="store_true", help="N>1: skip the RCCL scatter / gather measurement")
     args = ap.parse_args()
 
     import torch
@@ -255,28 +477,37 @@ def main():
     d_total /= args.steps
     assert torch.equal(out, data), "round trip is not bit exact after the timed loop"
 
+    # ---- N > 1: the movement configs[4] names, over RCCL (not part of `value`, which stays the kernel-only rate)
+    dp = None
+    if world > 1 and not args.no_data_path:
+        try:
+            r = data_path(dist, torch, dev, rank, world, data, comp, csizes)
+            ok = bool(torch.equal(r["received"], data)) if rank == 0 else True       # rank 0 scattered copies of its own shard
+            if rank == 0:                                    # every gathered block of rank 0 is byte-identical to its slot
+                ok = ok and all(bool(torch.equal(r["blocks"][i], comp[i, :csizes[i]])) for i in range(0, nb, max(1, nb // 16)))
+                ok = ok and len(r["blocks"]) == world * nb
+            dp = {k: aggregate(dist, r[k], 0, device=dev)[0] for k in ("scatter_s", "sizes_s", "gather_s")}
+            dp.update({"ok": ok, "scatter_bytes": r["scatter_bytes"], "gather_bytes": r["gather_bytes"]})
+        except Exception as e:
+            dp = {"error": str(e)}
+
     # ---- not part of the step: the batched XXH32 kernel (frame block checksums) over the same blocks
     xplan = lz4_amd.Plan(ctx, lz4_amd.OP_XXH32, lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb, [0] * nb, [0] * nb))
     xplan.launch(stream); xplan.results(stream)
     x_ms = sum(xplan.launch_timed(stream)[1] for _ in range(3)) / 3
 
     if rank == 0:
+        copy_gbps = stream_copy_gbps(ctx, lz4_amd, torch, 1 << 30, stream)
         alg = {"compress": U + C, "decompress": U + C}        # U read + C written / C read + U written
+        pmc = measured_traffic() if (nb == 256 and bs == 4 << 20 and args.pct == 60) else {}
+        traffic = {k: pmc.get(k, {}).get("hbm_bytes_per_launch") for k in ("compress", "decompress")}
         kernels = []
         for name, ms in k_ms.items():
             gbps = alg[name] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             kernels.append({"kernel": name, "avg_ms": round(ms, 4), "algorithmic_bytes": alg[name],
-                            "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)})
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
-        traffic = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if nb == 256 and bs == 4 << 20 and args.pct == 60:
-                traffic = {k: pmc[k]["hbm_bytes_per_launch"] for k in ("compress", "decompress")}
-        except Exception:
-            pass
+                            "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+                            "frac_of_measured_copy": round(gbps / copy_gbps, 4) if copy_gbps else None})
         dom = max(kernels, key=lambda k: k["avg_ms"])
-        dec = next(k for k in kernels if k["kernel"] == "decompress")
         result = {
             "metric": "GB/s compress + decompress, 4 MB independent blocks (uncompressed bytes through one compress+decompress pass per second)",
             "value": round(bytes_all / t_max / 1e9, 3), "unit": "GB/s",
@@ -286,32 +517,50 @@ def main():
             "dtype": "u8", "data": "synthetic (datagen -P%d restated in tools/datagen.c, md5-pinned to the reference tool)" % args.pct,
             "config": {"workload": "configs[1]: %d independent %d-byte blocks per GPU (%.2f GiB), datagen -P%d -s<rank>, block compress + decompress, device resident"
                                    % (nb, bs, U / 2**30, args.pct),
-                       "blocks_per_gpu": nb, "block_bytes": bs, "parallelism": "blocks sharded over %d GPU(s), no data-path collective" % world},
+                       "blocks_per_gpu": nb, "block_bytes": bs, "parallelism": "blocks sharded over %d GPU(s), no collective inside the codec" % world},
             "compress_GBps": round(U / (c_total * 1e-3) / 1e9, 2),
             "decompress_GBps": round(U / (d_total * 1e-3) / 1e9, 2),
             "ratio": round(U / C, 4), "compressed_bytes": C,
-            "roofline": {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": traffic.get(dom["kernel"]),
-                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_ms": dom["avg_ms"]},
-            "roofline_decompress": {"bound": "hbm", "achieved": dec["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                    "frac": dec["frac_of_hbm_peak"], "traffic": traffic.get("decompress"),
-                                    "algorithmic_bytes_per_launch": dec["algorithmic_bytes"], "avg_ms": dec["avg_ms"]},
+            "roofline": roofline_obj(dom["kernel"], dom["avg_ms"], dom["algorithmic_bytes"], copy_gbps, traffic.get(dom["kernel"])),
+            "roofline_decompress": roofline_obj("decompress", k_ms["decompress"], alg["decompress"], copy_gbps, traffic.get("decompress")),
             "kernels": kernels,
+            "kernel_sources_sha": kernel_sources_sha(),
             "extras": {"xxh32_batch_GBps": round(U / (x_ms * 1e-3) / 1e9, 1), "xxh32_batch_ms": round(x_ms, 3),
                        "note": "XXH32 (seed 0) of every 4 MiB block, one wave per block; not in `value`"},
         }
+        if dp is not None:
+            if "error" not in dp:
+                move_s = dp["scatter_s"] + dp["sizes_s"] + dp["gather_s"]
+                step_s = t_max / args.steps
+                dp = {"collectives": "RCCL over xGMI: scatter of %d x %.2f GiB from rank 0, all_gather of int32 csize[%d], gather of the packed payloads"
+                                     % (world - 1, U / 2**30, nb),
+                      "scatter_s": round(dp["scatter_s"], 5), "sizes_s": round(dp["sizes_s"], 5), "gather_s": round(dp["gather_s"], 5),
+                      "scatter_GBps": round(dp["scatter_bytes"] / dp["scatter_s"] / 1e9, 2) if dp["scatter_s"] > 0 else None,
+                      "end_to_end_GBps": round(U * world / (step_s + move_s) / 1e9, 3), "kernel_only_GBps": round(bytes_all / t_max / 1e9, 3),
+                      "gather_GBps": round(dp["gather_bytes"] / dp["gather_s"] / 1e9, 2) if dp["gather_s"] > 0 else None,
+                      "payloads_reassembled": dp["ok"], "note": "one scatter + one compress/decompress step + one gather; unmeasured on hardware until a SCALE record exists"}
+            result["data_path"] = dp
         if world == 1 and not args.no_hc and U % (256 << 10) == 0:
             try:
-                result["hc"] = bench_hc(ctx, lz4_amd, torch, data, out, stream, args.pct, plan_s["seed"],
+                result["hc"] = bench_hc(ctx, lz4_amd, torch, data, out, stream, args.pct, plan_s["seed"], copy_gbps,
                                         with_cpu=not args.no_cpu_baseline)
             except Exception as e:                           # the side measurement never kills the bench line
                 result["hc"] = {"error": str(e)}
+        if world == 1 and not args.no_extras and nb == 256 and bs == 4 << 20:
+            try:
+                result["shape_2048"] = bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps)
+            except Exception as e:
+                result["shape_2048"] = {"error": str(e)}
+            try:
+                result["frame"] = bench_frame(lz4_amd, host)
+            except Exception as e:
+                result["frame"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(nb, bs, args.pct, plan_s["seed"])
+            cb = cpu_baseline(bs, args.pct, plan_s["seed"])
             result["cpu_baseline"] = cb
-            if cb and "ref_comp_bytes" in cb:
-                ours = sum(csizes[:min(nb, 64)])
-                result["ratio_vs_reference"] = round(cb["ref_comp_bytes"] / ours, 4)
+            if cb and "ref_comp_bytes_per_unique" in cb:
+                ours = sum(csizes[:min(nb, cb["unique_blocks"])])
+                result["ratio_vs_reference"] = round(cb["ref_comp_bytes_per_unique"] / ours, 4)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -102,6 +102,11 @@ void  lz4amd_dev_free(void* d_ptr);
 int   lz4amd_dev_upload(void* d_dst, const void* h_src, size_t bytes);
 int   lz4amd_dev_download(void* h_dst, const void* d_src, size_t bytes);
 
+/* Calibration for roofline reports: time `reps` launches of a plain 16-bytes-per-lane device copy of `bytes` bytes
+ * (d_src -> d_dst, both in HBM) with HIP events on `stream`; *best_ms = fastest launch.  Bandwidth = 2 * bytes / time
+ * (every byte is read once and written once). */
+int  lz4amd_stream_copy_ms(lz4amd_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int reps, void* stream, float* best_ms);
+
 #ifdef __cplusplus
 }
 #endif

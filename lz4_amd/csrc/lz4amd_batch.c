@@ -305,3 +305,28 @@ int lz4amd_compress_hc_batch(lz4amd_ctx* ctx, const void* const* d_src, const in
 int lz4amd_decompress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                             void* const* d_dst, const int* dst_caps, int* results, int n, void* stream)
 { return one_shot(ctx, LZ4AMD_OP_DECOMPRESS, d_src, src_sizes, d_dst, dst_caps, results, n, stream); }
+
+/* ------------------------------------------------------------------ calibration */
+int lz4amd_stream_copy_ms(lz4amd_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int reps, void* stream, float* best_ms)
+{
+    void *e0, *e1;
+    float best = -1.f;
+    int r;
+    if (!ctx || !d_dst || !d_src || !best_ms || bytes < 16 || reps < 1) return LZ4AMD_E_ARG;
+    e0 = lz4amd_hip_event_create(); e1 = lz4amd_hip_event_create();
+    if (!e0 || !e1) { lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1); return LZ4AMD_E_RUNTIME; }
+    for (r = 0; r < reps + 1; r++) {                       /* one untimed warm-up launch */
+        float ms;
+        if (lz4amd_hip_event_record(e0, stream) || lz4amd_hip_launch_stream_copy(d_dst, d_src, bytes, (unsigned)ctx->n_cus * 8u, stream)
+            || lz4amd_hip_event_record(e1, stream) || lz4amd_hip_event_sync(e1)) {
+            lz4amd_set_error(lz4amd_hip_errstr());
+            lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1);
+            return LZ4AMD_E_RUNTIME;
+        }
+        ms = lz4amd_hip_event_ms(e0, e1);
+        if (r > 0 && ms > 0.f && (best < 0.f || ms < best)) best = ms;
+    }
+    lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1);
+    *best_ms = best;
+    return best > 0.f ? LZ4AMD_OK : LZ4AMD_E_RUNTIME;
+}

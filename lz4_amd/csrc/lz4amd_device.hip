@@ -21,6 +21,12 @@ __global__ void __launch_bounds__(kCmpThreads) lz4amd_k_compress(lz4amd_comp_par
 __global__ void __launch_bounds__(kHcThreads) lz4amd_k_compress_hc(lz4amd_hc_params p) { hc_batch_body(p); }
 __global__ void __launch_bounds__(64) lz4amd_k_xxh32(lz4amd_xxh_params p) { xxh32_block_body(p); }
 
+// calibration: a plain 16-bytes-per-lane stream copy, the bandwidth this box's HBM actually delivers to a read+write stream
+__global__ void __launch_bounds__(256) lz4amd_k_stream_copy(const lz4amd_u32x4* __restrict__ src, lz4amd_u32x4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------- runtime glue
 static thread_local char g_err[256] = "";
 static int fail(hipError_t e, const char* what) {
@@ -89,6 +95,12 @@ extern "C" int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned
     if (!p->n_blocks || !grid) return 0;
     HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
     hipLaunchKernelGGL(lz4amd_k_compress_hc, dim3(grid), dim3(kHcThreads), kHcLdsBytes, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int lz4amd_hip_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, unsigned grid, void* s) {
+    if (bytes < 16 || !grid) return 0;
+    hipLaunchKernelGGL(lz4amd_k_stream_copy, dim3(grid), dim3(256), 0, (hipStream_t)s, (const lz4amd_u32x4*)d_src, (lz4amd_u32x4*)d_dst, bytes / 16);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -122,6 +122,66 @@ def test_decompress_hostile_input_matches_oracle(ctx, ocodec, datagen, golden):
     assert outs[-1][0] < 0                                             # fuzzer.c:1110-1119
 
 
+def test_decompress_hostile_input_against_the_real_reference(ctx, ocodec, reflib, datagen, golden):
+    """The same mutations, judged by the real LZ4_decompress_safe (oracle/_ref travels to the GPU box): whatever
+    the reference rejects we reject; whatever we accept is byte-identical to what the reference produces.  The
+    one allowed divergence - the reference's fast loop lets a few malformed streams through that its own safe
+    tail (and this decoder, which applies lz4.c:2279 / 2312-2318 / 2423 to every sequence) rejects - is counted
+    and bounded."""
+    rnd = random.Random(11)
+    muts, caps = [], []
+    for size, count in ((150000, 400), (3000, 400)):
+        base = ocodec.compress(datagen(size, 60, 9))[1]
+        for t in range(count):
+            cc = bytearray(base[:rnd.randint(1, len(base))] if t % 3 == 0 else base)
+            for _ in range(rnd.randint(1, 3)):
+                cc[rnd.randrange(len(cc))] = rnd.randrange(256)
+            muts.append(bytes(cc)); caps.append(size)
+    outs = gpu_decompress(ctx, muts, caps)
+    stricter = 0
+    for cc, cap, (r, o) in zip(muts, caps, outs):
+        dst = ctypes.create_string_buffer(cap + 8)
+        rr = reflib.LZ4_decompress_safe(cc, dst, len(cc), cap)
+        if rr < 0:
+            assert r < 0, "accepted a stream the reference rejects"
+        elif r >= 0:
+            assert r == rr and o == dst.raw[:rr]
+        else:
+            stricter += 1
+    assert stricter <= len(muts) // 50, stricter          # a handful at most (none on this seed set so far)
+
+
+def test_decompress_long_overlapping_matches(ctx, ocodec):
+    """Periodic runs longer than the output ring (see tests/test_kernels_emulated.py): reference-compressed,
+    decoded on the GPU, compared byte for byte."""
+    from test_kernels_emulated import _periodic_corpus
+    cases = _periodic_corpus()
+    comps = [ocodec.compress(d)[1] for d in cases]
+    for d, (r, o) in zip(cases, gpu_decompress(ctx, comps, [len(d) for d in cases])):
+        assert r == len(d) and o == d
+
+
+def test_compress_ratio_window_grid(ctx, reflib, datagen):
+    """The fast compressor's size stays within 3 % of the reference's on datagen P20 / P50 / P90 at 64 KiB,
+    256 KiB and 4 MiB blocks (BASELINE north_star: +-3 % of reference ratio), and every block decodes."""
+    import lz4_amd
+    for pct in (20, 50, 90):
+        for bs, nb in ((65536, 32), (262144, 8), (4 << 20, 2)):
+            data = datagen(bs * nb, pct, 7)
+            t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            comp, cs, _ = lz4_amd.compress_blocks(ctx, t, bs)
+            ref_total = 0
+            for i in range(nb):
+                blk = data[i * bs:(i + 1) * bs]
+                cap = bs + bs // 255 + 16
+                cb = ctypes.create_string_buffer(cap)
+                ref_total += reflib.LZ4_compress_default(blk, cb, bs, cap)
+            ours = sum(cs)
+            assert abs(ours - ref_total) <= 0.03 * ref_total, (pct, bs, ours, ref_total)
+            out, res, _ = lz4_amd.decompress_blocks(ctx, comp, cs, bs, bs * nb)
+            assert res == [bs] * nb and torch.equal(out, t)
+
+
 def test_compress_decodes_with_oracle_decoder(ctx, ocodec, corpus):
     outs = gpu_compress(ctx, corpus)
     for d, (r, c) in zip(corpus, outs):

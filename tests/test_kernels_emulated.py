@@ -97,6 +97,57 @@ def test_decompress_capacities_and_alignment(emu, ocodec, datagen):
         assert r == n and o == d
 
 
+def _periodic_corpus():
+    """Long matches that overlap themselves (offset < length): periods that do and do not divide the output ring,
+    runs far longer than the 64 KB window, plus a mix of random stretches, runs and ordinary matches."""
+    rnd = random.Random(3)
+    cases = []
+    for per in (1, 2, 3, 5, 7, 10, 15, 16, 17, 28, 100, 1000, 4097):
+        pat = bytes(rnd.randrange(256) for _ in range(per))
+        cases.append((pat * (250000 // per + 1))[:250000])
+    cases += [b"abcde" * 40000, b"0123456789" * 30000, (b"a line of twenty-eight bytes\n" * 10000)]
+    buf = bytearray()
+    while len(buf) < 600000:
+        k = rnd.randrange(4)
+        if k == 0:
+            buf += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 300)))
+        elif k == 1:
+            per = rnd.randrange(1, 40)
+            pat = bytes(rnd.randrange(256) for _ in range(per))
+            buf += pat * (rnd.randrange(1, 200000) // per + 1)
+        elif k == 2 and len(buf) > 100:
+            o = rnd.randrange(1, min(len(buf), 65535))
+            for _ in range(rnd.randrange(4, 2000)):
+                buf.append(buf[-o])
+        else:
+            buf += bytes([rnd.randrange(4)]) * rnd.randrange(1, 50)
+    cases.append(bytes(buf))
+    return cases
+
+
+def test_decompress_long_overlapping_matches(emu, ocodec):
+    """Periodic runs longer than the output ring: every byte must come from a period that is still resident
+    (the round-1 decoder read the FIRST period, which the ring had recycled after ~96 KB)."""
+    cases = _periodic_corpus()
+    comps = [ocodec.compress(d)[1] for d in cases]
+    for d, (r, o) in zip(cases, emu_decompress(emu, comps, [len(d) for d in cases])):
+        assert r == len(d) and o == d
+
+
+def test_decompress_records_longer_than_the_rings(emu, reflib):
+    """Few sequences with very long literal runs and matches (noise through the HC compressor, zeros): records
+    that the feeder cuts in pieces."""
+    cases = [random.Random(s).randbytes(1 << 20) for s in (11, 12)] + [bytes(2 << 20), b"0123456789abcdef" * (1 << 16)]
+    comps = []
+    for d in cases:
+        cap = len(d) + len(d) // 255 + 16
+        cb = ctypes.create_string_buffer(cap)
+        n = reflib.LZ4_compress_HC(d, cb, len(d), cap, 9)
+        comps.append(cb.raw[:n])
+    for d, (r, o) in zip(cases, emu_decompress(emu, comps, [len(d) for d in cases])):
+        assert r == len(d) and o == d
+
+
 def test_decompress_4mib_block(emu, ocodec, datagen):
     d = datagen(4 << 20, 60, 0)
     (r, o), = emu_decompress(emu, [ocodec.compress(d)[1]], [len(d)])

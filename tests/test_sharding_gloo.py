@@ -1,5 +1,9 @@
-"""The N>1 path of bench.py on CPU: world size 2 over gloo.  Blocks shard across ranks with no
-data-path collective; the only collectives are the max-over-ranks time and the sum of bytes."""
+"""The N>1 path of bench.py on CPU: world size 2 over gloo.  Blocks shard across ranks; the codec has no
+collective; the movement of BASELINE configs[4] (scatter of the input from rank 0, all-gather of the compressed
+sizes, gather of the payloads - bench.data_path, the very function the GPU job runs over RCCL) is exercised with real
+bytes: every rank's blocks are compressed by the oracle (the CPU stand-in for the kernels here), gathered, put back in
+(rank, block) order from the sizes table and decoded."""
+import ctypes
 import os
 import socket
 import sys
@@ -11,6 +15,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+NB, BS = 6, 20000          # blocks per rank, bytes per block (ragged compressed sizes)
+
 
 def _free_port():
     s = socket.socket()
@@ -18,6 +24,14 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _oracle():
+    so = os.path.join(ROOT, "oracle", "liblz4oracle.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liblz4oracle.so"], check=True)
+    return ctypes.CDLL(so)
 
 
 def _worker(rank, world, port, out):
@@ -31,20 +45,56 @@ def _worker(rank, world, port, out):
     owned[plan["first_block"]:plan["first_block"] + plan["n_blocks"]] = 1
     dist.all_reduce(owned)
     t_max, b_sum = bench.aggregate(dist, 1.0 + rank, 1000 * (rank + 1))
-    out[rank] = (plan, int(owned.min()), int(owned.max()), t_max, b_sum)
+
+    # ---- real bytes through the scatter / all-gather / gather path
+    orc = _oracle()
+    dev = torch.device("cpu")
+    # rank 0 is the only one with the corpus: what the other ranks hold before the scatter is scratch
+    host = bench.gen_data(NB * BS, 60 - 10 * rank, 3) if rank == 0 else bench.gen_data(NB * BS, 90, 99)
+    data = torch.from_numpy(host.copy())
+    stride = orc.lz4o_compress_bound(BS)
+    # (the scatter hands every rank a copy of rank 0's shard list entry; see bench.data_path)
+    comp = torch.zeros((NB, stride), dtype=torch.uint8)
+    csizes = []
+    # compress AFTER the scatter in the real job; here the scatter result is checked first, then the received bytes are compressed
+    recv_probe = bench.data_path(dist, torch, dev, rank, world, data, comp, [1] * NB)["received"]
+    src = recv_probe.numpy()
+    for i in range(NB):
+        blk = src[i * BS:(i + 1) * BS].tobytes()
+        dst = ctypes.create_string_buffer(stride)
+        c = orc.lz4o_compress_default(blk, dst, BS, stride)
+        assert c > 0
+        comp[i, :c] = torch.frombuffer(bytearray(dst.raw[:c]), dtype=torch.uint8)
+        csizes.append(c)
+    r = bench.data_path(dist, torch, dev, rank, world, torch.from_numpy(src.copy()), comp, csizes)
+    ok_blocks = None
+    if rank == 0:
+        ok_blocks = 0
+        for k, blk in enumerate(r["blocks"]):               # every gathered block decodes to the block it came from
+            cbytes = blk.numpy().tobytes()
+            dst = ctypes.create_string_buffer(BS)
+            n = orc.lz4o_decompress_safe(cbytes, dst, len(cbytes), BS)
+            i = k % NB
+            if n == BS and dst.raw == host[i * BS:(i + 1) * BS].tobytes():
+                ok_blocks += 1
+    out[rank] = (plan, int(owned.min()), int(owned.max()), t_max, b_sum,
+                 bool(torch.equal(recv_probe, torch.from_numpy(bench.gen_data(NB * BS, 60, 3)))), r["sizes"], ok_blocks)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_aggregation():
+def test_two_rank_sharding_movement_and_aggregation():
     world, port = 2, _free_port()
     with mp.Manager() as m:
         out = m.dict()
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         res = dict(out)
     assert set(res) == {0, 1}
-    for rank, (plan, omin, omax, t_max, b_sum) in res.items():
+    for rank, (plan, omin, omax, t_max, b_sum, scattered_ok, sizes, ok_blocks) in res.items():
         assert plan["rank"] == rank and plan["world"] == world and plan["seed"] == rank
         assert omin == 1 and omax == 1                     # a partition: every block exactly once
         assert t_max == 2.0                                # max over ranks
         assert b_sum == 3000.0                             # sum over ranks
+        assert scattered_ok                                # every rank received rank 0's bytes
+        assert len(sizes) == world and all(len(s) == NB for s in sizes) and sizes[0] == sizes[1]   # same input -> same sizes, known everywhere
+    assert res[0][7] == world * NB                         # rank 0 put every payload back in order and decoded it
