@@ -668,7 +668,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
         { const uint64_t t = clock_ticks(); t_work += t - ts - tr; t_retry += tr; }
     }
 out:
-    if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[2] = n_iters | ((uint64_t)n_retried << 32); prof[3] = k; }
+    if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[5] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); }
 }
 
 // ------------------------------------------------------------------------------ one block
@@ -698,7 +698,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
 
     // ---- stage A: the record table (a malformed block ends here, nothing written)
     uint32_t nseq = 0, total = 0;
-    if (!pre::preparse_block(src, csize, cap, prefix, rectab, smem, nseq, total, nullptr)) {
+    if (!pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof)) {
         if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]);
         return;
     }

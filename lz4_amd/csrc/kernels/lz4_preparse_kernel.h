@@ -1,17 +1,28 @@
 // lz4_preparse_kernel.h -- stage A of the LZ4 block decoder (gfx950): the serial token chain of a block becomes a
-// table of sequence records.  All 1024 threads of the workgroup take part.
+// table of sequence records {output position, literal source, literal length, offset} in the workgroup's scratch.
+// All 1024 threads of the workgroup take part; the stream is read from memory (L1 / L2), everything else is LDS.
 //
-// The compressed stream is cut in 1024 SEGMENTS; every thread follows the chain of its own segment, starting 768
-// bytes EARLY at an arbitrary byte and relying on LZ4 chains self-synchronising (a wrong start merges with the true
-// chain after a few hundred bytes).  A fix-point pass then makes it exact: segment j is right iff it started where
-// segment j-1 exited; threads whose guess was wrong re-walk from the true entry (segment 0 starts at byte 0, so by
-// induction the result is the true chain for every input; 1-3 rounds on real data).  An accounting walk counts
-// sequences and output bytes and applies the input-side format rules (read_variable_length lz4.c:1979-2014, the
-// last-literals test lz4.c:2279, 2312-2318), block-wide prefix sums give every segment its first sequence number and
-// output position, and a last walk writes the records (output-side rules lz4.c:2356, 2423 applied) - so a malformed
-// block is rejected before a byte of output is written.  The warm-up walk runs mostly over literal bytes misread as
-// tokens (a step per ~6.5 bytes), so it is a position-only loop with one byte load per trip; rarer token shapes are
-// parked and handled every fourth trip.  Blocks whose compressed bytes fit in LDS are walked out of LDS.
+// The stream is handled in SPANS of at most 1 MB (the span's token bitmap, one bit per stream byte, is 128 KB of LDS).
+// A span is cut in up to 1024 SEGMENTS, one per thread:
+//   P1  every thread walks the chain of its segment from the segment's first byte (the thread of the span's true
+//       entry: from the entry), marking the token positions it visits in the bitmap.  A wrong start walks over
+//       literal bytes misread as tokens (~6.5 B per step) and merges with the true chain after a few hundred bytes
+//       (LZ4 chains self-synchronise).  One stream byte per trip, no divergence.
+//   P2  every thread walks on from its exit (the "bridge") until it steps on a position a later thread marked.
+//   P3  the true chain is stitched by induction: the entry's thread is true from the entry; where a true thread's
+//       bridge merged into thread k's marks, thread k is true from there on.  The set of true threads is found by
+//       pointer doubling over the merge links (10 rounds).  A bridge that never merged ends the span early at its
+//       last (true) token - never a wrong answer, only a shorter span.
+//   P4  marks before a thread's merge point and marks of skipped threads are dropped, the bridges of the true
+//       threads are added: the bitmap now holds exactly the true tokens of the span.
+//   P5  the token positions go to a list; 1024 tokens at a time, a thread decodes one sequence completely (both
+//       length fields, offset), checks that it starts where its predecessor ended - the decoder, not the walk, is the
+//       authority on the chain - and that it obeys the reference's input-side rules (read_variable_length
+//       lz4.c:1979-2014); a block-wide scan places the sequences in the output; the output-side rules (lz4.c:2279,
+//       2356, 2423) are applied and the records written, coalesced.
+// Tokens with a length field longer than 64 bytes and the block's last sequence (lz4.c:2279, 2312-2318) go through a
+// wave-cooperative SLOW PATH that takes one token at a time, whatever its size.
+// A malformed block is rejected here, before a byte of output is written.
 #pragma once
 #include "lz4_common.h"
 
@@ -20,27 +31,37 @@ namespace lz4amd { namespace pre {
 struct alignas(16) SeqRec { uint32_t outpos, litpos, ll, off; };
 
 enum : uint32_t {
-    kDecThreads = 1024,
-    kSegShift = 8,
-    kSeg = 1u << kSegShift,                     // compressed bytes per pre-parse segment (granularity)
-    kPreLanes = 1024,                           // pre-parse lanes per block (segments)
-    kPreWarm = 768,                             // speculative warm-up distance
+    kThreads = 1024,
+    kSpanMax = 1u << 20,                        // stream bytes per span
+    kSegMin = 256,                              // a thread's segment is at least this long (short blocks use fewer threads)
+    kBridgeTrips = 192,                         // lockstep trips of the bridge walk
+    kExtMax = 64,                               // longer length fields take the slow path
     kBias = 65536,                              // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kNone = 0xFFFFFFFFu,
 };
 
 // LDS carve-up (bytes)
 enum : uint32_t {
-    kOffScan = 0,                                            // u32[64] (3 per wave needed)
-    kOffMisc = kOffScan + 64 * 4,                            // u32[32]
-    kOffSegExit = kOffMisc + 32 * 4,
-    kOffRecStage = kOffSegExit + kPreLanes * 4,              // SeqRec[4][kPreLanes]: records wait here to leave four at a time
-    kOffCStage = kOffRecStage,                               // the compressed block itself, when it fits (then the records need no staging)
-    kPreLdsBytes = 152u << 10,
-    kCStageMax = kPreLdsBytes - kOffCStage - 32,             // largest compressed block the pre-parse walks out of LDS
+    kOffScan = 0,                               // u32[64] block scans
+    kOffMisc = kOffScan + 64 * 4,               // u32[32]
+    kOffOpos = kOffMisc + 32 * 4,               // u32[kThreads] where a thread's bridge ended
+    kOffTin = kOffOpos + kThreads * 4,          // u32[kThreads] where the true chain enters a thread's marks
+    kOffJump = kOffTin + kThreads * 4,          // u16[kThreads] merge links
+    kOffKind = kOffJump + kThreads * 2,         // u8[kThreads] how a thread's bridge ended
+    kOffMark = kOffKind + kThreads,             // u8[kThreads] on the true chain?
+    kOffBitmap = (kOffMark + kThreads + 15) & ~15u,   // u32[kSpanMax / 32]
+    kPreLdsBytes = kOffBitmap + kSpanMax / 8,
 };
-static_assert(kOffRecStage + 4 * kPreLanes * 16 <= kPreLdsBytes, "LDS budget");
-enum : uint32_t { M_ERR = 1, M_FIRSTBAD = 5 };
+static_assert(kPreLdsBytes <= 152u * 1024u, "LDS budget");
+enum : uint32_t { M_ERR = 1, M_TERM = 8, M_NX, M_OBASE, M_NREC, M_RC };
+
+// scratch of one workgroup: the record table (every sequence but the last takes >= 3 stream bytes; +1 last, +1 sentinel)
+// followed by the token list of one span
+__host__ __device__ inline uint64_t table_bytes(uint32_t max_csize) { return ((uint64_t)max_csize / 3 + 4) * sizeof(SeqRec); }
+__host__ __device__ inline uint64_t scratch_bytes(uint32_t max_csize) {
+    const uint32_t span = max_csize < kSpanMax ? max_csize : kSpanMax;
+    return table_bytes(max_csize) + ((uint64_t)span / 3 + 8) * 4;
+}
 
 // 16 bytes as four dwords; byte i of the chunk is byte (i & 3) of dword (i >> 2).
 // (written with selects on whole dwords: indexing the vector dynamically would send it to scratch)
@@ -57,293 +78,7 @@ __device__ __forceinline__ void chunk_set_byte(U32x4& a, uint32_t i, uint32_t b)
     a[2] = (k == 2) ? ((a[2] & ~m) | v) : a[2];
     a[3] = (k == 3) ? ((a[3] & ~m) | v) : a[3];
 }
-
-
-// scratch of one workgroup: the sequence-record table of the block it is decoding.  Every sequence
-// but the last takes >= 3 compressed bytes; +1 last, +1 sentinel.
-__host__ __device__ inline uint64_t scratch_bytes(uint32_t max_csize) {
-    return ((uint64_t)max_csize / 3 + 4) * sizeof(SeqRec);
-}
-
-
-// The compressed stream as the pre-parse walkers see it: global memory, served by the CU's L1 (few lanes
-// walk long stretches - see preparse_block - so their current lines stay L1 resident) - or, for a block
-// whose compressed bytes fit beside the pre-parse's own LDS (<= kCStageMax: every block up to 256 KB at
-// ratio >= 1.8), a copy of it in LDS: a walk is a chain of dependent loads, ~2 k cycles each from memory,
-// ~150 from LDS, and for small blocks that chain (the fixed 768-byte warm-up) is most of the decode time.
-struct CView {
-    lz4amd_gsrc g;
-    const uint8_t* l;           // LDS copy of the block, or nullptr
-    uint32_t csize;
-    __device__ __forceinline__ uint32_t u8(uint32_t p) const { return l ? (uint32_t)l[p] : (uint32_t)g[p]; }
-    __device__ __forceinline__ uint32_t u16(uint32_t p) const { return u8(p) | (u8(p + 1) << 8); }
-    __device__ __forceinline__ bool in(uint32_t p) const { return p < csize; }
-    __device__ __forceinline__ bool has8(uint32_t p) const { return p < csize && csize - p >= 8; }
-    __device__ __forceinline__ uint64_t ld8_if(uint32_t p, bool ok) const {
-        uint64_t v = 0;
-        if (ok) {
-            if (l) {            // three aligned dwords + two v_alignbyte (the copy is padded past csize)
-                const uint32_t* w = (const uint32_t*)(l + (p & ~3u));
-                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = p & 3u;
-                v = (uint64_t)align_bytes(w1, w0, sh) | ((uint64_t)align_bytes(w2, w1, sh) << 32);
-            } else __builtin_memcpy(&v, g + p, 8);
-        }
-        return v;
-    }
-};
-
-struct WalkOut { uint32_t exit, n, ob, err; };
-
-// Literal-length field of the token at p (lz4.c:1979-2014, limit iend-15).  q = first literal byte.
-// Fast path: token and up to 6 extension bytes in one 8-byte LDS read.
-__device__ __forceinline__ bool read_litlen(const CView& V, uint32_t csize, uint32_t p, uint32_t& t,
-                                            uint32_t& ll, uint32_t& q) {
-    uint64_t w = 0;
-    const bool fast = V.has8(p);
-    if (fast) { w = V.ld8_if(p, true); t = (uint32_t)w & 0xFFu; } else t = V.u8(p);
-    ll = t >> 4; q = p + 1;
-    if (ll != 15) return true;
-    if (fast) {
-        const uint64_t x = w >> 8, inv = ~x & 0x00FFFFFFFFFFFFFFull;     // 7 extension bytes
-        const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 7u;
-        if (k < 7) {
-            if (q + k + 15 >= csize) return false;                   // the last byte read is q + k
-            ll = 15 + 255 * k + ((uint32_t)(x >> (8 * k)) & 0xFFu);
-            q += k + 1;
-            return true;
-        }
-    }
-    uint32_t b;
-    do {
-        if (q + 15 >= csize) return false;
-        b = V.u8(q); q++; ll += b;
-        if (ll > csize) return false;
-    } while (b == 255);
-    return true;
-}
-// Offset and match-length field at m (limit iend-LASTLITERALS+1).  nx = next token.
-__device__ __forceinline__ bool read_match(const CView& V, uint32_t csize, uint32_t m, uint32_t t,
-                                           uint32_t& off, uint32_t& ml, uint32_t& nx) {
-    uint64_t y = 0;
-    const bool fast = V.has8(m);
-    if (fast) { y = V.ld8_if(m, true); off = (uint32_t)y & 0xFFFFu; } else off = V.u16(m);
-    ml = t & 15; nx = m + 2;
-    if (ml != 15) return true;
-    if (fast) {
-        const uint64_t z = y >> 16, inv = ~z & 0x0000FFFFFFFFFFFFull;     // 6 extension bytes
-        const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 6u;
-        if (k < 6) {
-            nx += k + 1;
-            if (nx + 4 > csize) return false;
-            ml = 15 + 255 * k + ((uint32_t)(z >> (8 * k)) & 0xFFu);
-            return true;
-        }
-    }
-    uint32_t b;
-    do {
-        b = V.u8(nx); nx++; ml += b;
-        if (nx + 4 > csize || ml > 0x7FFFFFF0u) return false;
-    } while (b == 255);
-    return true;
-}
-
-// One sequence of the chain, as the walkers need it.
-struct SeqStep { uint32_t ll, q, off, ml, nx; bool last, bad; };
-
-// Generic (byte-wise) decode of the sequence at p: any field length, window misses allowed.
-__device__ __forceinline__ SeqStep seq_step_slow(const CView& V, uint32_t csize, uint32_t p, uint32_t out_room, bool emit) {
-    SeqStep s; s.off = 0; s.ml = 0; s.nx = 0; s.last = false; s.bad = true;
-    uint32_t t;
-    if (!read_litlen(V, csize, p, t, s.ll, s.q)) return s;
-    const uint32_t rem = csize - s.q;
-    s.last = (rem < s.ll + 8) || (emit && out_room < s.ll + kMfLimit);
-    if (s.last) { s.bad = false; return s; }
-    if (!read_match(V, csize, s.q + s.ll, t, s.off, s.ml, s.nx)) return s;
-    s.bad = false;
-    return s;
-}
-
-// Follow the token chain from p while p < e (e <= csize).  err != 0 => malformed at err-1.
-// EMIT: also write SeqRec's (ring, from sequence number `seq`, output position `o`) and apply the
-// output-side rules (needs cap).  The input-side rules are those of the reference's safe loop
-// (lz4.c:1979-2014 length fields, lz4.c:2279 last-literals test).  The common case - both length
-// fields and the offset inside two 8-byte LDS reads - is straight-line code with selects; anything
-// else (fields longer than 6 extension bytes, bytes outside the LDS window) takes the byte-wise
-// path above.
-// Records leave through a small LDS staging area, four at a time (64 contiguous bytes per lane): a store
-// after every sequence would sit in the same in-order memory queue as the next sequence's loads, and the
-// walk would wait for the write latency at every step (measured: 0.8 M of the 1.6 M cycles of this pass).
-template <bool EMIT>
-__device__ __forceinline__ WalkOut walk_chain(const CView& V, uint32_t csize, uint32_t p, uint32_t e,
-                                              SeqRec* recs, uint32_t seq, uint32_t o, uint32_t cap, uint32_t low,
-                                              SeqRec* stage = nullptr) {
-    WalkOut r; r.n = 0; r.ob = 0; r.err = 0;
-    const uint32_t seq0 = seq;
-    uint32_t nbuf = 0;
-    auto put = [&](const SeqRec& rec) {
-        if (stage == nullptr) { recs[seq0 + nbuf] = rec; nbuf++; return; }         // (loads come from LDS: nothing queues behind the store)
-        stage[(nbuf & 3) * kPreLanes] = rec;
-        nbuf++;
-        if ((nbuf & 3) == 0) {
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) recs[seq0 + nbuf - 4 + i] = stage[i * kPreLanes];
-        }
-    };
-    while (p < e) {
-        SeqStep s;
-        const uint32_t room = EMIT ? cap - o : 0u;
-        // ---- token + literal length
-        bool slow = !V.has8(p);
-        const uint64_t w = V.ld8_if(p, !slow);
-        const uint32_t t = (uint32_t)w & 0xFFu, nib = t >> 4;
-        const uint64_t x = w >> 8, inv = ~x & 0x00FFFFFFFFFFFFFFull;
-        const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 7u;
-        const bool l15 = nib == 15;
-        slow = slow || (l15 && k >= 7);
-        s.ll = l15 ? 15 + 255 * k + ((uint32_t)(x >> (8 * (k & 7))) & 0xFFu) : nib;
-        s.q = p + 1 + (l15 ? k + 1 : 0);
-        s.bad = l15 && (p + k + 16 >= csize);                    // extension byte i is read only if q0+i+15 < csize
-        const uint32_t rem = csize - s.q;
-        s.last = (rem < s.ll + 8) || (EMIT && room < s.ll + kMfLimit);
-        // ---- offset + match length
-        const uint32_t m = s.q + s.ll;
-        const bool need2 = !slow && !s.bad && !s.last;
-        const bool ok2 = need2 && V.has8(m);
-        slow = slow || (need2 && !ok2);
-        const uint64_t y = V.ld8_if(m, ok2);
-        s.off = (uint32_t)y & 0xFFFFu;
-        const uint64_t z = y >> 16, invz = ~z & 0x0000FFFFFFFFFFFFull;
-        const uint32_t km = invz ? ((uint32_t)__ffsll((long long)invz) - 1) >> 3 : 6u;
-        const uint32_t mnib = t & 15;
-        const bool m15 = mnib == 15;
-        slow = slow || (ok2 && m15 && km >= 6);
-        s.ml = m15 ? 15 + 255 * km + ((uint32_t)(z >> (8 * (km & 7))) & 0xFFu) : mnib;
-        s.nx = m + 2 + (m15 ? km + 1 : 0);
-        if (ok2 && m15 && s.nx + 4 > csize) s.bad = true;
-        if (slow) s = seq_step_slow(V, csize, p, room, EMIT);
-        if (s.bad) { r.err = p + 1; break; }
-        if (s.last) {
-            if (csize - s.q != s.ll) { r.err = p + 1; break; }    // must end the input exactly
-            if (EMIT) {
-                if (room < s.ll) { r.err = p + 1; break; }
-                SeqRec rec; rec.outpos = o; rec.litpos = s.q; rec.ll = s.ll; rec.off = 0;
-                put(rec);
-            }
-            r.n++; r.ob += s.ll; o += s.ll; seq++;
-            p = csize;
-            break;
-        }
-        const uint32_t ml = s.ml + kMinMatch;
-        if (EMIT) {
-            const uint32_t ms = o + s.ll;        // match start in the output
-            if (s.off == 0 || s.off > ms - low) { r.err = p + 1; break; } // lz4.c:2356 (low = first position with history)
-            if (cap - ms < ml + kLastLiterals) { r.err = p + 1; break; } // lz4.c:2423
-            SeqRec rec; rec.outpos = o; rec.litpos = s.q; rec.ll = s.ll; rec.off = s.off;
-            put(rec);
-        }
-        if (r.ob + s.ll + ml < r.ob) { r.err = p + 1; break; }           // u32 overflow
-        r.n++; r.ob += s.ll + ml; o += s.ll + ml; seq++;
-        p = s.nx;
-    }
-    if (EMIT && stage != nullptr) { for (uint32_t i = 0; i < (nbuf & 3); i++) recs[seq0 + (nbuf & ~3u) + i] = stage[i * kPreLanes]; }
-    r.exit = p;
-    return r;
-}
-
-// Position-only generic step: next token position after the sequence at p (csize at the end of
-// the block or on any violation - the accounting walk over the true chain reports those).
-__device__ __forceinline__ uint32_t next_pos_slow(const CView& V, uint32_t csize, uint32_t p) {
-    const SeqStep s = seq_step_slow(V, csize, p, 0, false);
-    return (s.bad || s.last) ? csize : s.nx;
-}
-// Position-only walk from p to the first chain position >= e (e <= csize), at most max_trips loop
-// trips (kNone if it did not get there).  This is what the speculative warm-up runs on, mostly over
-// literal bytes misread as tokens (one step per ~6.5 bytes), so a trip is a single LDS byte read
-// and a handful of VALU instructions: tokens with both nibbles < 15 are stepped over directly;
-// anything else (length extensions, window edge, end of block) parks the lane until the next
-// multiple-of-4 trip, where all parked lanes take the generic step together.
-__device__ __forceinline__ uint32_t walk_pos(const CView& V, uint32_t csize, uint32_t p, uint32_t e, uint32_t max_trips) {
-    bool parked = false;
-    uint32_t trip = 0;
-    while (p < e) {
-        if (trip >= max_trips) { p = kNone; break; }
-        if (!parked) {
-            const bool inwin = V.in(p);
-            const uint32_t b = inwin ? V.u8(p) : 0u;
-            const uint32_t ll = b >> 4, ml = b & 15;
-            if (inwin && ll != 15 && ml != 15 && p + ll + 9 <= csize) p += 3 + ll;
-            else parked = true;
-        }
-        trip++;
-        if ((trip & 3) == 0 && parked) { p = next_pos_slow(V, csize, p); parked = false; }
-    }
-    return p;
-}
-
-// The pre-parse walker: positions, sequence count and output bytes only (no offsets, no records).
-// Most of its steps are speculative warm-up over literal bytes misread as tokens (about one step
-// per 6.5 bytes on datagen data), so a step must be cheap: ONE 8-byte LDS read per loop trip.  A
-// lane is either at a token (mode 0: decodes token + literal length, and is done with the sequence
-// unless the match length nibble is 15) or at the offset field of a long match (mode 1: decodes the
-// match-length extension).  Same input-side rules as walk_chain<false>.
-__device__ __forceinline__ WalkOut walk_count(const CView& V, uint32_t csize, uint32_t p, uint32_t e, uint32_t max_trips) {
-    WalkOut r; r.n = 0; r.ob = 0; r.err = 0;
-    uint32_t rp = p, pend = 0;          // read position; literal length of the sequence in mode 1
-    uint32_t trips = 0;
-    bool mode1 = false;
-    while (p < e) {
-        if (trips++ >= max_trips) { p = kNone; break; }           // gave up (unconfirmed re-walk)
-        bool slow = !V.has8(rp);
-        const uint64_t w = V.ld8_if(rp, !slow);
-        uint32_t add_ob = 0, next_p = p, next_rp = rp;
-        bool bad = false, last = false, next_mode1 = false, complete = false;
-        uint32_t last_ll = 0, last_q = 0;
-        if (!mode1) {
-            const uint32_t t = (uint32_t)w & 0xFFu, nib = t >> 4;
-            const uint64_t x = w >> 8, inv = ~x & 0x00FFFFFFFFFFFFFFull;
-            const uint32_t k = inv ? ((uint32_t)__ffsll((long long)inv) - 1) >> 3 : 7u;
-            const bool l15 = nib == 15;
-            slow = slow || (l15 && k >= 7);
-            const uint32_t ll = l15 ? 15 + 255 * k + ((uint32_t)(x >> (8 * (k & 7))) & 0xFFu) : nib;
-            const uint32_t q = p + 1 + (l15 ? k + 1 : 0);
-            bad = l15 && (p + k + 16 >= csize);
-            last = !bad && (csize - q < ll + 8);
-            last_ll = ll; last_q = q;
-            const uint32_t m = q + ll, mnib = t & 15;
-            if (mnib == 15) { next_mode1 = true; next_rp = m; pend = ll; }
-            else { complete = true; add_ob = ll + mnib + kMinMatch; next_p = next_rp = m + 2; }
-        } else {
-            const uint64_t z = w >> 16, invz = ~z & 0x0000FFFFFFFFFFFFull;
-            const uint32_t km = invz ? ((uint32_t)__ffsll((long long)invz) - 1) >> 3 : 6u;
-            slow = slow || km >= 6;
-            const uint32_t nx = rp + 2 + km + 1;
-            bad = nx + 4 > csize;
-            complete = true;
-            add_ob = pend + 15 + 255 * km + ((uint32_t)(z >> (8 * (km & 7))) & 0xFFu) + kMinMatch;
-            next_p = next_rp = nx;
-        }
-        if (slow) {                                     // byte-wise redo of the whole sequence at p
-            const SeqStep s = seq_step_slow(V, csize, p, 0, false);
-            bad = s.bad; last = !s.bad && s.last; last_ll = s.ll; last_q = s.q;
-            complete = true; next_mode1 = false;
-            add_ob = s.ll + s.ml + kMinMatch; next_p = next_rp = s.nx;
-        }
-        if (bad) { r.err = p + 1; break; }
-        if (last) {
-            if (csize - last_q != last_ll) { r.err = p + 1; break; }
-            r.n++; r.ob += last_ll; p = csize;
-            break;
-        }
-        if (complete) {
-            if (r.ob + add_ob < r.ob) { r.err = p + 1; break; }          // u32 overflow
-            r.n++; r.ob += add_ob;
-        }
-        p = next_p; rp = next_rp; mode1 = next_mode1;
-    }
-    r.exit = p;
-    return r;
-}
-// 16 bytes of the compressed stream at position P (tail of the block zero padded)
+// 16 bytes of the compressed stream at position P (tail of the block zero padded; never reads past csize)
 __device__ __forceinline__ U32x4 load_granule(lz4amd_gsrc src, uint32_t csize, uint32_t P) {
     if (P + 16 <= csize) return ld_global16(src + P);
     U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
@@ -352,98 +87,318 @@ __device__ __forceinline__ U32x4 load_granule(lz4amd_gsrc src, uint32_t csize, u
     return v;
 }
 
+// A thread's view of the stream: 16 bytes in registers, reloaded when the position leaves them (one unaligned
+// 16-byte load per ~2.5 walker steps instead of one byte load per step: the walkers of a workgroup touch 1024
+// different cache lines at a time, so every load is an L2 round trip).
+struct Win { U32x4 v; uint32_t base; };
+__device__ __forceinline__ void win_init(Win& W) { W.v[0] = W.v[1] = W.v[2] = W.v[3] = 0; W.base = kNone - 64; }
+__device__ __forceinline__ uint32_t win_byte(Win& W, lz4amd_gsrc g, uint32_t csize, uint32_t p) {      // p < csize
+    if (p - W.base >= 16u) { W.base = p; W.v = load_granule(g, csize, p); }
+    return chunk_byte(W.v, p - W.base);
+}
+
+struct TokInfo { uint32_t ll, q, off, ml, nx, st; };      // st: 0 decoded, 1 slow path (last sequence, very long field), 2 malformed
+// Decode the sequence whose token is at p (p < csize): the authority on the fields and on the reference's input-side rules.
+__device__ __forceinline__ TokInfo tok_decode(lz4amd_gsrc g, uint32_t csize, uint32_t p) {
+    TokInfo r; r.ll = 0; r.q = 0; r.off = 0; r.ml = 0; r.nx = 0; r.st = 1;
+    const uint32_t b = g[p];
+    uint32_t ll = b >> 4, q = p + 1;
+    if (ll == 15) {
+        uint32_t n = 0, x;
+        do {
+            if (n >= kExtMax) return r;
+            if (q + 15 >= csize) { r.st = 2; return r; }              // lz4.c:1986-2006: a length byte is read only there
+            x = g[q]; q++; n++; ll += x;
+        } while (x == 255);
+    }
+    r.ll = ll; r.q = q;
+    if (q > csize || csize - q < ll + 8) return r;                   // the block's last sequence (or a malformed one): slow path
+    const uint32_t m = q + ll;
+    uint32_t nx = m + 2, ml = b & 15;
+    if (ml == 15) {
+        uint32_t n = 0, x;
+        do {
+            if (n >= kExtMax) return r;
+            x = g[nx]; nx++; n++; ml += x;
+            if (nx + 4 > csize) { r.st = 2; return r; }
+        } while (x == 255);
+    }
+    r.off = (uint32_t)g[m] | ((uint32_t)g[m + 1] << 8);
+    r.ml = ml + kMinMatch; r.nx = nx; r.st = 0;
+    return r;
+}
+
+// The walkers' view of the chain: one stream byte per trip, no branches.  A thread is at a token (mode 0), inside a
+// literal-length field (mode 1) or inside a match-length field (mode 2).  It stops (dead, at the token `tok`) where
+// tok_decode says "slow path" - and, off the true chain, wherever the bytes make no sense.
+struct WalkState { uint32_t p, tok, acc, mode, cnt; bool mlf, dead; };
+__device__ __forceinline__ void walk_init(WalkState& s, uint32_t p) { s.p = p; s.tok = p; s.acc = 0; s.mode = 0; s.cnt = 0; s.mlf = false; s.dead = false; }
+// consume byte b = stream[s.p] (the caller checked s.p < csize)
+__device__ __forceinline__ void walk_step(WalkState& s, uint32_t b, uint32_t csize) {
+    const bool m0 = s.mode == 0, m1 = s.mode == 1, m2 = s.mode == 2;
+    const bool is255 = b == 255;
+    const uint32_t ll0 = b >> 4;
+    const bool ext0 = ll0 == 15;
+    const bool litdone = (m0 && !ext0) || (m1 && !is255);                  // the literal length is complete with this byte
+    const uint32_t ll = m0 ? ll0 : s.acc + b;
+    const uint32_t m = s.p + 1 + ll;                                        // first byte after the literals
+    const bool mlf = m0 ? (b & 15) == 15 : s.mlf;
+    const bool cont = (m0 && ext0) || ((m1 || m2) && is255);               // the length field goes on
+    const uint32_t cnt = m0 ? 0u : s.cnt + 1;
+    const bool stop = (litdone && (m + 8 > csize || m < s.p)) || (cont && cnt >= kExtMax);
+    s.tok = m0 ? s.p : s.tok;
+    s.dead = stop;
+    s.acc = m0 ? 15u : s.acc + b;
+    s.mlf = mlf;
+    s.cnt = litdone ? 0u : cnt;
+    s.mode = litdone ? (mlf ? 2u : 0u) : (cont ? (m2 ? 2u : 1u) : 0u);
+    s.p = litdone ? m + 2 : s.p + 1;
+}
+
+enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_IDLE = 4 };
+
+// SLOW PATH (wave 0, every lane the same values; length fields are scanned 64 bytes at a time): the sequence whose
+// token is at p, whatever its size, with the reference's rules; its record goes to rectab[nrec].
+// Returns 0: go on at nx, 1: that was the block's last sequence, 2: malformed (position in errpos).
+__device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_t capB, uint32_t low, uint32_t p,
+                                          uint32_t& obase, uint32_t& nrec, SeqRec* rectab, uint32_t& nx_out, uint32_t& errpos) {
+    const uint32_t lane = lane_id();
+    errpos = p < csize ? p : (csize ? csize - 1 : 0);
+    if (p >= csize) return 2;
+    const uint32_t t = g[p];
+    uint32_t ll = t >> 4, q = p + 1;
+    if (ll == 15) {
+        for (;;) {
+            const uint32_t pos = q + lane;
+            const bool inb = pos + 15 < csize;
+            const uint32_t x = inb ? (uint32_t)g[pos] : 0u;
+            const unsigned long long stopm = __ballot(!inb || x != 255);
+            if (!stopm) { ll += 255 * 64; q += 64; if (ll > csize) return 2; continue; }
+            const uint32_t kk = (uint32_t)__ffsll((long long)stopm) - 1;
+            if (!wave_readlane(inb ? 1u : 0u, kk)) return 2;
+            ll += 255 * kk + wave_readlane(x, kk); q += kk + 1;
+            break;
+        }
+        if (ll > csize) return 2;
+    }
+    const uint32_t rem = csize - q, room = capB - obase;
+    const bool last = rem < ll + 8 || room < ll + kMfLimit;                 // lz4.c:2279
+    if (last) {
+        if (rem != ll || room < ll) return 2;                               // lz4.c:2312-2318
+        if (lane == 0) { SeqRec r; r.outpos = obase; r.litpos = q; r.ll = ll; r.off = 0; rectab[nrec] = r; }
+        nrec++; obase += ll;
+        return 1;
+    }
+    const uint32_t m = q + ll;                                              // m + 8 <= csize
+    const uint32_t off = (uint32_t)g[m] | ((uint32_t)g[m + 1] << 8);
+    uint32_t ml = t & 15, nx = m + 2;
+    if (ml == 15) {
+        for (;;) {
+            const uint32_t pos = nx + lane;
+            const uint32_t x = pos < csize ? (uint32_t)g[pos] : 0u;
+            const bool badafter = pos + 5 > csize;                          // after a length byte at least 4 more bytes must follow
+            const unsigned long long stopm = __ballot(x != 255 || badafter);
+            if (!stopm) { ml += 255 * 64; nx += 64; if (ml > 0x7FFFFFF0u) return 2; continue; }
+            const uint32_t kk = (uint32_t)__ffsll((long long)stopm) - 1;
+            ml += 255 * kk + wave_readlane(x, kk); nx += kk + 1;
+            if (wave_readlane(badafter ? 1u : 0u, kk) || ml > 0x7FFFFFF0u) return 2;
+            break;
+        }
+    }
+    ml += kMinMatch;
+    const uint32_t ms = obase + ll;
+    if (off == 0 || off > ms - low) return 2;                               // lz4.c:2356
+    if (capB - ms < ml + kLastLiterals) return 2;                           // lz4.c:2423
+    if (lane == 0) { SeqRec r; r.outpos = obase; r.litpos = q; r.ll = ll; r.off = off; rectab[nrec] = r; }
+    nrec++; obase = ms + ml;
+    nx_out = nx;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ stage A
-// The whole block at once: kPreLanes lanes, each owning one SEGMENT of G = csize/kPreLanes bytes
-// (rounded up to 256).  Long segments are the point: the speculative warm-up is a fixed price per
-// lane (~120 slow steps over literals misread as tokens), the true chain inside the segment costs
-// one step per ~40 bytes, and with few lanes every lane's current cache line stays in the CU's L1.
-// Returns false (uniformly) when the block is malformed; nseq_out / total_out otherwise.
+// Returns false (uniformly) when the block is malformed (position in misc[M_ERR]); nseq_out / total_out otherwise.
 __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix,
-                                               SeqRec* rectab, char* smem,
-                                               uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof) {
-    uint64_t pt_walk = 0, pt_fix = 0, pt_iters = 0, pt0 = 0;
+                                               SeqRec* rectab, char* smem, uint64_t table_size,
+                                               uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof = nullptr) {
+    uint64_t pt[6] = {0, 0, 0, 0, 0, 0}, pq = prof ? clock_ticks() : 0;       // developer profile: cycles in P1, P2, P3, P4, list, P5
+#define LZ4AMD_PSTAMP(i) do { if (prof) { const uint64_t t_ = clock_ticks(); pt[i] += t_ - pq; pq = t_; } } while (0)
     const uint32_t tid = threadIdx.x;
     uint32_t* scan = (uint32_t*)(smem + kOffScan);
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    uint32_t* seg_exit = (uint32_t*)(smem + kOffSegExit);
+    uint32_t* oposv = (uint32_t*)(smem + kOffOpos);
+    uint32_t* tinv = (uint32_t*)(smem + kOffTin);
+    uint16_t* jump = (uint16_t*)(smem + kOffJump);
+    uint8_t* kindv = (uint8_t*)(smem + kOffKind);
+    uint8_t* mark = (uint8_t*)(smem + kOffMark);
+    uint32_t* bm = (uint32_t*)(smem + kOffBitmap);
+    uint32_t* toks = (uint32_t*)((char*)rectab + table_size);
+    const uint32_t capB = cap + kBias, low = kBias - prefix;
     if (tid == 0) misc[M_ERR] = kNone;
-    if (prof) pt0 = clock_ticks();
 
-    uint32_t G = ((csize + kPreLanes - 1) / kPreLanes + kSeg - 1) & ~(kSeg - 1);
-    if (G < kSeg) G = kSeg;
-    const uint32_t nst = (csize + G - 1) / G;               // <= kPreLanes
-    const uint32_t recap = 64 + G / 8;                       // trips an unconfirmed re-walk may take
-    CView V; V.g = src; V.csize = csize; V.l = nullptr;
-    const bool staged = csize <= kCStageMax;
-    if (staged) {
-        uint8_t* const cs = (uint8_t*)(smem + kOffCStage);
-        for (uint32_t P = 16 * tid; P < csize + 16; P += 16 * kDecThreads) *(U32x4*)(cs + P) = load_granule(src, csize, P);
-        V.l = cs;
-        __syncthreads();
-    }
-    const bool has_seg = tid < nst;
-    const uint32_t s = tid * G;
-    uint32_t e = s + G; if (e > csize || e < s) e = csize;
-    // -- 1. positions: speculative entry (warm-up) and exit of every segment
-    //    (the segment itself is walked with the accounting walker: sequences, output bytes and format
-    //    errors of the LAST walk of a segment are the ones that count, and that walk starts at the true entry)
-    uint32_t my_entry = kNone;
-    WalkOut w; w.exit = 0; w.n = 0; w.ob = 0; w.err = 0;
-    if (has_seg) {
-        my_entry = s > 0 ? walk_pos(V, csize, s > kPreWarm ? s - kPreWarm : 0, s, kNone) : 0u;
-        w = walk_count(V, csize, my_entry, e, kNone);
-        seg_exit[tid] = w.err ? csize : w.exit;               // a malformed chain ends the block
-    }
-    // -- 2. fix-point: segment j is right iff it started where segment j-1 exited.  F = first
-    //    segment that is not; everything before it is the true chain, so X = exit of segment F-1 is
-    //    a true chain position: segments the chain jumps over completely (long literal runs) and
-    //    the segment X falls into are settled at once; the others re-walk from their predecessor's
-    //    current exit, for a bounded number of trips (that exit may still be garbage, and garbage
-    //    is slow to walk: they try again once it has settled).  F grows every round.
-    bool first_iter = true;
+    uint32_t e = 0, obase = kBias, nrec = 0;          // uniform: next true token, output position, records written
     for (;;) {
+        // ---- the span and its segments
+        const uint32_t sp0 = e & ~31u;
+        const uint32_t span = csize - sp0 < kSpanMax ? csize - sp0 : kSpanMax, sp1 = sp0 + span;
+        uint32_t S = ((span + kThreads - 1) / kThreads + 63) & ~63u; if (S < kSegMin) S = kSegMin;
+        const uint32_t nl = (span + S - 1) / S, wps = S / 32;           // threads in use, bitmap words per segment
+        const uint32_t je = (e - sp0) / S;
+        for (uint32_t w = tid; w < (span + 31) / 32; w += kThreads) bm[w] = 0;
         __syncthreads();
-        if (prof) { const uint64_t t1 = clock_ticks(); if (first_iter) pt_walk += t1 - pt0; else { pt_fix += t1 - pt0; pt_iters++; } pt0 = t1; first_iter = false; }
-        if (tid == 0) misc[M_FIRSTBAD] = nst;
-        uint32_t want = kNone;
-        if (has_seg) want = (tid == 0) ? 0u : seg_exit[tid - 1];
-        __syncthreads();
-        if (has_seg && (want != my_entry || want == kNone)) atomicMin(&misc[M_FIRSTBAD], tid);
-        __syncthreads();
-        const uint32_t F = misc[M_FIRSTBAD];
-        if (F >= nst) break;
-        const uint32_t X = (F == 0) ? 0u : seg_exit[F - 1];       // != kNone: segment F-1 is right
-        __syncthreads();
-        if (has_seg && tid >= F) {
-            if (X >= e) { my_entry = X; seg_exit[tid] = X; w.n = 0; w.ob = 0; w.err = 0; }   // the chain jumps over this segment
-            else if (X >= s) { my_entry = X; w = walk_count(V, csize, X, e, kNone); seg_exit[tid] = w.err ? csize : w.exit; }   // ... enters it at X
-            else if (want != kNone && want != my_entry) {
-                w = walk_count(V, csize, want, e, recap);
-                seg_exit[tid] = w.exit == kNone ? kNone : (w.err ? csize : w.exit);
-                my_entry = (w.exit == kNone) ? kNone : want;             // gave up: not resolved yet
+        // ---- P1: walk my segment, marking the tokens
+        const uint32_t seg_lo = sp0 + tid * S, seg_hi = seg_lo + S;
+        const bool inuse = tid < nl && tid >= je;
+        WalkState s; walk_init(s, tid == je ? e : seg_lo);
+        Win W; win_init(W);
+        for (;;) {
+            const bool run = inuse && !s.dead && !(s.mode == 0 && s.p >= seg_hi);
+            if (!__any(run)) break;
+            if (run) {
+                if (s.p >= csize) { s.tok = s.mode == 0 ? s.p : s.tok; s.dead = true; }       // ran off the block
+                else {
+                    if (s.mode == 0) atomicOr(&bm[(s.p - sp0) >> 5], 1u << ((s.p - sp0) & 31));
+                    walk_step(s, win_byte(W, src, csize, s.p), csize);
+                }
             }
         }
+        __syncthreads();
+        LZ4AMD_PSTAMP(0);
+        // ---- P2: walk on until a marked position (a token of a later thread's walk)
+        const uint32_t x = s.p;
+        uint32_t okind = !inuse ? OUT_IDLE : (s.dead ? OUT_STOP : OUT_NONE), opos = s.dead ? s.tok : s.p, nb = 0;
+        for (uint32_t trip = 0;; trip++) {
+            const bool run = okind == OUT_NONE;
+            if (!__any(run)) break;
+            if (run) {
+                const bool at_tok = s.mode == 0;
+                if (at_tok && s.p >= sp1) { okind = OUT_EXIT; opos = s.p; }
+                else if (at_tok && ((bm[(s.p - sp0) >> 5] >> ((s.p - sp0) & 31)) & 1u)) { okind = OUT_MERGE; opos = s.p; }
+                else if (trip >= kBridgeTrips) { okind = OUT_EXIT; opos = at_tok ? s.p : s.tok; }   // (a token either way: the next span starts there)
+                else if (s.p >= csize) { okind = OUT_STOP; opos = at_tok ? s.p : s.tok; }
+                else {
+                    nb += at_tok ? 1u : 0u;
+                    walk_step(s, win_byte(W, src, csize, s.p), csize);
+                    if (s.dead) { okind = OUT_STOP; opos = s.tok; }
+                }
+            }
+        }
+        // ---- P3: which threads are on the true chain?  (merge links, pointer doubling)
+        __syncthreads();
+        LZ4AMD_PSTAMP(1);
+        oposv[tid] = opos; kindv[tid] = (uint8_t)okind;
+        jump[tid] = (uint16_t)(okind == OUT_MERGE ? (opos - sp0) / S : tid);
+        mark[tid] = tid == je ? 1 : 0;
+        tinv[tid] = tid == je ? e : kNone;
+        __syncthreads();
+        for (uint32_t r = 0; r < 10; r++) {
+            const uint32_t jt = jump[tid];
+            const bool mine = mark[tid] != 0;
+            __syncthreads();
+            if (mine) mark[jt] = 1;
+            const uint32_t j2 = jump[jt];
+            __syncthreads();
+            jump[tid] = (uint16_t)j2;
+            __syncthreads();
+        }
+        const bool active = mark[tid] != 0;
+        if (active && okind == OUT_MERGE) tinv[(opos - sp0) / S] = opos;
+        if (active && okind != OUT_MERGE) misc[M_TERM] = tid;
+        __syncthreads();
+        const uint32_t term = misc[M_TERM];
+        const uint32_t tend = oposv[term];
+        const bool stop = kindv[term] == OUT_STOP;
+        const uint32_t myT = tinv[tid];
+        LZ4AMD_PSTAMP(2);
+        // ---- P4: the bitmap of the true tokens in [e, tend)
+        for (uint32_t w = 0; w < wps; w++) {
+            const uint32_t base = seg_lo + 32 * w;
+            if (tid < nl && base < sp1) {
+                uint32_t v = bm[tid * wps + w];
+                if (!active) v = 0;
+                else if (myT > base) v = (myT - base >= 32) ? 0u : (v & (0xFFFFFFFFu << (myT - base)));
+                if (tend <= base) v = 0; else if (tend - base < 32) v &= (1u << (tend - base)) - 1u;
+                bm[tid * wps + w] = v;
+            }
+        }
+        __syncthreads();
+        {   // the bridges of the true threads (walked again: they were not kept)
+            WalkState b; walk_init(b, x);
+            win_init(W);
+            uint32_t left = active ? nb : 0;
+            while (__any(left != 0)) {
+                if (left) {
+                    if (b.mode == 0) { if (b.p < tend && b.p < sp1) atomicOr(&bm[(b.p - sp0) >> 5], 1u << ((b.p - sp0) & 31)); left--; }
+                    if (left) walk_step(b, win_byte(W, src, csize, b.p), csize);
+                }
+            }
+        }
+        __syncthreads();
+        LZ4AMD_PSTAMP(3);
+        // ---- the token list
+        uint32_t cnt = 0;
+        for (uint32_t w = 0; w < wps; w++) if (tid < nl && seg_lo + 32 * w < sp1) cnt += (uint32_t)__popc(bm[tid * wps + w]);
+        uint32_t ea, ta; uint64_t eb, tb;
+        block_excl_sum2(cnt, 0ull, scan, ea, eb, ta, tb);
+        {
+            uint32_t k = ea;
+            for (uint32_t w = 0; w < wps; w++) {
+                if (tid < nl && seg_lo + 32 * w < sp1) {
+                    uint32_t v = bm[tid * wps + w];
+                    while (v) { const uint32_t b = (uint32_t)__ffs((int)v) - 1; v &= v - 1; toks[k++] = seg_lo + 32 * w + b; }
+                }
+            }
+        }
+        const uint32_t N = ta;
+        __syncthreads();
+        LZ4AMD_PSTAMP(4);
+        // ---- P5: decode, check, place, write the records - 1024 tokens at a time
+        int bad = 0;
+        for (uint32_t base = 0; base < N; base += kThreads) {
+            const uint32_t i = base + tid;
+            const bool have = i < N;
+            TokInfo ti; ti.ll = ti.q = ti.off = ti.ml = ti.nx = 0; ti.st = 0;
+            uint32_t tp = 0, follow = 0;
+            if (have) {
+                tp = toks[i]; follow = i + 1 < N ? toks[i + 1] : tend;
+                ti = tok_decode(src, csize, tp);
+            }
+            const uint32_t len = have && ti.st == 0 ? ti.ll + ti.ml : 0;
+            uint32_t e2, t2; uint64_t eo, to;
+            block_excl_sum2(0u, (uint64_t)len, scan, e2, eo, t2, to);
+            if (have) {
+                const uint64_t o64 = (uint64_t)obase + eo;
+                const uint32_t o = (uint32_t)o64;
+                bool b = ti.st != 0 || ti.nx != follow || (i == 0 && tp != e);          // the chain, as the decoder sees it
+                b = b || o64 > capB || capB - o < ti.ll + kMfLimit || ti.off == 0 || ti.off > o + ti.ll - low
+                      || capB - (o + ti.ll) < ti.ml + kLastLiterals;                    // lz4.c:2279 (a sequence here is never the last), 2356, 2423
+                if (b) { atomicMin(&misc[M_ERR], tp); bad = 1; }
+                else { SeqRec r; r.outpos = o; r.litpos = ti.q; r.ll = ti.ll; r.off = ti.off; rectab[nrec + i] = r; }
+            }
+            if (__syncthreads_or(bad)) return false;
+            obase += (uint32_t)to;
+        }
+        nrec += N;
+        LZ4AMD_PSTAMP(5);
+        // ---- a token the walk could not pass: the slow path takes it (wave 0), then the next span starts behind it
+        if (stop) {
+            if (tid < 64) {
+                uint32_t nx = 0, ep = 0;
+                const int rc = slow_token(src, csize, capB, low, tend, obase, nrec, rectab, nx, ep);
+                if (tid == 0) { misc[M_RC] = (uint32_t)rc; misc[M_NX] = nx; misc[M_OBASE] = obase; misc[M_NREC] = nrec; if (rc == 2) misc[M_ERR] = ep; }
+            }
+            __syncthreads();
+            const uint32_t rc = misc[M_RC];
+            if (rc == 2) return false;
+            obase = misc[M_OBASE]; nrec = misc[M_NREC];
+            if (rc == 1) break;
+            e = misc[M_NX];
+        } else e = tend;
+        __syncthreads();
     }
-    // -- 3. sequence numbers and output positions of the segments
-    if (!has_seg) { w.n = 0; w.ob = 0; w.err = 0; }
-    uint32_t ea, ta; uint64_t eb, tb;
-    block_excl_sum2(w.n, (uint64_t)w.ob, scan, ea, eb, ta, tb);
-    int bad = 0;
-    if (w.err) { atomicMin(&misc[M_ERR], w.err - 1); bad = 1; }
-    // output positions beyond the capacity are errors (this also keeps them inside u32)
-    if (has_seg && eb + w.ob > cap) { atomicMin(&misc[M_ERR], my_entry < csize ? my_entry : csize - 1); bad = 1; }
-    if (__syncthreads_or(bad)) return false;
-    if (prof) { const uint64_t t1 = clock_ticks(); if (tid == 0) prof[5] = t1 - pt0; pt0 = t1; }
-    // -- 4. the records, at their final place in the block's table
-    if (has_seg && w.n) {
-        const WalkOut w2 = walk_chain<true>(V, csize, my_entry, e, rectab, ea, (uint32_t)eb + kBias, cap + kBias, kBias - prefix,
-                                            staged ? nullptr : (SeqRec*)(smem + kOffRecStage) + tid);
-        if (w2.err) { atomicMin(&misc[M_ERR], w2.err - 1); bad = 1; }
-    }
-    if (tid == 0) { SeqRec rec; rec.outpos = (uint32_t)tb + kBias; rec.litpos = csize; rec.ll = 0; rec.off = 0; rectab[ta] = rec; }
-    if (__syncthreads_or(bad)) return false;
-    nseq_out = ta; total_out = (uint32_t)tb;
-    if (prof && tid == 0) { prof[6] = pt_walk; prof[7] = pt_fix | (pt_iters << 48); }
+    if (tid == 0) { SeqRec r; r.outpos = obase; r.litpos = csize; r.ll = 0; r.off = 0; rectab[nrec] = r; }      // sentinel row
+    nseq_out = nrec; total_out = obase - kBias;
+    if (prof && tid == 0) { prof[2] = pt[0] | (pt[1] << 32); prof[3] = pt[2] | (pt[3] << 32); prof[4] = pt[4] | (pt[5] << 32); }
+#undef LZ4AMD_PSTAMP
     return true;
 }
 

@@ -30,7 +30,8 @@ if os.environ.get("LZ4AMD_DEC", "v2") != "v1":
     med = lambda f: statistics.median([f(i) for i in range(nw)])
     print("cycles per workgroup pass (median over %d workgroups; last block each):" % nw)
     print("  block total        %10d" % med(lambda i: w[i * 8]))
-    print("  pre-parse %d" % med(lambda i: w[i * 8 + 1]))
-    print("  copy wave 0: regions %d, with retry %d, retry iterations %d" % (med(lambda i: w[i * 8 + 3]), med(lambda i: w[i * 8 + 2] >> 32), med(lambda i: w[i * 8 + 2] & 0xFFFFFFFF)))
+    print("  pre-parse %d  (P1 %d  P2 %d  P3 %d  P4 %d  list %d  P5 %d)" % (med(lambda i: w[i * 8 + 1]), med(lambda i: w[i * 8 + 2] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 2] >> 32),
+          med(lambda i: w[i * 8 + 3] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 3] >> 32), med(lambda i: w[i * 8 + 4] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 4] >> 32)))
+    print("  copy wave 0: regions %d, with retry %d, retry iterations %d" % (med(lambda i: w[i * 8 + 5] >> 48), med(lambda i: (w[i * 8 + 5] >> 32) & 0xFFFF), med(lambda i: w[i * 8 + 5] & 0xFFFFFFFF)))
     print("  copy wave 0: wait records %d  wait lead %d  work %d  retry (sources in flight) %d" % (
         med(lambda i: w[i * 8 + 6] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 6] >> 32), med(lambda i: w[i * 8 + 7] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 7] >> 32)))
