@@ -60,18 +60,24 @@ enum : uint32_t {
     kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
+    kStripFields = 9,
 };
 // LDS carve-up (bytes)
 enum : uint32_t {
     kCOffMisc = 0,                                        // u32[32]
-    kCOffStrip = kCOffMisc + 32 * 4,                      // u32[2][6][16] per-strip summaries (two tiles in flight)
-    kCOffTab = kCOffStrip + 2 * 6 * kCmpWaves * 4,        // u32[1 << kHashBits]
+    kCOffStrip = kCOffMisc + 32 * 4,                      // u32[2][kStripFields][16] per-strip summaries (two tiles in flight)
+    kCOffTab = kCOffStrip + 2 * kStripFields * kCmpWaves * 4,   // u32[1 << kHashBits]
     kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kCmpWaves][kRecsPerStrip]
-    kCOffRing = kCOffRecs + 2 * kCmpWaves * kRecsPerStrip * 8,
+    kCOffEnds = kCOffRecs + 2 * kCmpWaves * kRecsPerStrip * 8,      // u16[2][kCmpWaves][kRecsPerStrip] where a record's match ends (from the strip's start)
+    kCOffEncp = kCOffEnds + 2 * kCmpWaves * kRecsPerStrip * 2,      // u16[2][kCmpWaves][kRecsPerStrip] encoded bytes of the strip's records before it
+    kCOffRing = kCOffEncp + 2 * kCmpWaves * kRecsPerStrip * 2,
     kCmpLdsBytes = kCOffRing + kSrcRing + kSrcPad,
 };
 enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3 };
-enum : uint32_t { S_N = 0, S_ENC = 1, S_LL0 = 2, S_TAIL = 3, S_OUT = 4, S_CARRY = 5 };
+enum : uint32_t { S_N = 0, S_ENC = 1, S_LL0 = 2, S_TAIL = 3, S_OUT = 4, S_CARRY = 5,
+                  S_END = 6,      // where the strip's last match ends when it runs past the strip (else 0)
+                  S_FIRST = 7,    // first record that is emitted (the ones before it were covered by an earlier strip's match)
+                  S_P = 8 };      // first source position the strip emits
 
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t len_minus_nibble_base) {
     // bytes needed after the token for a length field whose value is >= 15 (block format doc)
@@ -176,15 +182,16 @@ __device__ __forceinline__ void tile_geometry(uint32_t t0, bool small, uint32_t&
 }
 
 // ------------------------------------------------------------------------------ match (one strip)
-__device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint32_t* strip,
-                                            uint32_t w, uint32_t n, uint32_t cs, uint32_t ce) {
+__device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
+                                            uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend) {
     const uint32_t lane = lane_id();
     const bool small = n < kSmallBlockLimit;
     uint32_t nseq = 0, enc = 0, ll0 = 0, anchor = cs;
     // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= ce
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         const uint32_t last_q = n - kMfLimit;                  // inclusive; q + 8 <= n - 4 holds for all probes
-        uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
+        // a match may run past the strip up to the tile's end: the strips it covers give way (resolve_overruns)
+        uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t cs_off = src_ring_off(cs);
         // big blocks probe every second position (the backward extension recovers the odd starts):
         // half the work for about 4 % of the matches, which the larger table more than pays for
@@ -274,7 +281,9 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                     my_enc = enc_size(my_ll, mlen - kMinMatch);
                 }
                 if (nseq == 0) ll0 = wave_readlane(my_ll, (uint32_t)__ffsll((long long)taken) - 1);
-                enc += wave_readlane(wave_incl_sum(my_enc), 63);
+                const uint32_t enc_incl = wave_incl_sum(my_enc);
+                if (mine) { const uint32_t i = nseq + lanes_below(taken); ends[i] = (uint16_t)(e - cs); encp[i] = (uint16_t)(enc + enc_incl - my_enc); }
+                enc += wave_readlane(enc_incl, 63);
                 nseq += ntaken;
                 anchor = wend;
             }
@@ -285,7 +294,8 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
         strip[S_N * kCmpWaves + w] = nseq;
         strip[S_ENC * kCmpWaves + w] = enc;
         strip[S_LL0 * kCmpWaves + w] = ll0;
-        strip[S_TAIL * kCmpWaves + w] = ce - anchor;
+        strip[S_TAIL * kCmpWaves + w] = anchor < ce ? ce - anchor : 0;
+        strip[S_END * kCmpWaves + w] = anchor > ce ? anchor : 0;
     }
 }
 
@@ -359,6 +369,76 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
 // Output offset and carried-in literals of every strip of a tile, from the strips' summaries (lane k holds
 // strip k).  All strips at once: the literals carried into a strip that has sequences are the tails of the
 // strips since the last one that had any (or since the previous tile); the sizes then scan to offsets.
+// A strip's last match may have run past the strip's end (up to the tile's end).  The strips behind it were parsed
+// at the same time, not knowing: here every strip gives up what an earlier strip's match already covers - the records
+// that end inside the covered stretch go, the one that straddles its end loses its literals or the front of its match
+// (same offset, the bytes are the same), or goes as well when less than a minimal match is left - and its summary is
+// brought up to date.  One wave: a short serial walk over the strips settles where each one starts (a strip's own
+// overrun counts only if its last match survives), then lane k puts strip k right (binary search in the record ends).
+__device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs_tile, const uint16_t* ends_tile, const uint16_t* encp_tile,
+                                                 uint32_t nstrips, uint32_t t0, uint32_t strip_len, uint32_t t1, uint32_t n) {
+    const uint32_t lane = lane_id();
+    const bool mine = lane < nstrips;
+    const uint32_t cs = t0 + lane * strip_len;
+    uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
+    const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, own_end = mine ? strip[S_END * kCmpWaves + lane] : 0;
+    MatchRec* rk = recs_tile + lane * kRecsPerStrip;
+    const uint16_t* ek = ends_tile + lane * kRecsPerStrip;
+    const uint16_t* pk = encp_tile + lane * kRecsPerStrip;
+    uint32_t q_last = 0;                                  // where my last match starts (strips whose last match runs over)
+    if (own_end) q_last = own_end - ((rk[nk - 1].mo >> 16) + kMinMatch);
+    if (!__any(own_end != 0)) {                           // nothing ran over in this tile
+        if (mine) { strip[S_FIRST * kCmpWaves + lane] = 0; strip[S_P * kCmpWaves + lane] = cs; }
+        return;
+    }
+    // ---- where does every strip start?
+    uint32_t cover = 0, P = cs;
+    for (uint32_t k = 0; k < nstrips; k++) {
+        const uint32_t cs_k = t0 + k * strip_len, Pk = cover > cs_k ? cover : cs_k;
+        if (lane == k) P = Pk;
+        const uint32_t e_k = wave_readlane(own_end, k), q_k = wave_readlane(q_last, k);
+        const bool survives = e_k != 0 && (Pk <= q_k || (e_k >= Pk + kMinMatch && Pk <= n - kMfLimit));
+        if (survives && e_k > cover) cover = e_k;
+    }
+    // ---- put my strip right
+    if (mine) {
+        uint32_t first = 0, nk2 = nk, enc = strip[S_ENC * kCmpWaves + lane], ll0 = strip[S_LL0 * kCmpWaves + lane], tail = strip[S_TAIL * kCmpWaves + lane];
+        if (P > cs) {
+            uint32_t lo = 0, hi = nk;                         // first record whose match ends behind P
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cs + ek[mid] > P) hi = mid; else lo = mid + 1; }
+            uint32_t f = lo;
+            first = nk; nk2 = 0; enc = 0; ll0 = 0; tail = ce > P ? ce - P : 0;
+            if (f < nk) {
+                MatchRec r = rk[f];
+                const uint32_t ef = cs + ek[f], qf = ef - ((r.mo >> 16) + kMinMatch);
+                const uint32_t old_enc = enc_size(r.ll, r.mo >> 16), enc_total = strip[S_ENC * kCmpWaves + lane];
+                bool dropped = false;
+                if (P > qf) {
+                    const uint32_t left = ef - P;
+                    dropped = left < kMinMatch || P > n - kMfLimit;         // a match starts at least 12 bytes before the block's end (lz4.c:1030)
+                    if (!dropped) { r.ll = 0; r.mo = (r.mo & 0xFFFFu) | ((left - kMinMatch) << 16); }
+                } else r.ll = qf - P;
+                if (!dropped) {
+                    rk[f] = r;
+                    first = f; nk2 = nk - f; ll0 = r.ll;
+                    enc = enc_total - pk[f] - old_enc + enc_size(r.ll, r.mo >> 16);
+                } else if (f + 1 < nk) {
+                    // its bytes [P, ef) are literals of the next record
+                    MatchRec r2 = rk[f + 1];
+                    const uint32_t old2 = enc_size(r2.ll, r2.mo >> 16);
+                    r2.ll += ef - P;
+                    rk[f + 1] = r2;
+                    first = f + 1; nk2 = nk - f - 1; ll0 = r2.ll;
+                    enc = enc_total - pk[f + 1] - old2 + enc_size(r2.ll, r2.mo >> 16);
+                }
+                if (nk2) { const uint32_t e_last = cs + ek[nk - 1]; tail = e_last < ce ? ce - e_last : 0; }
+            }
+        }
+        strip[S_N * kCmpWaves + lane] = nk2; strip[S_ENC * kCmpWaves + lane] = enc; strip[S_LL0 * kCmpWaves + lane] = ll0;
+        strip[S_TAIL * kCmpWaves + lane] = tail; strip[S_FIRST * kCmpWaves + lane] = first; strip[S_P * kCmpWaves + lane] = P;
+    }
+}
+
 struct StripTotals { uint32_t out, carry, fail; };
 __device__ __forceinline__ StripTotals strip_offsets(uint32_t* strip, uint32_t nstrips, uint32_t out0, uint32_t carry0,
                                                      uint32_t fail, uint32_t cap) {
@@ -393,6 +473,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint32_t* strip = (uint32_t*)(smem + kCOffStrip);
     uint32_t* tab = (uint32_t*)(smem + kCOffTab);
     MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + w * kRecsPerStrip;      // + parity * kCmpWaves * kRecsPerStrip
+    uint16_t* ends = (uint16_t*)(smem + kCOffEnds) + w * kRecsPerStrip;
+    uint16_t* encp = (uint16_t*)(smem + kCOffEncp) + w * kRecsPerStrip;
     uint8_t* ring = (uint8_t*)(smem + kCOffRing);
 
     // history (linked blocks, lz4io.c:741-744 / LZ4_compress_fast_continue in prefix mode lz4.c:1707): the
@@ -434,8 +516,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint32_t prev_t0 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
     while (t0 < n) {
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
-        uint32_t* strip_k = strip + par * 6 * kCmpWaves;
-        uint32_t* strip_p = strip + (par ^ 1) * 6 * kCmpWaves;
+        uint32_t* strip_k = strip + par * kStripFields * kCmpWaves;
+        uint32_t* strip_p = strip + (par ^ 1) * kStripFields * kCmpWaves;
         MatchRec* recs_k = recs + par * kCmpWaves * kRecsPerStrip;
         MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
@@ -453,18 +535,21 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (w < nstrips) {
             const uint32_t cs = t0 + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
-            match_strip(ring, tab, recs_k, strip_k, w, n, cs, ce);
+            match_strip(ring, tab, recs_k, ends + par * kCmpWaves * kRecsPerStrip, encp + par * kCmpWaves * kRecsPerStrip, strip_k, w, n, cs, ce, t1);
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: emit tile k-1
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         if (w < prev_nstrips && !misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
-            emit_strip(ring, recs_p, strip_p, w, src, dst, prev_t0 + w * prev_strip_len, ring_lo);
+            emit_strip(ring, recs_p + strip_p[S_FIRST * kCmpWaves + w], strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
         // -- B: offsets (wave 0) ...
         if (w == 0 && parse) {
+            resolve_overruns(strip_k, recs_k - w * kRecsPerStrip, ends + par * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip,
+                             encp + par * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip, nstrips, t0, strip_len, t1, n);
+            wave_lds_fence();
             const StripTotals t = strip_offsets(strip_k, nstrips, misc[CM_OUT], misc[CM_CARRY], misc[CM_FAIL], cap);
             if (lane_id() == 0) { misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; }
         }
@@ -497,11 +582,11 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     __syncthreads();
     // -- the last tile's sequences
     {
-        const uint32_t* strip_p = strip + (par ^ 1) * 6 * kCmpWaves;
+        const uint32_t* strip_p = strip + (par ^ 1) * kStripFields * kCmpWaves;
         const MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         if (w < prev_nstrips && !misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
-            emit_strip(ring, recs_p, strip_p, w, src, dst, prev_t0 + w * prev_strip_len, ring_lo);
+            emit_strip(ring, recs_p + strip_p[S_FIRST * kCmpWaves + w], strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
     }
     __syncthreads();
     if (prof) {
