@@ -391,14 +391,24 @@ __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs
         if (mine) { strip[S_FIRST * kCmpWaves + lane] = 0; strip[S_P * kCmpWaves + lane] = cs; }
         return;
     }
-    // ---- where does every strip start?
-    uint32_t cover = 0, P = cs;
-    for (uint32_t k = 0; k < nstrips; k++) {
-        const uint32_t cs_k = t0 + k * strip_len, Pk = cover > cs_k ? cover : cs_k;
-        if (lane == k) P = Pk;
-        const uint32_t e_k = wave_readlane(own_end, k), q_k = wave_readlane(q_last, k);
-        const bool survives = e_k != 0 && (Pk <= q_k || (e_k >= Pk + kMinMatch && Pk <= n - kMfLimit));
-        if (survives && e_k > cover) cover = e_k;
+    // ---- where does every strip start?  Behind every earlier strip's overrun: a prefix maximum - exact as long as every
+    //      overrunning match survives the cut at its own strip's start (nearly always: it is long); else walk the strips.
+    uint32_t P;
+    {
+        const uint32_t im = wave_incl_max(own_end);
+        uint32_t cover = (uint32_t)__shfl_up(im, 1u); if (lane == 0) cover = 0;
+        P = cover > cs ? cover : cs;
+        const bool survives = own_end == 0 || P <= q_last || (own_end >= P + kMinMatch && P <= n - kMfLimit);
+        if (__any(mine && !survives)) {
+            cover = 0;
+            for (uint32_t k = 0; k < nstrips; k++) {
+                const uint32_t cs_k = t0 + k * strip_len, Pk = cover > cs_k ? cover : cs_k;
+                if (lane == k) P = Pk;
+                const uint32_t e_k = wave_readlane(own_end, k), q_k = wave_readlane(q_last, k);
+                const bool sv = e_k != 0 && (Pk <= q_k || (e_k >= Pk + kMinMatch && Pk <= n - kMfLimit));
+                if (sv && e_k > cover) cover = e_k;
+            }
+        }
     }
     // ---- put my strip right
     if (mine) {
