@@ -16,6 +16,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 
 pthread_mutex_t lz4amd_default_lock = PTHREAD_MUTEX_INITIALIZER;   /* shared with lz4frame_api.c */
 #define g_lock lz4amd_default_lock
@@ -49,33 +50,90 @@ int LZ4_versionNumber(void) { return LZ4_VERSION_NUMBER; }
 const char* LZ4_versionString(void) { return LZ4_VERSION_STRING; }
 int LZ4_compressBound(int inputSize) { return lz4amd_compress_bound(inputSize); }
 
-/* one block through the device; op selects the kernel set.  Returns the per-block result, or
- * `fail` when the device path cannot run. */
+/* One block through the device; op selects the kernel.  Returns the per-block result, or `fail` when the device path
+ * cannot run.  The reference's block functions are re-entrant and its CLI calls them from up to 200 threads
+ * (lz4conf.h:60-61): every calling thread keeps its own stream, device staging buffers and one-row plans (no device
+ * allocation, no lock in the steady state; the blocks of different threads run side by side on different CUs). */
+typedef struct {
+    void* stream;
+    void* d_in;  size_t in_cap;
+    void* d_out; size_t out_cap;
+    char* h_in;  size_t hin_cap;        /* page-locked staging: the copies to and from them are truly asynchronous */
+    char* h_out; size_t hout_cap;
+    int* rows;                          /* page-locked, read / written by the kernels: 3 plans x {source size, capacity, result} */
+    lz4amd_plan* plan[3];               /* by lz4amd_op: COMPRESS, DECOMPRESS, COMPRESS_HC - bound to d_in / d_out */
+} lz4amd_thread_slot;
+static pthread_key_t g_slot_key;
+static pthread_once_t g_slot_once = PTHREAD_ONCE_INIT;
+static void slot_free(void* v)
+{
+    lz4amd_thread_slot* t = (lz4amd_thread_slot*)v;
+    int i;
+    if (!t) return;
+    for (i = 0; i < 3; i++) lz4amd_plan_destroy(t->plan[i]);
+    lz4amd_hip_free(t->d_in); lz4amd_hip_free(t->d_out);
+    lz4amd_hip_host_free(t->h_in); lz4amd_hip_host_free(t->h_out); lz4amd_hip_host_free(t->rows);
+    lz4amd_hip_stream_destroy(t->stream);
+    free(t);
+}
+static void slot_key_init(void) { (void)pthread_key_create(&g_slot_key, slot_free); }
+static lz4amd_thread_slot* slot_get(void)
+{
+    lz4amd_thread_slot* t;
+    pthread_once(&g_slot_once, slot_key_init);
+    t = (lz4amd_thread_slot*)pthread_getspecific(g_slot_key);
+    if (!t) {
+        t = (lz4amd_thread_slot*)calloc(1, sizeof *t);
+        if (!t) return NULL;
+        t->stream = lz4amd_hip_stream_create();
+        t->rows = (int*)lz4amd_hip_host_alloc(16 * sizeof(int));
+        if (!t->stream || !t->rows || pthread_setspecific(g_slot_key, t)) { slot_free(t); return NULL; }
+    }
+    return t;
+}
+
 int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail)
 {
     lz4amd_ctx* ctx;
-    lz4amd_plan* plan = NULL;
-    int result = fail, rc;
-    const void* dsrc; void* ddst;
+    lz4amd_thread_slot* t;
+    int result = fail, i;
     size_t in_bytes = srcSize > 0 ? (size_t)srcSize : 0;
     size_t out_bytes = dstCapacity > 0 ? (size_t)dstCapacity : 0;
+    if ((int)op < 0 || (int)op > 2) return fail;
 
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&g_lock);                     /* (only the first call creates the context) */
     ctx = lz4amd_default_ctx();
-    if (!ctx) goto done;
-    if (stage_reserve(&g_stage_in, &g_stage_in_cap, in_bytes + 16) ||
-        stage_reserve(&g_stage_out, &g_stage_out_cap, out_bytes + 16)) goto done;
-    if (in_bytes && lz4amd_hip_h2d(g_stage_in, src, in_bytes, NULL)) goto done;
-    dsrc = g_stage_in; ddst = g_stage_out;
-    rc = lz4amd_plan_create(ctx, &plan, op, 1, &dsrc, &srcSize, &ddst, &dstCapacity, level);
-    if (rc) goto done;
-    if (lz4amd_plan_launch(plan, NULL) || lz4amd_plan_results(plan, &result, NULL)) { result = fail; goto done; }
-    if (result > 0 && (size_t)result <= out_bytes) {
-        if (lz4amd_hip_d2h(dst, g_stage_out, (size_t)result, NULL) || lz4amd_hip_sync(NULL)) result = fail;
-    }
-done:
-    lz4amd_plan_destroy(plan);
     pthread_mutex_unlock(&g_lock);
+    if (!ctx || lz4amd_hip_use_device(ctx->device)) return fail;
+    t = slot_get();
+    if (!t) return fail;
+    if (in_bytes + 16 > t->in_cap || out_bytes + 16 > t->out_cap) {
+        /* the buffers grow: the plans bound to them go (rare: sizes settle after the first blocks) */
+        for (i = 0; i < 3; i++) { lz4amd_plan_destroy(t->plan[i]); t->plan[i] = NULL; }
+        if (stage_reserve(&t->d_in, &t->in_cap, in_bytes + 16) || stage_reserve(&t->d_out, &t->out_cap, out_bytes + 16)) return fail;
+        if (t->in_cap > t->hin_cap) { lz4amd_hip_host_free(t->h_in); t->h_in = (char*)lz4amd_hip_host_alloc(t->in_cap); t->hin_cap = t->h_in ? t->in_cap : 0; }
+        if (t->out_cap > t->hout_cap) { lz4amd_hip_host_free(t->h_out); t->h_out = (char*)lz4amd_hip_host_alloc(t->out_cap); t->hout_cap = t->h_out ? t->out_cap : 0; }
+        if (!t->h_in || !t->h_out) return fail;
+    }
+    if (!t->plan[op]) {
+        /* sized for the largest block the buffers take (decoder / HC scratch follow the source size) */
+        const void* dsrc = t->d_in; void* ddst = t->d_out;
+        int smax = t->in_cap - 16 > 0x7E000000u ? 0x7E000000 : (int)(t->in_cap - 16), cmax = t->out_cap - 16 > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)(t->out_cap - 16);
+        if (lz4amd_plan_create(ctx, &t->plan[op], op, 1, &dsrc, &smax, &ddst, &cmax, level)) return fail;
+        if (lz4amd_plan_bind_host_row(t->plan[op], t->rows + 4 * (int)op)) return fail;
+    }
+    {
+        int* row = t->rows + 4 * (int)op;
+        row[0] = srcSize; row[1] = dstCapacity; row[2] = fail;
+        lz4amd_plan_set_level(t->plan[op], level);
+        if (in_bytes) { memcpy(t->h_in, src, in_bytes); if (lz4amd_hip_h2d(t->d_in, t->h_in, in_bytes, t->stream)) return fail; }
+        if (lz4amd_plan_launch(t->plan[op], t->stream) || lz4amd_hip_sync(t->stream)) return fail;
+        result = row[2];
+        if (result > 0 && (size_t)result <= out_bytes) {
+            if (lz4amd_hip_d2h(t->h_out, t->d_out, (size_t)result, t->stream) || lz4amd_hip_sync(t->stream)) return fail;
+            memcpy(dst, t->h_out, (size_t)result);
+        }
+    }
     return result;
 }
 

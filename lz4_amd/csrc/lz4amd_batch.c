@@ -72,6 +72,7 @@ void lz4amd_plan_destroy(lz4amd_plan* p)
 {
     int i;
     if (!p) return;
+    if (p->ctx) (void)lz4amd_hip_use_device(p->ctx->device);
     for (i = 0; i < LZ4AMD_PLAN_MAX_BUFS; i++) lz4amd_hip_free(p->bufs[i]);
     for (i = 0; i < 5; i++) lz4amd_hip_event_destroy(p->ev[i]);
     free(p);
@@ -87,6 +88,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
     if (!ctx || !out || n < 0 || (n > 0 && (!d_src || !src_sizes))) return LZ4AMD_E_ARG;
     if (n > 0 && op != LZ4AMD_OP_XXH32 && (!d_dst || !dst_caps)) return LZ4AMD_E_ARG;
     *out = NULL;
+    if (lz4amd_hip_use_device(ctx->device)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
     p = (lz4amd_plan*)calloc(1, sizeof *p);
     if (!p) return LZ4AMD_E_MEMORY;
     p->ctx = ctx; p->op = op; p->n = n; p->level = level;
@@ -224,6 +226,7 @@ int lz4amd_plan_launch(lz4amd_plan* p, void* stream)
 {
     int s;
     if (!p) return LZ4AMD_E_ARG;
+    if (lz4amd_hip_use_device(p->ctx->device)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
     for (s = 0; s < n_stages(p); s++)
         if (launch_stage(p, s, stream)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
     return LZ4AMD_OK;
@@ -233,6 +236,7 @@ int lz4amd_plan_launch_timed(lz4amd_plan* p, void* stream, float kernel_ms[4], f
 {
     int s, ns;
     if (!p) return LZ4AMD_E_ARG;
+    if (lz4amd_hip_use_device(p->ctx->device)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
     ns = n_stages(p);
     for (s = 0; s <= ns; s++)
         if (!p->ev[s] && !(p->ev[s] = lz4amd_hip_event_create())) { lz4amd_set_error("hipEventCreate failed"); return LZ4AMD_E_RUNTIME; }
@@ -256,6 +260,7 @@ int lz4amd_plan_profile(lz4amd_plan* p, unsigned long long* words, int max_words
     if (!p) return 0;
     src = p->op == LZ4AMD_OP_DECOMPRESS ? p->dec.prof : p->op == LZ4AMD_OP_COMPRESS_HC ? p->hc.prof : p->comp.prof;
     if (!src) return 0;
+    (void)lz4amd_hip_use_device(p->ctx->device);
     n = (int)p->grid * 8;
     if (n > max_words) n = max_words;
     if (lz4amd_hip_d2h(words, src, (size_t)n * 8, NULL) || lz4amd_hip_sync(NULL)) return 0;
@@ -267,6 +272,7 @@ const int* lz4amd_plan_device_results(const lz4amd_plan* p) { return p ? p->d_re
 int lz4amd_plan_results(lz4amd_plan* p, int* results, void* stream)
 {
     if (!p || (p->n && !results)) return LZ4AMD_E_ARG;
+    (void)lz4amd_hip_use_device(p->ctx->device);
     if (lz4amd_hip_d2h(results, p->d_results, (size_t)p->n * sizeof(int), stream) || lz4amd_hip_sync(stream)) {
         lz4amd_set_error(lz4amd_hip_errstr());
         return LZ4AMD_E_RUNTIME;
@@ -306,6 +312,35 @@ int lz4amd_decompress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int
                             void* const* d_dst, const int* dst_caps, int* results, int n, void* stream)
 { return one_shot(ctx, LZ4AMD_OP_DECOMPRESS, d_src, src_sizes, d_dst, dst_caps, results, n, stream); }
 
+int lz4amd_plan_set_row0(lz4amd_plan* p, int src_size, int dst_cap, int level, void* stream)
+{
+    const int32_t* dsz; const int32_t* dcap;
+    if (!p || p->n != 1) return LZ4AMD_E_ARG;
+    if (p->op == LZ4AMD_OP_DECOMPRESS) { dsz = p->dec.src_size; dcap = p->dec.dst_cap; }
+    else if (p->op == LZ4AMD_OP_COMPRESS_HC) { dsz = p->hc.src_size; dcap = p->hc.dst_cap; p->hc.level = level; }
+    else if (p->op == LZ4AMD_OP_COMPRESS) { dsz = p->comp.src_size; dcap = p->comp.dst_cap; }
+    else return LZ4AMD_E_ARG;
+    p->row0[0] = src_size; p->row0[1] = dst_cap;          /* (the copies are asynchronous: the source must outlive the call) */
+    if (lz4amd_hip_h2d((void*)dsz, &p->row0[0], sizeof(int), stream) || lz4amd_hip_h2d((void*)dcap, &p->row0[1], sizeof(int), stream)) {
+        lz4amd_set_error(lz4amd_hip_errstr());
+        return LZ4AMD_E_RUNTIME;
+    }
+    return LZ4AMD_OK;
+}
+
+void lz4amd_plan_set_level(lz4amd_plan* p, int level) { if (p && p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.level = level; p->level = level; } }
+
+int lz4amd_plan_bind_host_row(lz4amd_plan* p, int* row)
+{
+    if (!p || p->n != 1 || !row) return LZ4AMD_E_ARG;
+    if (p->op == LZ4AMD_OP_DECOMPRESS) { p->dec.src_size = row; p->dec.dst_cap = row + 1; p->dec.result = row + 2; }
+    else if (p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.src_size = row; p->hc.dst_cap = row + 1; p->hc.result = row + 2; }
+    else if (p->op == LZ4AMD_OP_COMPRESS) { p->comp.src_size = row; p->comp.dst_cap = row + 1; p->comp.result = row + 2; }
+    else return LZ4AMD_E_ARG;
+    p->d_results = row + 2;
+    return LZ4AMD_OK;
+}
+
 /* ------------------------------------------------------------------ calibration */
 int lz4amd_stream_copy_ms(lz4amd_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int reps, void* stream, float* best_ms)
 {
@@ -313,6 +348,7 @@ int lz4amd_stream_copy_ms(lz4amd_ctx* ctx, void* d_dst, const void* d_src, size_
     float best = -1.f;
     int r;
     if (!ctx || !d_dst || !d_src || !best_ms || bytes < 16 || reps < 1) return LZ4AMD_E_ARG;
+    (void)lz4amd_hip_use_device(ctx->device);
     e0 = lz4amd_hip_event_create(); e1 = lz4amd_hip_event_create();
     if (!e0 || !e1) { lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1); return LZ4AMD_E_RUNTIME; }
     for (r = 0; r < reps + 1; r++) {                       /* one untimed warm-up launch */

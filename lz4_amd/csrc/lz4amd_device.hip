@@ -57,6 +57,10 @@ extern "C" int lz4amd_hip_init(int device, int* n_cus) {
     return 0;
 }
 
+// Every entry point that takes a context or a plan selects the context's device first: contexts on different GPUs, or a
+// context used from another thread than the one that made it, must not land on whatever device is current there.
+extern "C" int lz4amd_hip_use_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
+
 extern "C" void* lz4amd_hip_malloc(size_t bytes) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
@@ -77,6 +81,11 @@ extern "C" int lz4amd_hip_memset(void* d, int v, size_t n, void* s) {
     HIPCHK(hipMemsetAsync(d, v, n, (hipStream_t)s)); return 0;
 }
 extern "C" int lz4amd_hip_sync(void* s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
+// page-locked host memory, readable and writable by the device through the same pointer
+extern "C" void* lz4amd_hip_host_alloc(size_t bytes) { void* p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
+extern "C" void lz4amd_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+extern "C" void* lz4amd_hip_stream_create(void) { hipStream_t s; if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr; return (void*)s; }
+extern "C" void lz4amd_hip_stream_destroy(void* s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 extern "C" void* lz4amd_hip_event_create(void) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void*)e; }
 extern "C" void lz4amd_hip_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 extern "C" int lz4amd_hip_event_record(void* ev, void* s) { HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return 0; }

@@ -12,12 +12,17 @@ extern "C" {
 
 int         lz4amd_hip_init(int device, int* n_cus);            /* 0 ok */
 const char* lz4amd_hip_errstr(void);
+int         lz4amd_hip_use_device(int device);                  /* hipSetDevice for the calling thread */
 void*       lz4amd_hip_malloc(size_t bytes);
 void        lz4amd_hip_free(void* d);
 int         lz4amd_hip_h2d(void* d, const void* h, size_t n, void* stream);
 int         lz4amd_hip_d2h(void* h, const void* d, size_t n, void* stream);
 int         lz4amd_hip_memset(void* d, int value, size_t n, void* stream);
 int         lz4amd_hip_sync(void* stream);
+void*       lz4amd_hip_host_alloc(size_t bytes);                /* page-locked, device-accessible host memory */
+void        lz4amd_hip_host_free(void* p);
+void*       lz4amd_hip_stream_create(void);                     /* a non-blocking stream, NULL on failure */
+void        lz4amd_hip_stream_destroy(void* stream);
 void*       lz4amd_hip_event_create(void);
 void        lz4amd_hip_event_destroy(void* ev);
 int         lz4amd_hip_event_record(void* ev, void* stream);

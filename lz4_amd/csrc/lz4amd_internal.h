@@ -24,9 +24,17 @@ struct lz4amd_plan {
     lz4amd_comp_params comp;
     lz4amd_hc_params hc;
     lz4amd_xxh_params xxh;
+    int row0[2];                        /* lz4amd_plan_set_row0: host copy of the sizes in flight */
 };
 
 void lz4amd_set_error(const char* msg);
+
+/* a one-block plan kept by a thread: new sizes (and HC level) for its only row, sent on `stream` before the launch */
+int lz4amd_plan_set_row0(lz4amd_plan* p, int src_size, int dst_cap, int level, void* stream);
+/* ... or its sizes and its result live in page-locked host memory the device reads and writes directly
+ * (row[0] = source size, row[1] = capacity, row[2] = result): no copy calls for them at all */
+int lz4amd_plan_bind_host_row(lz4amd_plan* p, int* row);
+void lz4amd_plan_set_level(lz4amd_plan* p, int level);      /* LZ4_compress_HC level of the next launch */
 
 /* process-wide default context used by the classic one-block API (lz4_api.c) */
 lz4amd_ctx* lz4amd_default_ctx(void);

@@ -234,6 +234,52 @@ def test_classic_host_pointer_api(ctx, ocodec, datagen):
     assert L.LZ4_decompress_safe(c, back, len(c), len(d)) == len(d) and back.raw == d
 
 
+def test_classic_api_from_many_threads(ctx, ocodec, datagen):
+    """The reference's block functions are re-entrant and its CLI calls them from up to 200 threads
+    (lz4conf.h:60-61).  16 threads x 64 KiB blocks through LZ4_compress_default / LZ4_decompress_safe: every result is
+    right, blocks of different sizes keep working (the per-thread buffers grow), and the calls of different threads
+    overlap (per-thread streams and plans, no device allocation in the steady state)."""
+    import threading
+    import time
+    import lz4_amd
+    L = lz4_amd.lib()
+    blocks = [datagen(65536, 40 + 5 * (i % 8), i) for i in range(16)]
+    calls = 200
+    errors = []
+
+    def worker(i, n):
+        d = blocks[i]
+        dst = ctypes.create_string_buffer(L.LZ4_compressBound(len(d)))
+        back = ctypes.create_string_buffer(len(d))
+        for k in range(n):
+            r = L.LZ4_compress_default(d, dst, len(d), len(dst))
+            if r <= 0 or (k % 50 == 0 and (L.LZ4_decompress_safe(dst.raw[:r], back, r, len(d)) != len(d) or back.raw != d)):
+                errors.append((i, k, r))
+                return
+        big = datagen(300000, 60, i)                                    # a larger block afterwards: the buffers grow
+        bdst = ctypes.create_string_buffer(L.LZ4_compressBound(len(big)))
+        r = L.LZ4_compress_default(big, bdst, len(big), len(bdst))
+        ro, o = ocodec.decompress(bdst.raw[:r], len(big))
+        if r <= 0 or ro != len(big) or o != big:
+            errors.append((i, "big", r))
+
+    worker(0, 20)                                                        # warm up: context, kernels
+    t0 = time.perf_counter(); worker(0, calls); t1 = time.perf_counter() - t0
+    th = [threading.Thread(target=worker, args=(i, calls)) for i in range(16)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    t16 = time.perf_counter() - t0
+    assert not errors, errors[:3]
+    speedup = 16 * t1 / t16                                              # call rate of 16 threads over one thread's
+    print("classic ABI: %.0f calls/s on one thread, x%.1f with 16 threads" % (calls / t1, speedup))
+    # measured on MI355X / ROCm 7.2: x2.1 - x2.3; the HIP runtime serialises most of what a call does (copy, launch,
+    # synchronise) per device, whatever the stream - the library itself holds no lock and allocates nothing here
+    assert speedup > 1.5, speedup
+
+
 def test_full_size_roundtrip_properties(ctx, golden, datagen, ocodec):
     """BASELINE config 2 shape at 256 MiB: independent 4 MiB datagen -P60 blocks, device resident."""
     import lz4_amd
