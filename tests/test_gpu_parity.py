@@ -280,6 +280,22 @@ def test_classic_api_from_many_threads(ctx, ocodec, datagen):
     assert speedup > 1.5, speedup
 
 
+def test_reference_round_trip_driver_linked_against_the_library(ctx, datagen, tmp_path):
+    """The reference's own tests/roundTripTest.c, unmodified, linked against liblz4_amd.so (oracle/Makefile builds it
+    into oracle/_ref; link pattern of tests/Makefile:120-122): LZ4_compress_fast / LZ4_compress_HC ->
+    LZ4_decompress_safe -> XXH32 comparison, on three datagen files at the default level and at HC level 9."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "roundTripTest_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/roundTripTest_amd not built (needs /root/reference at build time)")
+    for k, (size, pct) in enumerate(((65536, 50), (1 << 20, 60), (3000000, 90))):
+        f = tmp_path / ("rt%d.bin" % k)
+        f.write_bytes(datagen(size, pct, k))
+        for level in ((), ("-9",)):
+            r = subprocess.run([exe, *level, str(f)], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, (size, pct, level, r.stdout[-300:], r.stderr[-300:])
+
+
 def test_full_size_roundtrip_properties(ctx, golden, datagen, ocodec):
     """BASELINE config 2 shape at 256 MiB: independent 4 MiB datagen -P60 blocks, device resident."""
     import lz4_amd
