@@ -4,11 +4,14 @@
  * 883 / compressEnd 1206) and LZ4F_decompress (lz4frame.c:1613-2116; header 1346-1437).
  *
  * Host C only handles the container: magic, FLG/BD, optional content size / dictID, header
- * checksum, per-block size fields, end mark, content checksum.  All blocks of a frame go to the
- * device in ONE block table (lz4amd_batch.c): compression, decompression and block checksums are
- * single launches over the whole frame.  The content checksum is one serial XXH32 over the whole
- * content (xxhash.c:352-389; the recurrence cannot be split), computed on the calling thread while
- * the GPU works.  There is no CPU codec here: without a HIP device every call returns an error.
+ * checksum, per-block size fields, end mark, content checksum.  LZ4F_compressFrame sends all blocks
+ * of the frame to the device in ONE block table (lz4amd_batch.c); LZ4F_decompress is a streaming
+ * state machine that decodes the complete blocks it holds as one table whenever the caller's input
+ * runs dry, the frame ends or a batch (64 MiB / 1024 blocks) is full, and delivers their bytes
+ * before taking more input - memory is bounded by a batch, not by the frame.  The content checksum
+ * is one serial XXH32 over the content (xxhash.c:352-389; the recurrence cannot be split), computed
+ * on the calling thread.  There is no CPU codec here: a compressed block needs a HIP device (stored
+ * blocks are copied, as in lz4frame.c:1790-1830), without one every call returns an error.
  */
 #include "../../include/lz4frame.h"
 #include "../../include/lz4amd.h"
@@ -44,33 +47,8 @@ const char* LZ4F_getErrorName(LZ4F_errorCode_t code)
 unsigned LZ4F_getVersion(void) { return LZ4F_VERSION; }
 
 /* ---------------------------------------------------------------- XXH32 (host: header / content checksum) */
-#define P1 0x9E3779B1u
-#define P2 0x85EBCA77u
-#define P3 0xC2B2AE3Du
-#define P4 0x27D4EB2Fu
-#define P5 0x165667B1u
-static uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
-static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-static void wr32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
-static uint32_t xxh32(const uint8_t* p, size_t len)
-{   /* xxhash.c:352-389 stripes, 291-348 tail and avalanche; seed 0 */
-    const uint8_t* const end = p + len;
-    uint32_t h;
-    if (len >= 16) {
-        uint32_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0u - P1;
-        do {
-            v1 = rotl(v1 + rd32(p) * P2, 13) * P1;      v2 = rotl(v2 + rd32(p + 4) * P2, 13) * P1;
-            v3 = rotl(v3 + rd32(p + 8) * P2, 13) * P1;  v4 = rotl(v4 + rd32(p + 12) * P2, 13) * P1;
-            p += 16;
-        } while (p + 16 <= end);
-        h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
-    } else h = P5;
-    h += (uint32_t)len;
-    while (p + 4 <= end) { h = rotl(h + rd32(p) * P3, 17) * P4; p += 4; }
-    while (p < end) { h = rotl(h + (*p++) * P5, 11) * P1; }
-    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
-    return h;
-}
+#include "xxh32_host.h"
+static uint32_t xxh32(const uint8_t* p, size_t len) { return xxh32_once(p, len); }
 
 static size_t block_size_of(unsigned id)
 {   /* lz4frame.c:333-341 */
@@ -210,14 +188,26 @@ finish_frame:
 }
 
 /* ---------------------------------------------------------------- decompression */
+/* Streaming decoder (lz4frame.c:1613-2060 is the reference's state machine).  Input is copied into `in` one item at a
+ * time (header, block header + block + block checksum, content checksum), never past the frame's end; complete
+ * blocks are decoded in batches - as soon as the caller's input runs dry, the end mark shows up or kBatchBytes /
+ * kBatchBlocks are buffered - and their bytes are delivered before more input is taken, so memory is bounded by
+ * one batch whatever the frame's size and a flushed block never waits for the rest of the frame.  Linked blocks
+ * (lz4frame.c:1901-1915) keep the last 64 KB of output on the host between batches. */
+enum { ST_HEADER = 0, ST_SKIP, ST_BLOCKS, ST_TAIL, ST_DONE };
+enum { kBatchBlocks = 1024 };
+static const size_t kBatchBytes = (size_t)64 << 20;
 struct LZ4F_dctx_s {
-    uint8_t* in; size_t in_size, in_cap;          /* the frame's bytes so far */
-    uint8_t* out; size_t out_size, out_pos;       /* decoded content, and how much of it was delivered */
-    int header_done, frame_done, decoded;
-    size_t header_size, frame_size;               /* frame_size: total bytes of the frame once known */
+    int stage;
+    uint8_t* in; size_t in_size, in_cap;          /* bytes of the item(s) being collected */
+    size_t scan_pos; size_t nready;               /* complete blocks in in[0, scan_pos) */
+    int end_seen;                                 /* in[scan_pos, scan_pos+4) is the end mark */
+    uint8_t* out; size_t out_size, out_pos, out_cap;   /* decoded bytes of the last batch, and how many were delivered */
     LZ4F_frameInfo_t info;
     size_t block_max;
-    size_t scan_pos;                              /* next block header to look at */
+    unsigned long long total_out, skip_left;
+    xxh32_state xxh;
+    uint8_t* hist; size_t hist_len;               /* linked frames: the 64 KB before the next batch */
 };
 
 LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version)
@@ -228,15 +218,16 @@ LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned v
     return *dctxPtr ? 0 : ERR(allocation_failed);
 }
 void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
-{
+{   /* lz4frame.c:1322-1330; the buffers are kept */
     if (!d) return;
-    free(d->out); d->out = NULL; d->out_size = d->out_pos = 0;
-    d->in_size = 0; d->header_done = d->frame_done = d->decoded = 0;
-    d->header_size = d->frame_size = d->scan_pos = 0;
+    d->stage = ST_HEADER;
+    d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
+    d->out_size = d->out_pos = 0;
+    d->total_out = d->skip_left = 0; d->hist_len = 0;
 }
 LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* d)
 {
-    if (d) { free(d->in); free(d->out); free(d); }
+    if (d) { free(d->in); free(d->out); free(d->hist); free(d); }
     return 0;
 }
 
@@ -278,51 +269,96 @@ static size_t parse_header(const uint8_t* p, size_t n, LZ4F_frameInfo_t* info, s
     return hs;
 }
 
-size_t LZ4F_getFrameInfo(LZ4F_dctx* d, LZ4F_frameInfo_t* info, const void* srcBuffer, size_t* srcSizePtr)
-{   /* lz4frame.c:1464-1512 (one-shot form: the header must be in srcBuffer) */
-    size_t bm = 0, hs;
-    if (!d || !info || !srcSizePtr) return ERR(parameter_null);
-    if (d->header_done) { *info = d->info; *srcSizePtr = 0; return 1; }
-    hs = parse_header((const uint8_t*)srcBuffer, *srcSizePtr, info, &bm);
-    if (LZ4F_isError(hs)) { *srcSizePtr = 0; return hs; }
-    if (hs == 0) { *srcSizePtr = 0; return ERR(frameHeader_incomplete); }
-    *srcSizePtr = 0;                       /* nothing consumed: LZ4F_decompress will read the header again */
-    return 4;
+/* bytes of the header needed to know its size, then the size itself (lz4frame.c:1441-1462) */
+static size_t header_want(const uint8_t* p, size_t n)
+{
+    if (n >= 4 && (rd32(p) & 0xFFFFFFF0u) == MAGIC_SKIP) return 8;
+    if (n < 7) return 7;                         /* the smallest header; the smallest frame is 11 bytes, so this never reads past one */
+    return 7 + ((p[4] & 8) ? 8 : 0) + ((p[4] & 1) ? 4 : 0);
+}
+static void enter_frame(LZ4F_dctx* d, size_t block_max)
+{
+    d->block_max = block_max;
+    d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
+    d->total_out = 0; d->hist_len = 0;
+    xxh32_reset(&d->xxh);
+    if (d->info.frameType == LZ4F_skippableFrame) { d->skip_left = d->info.contentSize; d->stage = d->skip_left ? ST_SKIP : ST_DONE; }
+    else d->stage = ST_BLOCKS;
 }
 
-/* decode the complete frame held in d->in into d->out */
-static size_t decode_buffered_frame(LZ4F_dctx* d, int skip_checksums)
+size_t LZ4F_getFrameInfo(LZ4F_dctx* d, LZ4F_frameInfo_t* info, const void* srcBuffer, size_t* srcSizePtr)
+{   /* lz4frame.c:1464-1512: decodes AND consumes the header; a header that is not whole is an error and consumes nothing */
+    const uint8_t* src = (const uint8_t*)srcBuffer;
+    size_t bm = 0, hs, avail;
+    if (!d || !info || !srcSizePtr) return ERR(parameter_null);
+    avail = *srcSizePtr; *srcSizePtr = 0;
+    if (d->stage != ST_HEADER) { *info = d->info; return 4; }            /* lz4frame.c:1470-1477: already known */
+    if (d->in_size) return ERR(frameDecoding_alreadyStarted);            /* lz4frame.c:1478-1482: in the middle of the header */
+    if (!src || avail < 7) return ERR(frameHeader_incomplete);
+    if (avail < header_want(src, avail)) return ERR(frameHeader_incomplete);
+    hs = parse_header(src, avail, &d->info, &bm);
+    if (LZ4F_isError(hs)) return hs;
+    if (hs == 0) return ERR(frameHeader_incomplete);
+    enter_frame(d, bm);
+    *info = d->info; *srcSizePtr = hs;
+    return 4;                                                            /* next: a block header */
+}
+
+static int grow(uint8_t** buf, size_t* cap, size_t need, size_t keep)
+{
+    uint8_t* nb;
+    if (need <= *cap) return 0;
+    need += (need >> 2) + 4096;
+    nb = (uint8_t*)malloc(need);
+    if (!nb) return -1;
+    if (keep) memcpy(nb, *buf, keep);
+    free(*buf); *buf = nb; *cap = need;
+    return 0;
+}
+
+/* decode the nb complete blocks held in d->in[0, end) into d->out */
+static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksums)
 {
     const uint8_t* const base = d->in;
-    size_t pos = d->header_size, nb = 0, i, out_total = 0, result = ERR(GENERIC);
+    size_t pos, i, out_total = 0, result = ERR(GENERIC);
     const int bchk = d->info.blockChecksumFlag == LZ4F_blockChecksumEnabled;
     const int linked = d->info.blockMode == LZ4F_blockLinked;
+    const size_t h0 = linked ? d->hist_len : 0;
     lz4amd_ctx* ctx;
     lz4amd_plan *dplan = NULL, *xplan = NULL;
     const void** d_src = NULL; void** d_dst = NULL; int *sizes = NULL, *caps = NULL, *res = NULL, *sums = NULL, *prefix = NULL;
     size_t* in_off = NULL; uint8_t* raw = NULL;
-    size_t ncomp = 0, in_bytes = 0;
+    size_t ncomp = 0;
 
-    /* pass 1: count blocks */
-    for (pos = d->header_size;;) { const uint32_t f = rd32(base + pos); if (!f) break; pos += 4 + (f & 0x7FFFFFFFu) + (bchk ? 4 : 0); nb++; }
-    if (nb == 0) { d->out = (uint8_t*)malloc(1); d->out_size = 0; goto checksum; }
+    d->out_size = d->out_pos = 0;
     d_src = (const void**)malloc(nb * sizeof *d_src); d_dst = (void**)malloc(nb * sizeof *d_dst);
     sizes = (int*)malloc(nb * sizeof *sizes); caps = (int*)malloc(nb * sizeof *caps); res = (int*)malloc(nb * sizeof *res);
     sums = (int*)malloc(nb * sizeof *sums); prefix = (int*)malloc(nb * sizeof *prefix);
     in_off = (size_t*)malloc(nb * sizeof *in_off); raw = (uint8_t*)malloc(nb);
     if (!d_src || !d_dst || !sizes || !caps || !res || !sums || !prefix || !in_off || !raw) { result = ERR(allocation_failed); goto done_unlocked; }
-    for (pos = d->header_size, i = 0; i < nb; i++) {
+    for (pos = 0, i = 0; i < nb; i++) {
         const uint32_t f = rd32(base + pos);
         sizes[i] = (int)(f & 0x7FFFFFFFu); raw[i] = (uint8_t)(f >> 31); in_off[i] = pos + 4;
         pos += 4 + (size_t)sizes[i] + (bchk ? 4 : 0);
     }
-    in_bytes = pos;
+    if (pos != end) goto done_unlocked;
+    {   /* a batch of stored blocks only (lz4frame.c:1790-1830 copies them too) never visits the device */
+        int all_raw = !(bchk && !skip_checksums);
+        for (i = 0; i < nb && all_raw; i++) if (!raw[i]) all_raw = 0;
+        if (all_raw) {
+            size_t o = 0;
+            for (i = 0; i < nb; i++) { if ((size_t)sizes[i] > d->block_max) { result = ERR(decompressionFailed); goto done_unlocked; } out_total += (size_t)sizes[i]; }
+            if (grow(&d->out, &d->out_cap, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done_unlocked; }
+            for (i = 0; i < nb; i++) { memcpy(d->out + o, base + in_off[i], (size_t)sizes[i]); o += (size_t)sizes[i]; }
+            goto host_tail;
+        }
+    }
 
     pthread_mutex_lock(&lz4amd_default_lock);
     ctx = lz4amd_default_ctx();
     if (!ctx) goto done;
-    if (stage_fit(&g_stage.in, &g_stage.in_cap, in_bytes + 64) || stage_fit(&g_stage.out, &g_stage.out_cap, nb * d->block_max + 64)) { result = ERR(allocation_failed); goto done; }
-    if (lz4amd_hip_h2d(g_stage.in, base, in_bytes, NULL)) goto done;
+    if (stage_fit(&g_stage.in, &g_stage.in_cap, end + 64) || stage_fit(&g_stage.out, &g_stage.out_cap, h0 + nb * d->block_max + 64)) { result = ERR(allocation_failed); goto done; }
+    if (lz4amd_hip_h2d(g_stage.in, base, end, NULL)) goto done;
     /* block checksums: XXH32 of every block as stored (lz4frame.c:1878), one launch */
     if (bchk && !skip_checksums) {
         for (i = 0; i < nb; i++) d_src[i] = (const char*)g_stage.in + in_off[i];
@@ -330,13 +366,11 @@ static size_t decode_buffered_frame(LZ4F_dctx* d, int skip_checksums)
         if (lz4amd_plan_launch(xplan, NULL) || lz4amd_plan_results(xplan, sums, NULL)) goto done;
         for (i = 0; i < nb; i++) if ((uint32_t)sums[i] != rd32(base + in_off[i] + (size_t)sizes[i])) { result = ERR(blockChecksum_invalid); goto done; }
     }
-    /* compressed blocks -> one block table; every block owns a block_max slot of the output.
-     * Linked frames (lz4frame.c:1901-1915: the previous 64 KB of output are the dictionary) need
-     * the blocks decoded in order with a packed output: the table then runs on ONE workgroup. */
     if (linked) {
-        /* packed output needs the decoded sizes in advance only for raw blocks; compressed ones
-         * are decoded one after the other, each told how much history precedes it */
-        size_t o = 0;
+        /* lz4frame.c:1901-1915: the previous 64 KB of output are the dictionary.  The history of the earlier batches
+         * goes in front of the packed output; the blocks are decoded in order, each told how much precedes it. */
+        size_t o = h0;
+        if (h0 && lz4amd_hip_h2d(g_stage.out, d->hist, h0, NULL)) goto done;
         for (i = 0; i < nb; i++) {
             d_dst[i] = (char*)g_stage.out + o;
             if (raw[i]) {
@@ -354,7 +388,7 @@ static size_t decode_buffered_frame(LZ4F_dctx* d, int skip_checksums)
             }
             o += (size_t)res[i];
         }
-        out_total = o;
+        out_total = o - h0;
     } else {
         for (i = 0; i < nb; i++) {
             d_dst[i] = (char*)g_stage.out + i * d->block_max;
@@ -380,9 +414,8 @@ static size_t decode_buffered_frame(LZ4F_dctx* d, int skip_checksums)
         }
         for (i = 0; i < nb; i++) out_total += (size_t)res[i];
     }
-    d->out = (uint8_t*)malloc(out_total ? out_total : 1);
-    if (!d->out) { result = ERR(allocation_failed); goto done; }
-    if (linked) { if (out_total && lz4amd_hip_d2h(d->out, g_stage.out, out_total, NULL)) goto done; }
+    if (grow(&d->out, &d->out_cap, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done; }
+    if (linked) { if (out_total && lz4amd_hip_d2h(d->out, (char*)g_stage.out + h0, out_total, NULL)) goto done; }
     else {
         size_t o = 0;
         for (i = 0; i < nb; i++) {
@@ -392,18 +425,22 @@ static size_t decode_buffered_frame(LZ4F_dctx* d, int skip_checksums)
         }
     }
     if (lz4amd_hip_sync(NULL)) goto done;
-    d->out_size = out_total;
     pthread_mutex_unlock(&lz4amd_default_lock);
-    lz4amd_plan_destroy(dplan); lz4amd_plan_destroy(xplan);
-    free(d_src); free(d_dst); free(sizes); free(caps); free(res); free(sums); free(prefix); free(in_off); free(raw);
-checksum:
-    if (d->info.contentSize && d->info.contentSize != d->out_size) return ERR(frameSize_wrong);     /* lz4frame.c:1984 */
-    if (d->info.contentChecksumFlag && !skip_checksums) {
-        const uint8_t* tail = d->in + d->frame_size - 4;
-        if (rd32(tail) != xxh32(d->out, d->out_size)) return ERR(contentChecksum_invalid);          /* lz4frame.c:2021 */
+host_tail:
+    d->out_size = out_total; d->total_out += out_total;
+    if (d->info.contentChecksumFlag && !skip_checksums) xxh32_update(&d->xxh, d->out, out_total);   /* lz4frame.c:1896, 1967 */
+    if (linked) {                                   /* the 64 KB the next batch may reference */
+        if (!d->hist && !(d->hist = (uint8_t*)malloc(65536))) { result = ERR(allocation_failed); goto done_unlocked; }
+        if (out_total >= 65536) { memcpy(d->hist, d->out + out_total - 65536, 65536); d->hist_len = 65536; }
+        else {
+            const size_t keep = d->hist_len + out_total > 65536 ? 65536 - out_total : d->hist_len;
+            memmove(d->hist, d->hist + d->hist_len - keep, keep);
+            memcpy(d->hist + keep, d->out, out_total);
+            d->hist_len = keep + out_total;
+        }
     }
-    d->decoded = 1;
-    return 0;
+    result = 0;
+    goto done_unlocked;
 done:
     pthread_mutex_unlock(&lz4amd_default_lock);
 done_unlocked:
@@ -412,76 +449,121 @@ done_unlocked:
     return result;
 }
 
+/* append up to `want - in_size` bytes of the caller's input to d->in; returns 1 when in_size reached want */
+static int take_input(LZ4F_dctx* d, size_t want, const uint8_t* src, size_t avail, size_t* used, size_t* err)
+{
+    size_t need, take;
+    if (d->in_size >= want) return 1;
+    need = want - d->in_size; take = avail - *used < need ? avail - *used : need;
+    if (take) {
+        if (grow(&d->in, &d->in_cap, d->in_size + take, d->in_size)) { *err = ERR(allocation_failed); return 0; }
+        memcpy(d->in + d->in_size, src + *used, take);
+        d->in_size += take; *used += take;
+    }
+    return d->in_size >= want;
+}
+
+/* bytes the decoder would like to see next (lz4frame.c's nextSrcSizeHint): what the current item still
+ * misses, plus the next block header when the item is a block */
+static size_t size_hint(const LZ4F_dctx* d)
+{
+    const size_t tail = d->info.blockChecksumFlag == LZ4F_blockChecksumEnabled ? 4 : 0;
+    switch (d->stage) {
+    case ST_HEADER: { const size_t w = header_want(d->in, d->in_size); return (w > d->in_size ? w - d->in_size : 0) + 4; }   /* lz4frame.c:1691, 1710: + the first block header */
+    case ST_SKIP:   return d->skip_left > ((size_t)1 << 30) ? ((size_t)1 << 30) : (size_t)d->skip_left;
+    case ST_BLOCKS:
+        if (d->end_seen) return d->info.contentChecksumFlag ? 4 : 0;
+        if (d->in_size < d->scan_pos + 4) return d->scan_pos + 4 - d->in_size;
+        {   const size_t bsz = rd32(d->in + d->scan_pos) & 0x7FFFFFFFu;
+            const size_t full = d->scan_pos + 4 + bsz + tail;
+            return (full > d->in_size ? full - d->in_size : 0) + 4; }
+    case ST_TAIL:   return 4 - d->in_size;
+    default:        return 0;
+    }
+}
+
 size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
                        const void* srcBuffer, size_t* srcSizePtr, const LZ4F_decompressOptions_t* opt)
 {
     const uint8_t* src = (const uint8_t*)srcBuffer;
-    size_t avail, used = 0, dcap;
+    uint8_t* dst = (uint8_t*)dstBuffer;
+    size_t avail, used = 0, dcap, given = 0, err = 0;
+    const int skipc = opt && opt->skipChecksums;
     if (!d || !dstSizePtr || !srcSizePtr) return ERR(parameter_null);
-    avail = *srcSizePtr; dcap = *dstSizePtr;
+    avail = src ? *srcSizePtr : 0; dcap = dst ? *dstSizePtr : 0;
     *srcSizePtr = 0; *dstSizePtr = 0;
-    if (d->frame_done && d->decoded && d->out_pos >= d->out_size) LZ4F_resetDecompressionContext(d);   /* next frame */
 
-    /* -- take input until the end of the frame is known and reached */
-    while (!d->frame_done) {
-        size_t want;                            /* bytes of the frame needed to make the next decision */
-        if (!d->header_done) {
-            size_t bm = 0, hs = parse_header(d->in, d->in_size, &d->info, &bm);
-            if (LZ4F_isError(hs)) return hs;
-            if (hs) {
-                d->header_done = 1; d->header_size = hs; d->block_max = bm; d->scan_pos = hs;
-                if (d->info.frameType == LZ4F_skippableFrame) { d->frame_size = hs + (size_t)d->info.contentSize; }
+    for (;;) {
+        /* -- decoded bytes go out before anything else is taken in */
+        if (d->out_pos < d->out_size) {
+            const size_t left = d->out_size - d->out_pos, give = left < dcap - given ? left : dcap - given;
+            if (give) memcpy(dst + given, d->out + d->out_pos, give);
+            d->out_pos += give; given += give;
+            if (d->out_pos < d->out_size) break;                            /* dst is full: call again */
+        }
+        if (d->stage == ST_DONE) {                                           /* frame complete and delivered */
+            LZ4F_resetDecompressionContext(d);
+            *srcSizePtr = used; *dstSizePtr = given;
+            return 0;
+        }
+        if (d->stage == ST_HEADER) {
+            size_t bm = 0, hs;
+            if (!take_input(d, header_want(d->in, d->in_size), src, avail, &used, &err)) { if (err) goto fail; break; }
+            if (d->in_size < header_want(d->in, d->in_size)) continue;       /* the size is known now: take the rest */
+            hs = parse_header(d->in, d->in_size, &d->info, &bm);
+            if (LZ4F_isError(hs)) { err = hs; goto fail; }
+            if (hs == 0) { err = ERR(frameHeader_incomplete); goto fail; }
+            enter_frame(d, bm);
+            continue;
+        }
+        if (d->stage == ST_SKIP) {                                           /* lz4frame.c:2037-2055: user data is skipped, not kept */
+            const unsigned long long n = avail - used < d->skip_left ? avail - used : d->skip_left;
+            used += (size_t)n; d->skip_left -= n;
+            if (d->skip_left) break;
+            d->stage = ST_DONE;
+            continue;
+        }
+        if (d->stage == ST_TAIL) {                                           /* content checksum, lz4frame.c:2005-2030 */
+            if (!take_input(d, 4, src, avail, &used, &err)) { if (err) goto fail; break; }
+            if (!skipc && rd32(d->in) != xxh32_digest(&d->xxh)) { err = ERR(contentChecksum_invalid); goto fail; }
+            d->in_size = 0; d->stage = ST_DONE;
+            continue;
+        }
+        /* -- ST_BLOCKS: collect whole blocks, decode them when there is no reason to wait for more */
+        {   const size_t tail = d->info.blockChecksumFlag == LZ4F_blockChecksumEnabled ? 4 : 0;
+            int starved = 0;
+            while (!d->end_seen && d->nready < (size_t)kBatchBlocks && d->scan_pos < kBatchBytes) {
+                uint32_t f;
+                if (!take_input(d, d->scan_pos + 4, src, avail, &used, &err)) { if (err) goto fail; starved = 1; break; }
+                f = rd32(d->in + d->scan_pos);
+                if (f == 0) { d->end_seen = 1; break; }                      /* end mark, lz4frame.c:1730 */
+                if ((f & 0x7FFFFFFFu) > d->block_max) { err = ERR(maxBlockSize_invalid); goto fail; }   /* lz4frame.c:1737 */
+                if (!take_input(d, d->scan_pos + 4 + (f & 0x7FFFFFFFu) + tail, src, avail, &used, &err)) { if (err) goto fail; starved = 1; break; }
+                d->scan_pos += 4 + (f & 0x7FFFFFFFu) + tail; d->nready++;
+            }
+            if (d->nready) {                                                 /* starved, end of frame or a full batch */
+                const size_t r = decode_batch(d, d->nready, d->scan_pos, skipc);
+                if (LZ4F_isError(r)) { err = r; goto fail; }
+                memmove(d->in, d->in + d->scan_pos, d->in_size - d->scan_pos);
+                d->in_size -= d->scan_pos; d->scan_pos = 0; d->nready = 0;
                 continue;
             }
-            if (d->in_size < 5) want = 5;
-            else if ((rd32(d->in) & 0xFFFFFFF0u) == MAGIC_SKIP) want = 8;
-            else want = 7 + ((d->in[4] & 8) ? 8 : 0) + ((d->in[4] & 1) ? 4 : 0);     /* never read past the header */
-        } else if (d->info.frameType == LZ4F_skippableFrame) {
-            if (d->in_size >= d->frame_size) { d->frame_done = 1; d->decoded = 1; d->out_size = d->out_pos = 0; break; }
-            want = d->frame_size;
-        } else if (d->in_size < d->scan_pos + 4) {
-            want = d->scan_pos + 4;
-        } else {
-            const uint32_t f = rd32(d->in + d->scan_pos);
-            if (f == 0) {                                           /* end mark */
-                d->frame_size = d->scan_pos + 4 + (d->info.contentChecksumFlag ? 4 : 0);
-                if (d->in_size >= d->frame_size) { d->frame_done = 1; break; }
-                want = d->frame_size;
-            } else {
-                const size_t bsz = f & 0x7FFFFFFFu;
-                if (bsz > d->block_max) return ERR(maxBlockSize_invalid);                  /* lz4frame.c:1737 */
-                if (d->in_size >= d->scan_pos + 4 + bsz + (d->info.blockChecksumFlag ? 4 : 0)) {
-                    d->scan_pos += 4 + bsz + (d->info.blockChecksumFlag ? 4 : 0);
-                    continue;
-                }
-                want = d->scan_pos + 4 + bsz + (d->info.blockChecksumFlag ? 4 : 0);
+            if (d->end_seen) {
+                if (d->info.contentSize && d->info.contentSize != d->total_out) { err = ERR(frameSize_wrong); goto fail; }   /* lz4frame.c:1984 */
+                d->in_size = 0; d->end_seen = 0;
+                d->stage = d->info.contentChecksumFlag ? ST_TAIL : ST_DONE;
+                continue;
             }
-        }
-        {   /* copy what is needed (and available) from the caller's buffer */
-            size_t need = want - d->in_size, take = avail - used < need ? avail - used : need;
-            if (take == 0) break;
-            if (d->in_size + take > d->in_cap) {
-                size_t nc = (d->in_size + take) * 2 + 4096;
-                uint8_t* nbuf = (uint8_t*)realloc(d->in, nc);
-                if (!nbuf) return ERR(allocation_failed);
-                d->in = nbuf; d->in_cap = nc;
-            }
-            memcpy(d->in + d->in_size, src + used, take);
-            d->in_size += take; used += take;
+            (void)starved;
+            break;                                                           /* needs more input */
         }
     }
-    *srcSizePtr = used;
-    if (!d->frame_done) {                        /* hint: bytes still missing for the next step (>= 1) */
-        return 4;
+    *srcSizePtr = used; *dstSizePtr = given;
+    {   const size_t h = size_hint(d);
+        return h ? h : 1;                                                    /* output pending with nothing more to read: call again */
     }
-    if (!d->decoded) {
-        size_t r = decode_buffered_frame(d, opt && opt->skipChecksums);
-        if (LZ4F_isError(r)) { LZ4F_resetDecompressionContext(d); return r; }
-    }
-    {   size_t left = d->out_size - d->out_pos, give = left < dcap ? left : dcap;
-        if (give) memcpy(dstBuffer, d->out + d->out_pos, give);
-        d->out_pos += give; *dstSizePtr = give;
-        if (d->out_pos < d->out_size) return d->out_size - d->out_pos;       /* more output pending: call again */
-    }
-    return 0;
+fail:
+    LZ4F_resetDecompressionContext(d);                                       /* lz4frame.c:2034: an error leaves the context reusable */
+    *srcSizePtr = used; *dstSizePtr = given;
+    return err;
 }
