@@ -36,7 +36,9 @@ typedef enum {
     LZ4AMD_OP_COMPRESS   = 0,   /* LZ4_compress_default per block (lz4.c:1472) */
     LZ4AMD_OP_DECOMPRESS = 1,   /* LZ4_decompress_safe per block (lz4.c:2451) */
     LZ4AMD_OP_COMPRESS_HC = 2,  /* LZ4_compress_HC per block (lz4hc.c:1519) */
-    LZ4AMD_OP_XXH32 = 3         /* XXH32(seed 0) per block (xxhash.c:392); result = hash as int */
+    LZ4AMD_OP_XXH32 = 3,        /* XXH32(seed 0) per block (xxhash.c:392); result = hash as int */
+    LZ4AMD_OP_GATHER = 4        /* copy src_sizes[i] bytes of d_src[i] to d_dst[i], any alignment: packs compressed blocks
+                                 * behind one another the way LZ4F_makeBlock appends them (lz4frame.c:883-914) */
 } lz4amd_op;
 
 int         lz4amd_ctx_create(lz4amd_ctx** out, int device);

@@ -33,6 +33,9 @@ template <class Ptr> __device__ __forceinline__ void st_global16(Ptr p, const U3
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) { return wave_incl_sum_u32(v); }
 __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) { return wave_incl_max_u32(v); }
 
+__device__ __forceinline__ uint64_t wave_readlane64(uint64_t v, uint32_t l) {
+    return (uint64_t)wave_readlane((uint32_t)v, l) | ((uint64_t)wave_readlane((uint32_t)(v >> 32), l) << 32);
+}
 // ---- block-level exclusive sum of two values per thread (a: u32, b: u64) ---------------
 // scratch: 3 * nwaves uint32 in LDS.  Returns exclusive prefixes; totals via ta, tb.
 // Contains two __syncthreads(); every thread of the block must call it.

@@ -181,6 +181,9 @@ __device__ __forceinline__ void tile_geometry(uint32_t t0, bool small, uint32_t&
     strip_len = t / kCmpWaves; if (strip_len < kStripMin) strip_len = kStripMin;
 }
 
+#ifndef LZ4AMD_PROBE_SH
+#define LZ4AMD_PROBE_SH 1
+#endif
 // ------------------------------------------------------------------------------ match (one strip)
 __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
                                             uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend) {
@@ -195,7 +198,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
         const uint32_t cs_off = src_ring_off(cs);
         // big blocks probe every second position (the backward extension recovers the odd starts):
         // half the work for about 4 % of the matches, which the larger table more than pays for
-        const uint32_t sh = small ? 0u : 1u, span = 64u << sh;
+        const uint32_t sh = small ? 0u : (uint32_t)LZ4AMD_PROBE_SH, span = 64u << sh, smask = (1u << sh) - 1u;
         uint32_t p = cs, cur = cs;                             // cur: first position not yet covered
         while (p < ce && p <= last_q && nseq < kRecsPerStrip) {
             const uint32_t q = p + (lane << sh);
@@ -234,7 +237,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
             uint32_t ntaken = 0, wend = anchor;                    // wend: end of the last match taken so far
             while (m) {
                 // candidates that start inside what is already covered are out
-                if (cur > p) { const uint32_t k = (cur - p + sh) >> sh; if (k >= 64) break; m &= ~0ull << k; if (!m) break; }
+                if (cur > p) { const uint32_t k = (cur - p + smask) >> sh; if (k >= 64) break; m &= ~0ull << k; if (!m) break; }
                 const uint32_t l = (uint32_t)__ffsll((long long)m) - 1;
                 m &= m - 1;
                 uint32_t el = wave_readlane(e, l);
@@ -287,7 +290,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                 nseq += ntaken;
                 anchor = wend;
             }
-            p = cur > p + span ? (cur + sh) & ~sh : p + span;
+            p = cur > p + span ? (cur + smask) & ~smask : p + span;
         }
     }
     if (lane == 0) {

@@ -97,6 +97,20 @@ __device__ __forceinline__ uint32_t win_byte(Win& W, lz4amd_gsrc g, uint32_t csi
     return chunk_byte(W.v, p - W.base);
 }
 
+// index in [from, 16) of the chunk's first byte that is not 255; 16 when there is none (from = 1 or 2)
+__device__ __forceinline__ uint32_t first_not255(const U32x4& a, uint32_t from) {
+    uint64_t lo = 0, hi = 0;
+    {   const uint32_t t0 = ~a[0], t1 = ~a[1], t2 = ~a[2], t3 = ~a[3];          // a byte that was 255 is 0 now
+        const uint32_t n0 = (((t0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t0) & 0x80808080u, n1 = (((t1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t1) & 0x80808080u;
+        const uint32_t n2 = (((t2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t2) & 0x80808080u, n3 = (((t3 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t3) & 0x80808080u;
+        lo = (uint64_t)n0 | ((uint64_t)n1 << 32); hi = (uint64_t)n2 | ((uint64_t)n3 << 32);
+    }
+    lo &= ~0ull << (8 * from);
+    if (lo) return ((uint32_t)__ffsll((long long)lo) - 1) >> 3;
+    if (hi) return 8 + (((uint32_t)__ffsll((long long)hi) - 1) >> 3);
+    return 16;
+}
+
 struct TokInfo { uint32_t ll, q, off, ml, nx, st; };      // st: 0 decoded, 1 slow path (last sequence, very long field), 2 malformed
 // Decode the sequence whose token is at p (p < csize): the authority on the fields and on the reference's input-side rules.
 __device__ __forceinline__ TokInfo tok_decode(lz4amd_gsrc g, uint32_t csize, uint32_t p) {
@@ -155,6 +169,7 @@ __device__ __forceinline__ void walk_step(WalkState& s, uint32_t b, uint32_t csi
     s.p = litdone ? m + 2 : s.p + 1;
 }
 
+constexpr uint32_t kTokPerThread = 4;
 enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_IDLE = 4 };
 
 // SLOW PATH (wave 0, every lane the same values; length fields are scanned 64 bytes at a time): the sequence whose
@@ -351,28 +366,83 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         const uint32_t N = ta;
         __syncthreads();
         LZ4AMD_PSTAMP(4);
-        // ---- P5: decode, check, place, write the records - 1024 tokens at a time
+        // ---- P5: decode, check, place, write the records - 4 consecutive tokens per thread, 4096 per trip.  A token costs
+        // two dependent trips to memory (its own bytes, then the offset / match length behind its literals); a thread
+        // keeps the four of them in flight together (one token per thread and trip was bound by exactly that latency:
+        // 0.7 M cycles per 4 MiB block).  The fast form below covers length fields that end inside the 16 bytes loaded (lengths < 3585), away
+        // from the block's end; anything else goes through tok_decode, the authority.
         int bad = 0;
-        for (uint32_t base = 0; base < N; base += kThreads) {
-            const uint32_t i = base + tid;
-            const bool have = i < N;
-            TokInfo ti; ti.ll = ti.q = ti.off = ti.ml = ti.nx = 0; ti.st = 0;
-            uint32_t tp = 0, follow = 0;
-            if (have) {
-                tp = toks[i]; follow = i + 1 < N ? toks[i + 1] : tend;
-                ti = tok_decode(src, csize, tp);
+        for (uint32_t base = 0; base < N; base += kThreads * kTokPerThread) {
+            // wave w takes the tokens base + 256 w .. + 255; lane l the tokens l, l + 64, l + 128, l + 192 of them, so that
+            // every load and store of the wave walks over neighbouring tokens (a lane with four tokens in a row touched
+            // 64 different cache lines per instruction, and the pass was bound by that, not by latency)
+            const uint32_t i0 = base + (tid >> 6) * (64 * kTokPerThread) + (tid & 63);
+            uint32_t tp[kTokPerThread], tnext[kTokPerThread];
+#pragma unroll
+            for (uint32_t j = 0; j < kTokPerThread; j++) {
+                const uint32_t i = i0 + 64 * j;
+                tp[j] = i < N ? toks[i] : tend;
+                tnext[j] = i + 1 < N ? toks[i + 1] : tend;
             }
-            const uint32_t len = have && ti.st == 0 ? ti.ll + ti.ml : 0;
+            TokInfo ti[kTokPerThread];
+            U32x4 g0[kTokPerThread], g1[kTokPerThread];
+            bool fast[kTokPerThread];
+            uint32_t mpos[kTokPerThread];
+#pragma unroll
+            for (uint32_t j = 0; j < kTokPerThread; j++) {
+                fast[j] = i0 + 64 * j < N && tp[j] + 16 <= csize;
+                g0[j][0] = g0[j][1] = g0[j][2] = g0[j][3] = 0;
+                if (fast[j]) g0[j] = ld_global16(src + tp[j]);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kTokPerThread; j++) {
+                const uint32_t b = g0[j][0] & 0xFFu;
+                const bool ext = (b >> 4) == 15;
+                const uint32_t k = first_not255(g0[j], 1);                     // 15 + 255 per full byte + the byte that ends the field
+                ti[j].ll = ext ? 15 + 255 * (k - 1) + chunk_byte(g0[j], k & 15) : b >> 4;
+                ti[j].q = tp[j] + (ext ? k + 1 : 1u);
+                mpos[j] = ti[j].q + ti[j].ll;
+                fast[j] = fast[j] && !(ext && k == 16) && mpos[j] + 16 <= csize;
+                g1[j][0] = g1[j][1] = g1[j][2] = g1[j][3] = 0;
+                if (fast[j]) g1[j] = ld_global16(src + mpos[j]);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kTokPerThread; j++) {
+                const uint32_t b = g0[j][0] & 0xFFu;
+                const bool ext = (b & 15) == 15;
+                const uint32_t k = first_not255(g1[j], 2);
+                const uint32_t nx = mpos[j] + (ext ? k + 1 : 2u);
+                if (fast[j] && !(ext && k == 16) && nx + 4 <= csize) {
+                    ti[j].off = g1[j][0] & 0xFFFFu;
+                    ti[j].ml = (ext ? 15 + 255 * (k - 2) + chunk_byte(g1[j], k & 15) : b & 15) + kMinMatch;
+                    ti[j].nx = nx;
+                    ti[j].st = 0;
+                } else if (i0 + 64 * j < N) ti[j] = tok_decode(src, csize, tp[j]);
+                else { ti[j].ll = ti[j].q = ti[j].off = ti[j].ml = ti[j].nx = 0; ti[j].st = 0; }
+            }
+            // output positions: a scan over the wave's 256 tokens in token order (lane fastest), then over the waves
+            uint32_t excl[kTokPerThread], wsum = 0;             // 256 sequences of < 2^16 bytes each (fields of <= kExtMax bytes): 32 bits are plenty inside the wave
+#pragma unroll
+            for (uint32_t j = 0; j < kTokPerThread; j++) {
+                const uint32_t len = i0 + 64 * j < N && ti[j].st == 0 ? ti[j].ll + ti[j].ml : 0u;
+                const uint32_t incl = wave_incl_sum(len);
+                excl[j] = wsum + incl - len;
+                wsum += wave_readlane(incl, 63);
+            }
             uint32_t e2, t2; uint64_t eo, to;
-            block_excl_sum2(0u, (uint64_t)len, scan, e2, eo, t2, to);
-            if (have) {
-                const uint64_t o64 = (uint64_t)obase + eo;
-                const uint32_t o = (uint32_t)o64;
-                bool b = ti.st != 0 || ti.nx != follow || (i == 0 && tp != e);          // the chain, as the decoder sees it
-                b = b || o64 > capB || capB - o < ti.ll + kMfLimit || ti.off == 0 || ti.off > o + ti.ll - low
-                      || capB - (o + ti.ll) < ti.ml + kLastLiterals;                    // lz4.c:2279 (a sequence here is never the last), 2356, 2423
-                if (b) { atomicMin(&misc[M_ERR], tp); bad = 1; }
-                else { SeqRec r; r.outpos = o; r.litpos = ti.q; r.ll = ti.ll; r.off = ti.off; rectab[nrec + i] = r; }
+            block_excl_sum2(0u, (tid & 63) == 0 ? (uint64_t)wsum : 0ull, scan, e2, eo, t2, to);
+            const uint64_t wbase = (uint64_t)obase + wave_readlane64(eo, 0);
+#pragma unroll
+            for (uint32_t j = 0; j < kTokPerThread; j++) {
+                if (i0 + 64 * j < N) {
+                    const uint64_t o64 = wbase + excl[j];
+                    const uint32_t o = (uint32_t)o64;
+                    bool b = ti[j].st != 0 || ti[j].nx != tnext[j] || (i0 + 64 * j == 0 && tp[j] != e);   // the chain, as the decoder sees it
+                    b = b || o64 > capB || capB - o < ti[j].ll + kMfLimit || ti[j].off == 0 || ti[j].off > o + ti[j].ll - low
+                          || capB - (o + ti[j].ll) < ti[j].ml + kLastLiterals;          // lz4.c:2279 (a sequence here is never the last), 2356, 2423
+                    if (b) { atomicMin(&misc[M_ERR], tp[j]); bad = 1; }
+                    else { SeqRec r; r.outpos = o; r.litpos = ti[j].q; r.ll = ti[j].ll; r.off = ti[j].off; rectab[nrec + i0 + 64 * j] = r; }
+                }
             }
             if (__syncthreads_or(bad)) return false;
             obase += (uint32_t)to;

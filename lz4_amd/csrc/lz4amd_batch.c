@@ -167,6 +167,12 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         p->grid = (unsigned)n;
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
+    } else if (op == LZ4AMD_OP_GATHER) {
+        lz4amd_gather_params* q = &p->gather;
+        p->grid = (unsigned)n;
+        q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
+        q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
+        q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
     } else {
         lz4amd_set_error("operation not implemented on the device yet");
         lz4amd_plan_destroy(p);
@@ -217,6 +223,7 @@ static int launch_stage(lz4amd_plan* p, int stage, void* stream)
     if (p->op == LZ4AMD_OP_DECOMPRESS)
         return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
     if (p->op == LZ4AMD_OP_XXH32) return stage == 0 ? lz4amd_hip_launch_xxh32(&p->xxh, stream) : 0;
+    if (p->op == LZ4AMD_OP_GATHER) return stage == 0 ? lz4amd_hip_launch_gather(&p->gather, stream) : 0;
     if (p->op == LZ4AMD_OP_COMPRESS_HC) return stage == 0 ? lz4amd_hip_launch_compress_hc(&p->hc, p->grid, stream) : 0;
     return stage == 0 ? lz4amd_hip_launch_compress(&p->comp, p->grid, stream) : 0;
 }

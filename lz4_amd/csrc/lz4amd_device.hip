@@ -6,6 +6,7 @@
 #include "kernels/lz4_compress_kernel.h"
 #include "kernels/lz4_hc_kernel.h"
 #include "kernels/xxh32_kernel.h"
+#include "kernels/gather_kernel.h"
 #include "lz4amd_ffi.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +21,7 @@ __global__ void __launch_bounds__(kCmpThreads) lz4amd_k_compress(lz4amd_comp_par
 
 __global__ void __launch_bounds__(kHcThreads) lz4amd_k_compress_hc(lz4amd_hc_params p) { hc_batch_body(p); }
 __global__ void __launch_bounds__(64) lz4amd_k_xxh32(lz4amd_xxh_params p) { xxh32_block_body(p); }
+__global__ void __launch_bounds__(256) lz4amd_k_gather(lz4amd_gather_params p) { gather_block_body(p); }
 
 // calibration: a plain 16-bytes-per-lane stream copy, the bandwidth this box's HBM actually delivers to a read+write stream
 __global__ void __launch_bounds__(256) lz4amd_k_stream_copy(const lz4amd_u32x4* __restrict__ src, lz4amd_u32x4* __restrict__ dst, size_t n16) {
@@ -116,6 +118,12 @@ extern "C" int lz4amd_hip_launch_stream_copy(void* d_dst, const void* d_src, siz
 extern "C" int lz4amd_hip_launch_xxh32(const lz4amd_xxh_params* p, void* s) {
     if (!p->n_blocks) return 0;
     hipLaunchKernelGGL(lz4amd_k_xxh32, dim3(p->n_blocks), dim3(64), kXxhChunk, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int lz4amd_hip_launch_gather(const lz4amd_gather_params* p, void* s) {
+    if (!p->n_blocks) return 0;
+    hipLaunchKernelGGL(lz4amd_k_gather, dim3(p->n_blocks * kGatherSlices), dim3(kGatherThreads), 0, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -24,6 +24,7 @@ struct lz4amd_plan {
     lz4amd_comp_params comp;
     lz4amd_hc_params hc;
     lz4amd_xxh_params xxh;
+    lz4amd_gather_params gather;
     int row0[2];                        /* lz4amd_plan_set_row0: host copy of the sizes in flight */
 };
 

@@ -53,4 +53,13 @@ typedef struct lz4amd_xxh_params {
     uint32_t n_blocks;
 } lz4amd_xxh_params;
 
+typedef struct lz4amd_gather_params {
+    const uint8_t* const* src;      /* [n_blocks] */
+    const int32_t* src_size;        /* [n_blocks] bytes to copy */
+    uint8_t* const* dst;            /* [n_blocks] any alignment */
+    const int32_t* dst_cap;
+    int32_t* result;                /* [n_blocks] bytes copied, -1 if the row does not fit */
+    uint32_t n_blocks;
+} lz4amd_gather_params;
+
 #endif

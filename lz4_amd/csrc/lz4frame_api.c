@@ -65,7 +65,7 @@ static unsigned optimal_bsid(unsigned requested, size_t srcSize)
 }
 
 /* ---------------------------------------------------------------- device helpers */
-typedef struct { void* in; size_t in_cap; void* out; size_t out_cap; } dev_stage;
+typedef struct { void* in; size_t in_cap; void* out; size_t out_cap; void* pack; size_t pack_cap; } dev_stage;
 static dev_stage g_stage;                           /* guarded by lz4amd_default_lock */
 static int stage_fit(void** buf, size_t* cap, size_t need)
 {
@@ -78,6 +78,11 @@ static int stage_fit(void** buf, size_t* cap, size_t need)
 }
 
 /* ---------------------------------------------------------------- compression */
+/* The content checksum is one serial XXH32 over the source (lz4frame.c:1225): it runs on a helper thread from the
+ * first byte uploaded to the last byte downloaded, instead of holding the calling thread for ~0.2 s per GiB. */
+typedef struct { const uint8_t* p; size_t n; uint32_t h; } hash_job;
+static void* hash_thread(void* arg) { hash_job* j = (hash_job*)arg; j->h = xxh32(j->p, j->n); return NULL; }
+
 size_t LZ4F_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* prefs)
 {   /* lz4frame.c:406-416 with autoFlush: every block may be stored raw */
     LZ4F_preferences_t p;
@@ -99,10 +104,11 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     size_t bs, nb, stride, i, result = ERR(GENERIC);
     unsigned bsid;
     lz4amd_ctx* ctx;
-    lz4amd_plan *cplan = NULL, *xplan = NULL;
+    lz4amd_plan *cplan = NULL, *xplan = NULL, *gplan = NULL;
     const void** d_src = NULL; void** d_dst = NULL; int *sizes = NULL, *caps = NULL, *csz = NULL, *sums = NULL, *pres = NULL;
     uint32_t content_sum = 0;
-    int linked;
+    int linked, hashing = 0;
+    hash_job hj; pthread_t hthread;
 
     if (prefs) p = *prefs; else memset(&p, 0, sizeof p);
     if (!dst || (!src && srcSize)) return ERR(parameter_null);
@@ -126,6 +132,11 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
         *op = (uint8_t)(xxh32(desc, (size_t)(op - desc)) >> 8); op++;
     }
     if (nb == 0) goto finish_frame;
+    if (p.frameInfo.contentChecksumFlag) {
+        hj.p = src; hj.n = srcSize; hj.h = 0;
+        hashing = srcSize >= (1u << 20) && pthread_create(&hthread, NULL, hash_thread, &hj) == 0;
+        if (!hashing) content_sum = xxh32(src, srcSize);
+    }
 
     /* -- all blocks in one block table on the device */
     stride = (bs + bs / 255 + 16 + 255) & ~(size_t)255;
@@ -152,7 +163,6 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     } else
     if (lz4amd_plan_create_compress_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL)) goto done;
     if (lz4amd_plan_launch(cplan, NULL)) goto done;
-    if (p.frameInfo.contentChecksumFlag) content_sum = xxh32(src, srcSize);      /* the host hashes while the GPU compresses */
     if (lz4amd_plan_results(cplan, csz, NULL)) goto done;
     for (i = 0; i < nb; i++) if (csz[i] <= 0 || csz[i] >= sizes[i]) csz[i] = 0;   /* stored raw */
     if (p.frameInfo.blockChecksumFlag) {          /* lz4frame.c:904: XXH32 of the block as stored */
@@ -160,25 +170,44 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
         if (lz4amd_plan_create(ctx, &xplan, LZ4AMD_OP_XXH32, (int)nb, d_src, caps, NULL, NULL, 0)) goto done;
         if (lz4amd_plan_launch(xplan, NULL) || lz4amd_plan_results(xplan, sums, NULL)) goto done;
     }
-    for (i = 0; i < nb; i++) {
-        const uint32_t n = csz[i] ? (uint32_t)csz[i] : (uint32_t)sizes[i];
-        wr32(op, csz[i] ? n : (n | 0x80000000u)); op += 4;
-        if (csz[i]) { if (lz4amd_hip_d2h(op, (char*)g_stage.out + i * stride, n, NULL)) goto done; }
-        else memcpy(op, src + i * bs, n);
-        op += n;
-        if (p.frameInfo.blockChecksumFlag) { wr32(op, (uint32_t)sums[i]); op += 4; }
+    {   /* The blocks sit in bound-sized slots; their sizes say where each goes in the frame (lz4frame.c:883-914 appends
+         * them one behind the other).  One gather launch packs them on the device - stored blocks straight from the
+         * source - and the body of the frame comes back in ONE transfer; the 4-byte size fields and checksums are
+         * written into the gaps here. */
+        const size_t tailsz = p.frameInfo.blockChecksumFlag ? 4 : 0;
+        size_t total = 0;
+        for (i = 0; i < nb; i++) {
+            const size_t n = csz[i] ? (size_t)csz[i] : (size_t)sizes[i];
+            d_src[i] = csz[i] ? (const char*)g_stage.out + i * stride : (const char*)g_stage.in + i * bs;
+            caps[i] = (int)n;                                   /* rows: (source, size) -> body offset + 4 */
+            pres[i] = (int)n;
+            total += 4 + n + tailsz;
+        }
+        if (stage_fit(&g_stage.pack, &g_stage.pack_cap, total + 64)) { result = ERR(allocation_failed); goto done; }
+        {   size_t off = 0;
+            for (i = 0; i < nb; i++) { d_dst[i] = (char*)g_stage.pack + off + 4; off += 4 + (size_t)caps[i] + tailsz; }
+        }
+        if (lz4amd_plan_create(ctx, &gplan, LZ4AMD_OP_GATHER, (int)nb, d_src, caps, d_dst, pres, 0) || lz4amd_plan_launch(gplan, NULL)) goto done;
+        if (lz4amd_hip_d2h(op, g_stage.pack, total, NULL) || lz4amd_hip_sync(NULL)) goto done;
+        for (i = 0; i < nb; i++) {
+            const uint32_t n = (uint32_t)caps[i];
+            wr32(op, csz[i] ? n : (n | 0x80000000u)); op += 4 + n;          /* lz4frame.c:896-903 */
+            if (tailsz) { wr32(op, (uint32_t)sums[i]); op += 4; }           /* lz4frame.c:904-908 */
+        }
     }
     if (lz4amd_hip_sync(NULL)) goto done;
     pthread_mutex_unlock(&lz4amd_default_lock);
-    lz4amd_plan_destroy(cplan); lz4amd_plan_destroy(xplan); cplan = xplan = NULL;
+    lz4amd_plan_destroy(cplan); lz4amd_plan_destroy(xplan); lz4amd_plan_destroy(gplan); cplan = xplan = gplan = NULL;
     goto finish_frame_free;
 done:
     pthread_mutex_unlock(&lz4amd_default_lock);
 done_unlocked:
-    lz4amd_plan_destroy(cplan); lz4amd_plan_destroy(xplan);
+    if (hashing) pthread_join(hthread, NULL);
+    lz4amd_plan_destroy(cplan); lz4amd_plan_destroy(xplan); lz4amd_plan_destroy(gplan);
     free(d_src); free(d_dst); free(sizes); free(caps); free(csz); free(sums); free(pres);
     return result;
 finish_frame_free:
+    if (hashing) { pthread_join(hthread, NULL); content_sum = hj.h; }
     free(d_src); free(d_dst); free(sizes); free(caps); free(csz); free(sums); free(pres);
 finish_frame:
     if (nb == 0 && p.frameInfo.contentChecksumFlag) content_sum = xxh32(src, 0);
@@ -417,10 +446,15 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
     if (grow(&d->out, &d->out_cap, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done; }
     if (linked) { if (out_total && lz4amd_hip_d2h(d->out, (char*)g_stage.out + h0, out_total, NULL)) goto done; }
     else {
+        /* every block but the last is normally full, so the block_max-strided slots ARE the content: one transfer
+         * (stored blocks are then laid over their slots from the input); ragged tables go block by block */
         size_t o = 0;
+        int dense = 1;
+        for (i = 0; i + 1 < nb; i++) if ((size_t)res[i] != d->block_max) { dense = 0; break; }
+        if (dense && out_total && lz4amd_hip_d2h(d->out, g_stage.out, out_total, NULL)) goto done;
         for (i = 0; i < nb; i++) {
             if (raw[i]) memcpy(d->out + o, base + in_off[i], (size_t)res[i]);
-            else if (lz4amd_hip_d2h(d->out + o, d_dst[i], (size_t)res[i], NULL)) goto done;
+            else if (!dense && lz4amd_hip_d2h(d->out + o, d_dst[i], (size_t)res[i], NULL)) goto done;
             o += (size_t)res[i];
         }
     }

@@ -6,6 +6,7 @@
 #include "../../lz4_amd/csrc/kernels/lz4_compress_kernel.h"
 #include "../../lz4_amd/csrc/kernels/lz4_hc_kernel.h"
 #include "../../lz4_amd/csrc/kernels/xxh32_kernel.h"
+#include "../../lz4_amd/csrc/kernels/gather_kernel.h"
 #include <vector>
 
 extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int32_t* src_size,
@@ -60,6 +61,14 @@ extern "C" int emu_xxh32_batch(const uint8_t* const* src, const int32_t* src_siz
     using namespace lz4amd;
     XxhBatch P; P.src = src; P.src_size = src_size; P.result = result; P.n_blocks = n;
     if (n) simt::launch(n, 64, kXxhChunk, [&] { xxh32_block_body(P); });
+    return 0;
+}
+
+extern "C" int emu_gather_batch(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
+                                int32_t* result, uint32_t n) {
+    using namespace lz4amd;
+    GatherBatch P; P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result; P.n_blocks = n;
+    if (n) simt::launch(n * kGatherSlices, kGatherThreads, 0, [&] { gather_block_body(P); });
     return 0;
 }
 

@@ -134,6 +134,38 @@ def test_decompress_long_overlapping_matches(emu, ocodec):
         assert r == len(d) and o == d
 
 
+def _field_length_corpus():
+    """Blocks whose literal-length and match-length fields take 0 .. 16 extension bytes: noise runs and copies of the
+    lengths where a field grows by a byte (15+255k) and where it leaves the 16 bytes the record pass loads at once."""
+    edges = [3, 14, 15, 18, 19, 269, 270, 273, 274, 524, 525, 529, 3583, 3584, 3585, 3586, 3588, 3589, 3590, 3839, 3840, 3844, 4100, 20000]
+    rng = random.Random(99)
+    out = []
+    for variant in range(3):
+        d = bytearray(rng.randbytes(70000))
+        for k in range(400):
+            ll, ml = rng.choice(edges), rng.choice(edges)
+            d += rng.randbytes(ll)                                    # literals: noise does not match anything
+            back = rng.randint(1, 65000)
+            src = len(d) - back
+            for i in range(ml):                                       # a copy (overlapping when back < ml)
+                d.append(d[src + i])
+        out.append(bytes(d))
+    return out
+
+
+def test_decompress_length_fields_of_every_size(emu, ocodec, reflib):
+    cases = _field_length_corpus()
+    comps = [ocodec.compress(d)[1] for d in cases]
+    for d in cases[:1]:                                               # the HC parser takes the long copies whole
+        cap = len(d) + len(d) // 255 + 16
+        cb = ctypes.create_string_buffer(cap)
+        n = reflib.LZ4_compress_HC(d, cb, len(d), cap, 9)
+        comps.append(cb.raw[:n])
+    cases = cases + cases[:1]
+    for d, (r, o) in zip(cases, emu_decompress(emu, comps, [len(d) for d in cases])):
+        assert r == len(d) and o == d
+
+
 def test_decompress_records_longer_than_the_rings(emu, reflib):
     """Few sequences with very long literal runs and matches (noise through the HC compressor, zeros): records
     that the feeder cuts in pieces."""
@@ -424,3 +456,35 @@ def test_hc_with_history_decodes_with_prefix_oracle(emu, oracle, datagen):
         out = ctypes.create_string_buffer(data[pre - used:pre], used + n)
         r = oracle.lz4o_decompress_safe_prefix(dst.raw[:res[0]], ctypes.addressof(out) + used, res[0], n, used)
         assert r == n and out.raw[used:used + n] == data[pre:pre + n], (pre, n)
+
+
+def test_gather_rows_of_any_size_and_alignment(emu):
+    """The frame writer's packing launch: every row lands byte for byte at its destination, nothing around it moves."""
+    rng = random.Random(5)
+    sizes = [0, 1, 15, 16, 17, 31, 100, 4095, 16384, 16385, 70000, 131072 + 3, 1 << 20, (1 << 20) + 7]
+    rows = []
+    for k, n in enumerate(sizes * 2):
+        rows.append((rng.randbytes(n), rng.randrange(16), rng.randrange(16), n + (k % 3 == 0)))
+    rows.append((b"x" * 100, 3, 5, 99))                                # does not fit: refused, nothing written
+    n = len(rows)
+    srcs = [ctypes.create_string_buffer(len(d) + 32) for d, _, _, _ in rows]
+    dsts = [ctypes.create_string_buffer(max(cap, len(d)) + 64) for d, _, _, cap in rows]
+    al = lambda buf, a: ((ctypes.addressof(buf) + 15) & ~15) + a
+    for (d, sa, da, cap), s, t in zip(rows, srcs, dsts):
+        ctypes.memmove(al(s, sa), d, len(d))
+        ctypes.memset(t, CANARY, len(t))
+    sp = (ctypes.c_void_p * n)(*[al(s, r[1]) for s, r in zip(srcs, rows)])
+    dp = (ctypes.c_void_p * n)(*[al(t, r[2]) for t, r in zip(dsts, rows)])
+    ss = (ctypes.c_int32 * n)(*[len(r[0]) for r in rows])
+    dc = (ctypes.c_int32 * n)(*[r[3] for r in rows])
+    res = (ctypes.c_int32 * n)()
+    emu.emu_gather_batch(sp, ss, dp, dc, res, n)
+    for i, ((d, sa, da, cap), t) in enumerate(zip(rows, dsts)):
+        off = al(t, da) - ctypes.addressof(t)
+        raw = t.raw
+        if len(d) > cap:
+            assert res[i] == -1 and raw == bytes([CANARY]) * len(raw)
+            continue
+        assert res[i] == len(d), i
+        assert raw[off:off + len(d)] == d, i
+        assert raw[:off] == bytes([CANARY]) * off and raw[off + len(d):] == bytes([CANARY]) * (len(raw) - off - len(d)), i
