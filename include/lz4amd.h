@@ -74,6 +74,15 @@ int  lz4amd_plan_create_compress_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int 
 int  lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                            const void* const* d_src, const int* src_sizes,
                                            void* const* d_dst, const int* dst_caps, const int* prefix_sizes, int level);
+/* LZ4AMD_OP_DECOMPRESS over DEPENDENT blocks, all in one launch (lz4frame linked blocks, lz4frame.c:1901-1915:
+ * LZ4_decompress_safe_usingDict with the previous 64 KB of output as dictionary, block after block).  Block i's output
+ * starts where block i-1's ended: the packed output begins at d_dst0, where initial_prefix bytes of history (<= 64 KB
+ * used) already sit in front of it; dst_caps[i] bounds block i's decoded size (the frame's maximum block size);
+ * stored[i] != 0 marks a block that is copied as is (lz4frame.c:1758-1830), NULL = none.  results[i] = decoded size;
+ * a malformed block and every block behind it report a negative value. */
+int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                                           const void* const* d_src, const int* src_sizes,
+                                           void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix);
 void lz4amd_plan_destroy(lz4amd_plan* plan);
 /* enqueue the whole table on `stream` (asynchronous) */
 int  lz4amd_plan_launch(lz4amd_plan* plan, void* stream);

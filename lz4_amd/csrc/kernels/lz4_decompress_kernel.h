@@ -671,15 +671,97 @@ out:
     if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[5] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); }
 }
 
+// ------------------------------------------------------------------------------ stage B of one block
+__device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, uint32_t prefix,
+                                             const SeqRec* rectab, uint32_t nseq, char* smem, uint64_t* prof) {
+    const uint32_t tid = threadIdx.x, w = wave_id();
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
+    if (tid == 0) { misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_EMIT] = kBias; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
+    if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
+    if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
+    if (prefix) {
+        uint8_t* ring = (uint8_t*)(smem + kOffRing);
+        const uint32_t lo = kBias - prefix;
+        for (uint32_t v = (lo & ~15u) + 16 * tid; v < kBias; v += 16 * kDecThreads) {
+            U32x4 g; g[0] = g[1] = g[2] = g[3] = 0;
+#pragma nounroll
+            for (uint32_t i = 0; i < 16; i++) if (v + i >= lo) chunk_set_byte(g, i, (uint32_t)(dst - (kBias - (v + i)))[0]);
+            *(U32x4*)(ring + v) = g;                         // positions below kBias sit at ring address = position
+            if (v < kRingPad) *(U32x4*)(ring + kRingBytes + v) = g;
+        }
+    }
+    __syncthreads();
+
+    if (w == kFeedWave) feeder_role(csize, rectab, nseq, smem);
+    else if (w == kLoadWave) loader_role(src, csize, smem);
+    else copy_role(w, dst, smem, prof);
+
+}
+
+// ------------------------------------------------------------------------------ one DEPENDENT block
+// lz4frame's linked blocks (lz4frame.c:1901-1915): block b's output starts where block b-1's ended and its matches may
+// reach 64 KB back into it.  All blocks of the frame are in ONE launch: a workgroup pre-parses its block at once -
+// against the largest history there can be - then waits for the workgroup that owns b-1 to publish where its output
+// ended (tickets are handed out in block order to running workgroups, so that owner exists and progresses), checks the
+// lowest position its matches refer to against the history that is really there, and streams.  Only stage B is serial.
+__device__ __forceinline__ void chain_publish(const DecBatch& P, uint32_t b, long long v) {
+    __syncthreads();                                       // every store of the block was issued
+    if (threadIdx.x == 0) chain_store_release(&P.chain[b + 1], v);
+}
+__device__ __forceinline__ void decode_chained_block(const DecBatch& P, uint32_t b, char* smem) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
+    const int32_t csize_i = P.src_size[b], cap_i = P.dst_cap[b];
+    const bool stored = P.stored && P.stored[b];
+    SeqRec* rectab = (SeqRec*)(P.scratch + (uint64_t)blockIdx.x * P.scratch_stride);
+    uint32_t nseq = 0, total = 0;
+    bool ok = src != nullptr && csize_i > 0 && cap_i > 0;
+    if (ok && stored) { ok = csize_i <= cap_i; total = (uint32_t)csize_i; }
+    else if (ok) ok = pre::preparse_block(src, (uint32_t)csize_i, (uint32_t)cap_i, kBias, rectab, smem, pre::table_bytes((uint32_t)csize_i), nseq, total, nullptr);
+    const uint32_t minref = ((const uint32_t*)(smem + pre::kOffMisc))[pre::M_MINREF];
+    __syncthreads();                                       // stage A's LDS is dead from here
+    // -- where does my output start?
+    if (tid == 0) {
+        long long s;
+        while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
+        misc[M_CHI] = (uint32_t)(unsigned long long)s; misc[M_EMIT] = (uint32_t)((unsigned long long)s >> 32);
+    }
+    __syncthreads();
+    const long long start = (long long)((unsigned long long)misc[M_CHI] | ((unsigned long long)misc[M_EMIT] << 32));
+    __syncthreads();                                       // (stage B re-initialises those words)
+    if (start < 0 || !ok) {                                 // a predecessor failed, or this block is malformed: the chain ends
+        if (tid == 0) P.result[b] = -1;
+        chain_publish(P, b, -2);
+        return;
+    }
+    const unsigned long long before = (unsigned long long)start + (P.prefix ? (unsigned long long)(uint32_t)P.prefix[0] : 0ull);
+    const uint32_t prefix = before < kBias ? (uint32_t)before : kBias;
+    if (!stored && minref < kBias - prefix) {               // lz4.c:2356: a match from before the start of the history
+        if (tid == 0) P.result[b] = -1;
+        chain_publish(P, b, -2);
+        return;
+    }
+    const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[0]) + start;
+    if (stored) {
+        for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
+    } else stream_block(src, (uint32_t)csize_i, dst, prefix, rectab, nseq, smem, nullptr);
+    if (tid == 0) P.result[b] = (int32_t)total;
+    chain_publish(P, b, start + (long long)total);
+}
+
 // ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, char* smem) {
     const uint32_t tid = threadIdx.x, w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
 
     const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
-    const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
+    lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
     const int32_t csize_i = P.src_size[b];
     const int32_t cap_i = P.dst_cap[b];
+    const bool chained = P.chain != nullptr;
+    if (chained) { decode_chained_block(P, b, smem); return; }
 
     // -- degenerate inputs (lz4.c:2036, 2062-2069)
     if (src == nullptr || cap_i < 0) { if (tid == 0) P.result[b] = -1; return; }
@@ -705,26 +787,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     if (prof && tid == 0) prof[1] = clock_ticks() - tstart;
     __syncthreads();            // record table visible to the whole workgroup; stage A's LDS is dead
 
-    // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
-    if (tid == 0) { misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_EMIT] = kBias; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
-    if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
-    if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
-    if (prefix) {
-        uint8_t* ring = (uint8_t*)(smem + kOffRing);
-        const uint32_t lo = kBias - prefix;
-        for (uint32_t v = (lo & ~15u) + 16 * tid; v < kBias; v += 16 * kDecThreads) {
-            U32x4 g; g[0] = g[1] = g[2] = g[3] = 0;
-#pragma nounroll
-            for (uint32_t i = 0; i < 16; i++) if (v + i >= lo) chunk_set_byte(g, i, (uint32_t)(dst - (kBias - (v + i)))[0]);
-            *(U32x4*)(ring + v) = g;                         // positions below kBias sit at ring address = position
-            if (v < kRingPad) *(U32x4*)(ring + kRingBytes + v) = g;
-        }
-    }
-    __syncthreads();
-
-    if (w == kFeedWave) feeder_role(csize, rectab, nseq, smem);
-    else if (w == kLoadWave) loader_role(src, csize, smem);
-    else copy_role(w, dst, smem, prof);
+    stream_block(src, csize, dst, prefix, rectab, nseq, smem, prof);
 
     __syncthreads();
     if (tid == 0) {

@@ -53,7 +53,7 @@ enum : uint32_t {
     kPreLdsBytes = kOffBitmap + kSpanMax / 8,
 };
 static_assert(kPreLdsBytes <= 152u * 1024u, "LDS budget");
-enum : uint32_t { M_ERR = 1, M_TERM = 8, M_NX, M_OBASE, M_NREC, M_RC };
+enum : uint32_t { M_ERR = 1, M_MINREF = 2, M_TERM = 8, M_NX, M_OBASE, M_NREC, M_RC };   // M_MINREF: lowest (biased) position any match reads
 
 // scratch of one workgroup: the record table (every sequence but the last takes >= 3 stream bytes; +1 last, +1 sentinel)
 // followed by the token list of one span
@@ -176,7 +176,7 @@ enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_I
 // token is at p, whatever its size, with the reference's rules; its record goes to rectab[nrec].
 // Returns 0: go on at nx, 1: that was the block's last sequence, 2: malformed (position in errpos).
 __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_t capB, uint32_t low, uint32_t p,
-                                          uint32_t& obase, uint32_t& nrec, SeqRec* rectab, uint32_t& nx_out, uint32_t& errpos) {
+                                          uint32_t& obase, uint32_t& nrec, SeqRec* rectab, uint32_t& nx_out, uint32_t& errpos, uint32_t& minref) {
     const uint32_t lane = lane_id();
     errpos = p < csize ? p : (csize ? csize - 1 : 0);
     if (p >= csize) return 2;
@@ -223,6 +223,7 @@ __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_
     ml += kMinMatch;
     const uint32_t ms = obase + ll;
     if (off == 0 || off > ms - low) return 2;                               // lz4.c:2356
+    if (ms - off < minref) minref = ms - off;
     if (capB - ms < ml + kLastLiterals) return 2;                           // lz4.c:2423
     if (lane == 0) { SeqRec r; r.outpos = obase; r.litpos = q; r.ll = ll; r.off = off; rectab[nrec] = r; }
     nrec++; obase = ms + ml;
@@ -248,7 +249,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     uint32_t* bm = (uint32_t*)(smem + kOffBitmap);
     uint32_t* toks = (uint32_t*)((char*)rectab + table_size);
     const uint32_t capB = cap + kBias, low = kBias - prefix;
-    if (tid == 0) misc[M_ERR] = kNone;
+    if (tid == 0) { misc[M_ERR] = kNone; misc[M_MINREF] = kNone; }
 
     uint32_t e = 0, obase = kBias, nrec = 0;          // uniform: next true token, output position, records written
     for (;;) {
@@ -441,7 +442,8 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
                     b = b || o64 > capB || capB - o < ti[j].ll + kMfLimit || ti[j].off == 0 || ti[j].off > o + ti[j].ll - low
                           || capB - (o + ti[j].ll) < ti[j].ml + kLastLiterals;          // lz4.c:2279 (a sequence here is never the last), 2356, 2423
                     if (b) { atomicMin(&misc[M_ERR], tp[j]); bad = 1; }
-                    else { SeqRec r; r.outpos = o; r.litpos = ti[j].q; r.ll = ti[j].ll; r.off = ti[j].off; rectab[nrec + i0 + 64 * j] = r; }
+                    else if (o + ti[j].ll - ti[j].off < kBias) atomicMin(&misc[M_MINREF], o + ti[j].ll - ti[j].off);    // reaches into the history
+                    if (!b) { SeqRec r; r.outpos = o; r.litpos = ti[j].q; r.ll = ti[j].ll; r.off = ti[j].off; rectab[nrec + i0 + 64 * j] = r; }
                 }
             }
             if (__syncthreads_or(bad)) return false;
@@ -452,8 +454,9 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         // ---- a token the walk could not pass: the slow path takes it (wave 0), then the next span starts behind it
         if (stop) {
             if (tid < 64) {
-                uint32_t nx = 0, ep = 0;
-                const int rc = slow_token(src, csize, capB, low, tend, obase, nrec, rectab, nx, ep);
+                uint32_t nx = 0, ep = 0, mr = kNone;
+                const int rc = slow_token(src, csize, capB, low, tend, obase, nrec, rectab, nx, ep, mr);
+                if (tid == 0 && mr < misc[M_MINREF]) misc[M_MINREF] = mr;
                 if (tid == 0) { misc[M_RC] = (uint32_t)rc; misc[M_NX] = nx; misc[M_OBASE] = obase; misc[M_NREC] = nrec; if (rc == 2) misc[M_ERR] = ep; }
             }
             __syncthreads();

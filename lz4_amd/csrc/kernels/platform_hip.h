@@ -80,6 +80,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8); }
+__device__ __forceinline__ void chain_wait_pause() { __builtin_amdgcn_s_sleep(32); }      // waiting for another workgroup
 // issue priority of this wave among the waves of its SIMD (0..3)
 __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
 
@@ -125,6 +126,15 @@ __device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
 }
 
 // device-scope work-queue ticket
+// A word another WORKGROUP publishes (linked blocks: where the predecessor's output ended).  Agent scope: the writer's
+// earlier stores are visible to this CU's later loads once the value is seen (release -> acquire, MI355X_MICROARCH.md
+// "Correctness boundaries": workgroup scope is not enough across CUs / XCDs).
+__device__ __forceinline__ long long chain_load_acquire(const long long* w) {
+    return __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_store_release(long long* w, long long v) {
+    __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t take_ticket(uint32_t* counter) {
     return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

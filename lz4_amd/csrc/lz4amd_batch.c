@@ -218,6 +218,30 @@ int lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, in
                                           void* const* d_dst, const int* dst_caps, const int* prefix_sizes, int level)
 { return plan_create_with_prefix(ctx, out, LZ4AMD_OP_COMPRESS_HC, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes, level); }
 
+int lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                                          const void* const* d_src, const int* src_sizes,
+                                          void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix)
+{
+    void** dsts; int* pre; int rc, err = 0, i, k;
+    lz4amd_plan* p;
+    if (!out || n <= 0 || !d_dst0 || initial_prefix < 0) return LZ4AMD_E_ARG;
+    dsts = (void**)malloc((size_t)n * sizeof *dsts); pre = (int*)calloc((size_t)n, sizeof *pre);
+    if (!dsts || !pre) { free(dsts); free(pre); return LZ4AMD_E_MEMORY; }
+    for (i = 0; i < n; i++) dsts[i] = d_dst0;
+    pre[0] = initial_prefix;
+    rc = plan_create_with_prefix(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, dsts, dst_caps, pre, 0);
+    free(dsts); free(pre);
+    if (rc) return rc;
+    p = *out;
+    for (k = 0; k < LZ4AMD_PLAN_MAX_BUFS && p->bufs[k]; k++) {}
+    if (k + 2 > LZ4AMD_PLAN_MAX_BUFS) { lz4amd_plan_destroy(p); *out = NULL; return LZ4AMD_E_MEMORY; }
+    p->dec.chain = (long long*)(p->bufs[k] = dev_array(NULL, ((size_t)n + 1) * sizeof(long long), &err));
+    if (stored) p->dec.stored = (const uint8_t*)(p->bufs[k + 1] = dev_array(stored, (size_t)n, &err));
+    if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
+    if (err) { lz4amd_plan_destroy(p); *out = NULL; return err; }
+    return LZ4AMD_OK;
+}
+
 static int launch_stage(lz4amd_plan* p, int stage, void* stream)
 {
     if (p->op == LZ4AMD_OP_DECOMPRESS)

@@ -130,6 +130,11 @@ extern "C" int lz4amd_hip_launch_gather(const lz4amd_gather_params* p, void* s) 
 extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void* s) {
     if (!p->n_blocks || !grid) return 0;
     HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
+    if (p->chain) {                      /* dependent blocks: nothing is known but where the first one starts */
+        if (dec_use_v1()) return -1;
+        HIPCHK(hipMemsetAsync(p->chain, 0xFF, ((size_t)p->n_blocks + 1) * sizeof(long long), (hipStream_t)s));
+        HIPCHK(hipMemsetAsync(p->chain, 0, sizeof(long long), (hipStream_t)s));
+    }
     if (dec_use_v1()) hipLaunchKernelGGL(lz4amd_k_decompress_v1, dim3(grid), dim3(v1::kDecThreads), v1::kDecLdsBytes, (hipStream_t)s, *p);
     else hipLaunchKernelGGL(lz4amd_k_decompress, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());

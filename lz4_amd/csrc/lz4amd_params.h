@@ -16,6 +16,12 @@ typedef struct lz4amd_dec_params {
     uint8_t* scratch;               /* grid * scratch_stride bytes (per-workgroup segment tables) */
     uint64_t scratch_stride;
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase timestamps */
+    /* dependent blocks (lz4frame linked blocks): chain != NULL.  chain[i] = output bytes before block i (chain[0] = 0,
+     * the others -1 before the launch, written by the workgroup that finishes block i-1; < -1: a predecessor failed).
+     * Block i then writes at dst[0] + chain[i], sees min(64 KB, prefix[0] + chain[i]) bytes of history there, and
+     * stored[i] != 0 marks a block that is copied as is (lz4frame.c:1758-1830). */
+    long long* chain;               /* [n + 1] or NULL */
+    const uint8_t* stored;          /* [n] or NULL */
 } lz4amd_dec_params;
 
 typedef struct lz4amd_comp_params {

@@ -399,24 +399,19 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         /* lz4frame.c:1901-1915: the previous 64 KB of output are the dictionary.  The history of the earlier batches
          * goes in front of the packed output; the blocks are decoded in order, each told how much precedes it. */
         size_t o = h0;
-        if (h0 && lz4amd_hip_h2d(g_stage.out, d->hist, h0, NULL)) goto done;
+        unsigned char* st = (unsigned char*)malloc(nb);
+        if (!st) { result = ERR(allocation_failed); goto done; }
+        if (h0 && lz4amd_hip_h2d(g_stage.out, d->hist, h0, NULL)) { free(st); goto done; }
         for (i = 0; i < nb; i++) {
-            d_dst[i] = (char*)g_stage.out + o;
-            if (raw[i]) {
-                if ((size_t)sizes[i] > d->block_max) { result = ERR(decompressionFailed); goto done; }
-                if (lz4amd_hip_h2d(d_dst[i], base + in_off[i], (size_t)sizes[i], NULL)) goto done;
-                res[i] = sizes[i];
-            } else {
-                const void* s1 = (const char*)g_stage.in + in_off[i];
-                int cap1 = (int)d->block_max, pre1 = (int)(o < 65536 ? o : 65536);
-                lz4amd_plan* p1 = NULL;
-                if (lz4amd_plan_create_prefix(ctx, &p1, 1, &s1, &sizes[i], &d_dst[i], &cap1, &pre1)) goto done;
-                if (lz4amd_plan_launch(p1, NULL) || lz4amd_plan_results(p1, &res[i], NULL)) { lz4amd_plan_destroy(p1); goto done; }
-                lz4amd_plan_destroy(p1);
-                if (res[i] < 0) { result = ERR(decompressionFailed); goto done; }
-            }
-            o += (size_t)res[i];
+            d_src[i] = (const char*)g_stage.in + in_off[i]; caps[i] = (int)d->block_max; st[i] = raw[i];
+            if (raw[i] && (size_t)sizes[i] > d->block_max) { free(st); result = ERR(decompressionFailed); goto done; }
         }
+        /* one launch for the whole batch: every workgroup pre-parses its block at once, only the copy stages run one after
+         * the other (lz4amd_plan_create_decompress_chained); stored blocks are copied in place by the same launch */
+        if (lz4amd_plan_create_decompress_chained(ctx, &dplan, (int)nb, d_src, sizes, (char*)g_stage.out + h0, caps, st, (int)h0)
+            || lz4amd_plan_launch(dplan, NULL) || lz4amd_plan_results(dplan, res, NULL)) { free(st); goto done; }
+        free(st);
+        for (i = 0; i < nb; i++) { if (res[i] < 0) { result = ERR(decompressionFailed); goto done; } o += (size_t)res[i]; }
         out_total = o - h0;
     } else {
         for (i = 0; i < nb; i++) {

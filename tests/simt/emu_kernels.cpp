@@ -30,9 +30,30 @@ extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int3
     uint32_t ticket = 0;
     DecBatch P;
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
-    P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix;
+    P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix; P.chain = nullptr; P.stored = nullptr;
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.prof = nullptr;
     simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
+    return 0;
+}
+
+// dependent blocks: packed output at dst0, initial_prefix bytes of history before it, stored[i] marks blocks copied as is
+extern "C" int emu_decompress_chained(const uint8_t* const* src, const int32_t* src_size, uint8_t* dst0, const int32_t* dst_cap,
+                                      int32_t* result, uint32_t n, uint32_t grid, int32_t initial_prefix, const uint8_t* stored) {
+    using namespace lz4amd;
+    uint32_t max_c = 0;
+    for (uint32_t i = 0; i < n; i++) if (src_size[i] > 0 && (uint32_t)src_size[i] > max_c) max_c = src_size[i];
+    if (grid == 0) grid = n < 4 ? (n ? n : 1) : 4;
+    uint64_t stride = (dec_scratch_bytes(max_c) + 15) & ~15ull;
+    std::vector<uint8_t> scratch((size_t)(stride * grid + 64));
+    std::vector<uint8_t*> dsts(n ? n : 1, dst0);
+    std::vector<long long> chain(n + 1, -1); chain[0] = 0;
+    std::vector<int32_t> pre(n ? n : 1, 0); pre[0] = initial_prefix;
+    uint32_t ticket = 0;
+    DecBatch P;
+    P.src = src; P.src_size = src_size; P.dst = dsts.data(); P.dst_cap = dst_cap; P.result = result;
+    P.n_blocks = n; P.ticket = &ticket; P.prefix = pre.data(); P.chain = chain.data(); P.stored = stored;
+    P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.prof = nullptr;
+    if (n) simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
     return 0;
 }
 

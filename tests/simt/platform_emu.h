@@ -23,7 +23,10 @@ static inline void wave_lds_order() { (void)__ballot(1); }
 static inline void lds_store_relaxed(uint32_t* w, uint32_t v) { *(volatile uint32_t*)w = v; }
 static inline uint32_t lanes_below(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << (simt::cur()->tid & 63u)) - 1)); }
 static inline void spin_pause() { simt::yield_to_sched(); }
+static inline long long chain_load_acquire(const long long* w) { return __atomic_load_n(w, __ATOMIC_ACQUIRE); }
+static inline void chain_store_release(long long* w, long long v) { __atomic_store_n(w, v, __ATOMIC_RELEASE); }
 static inline void spin_pause_long() { simt::yield_to_sched(); }
+static inline void chain_wait_pause() { simt::external_wait(); }
 static inline void wave_priority_high() {}
 static inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));

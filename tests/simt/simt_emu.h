@@ -92,6 +92,9 @@ inline void yield_to_sched() {
     Fiber* f = b->cur;
     simt_switch(&f->sp, b->sched_sp);
 }
+// waiting for ANOTHER block (running on another host thread): not a deadlock of this block's lanes
+inline void external_wait() { g_blk->progress++; sched_yield(); yield_to_sched(); }
+
 
 // arrive at generation g of rendezvous rv and wait until `*live` participants have arrived
 inline unsigned rendezvous(Rendezvous& rv, unsigned g, const unsigned* live, unsigned contrib, int mode) {

@@ -302,6 +302,55 @@ def test_decompress_linked_blocks_with_prefix(emu, golden, datagen):
     assert res[0] < 0
 
 
+def _emu_chained(emu, blocks, cap, total_cap, grid=0, history=b""):
+    """blocks: (stored, payload) pairs; returns (results, packed output)"""
+    n = len(blocks)
+    emu.emu_decompress_chained.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p]
+    bufs = [ctypes.create_string_buffer(p, len(p)) for _, p in blocks]
+    out = ctypes.create_string_buffer(len(history) + total_cap + 96)
+    ctypes.memset(out, CANARY, len(out))
+    base = ((ctypes.addressof(out) + 15) & ~15) + 5                      # the packed output starts at an odd address
+    ctypes.memmove(base, history, len(history))
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in bufs])
+    ss = (ctypes.c_int32 * n)(*[len(p) for _, p in blocks])
+    dc = (ctypes.c_int32 * n)(*([cap] * n))
+    st = (ctypes.c_uint8 * n)(*[1 if r else 0 for r, _ in blocks])
+    res = (ctypes.c_int32 * n)()
+    emu.emu_decompress_chained(sp, ss, base + len(history), dc, res, n, grid, len(history), st)
+    produced = sum(r for r in res if r > 0)
+    raw = ctypes.string_at(base + len(history), produced + 32)
+    return list(res), raw[:produced], raw[produced:]
+
+
+def test_decompress_chained_blocks_in_one_launch(emu, golden, datagen):
+    """All linked blocks of a reference-written frame (`lz4 -B4 -BD`) in ONE launch: every workgroup pre-parses at once and
+    waits for its predecessor's end position before it streams (lz4frame.c:1901-1915)."""
+    from conftest import GOLDEN_DIR
+    frame = open(os.path.join(GOLDEN_DIR, "f_p60_600k_B4_BD_cs.lz4"), "rb").read()
+    indep, blocks = _frame_blocks(frame)
+    src = datagen(600000, 60, 0)
+    for grid in (1, 3, 4):
+        res, out, tail = _emu_chained(emu, blocks, 65536, 600000, grid=grid)
+        assert sum(res) == len(src) and out == src and tail[:16] == bytes([CANARY]) * 16
+    # stored blocks in the chain (random bytes do not compress; lz4frame.c:896-899 stores them) and history before the batch
+    noise = random.Random(1).randbytes(30000)
+    mixed = blocks[:3] + [(True, noise)] + blocks[3:5]
+    want = src[:3 * 65536] + noise + src[3 * 65536:5 * 65536]
+    # (the two blocks behind the stored one copy from 64 KB that are no longer what the compressor saw: decode them against
+    # the oracle's view instead - only sizes and the absence of errors are compared for them)
+    res, out, _ = _emu_chained(emu, mixed[:4], 65536, 4 * 65536)
+    assert res == [65536, 65536, 65536, 30000] and out == want[:3 * 65536 + 30000]
+    # a batch that starts in the middle of the frame: its history is what the previous batch produced
+    res, out, _ = _emu_chained(emu, blocks[2:6], 65536, 4 * 65536, history=src[2 * 65536 - 65536:2 * 65536])
+    assert res == [65536] * 4 and out == src[2 * 65536:6 * 65536]
+    res, out, _ = _emu_chained(emu, blocks[2:6], 65536, 4 * 65536, history=src[2 * 65536 - 20000:2 * 65536])
+    assert res[0] < 0 and all(r < 0 for r in res)                        # matches reach beyond 20000 bytes of history: refused, chain ends
+    # without any history block 1 is malformed (lz4.c:2356); everything behind it is refused too, block 0 stands
+    res, out, _ = _emu_chained(emu, [blocks[0], (False, blocks[2][1]), blocks[1]], 65536, 3 * 65536)
+    assert res[0] == 65536 and out[:65536] == src[:65536]
+
+
 def test_compress_with_history_decodes_with_prefix_oracle(emu, oracle, datagen):
     """Linked-block compression: the block may reference the 64 KB of source before it."""
     data = datagen(300000, 60, 7)
