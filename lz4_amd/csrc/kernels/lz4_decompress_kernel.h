@@ -709,51 +709,10 @@ __device__ __forceinline__ void chain_publish(const DecBatch& P, uint32_t b, lon
     __syncthreads();                                       // every store of the block was issued
     if (threadIdx.x == 0) chain_store_release(&P.chain[b + 1], v);
 }
-__device__ __forceinline__ void decode_chained_block(const DecBatch& P, uint32_t b, char* smem) {
-    const uint32_t tid = threadIdx.x;
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
-    const int32_t csize_i = P.src_size[b], cap_i = P.dst_cap[b];
-    const bool stored = P.stored && P.stored[b];
-    SeqRec* rectab = (SeqRec*)(P.scratch + (uint64_t)blockIdx.x * P.scratch_stride);
-    uint32_t nseq = 0, total = 0;
-    bool ok = src != nullptr && csize_i > 0 && cap_i > 0;
-    if (ok && stored) { ok = csize_i <= cap_i; total = (uint32_t)csize_i; }
-    else if (ok) ok = pre::preparse_block(src, (uint32_t)csize_i, (uint32_t)cap_i, kBias, rectab, smem, pre::table_bytes((uint32_t)csize_i), nseq, total, nullptr);
-    const uint32_t minref = ((const uint32_t*)(smem + pre::kOffMisc))[pre::M_MINREF];
-    __syncthreads();                                       // stage A's LDS is dead from here
-    // -- where does my output start?
-    if (tid == 0) {
-        long long s;
-        while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
-        misc[M_CHI] = (uint32_t)(unsigned long long)s; misc[M_EMIT] = (uint32_t)((unsigned long long)s >> 32);
-    }
-    __syncthreads();
-    const long long start = (long long)((unsigned long long)misc[M_CHI] | ((unsigned long long)misc[M_EMIT] << 32));
-    __syncthreads();                                       // (stage B re-initialises those words)
-    if (start < 0 || !ok) {                                 // a predecessor failed, or this block is malformed: the chain ends
-        if (tid == 0) P.result[b] = -1;
-        chain_publish(P, b, -2);
-        return;
-    }
-    const unsigned long long before = (unsigned long long)start + (P.prefix ? (unsigned long long)(uint32_t)P.prefix[0] : 0ull);
-    const uint32_t prefix = before < kBias ? (uint32_t)before : kBias;
-    if (!stored && minref < kBias - prefix) {               // lz4.c:2356: a match from before the start of the history
-        if (tid == 0) P.result[b] = -1;
-        chain_publish(P, b, -2);
-        return;
-    }
-    const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[0]) + start;
-    if (stored) {
-        for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
-    } else stream_block(src, (uint32_t)csize_i, dst, prefix, rectab, nseq, smem, nullptr);
-    if (tid == 0) P.result[b] = (int32_t)total;
-    chain_publish(P, b, start + (long long)total);
-}
-
 // ------------------------------------------------------------------------------ one block
+// (independent and dependent blocks share ONE copy of stage A and stage B: the kernel is instruction-cache bound enough)
 __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, char* smem) {
-    const uint32_t tid = threadIdx.x, w = wave_id();
+    const uint32_t tid = threadIdx.x;
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
 
     const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]);
@@ -761,17 +720,21 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     const int32_t csize_i = P.src_size[b];
     const int32_t cap_i = P.dst_cap[b];
     const bool chained = P.chain != nullptr;
-    if (chained) { decode_chained_block(P, b, smem); return; }
+    const bool stored = chained && P.stored && P.stored[b];
 
-    // -- degenerate inputs (lz4.c:2036, 2062-2069)
-    if (src == nullptr || cap_i < 0) { if (tid == 0) P.result[b] = -1; return; }
-    if (cap_i == 0) {
-        if (tid == 0) P.result[b] = (csize_i == 1 && src[0] == 0) ? 0 : -1;
-        return;
-    }
-    if (csize_i <= 0) { if (tid == 0) P.result[b] = -1; return; }
+    // -- degenerate inputs (lz4.c:2036, 2062-2069); in a chain they are failures like any other
+    bool ok = true;
+    if (!chained) {
+        if (src == nullptr || cap_i < 0) { if (tid == 0) P.result[b] = -1; return; }
+        if (cap_i == 0) {
+            if (tid == 0) P.result[b] = (csize_i == 1 && src[0] == 0) ? 0 : -1;
+            return;
+        }
+        if (csize_i <= 0) { if (tid == 0) P.result[b] = -1; return; }
+    } else ok = src != nullptr && csize_i > 0 && cap_i > 0 && !(stored && csize_i > cap_i);
     const uint32_t csize = (uint32_t)csize_i, cap = (uint32_t)cap_i;
-    uint32_t prefix = P.prefix ? (uint32_t)P.prefix[b] : 0u; if (prefix > kBias) prefix = kBias;
+    // a dependent block is pre-parsed against the largest history there can be; what is really there is checked below
+    uint32_t prefix = chained ? kBias : (P.prefix ? (uint32_t)P.prefix[b] : 0u); if (prefix > kBias) prefix = kBias;
 
     SeqRec* rectab = (SeqRec*)(P.scratch + (uint64_t)blockIdx.x * P.scratch_stride);
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
@@ -779,21 +742,46 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     if (prof && tid == 0) tstart = clock_ticks();
 
     // ---- stage A: the record table (a malformed block ends here, nothing written)
-    uint32_t nseq = 0, total = 0;
-    if (!pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof)) {
-        if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]);
-        return;
+    uint32_t nseq = 0, total = stored ? csize : 0u;
+    if (ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof)) {
+        if (!chained) { if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]); return; }
+        ok = false;
     }
     if (prof && tid == 0) prof[1] = clock_ticks() - tstart;
+    const uint32_t minref = ((const uint32_t*)(smem + pre::kOffMisc))[pre::M_MINREF];
     __syncthreads();            // record table visible to the whole workgroup; stage A's LDS is dead
 
-    stream_block(src, csize, dst, prefix, rectab, nseq, smem, prof);
+    long long start = 0;
+    if (chained) {
+        // -- where does my output start?  (published by the workgroup that owns block b-1)
+        if (tid == 0) {
+            long long s;
+            while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
+            misc[M_CHI] = (uint32_t)(unsigned long long)s; misc[M_EMIT] = (uint32_t)((unsigned long long)s >> 32);
+        }
+        __syncthreads();
+        start = (long long)((unsigned long long)misc[M_CHI] | ((unsigned long long)misc[M_EMIT] << 32));
+        __syncthreads();                                       // (stage B re-initialises those words)
+        const unsigned long long before = (unsigned long long)(start < 0 ? 0 : start) + (P.prefix ? (unsigned long long)(uint32_t)P.prefix[0] : 0ull);
+        prefix = before < kBias ? (uint32_t)before : kBias;
+        // a predecessor failed, this block is malformed, or a match reaches before the start of the history (lz4.c:2356)
+        if (start < 0 || !ok || (!stored && minref < kBias - prefix)) {
+            if (tid == 0) P.result[b] = -1;
+            chain_publish(P, b, -2);                            // the chain ends here
+            return;
+        }
+        dst = LZ4AMD_TO_GDST(P.dst[0]) + start;
+        if (stored) for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
+    }
+
+    if (!stored) stream_block(src, csize, dst, prefix, rectab, nseq, smem, prof);
 
     __syncthreads();
     if (tid == 0) {
         P.result[b] = (int32_t)total;
         if (prof) prof[0] = clock_ticks() - tstart;
     }
+    if (chained) chain_publish(P, b, start + (long long)total);
 }
 
 // Workgroups pull blocks from a device-wide ticket counter (load balance for ragged batches).

@@ -88,8 +88,10 @@ __device__ __forceinline__ U32x4 load_granule(lz4amd_gsrc src, uint32_t csize, u
 }
 
 // A thread's view of the stream: 16 bytes in registers, reloaded when the position leaves them (one unaligned
-// 16-byte load per ~2.5 walker steps instead of one byte load per step: the walkers of a workgroup touch 1024
-// different cache lines at a time, so every load is an L2 round trip).
+// 16-byte load per ~2.5 walker steps instead of one byte load per step).  Measured and dropped: windows of 32 and of
+// 64 bytes (a whole line asked for once) and refills in step across the wave - the walk's time did not move, the select
+// trees of the wider windows made the bridging pass slower: a walker step is a chain of ~80 dependent instructions plus
+// one load, and with four waves per SIMD that serial latency, not the memory system, sets the pace.
 struct Win { U32x4 v; uint32_t base; };
 __device__ __forceinline__ void win_init(Win& W) { W.v[0] = W.v[1] = W.v[2] = W.v[3] = 0; W.base = kNone - 64; }
 __device__ __forceinline__ uint32_t win_byte(Win& W, lz4amd_gsrc g, uint32_t csize, uint32_t p) {      // p < csize
@@ -170,6 +172,11 @@ __device__ __forceinline__ void walk_step(WalkState& s, uint32_t b, uint32_t csi
 }
 
 constexpr uint32_t kTokPerThread = 4;
+// Where word w of the token bitmap lives in LDS.  Walker k marks and reads words around w = k * (segment / 32): with
+// kilobyte segments that is a stride of 32 dwords - two banks for the whole wave, every LDS access of the walk serialised
+// 32 ways (that, not memory, was what a walker step cost: ~2.3 K cycles per step of the workgroup).  Rotating every group
+// of 32 words by its own number spreads neighbouring walkers over the banks.
+__device__ __forceinline__ uint32_t bm_word(uint32_t w) { return (w & ~31u) | ((w + (w >> 5)) & 31u); }
 enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_IDLE = 4 };
 
 // SLOW PATH (wave 0, every lane the same values; length fields are scanned 64 bytes at a time): the sequence whose
@@ -259,7 +266,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         uint32_t S = ((span + kThreads - 1) / kThreads + 63) & ~63u; if (S < kSegMin) S = kSegMin;
         const uint32_t nl = (span + S - 1) / S, wps = S / 32;           // threads in use, bitmap words per segment
         const uint32_t je = (e - sp0) / S;
-        for (uint32_t w = tid; w < (span + 31) / 32; w += kThreads) bm[w] = 0;
+        for (uint32_t w = tid; w < (((span + 31) / 32 + 31) & ~31u); w += kThreads) bm[w] = 0;      // whole 32-word groups (bm_word)
         __syncthreads();
         // ---- P1: walk my segment, marking the tokens
         const uint32_t seg_lo = sp0 + tid * S, seg_hi = seg_lo + S;
@@ -272,7 +279,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
             if (run) {
                 if (s.p >= csize) { s.tok = s.mode == 0 ? s.p : s.tok; s.dead = true; }       // ran off the block
                 else {
-                    if (s.mode == 0) atomicOr(&bm[(s.p - sp0) >> 5], 1u << ((s.p - sp0) & 31));
+                    if (s.mode == 0) atomicOr(&bm[bm_word((s.p - sp0) >> 5)], 1u << ((s.p - sp0) & 31));
                     walk_step(s, win_byte(W, src, csize, s.p), csize);
                 }
             }
@@ -288,7 +295,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
             if (run) {
                 const bool at_tok = s.mode == 0;
                 if (at_tok && s.p >= sp1) { okind = OUT_EXIT; opos = s.p; }
-                else if (at_tok && ((bm[(s.p - sp0) >> 5] >> ((s.p - sp0) & 31)) & 1u)) { okind = OUT_MERGE; opos = s.p; }
+                else if (at_tok && ((bm[bm_word((s.p - sp0) >> 5)] >> ((s.p - sp0) & 31)) & 1u)) { okind = OUT_MERGE; opos = s.p; }
                 else if (trip >= kBridgeTrips) { okind = OUT_EXIT; opos = at_tok ? s.p : s.tok; }   // (a token either way: the next span starts there)
                 else if (s.p >= csize) { okind = OUT_STOP; opos = at_tok ? s.p : s.tok; }
                 else {
@@ -329,11 +336,11 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         for (uint32_t w = 0; w < wps; w++) {
             const uint32_t base = seg_lo + 32 * w;
             if (tid < nl && base < sp1) {
-                uint32_t v = bm[tid * wps + w];
+                uint32_t v = bm[bm_word(tid * wps + w)];
                 if (!active) v = 0;
                 else if (myT > base) v = (myT - base >= 32) ? 0u : (v & (0xFFFFFFFFu << (myT - base)));
                 if (tend <= base) v = 0; else if (tend - base < 32) v &= (1u << (tend - base)) - 1u;
-                bm[tid * wps + w] = v;
+                bm[bm_word(tid * wps + w)] = v;
             }
         }
         __syncthreads();
@@ -343,7 +350,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
             uint32_t left = active ? nb : 0;
             while (__any(left != 0)) {
                 if (left) {
-                    if (b.mode == 0) { if (b.p < tend && b.p < sp1) atomicOr(&bm[(b.p - sp0) >> 5], 1u << ((b.p - sp0) & 31)); left--; }
+                    if (b.mode == 0) { if (b.p < tend && b.p < sp1) atomicOr(&bm[bm_word((b.p - sp0) >> 5)], 1u << ((b.p - sp0) & 31)); left--; }
                     if (left) walk_step(b, win_byte(W, src, csize, b.p), csize);
                 }
             }
@@ -352,14 +359,14 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         LZ4AMD_PSTAMP(3);
         // ---- the token list
         uint32_t cnt = 0;
-        for (uint32_t w = 0; w < wps; w++) if (tid < nl && seg_lo + 32 * w < sp1) cnt += (uint32_t)__popc(bm[tid * wps + w]);
+        for (uint32_t w = 0; w < wps; w++) if (tid < nl && seg_lo + 32 * w < sp1) cnt += (uint32_t)__popc(bm[bm_word(tid * wps + w)]);
         uint32_t ea, ta; uint64_t eb, tb;
         block_excl_sum2(cnt, 0ull, scan, ea, eb, ta, tb);
         {
             uint32_t k = ea;
             for (uint32_t w = 0; w < wps; w++) {
                 if (tid < nl && seg_lo + 32 * w < sp1) {
-                    uint32_t v = bm[tid * wps + w];
+                    uint32_t v = bm[bm_word(tid * wps + w)];
                     while (v) { const uint32_t b = (uint32_t)__ffs((int)v) - 1; v &= v - 1; toks[k++] = seg_lo + 32 * w + b; }
                 }
             }

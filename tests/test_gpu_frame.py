@@ -136,6 +136,24 @@ def test_hc_levels_in_frames(L, oracle, datagen):
     assert len(compress_frame(L, data, level=9, blockSizeID=4)) < len(compress_frame(L, data, level=9, blockSizeID=4, blockMode=1))
 
 
+def test_linked_frame_with_stored_blocks_in_the_chain(L, oracle, datagen):
+    """Linked blocks decode in one launch (lz4amd_plan_create_decompress_chained); incompressible blocks are stored
+    (lz4frame.c:896-899) and sit in the middle of the chain: the blocks behind them copy from their bytes."""
+    rng = random.Random(17)
+    data = datagen(200000, 60, 1) + rng.randbytes(150000) + datagen(300000, 60, 2) + rng.randbytes(70000) + datagen(100000, 50, 3)
+    for kw in (dict(blockSizeID=4, contentChecksumFlag=1), dict(blockSizeID=5, blockChecksumFlag=1)):
+        frame = compress_frame(L, data, **kw)
+        assert not frame[4] & 0x20                                            # linked
+        out = ctypes.create_string_buffer(len(data) + 1)
+        used = ctypes.c_size_t()
+        r = oracle.lz4o_frame_decompress(out, len(data), frame, len(frame), ctypes.byref(used))
+        assert r == len(data) and out.raw[:len(data)] == data
+        got, pos = decompress_frame(L, frame, len(data))
+        assert got == data and pos == len(frame)
+        got, pos = decompress_frame(L, frame, len(data), chunk_rng=rng)        # batches that start anywhere in the chain
+        assert got == data and pos == len(frame)
+
+
 def test_frame_header_known_answers(L, datagen):
     # SURVEY App-B: FLG 0x64 (v1, independent, content checksum) BD 0x70 (4 MB) -> HC 0xB9; FLG 0x60 -> 0x73
     data = datagen(5 << 20, 60, 0)
