@@ -337,7 +337,7 @@ def bench_frame(lz4_amd, host):
     d64["workload"] = "the same GiB as one frame of independent 64 KiB blocks (the frame format's default block size), no checksums"
     r["independent_64K"] = d64
     r["note"] = ("PCIe inclusive and single-threaded on the host side: a parity path, not the HBM-resident rate; second of two calls. "
-                 "Linked blocks decode one launch per block (each needs its predecessor's output); independent blocks decode 1024 per launch")
+                 "Linked blocks decode chained inside one launch per 64 MiB batch (only their copy stages run one after the other); independent blocks decode 1024 per launch")
     return r
 
 

@@ -6,7 +6,7 @@
  * observable behaviour of lib/lz4.c, lib/xxhash.c and lib/lz4frame.c.  Each function
  * cites the reference lines whose RESULT it reproduces.  Little-endian 64-bit hosts.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks byte equality of
+ * Parity status: PINNED.  tests/test_oracle.py checks byte equality of
  * lz4o_compress_fast against LZ4_compress_fast of oracle/_ref/liblz4_ref.so, decoder
  * equality in both directions, XXH32 known answers and frame interop
  * with the reference LZ4F_* functions; tests/golden/ holds vectors made by the real
