@@ -2,7 +2,6 @@
 // extern "C" launch / memory wrappers declared in lz4amd_ffi.h.  Kernel bodies live in kernels/*.h.
 #include "kernels/platform_hip.h"
 #include "kernels/lz4_decompress_kernel.h"
-#include "kernels/lz4_decompress_v1_kernel.h"
 #include "kernels/lz4_compress_kernel.h"
 #include "kernels/lz4_hc_kernel.h"
 #include "kernels/xxh32_kernel.h"
@@ -15,8 +14,6 @@ using namespace lz4amd;
 
 // ------------------------------------------------------------------------------- kernels
 __global__ void __launch_bounds__(kDecThreads) lz4amd_k_decompress(lz4amd_dec_params p) { decompress_batch_body(p); }
-// round-1 decoder, kept for A/B timing only (LZ4AMD_DEC=v1)
-__global__ void __launch_bounds__(v1::kDecThreads) lz4amd_k_decompress_v1(lz4amd_dec_params p) { v1::decompress_batch_body(p); }
 __global__ void __launch_bounds__(kCmpThreads) lz4amd_k_compress(lz4amd_comp_params p) { compress_batch_body(p); }
 
 __global__ void __launch_bounds__(kHcThreads) lz4amd_k_compress_hc(lz4amd_hc_params p) { hc_batch_body(p); }
@@ -53,7 +50,6 @@ extern "C" int lz4amd_hip_init(int device, int* n_cus) {
     if (n_cus) *n_cus = cus;
     // the decoder uses ~152 KB of the CU's 160 KB LDS: opt in to large dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress_v1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v1::kDecLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCmpLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress_hc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHcLdsBytes));
     return 0;
@@ -98,9 +94,7 @@ extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
     return ms;
 }
 
-// which decoder runs: LZ4AMD_DEC=v1 selects the round-1 kernel (A/B timing)
-static bool dec_use_v1() { const char* e = getenv("LZ4AMD_DEC"); return e && e[0] == 'v' && e[1] == '1'; }
-extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return dec_use_v1() ? (size_t)v1::dec_scratch_bytes(max_csize) : (size_t)dec_scratch_bytes(max_csize); }
+extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return (size_t)dec_scratch_bytes(max_csize); }
 extern "C" size_t lz4amd_hip_hc_scratch_bytes(unsigned max_src) { return (size_t)hc_scratch_bytes(max_src); }
 extern "C" int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned grid, void* s) {
     if (!p->n_blocks || !grid) return 0;
@@ -131,12 +125,10 @@ extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned
     if (!p->n_blocks || !grid) return 0;
     HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
     if (p->chain) {                      /* dependent blocks: nothing is known but where the first one starts */
-        if (dec_use_v1()) return -1;
         HIPCHK(hipMemsetAsync(p->chain, 0xFF, ((size_t)p->n_blocks + 1) * sizeof(long long), (hipStream_t)s));
         HIPCHK(hipMemsetAsync(p->chain, 0, sizeof(long long), (hipStream_t)s));
     }
-    if (dec_use_v1()) hipLaunchKernelGGL(lz4amd_k_decompress_v1, dim3(grid), dim3(v1::kDecThreads), v1::kDecLdsBytes, (hipStream_t)s, *p);
-    else hipLaunchKernelGGL(lz4amd_k_decompress, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
+    hipLaunchKernelGGL(lz4amd_k_decompress, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());
     return 0;
 }

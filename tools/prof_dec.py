@@ -20,9 +20,9 @@ for _ in range(5):
     best = min(best, km[0])
 U, C = nb * bs, sum(csizes)
 print("decoder %s: %d x %d B P%d%s  kernel ms %.3f  GB/s out %.1f  (U+C)/t %.1f GB/s = %.3f of 8 TB/s" % (
-    os.environ.get("LZ4AMD_DEC", "v2"), nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
+    "v4", nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
 assert torch.equal(out, data), "decode mismatch"
-if os.environ.get("LZ4AMD_DEC", "v2") != "v1":
+if True:
     L = lz4_amd.lib()
     w = (ctypes.c_ulonglong * (256 * 8))()
     n = L.lz4amd_plan_profile(plan._h, w, len(w))
