@@ -7,7 +7,7 @@ Mirrors the reference's block-table driving code (programs/bench.c:347-355 block
 import ctypes
 import os
 
-OP_COMPRESS, OP_DECOMPRESS, OP_COMPRESS_HC, OP_XXH32 = 0, 1, 2, 3
+OP_COMPRESS, OP_DECOMPRESS, OP_COMPRESS_HC, OP_XXH32, OP_GATHER = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -51,6 +51,7 @@ def lib():
     L.LZ4_compress_HC_extStateHC.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, i, i, i]
     L.LZ4_compressBound.argtypes = [i]
     L.LZ4_versionString.restype = ctypes.c_char_p
+    L.lz4amd_plan_create_decompress_chained.argtypes = [vp, ctypes.POINTER(vp), i, ctypes.POINTER(vp), ip, vp, ip, ctypes.c_char_p, i]
     L.lz4amd_plan_create_prefix.argtypes = [vp, ctypes.POINTER(vp), i, ctypes.POINTER(vp), ip, ctypes.POINTER(vp), ip, ip]
     _LIB = L
     return L
@@ -112,6 +113,19 @@ class Plan:
         _check(lib().lz4amd_plan_create(ctx._h, ctypes.byref(self._h), int(op), table.n,
                                         table.src_ptrs, table.src_sizes, table.dst_ptrs, table.dst_caps,
                                         int(level)), "lz4amd_plan_create")
+
+    @classmethod
+    def chained(cls, ctx, src_ptrs, src_sizes, dst0, dst_caps, stored=None, initial_prefix=0):
+        """Dependent blocks in one launch (lz4amd_plan_create_decompress_chained): packed output at dst0."""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.ctx, self.op = ctx, OP_DECOMPRESS
+        self.table = BlockTable(src_ptrs, src_sizes, [dst0] * len(src_ptrs), dst_caps)
+        flags = bytes(bytearray(1 if s else 0 for s in stored)) if stored is not None else None
+        _check(lib().lz4amd_plan_create_decompress_chained(ctx._h, ctypes.byref(self._h), self.table.n, self.table.src_ptrs,
+                                                           self.table.src_sizes, ctypes.c_void_p(int(dst0)), self.table.dst_caps,
+                                                           flags, int(initial_prefix)), "lz4amd_plan_create_decompress_chained")
+        return self
 
     def launch(self, stream=0):
         _check(lib().lz4amd_plan_launch(self._h, ctypes.c_void_p(stream)), "lz4amd_plan_launch")

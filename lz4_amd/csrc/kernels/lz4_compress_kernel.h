@@ -39,6 +39,10 @@
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
 
+#ifndef LZ4AMD_SHORT_RUN
+#define LZ4AMD_SHORT_RUN 16
+#endif
+
 namespace lz4amd {
 
 using CompBatch = ::lz4amd_comp_params;   // argument block (lz4amd_params.h)
@@ -57,7 +61,7 @@ enum : uint32_t {
     kHashBits = 13,
     kRecsPerStrip = 64,                // matches a strip may take (the rest of it becomes literals)
     kLaneLenCap = 24,                  // match bytes a lane measures on its own
-    kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane
+    kShortRun = LZ4AMD_SHORT_RUN,                    // literal runs up to this long are copied by the sequence's own lane
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
     kStripFields = 9,

@@ -237,7 +237,11 @@ struct LZ4F_dctx_s {
     unsigned long long total_out, skip_left;
     xxh32_state xxh;
     uint8_t* hist; size_t hist_len;               /* linked frames: the 64 KB before the next batch */
+    /* the content checksum of a batch runs on a helper thread while its bytes are delivered and the next input is taken */
+    int hashing; pthread_t hthread; size_t hash_n;
 };
+static void* dctx_hash_thread(void* arg) { LZ4F_dctx* d = (LZ4F_dctx*)arg; xxh32_update(&d->xxh, d->out, d->hash_n); return NULL; }
+static void dctx_hash_join(LZ4F_dctx* d) { if (d->hashing) { pthread_join(d->hthread, NULL); d->hashing = 0; } }
 
 LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version)
 {   /* lz4frame.c:1284-1310 */
@@ -249,6 +253,7 @@ LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned v
 void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
 {   /* lz4frame.c:1322-1330; the buffers are kept */
     if (!d) return;
+    dctx_hash_join(d);
     d->stage = ST_HEADER;
     d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
     d->out_size = d->out_pos = 0;
@@ -256,7 +261,7 @@ void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
 }
 LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* d)
 {
-    if (d) { free(d->in); free(d->out); free(d->hist); free(d); }
+    if (d) { dctx_hash_join(d); free(d->in); free(d->out); free(d->hist); free(d); }
     return 0;
 }
 
@@ -359,6 +364,7 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
     size_t* in_off = NULL; uint8_t* raw = NULL;
     size_t ncomp = 0;
 
+    dctx_hash_join(d);                              /* the previous batch's bytes are about to be overwritten */
     d->out_size = d->out_pos = 0;
     d_src = (const void**)malloc(nb * sizeof *d_src); d_dst = (void**)malloc(nb * sizeof *d_dst);
     sizes = (int*)malloc(nb * sizeof *sizes); caps = (int*)malloc(nb * sizeof *caps); res = (int*)malloc(nb * sizeof *res);
@@ -457,7 +463,11 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
     pthread_mutex_unlock(&lz4amd_default_lock);
 host_tail:
     d->out_size = out_total; d->total_out += out_total;
-    if (d->info.contentChecksumFlag && !skip_checksums) xxh32_update(&d->xxh, d->out, out_total);   /* lz4frame.c:1896, 1967 */
+    if (d->info.contentChecksumFlag && !skip_checksums) {                   /* lz4frame.c:1896, 1967 */
+        d->hash_n = out_total;
+        d->hashing = out_total >= (1u << 20) && pthread_create(&d->hthread, NULL, dctx_hash_thread, d) == 0;
+        if (!d->hashing) xxh32_update(&d->xxh, d->out, out_total);
+    }
     if (linked) {                                   /* the 64 KB the next batch may reference */
         if (!d->hist && !(d->hist = (uint8_t*)malloc(65536))) { result = ERR(allocation_failed); goto done_unlocked; }
         if (out_total >= 65536) { memcpy(d->hist, d->out + out_total - 65536, 65536); d->hist_len = 65536; }
@@ -554,6 +564,7 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
         }
         if (d->stage == ST_TAIL) {                                           /* content checksum, lz4frame.c:2005-2030 */
             if (!take_input(d, 4, src, avail, &used, &err)) { if (err) goto fail; break; }
+            dctx_hash_join(d);
             if (!skipc && rd32(d->in) != xxh32_digest(&d->xxh)) { err = ERR(contentChecksum_invalid); goto fail; }
             d->in_size = 0; d->stage = ST_DONE;
             continue;

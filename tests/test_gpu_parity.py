@@ -234,6 +234,65 @@ def test_classic_host_pointer_api(ctx, ocodec, datagen):
     assert L.LZ4_decompress_safe(c, back, len(c), len(d)) == len(d) and back.raw == d
 
 
+def test_gather_op_packs_rows_of_any_alignment(ctx):
+    """LZ4AMD_OP_GATHER: the frame writer's packing launch (lz4frame.c:883-914 appends blocks behind one another)."""
+    import lz4_amd
+    rng = random.Random(3)
+    sizes = [0, 1, 15, 16, 17, 1000, 16384, 16385, 70001, (1 << 20) + 5, 4 << 20, 3]
+    pool = torch.frombuffer(bytearray(rng.randbytes(sum(sizes) + 64 * len(sizes))), dtype=torch.uint8).cuda()
+    out = torch.full((sum(sizes) + 64 * len(sizes) + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    srcs, dsts, want, so, do = [], [], [], 0, 7
+    for n in sizes:
+        so += rng.randrange(1, 16)
+        srcs.append(pool.data_ptr() + so); dsts.append(out.data_ptr() + do)
+        want.append((do, pool[so:so + n].cpu()))
+        so += n; do += n + rng.randrange(0, 9)
+    caps = list(sizes); caps[5] = 999                                         # one row does not fit: refused, untouched
+    plan = lz4_amd.Plan(ctx, lz4_amd.OP_GATHER, lz4_amd.BlockTable(srcs, sizes, dsts, caps))
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    res = plan.results(torch.cuda.current_stream().cuda_stream)
+    host = out.cpu()
+    covered = torch.zeros_like(host, dtype=torch.bool)
+    for i, (n, (o, data)) in enumerate(zip(sizes, want)):
+        if i == 5:
+            assert res[i] == -1
+            continue
+        assert res[i] == n and torch.equal(host[o:o + n], data), i
+        covered[o:o + n] = True
+    assert bool((host[~covered] == 0xEE).all())
+    plan.close()
+
+
+def test_chained_plan_decodes_dependent_blocks(ctx, golden):
+    """lz4amd_plan_create_decompress_chained on the linked blocks of a reference-written frame: one launch, packed output;
+    a truncated block in the middle ends the chain there (negative results from it on, the blocks before it stand)."""
+    import lz4_amd
+    from conftest import GOLDEN_DIR
+    from test_kernels_emulated import _frame_blocks
+    import hashlib
+    frame = open(os.path.join(GOLDEN_DIR, "f_p60_600k_B4_BD_cs.lz4"), "rb").read()
+    indep, blocks = _frame_blocks(frame)
+    assert not indep
+    payloads = [p for _, p in blocks]
+    blob = torch.frombuffer(bytearray(b"".join(payloads)), dtype=torch.uint8).cuda()
+    offs = [sum(len(p) for p in payloads[:i]) for i in range(len(payloads))]
+    out = torch.zeros(600000 + 64, dtype=torch.uint8, device="cuda")
+    plan = lz4_amd.Plan.chained(ctx, [blob.data_ptr() + o for o in offs], [len(p) for p in payloads], out.data_ptr() + 3,
+                                [65536] * len(payloads), stored=[r for r, _ in blocks])
+    for _ in range(2):                                                        # the chain words are reset by every launch
+        plan.launch(torch.cuda.current_stream().cuda_stream)
+        res = plan.results(torch.cuda.current_stream().cuda_stream)
+        assert sum(res) == 600000 and all(r > 0 for r in res)
+        assert hashlib.md5(out[3:600003].cpu().numpy().tobytes()).hexdigest() == golden["frames"]["f_p60_600k_B4_BD_cs"]["src_md5"]
+    plan.close()
+    sizes = [len(p) for p in payloads]; sizes[4] -= 7                          # block 4 loses its tail
+    plan = lz4_amd.Plan.chained(ctx, [blob.data_ptr() + o for o in offs], sizes, out.data_ptr() + 3, [65536] * len(payloads))
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    res = plan.results(torch.cuda.current_stream().cuda_stream)
+    assert res[:4] == [65536] * 4 and all(r < 0 for r in res[4:])
+    plan.close()
+
+
 def test_classic_api_from_many_threads(ctx, ocodec, datagen):
     """The reference's block functions are re-entrant and its CLI calls them from up to 200 threads
     (lz4conf.h:60-61).  16 threads x 64 KiB blocks through LZ4_compress_default / LZ4_decompress_safe: every result is
