@@ -279,16 +279,22 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         const bool inuse = tid < nl && tid >= je;
         WalkState s; walk_init(s, tid == je ? e : seg_lo);
         Win W; win_init(W);
+        // (straight-line with selects: the nested-if form of this loop compiled to twice the instructions, most of them
+        //  scalar mask bookkeeping, and a walker step is latency bound by its own instruction chain)
         for (;;) {
-            const bool run = inuse && !s.dead && !(s.mode == 0 && s.p >= seg_hi);
-            if (!__any(run)) break;
-            if (run) {
-                if (s.p >= csize) { s.tok = s.mode == 0 ? s.p : s.tok; s.dead = true; }       // ran off the block
-                else {
-                    if (s.mode == 0) atomicOr(&bm[bm_word((s.p - sp0) >> 5)], 1u << ((s.p - sp0) & 31));
-                    walk_step(s, win_byte(W, src, csize, s.p), csize);
-                }
-            }
+            const bool at_tok = s.mode == 0;
+            const bool act = inuse && !s.dead && !(at_tok && s.p >= seg_hi);
+            if (!__any(act)) break;
+            const bool off = s.p >= csize;                                   // ran off the block
+            const bool go = act && !off;
+            if (go && at_tok) atomicOr(&bm[bm_word((s.p - sp0) >> 5)], 1u << ((s.p - sp0) & 31));
+            if (go && s.p - W.base >= 16u) { W.base = s.p; W.v = load_granule(src, csize, s.p); }
+            WalkState t = s;
+            walk_step(t, chunk_byte(W.v, (s.p - W.base) & 15u), csize);
+            s.tok = go ? t.tok : (act && at_tok ? s.p : s.tok);
+            s.dead = go ? t.dead : (s.dead || act);
+            s.acc = go ? t.acc : s.acc; s.mlf = go ? t.mlf : s.mlf; s.cnt = go ? t.cnt : s.cnt;
+            s.mode = go ? t.mode : s.mode; s.p = go ? t.p : s.p;
         }
         __syncthreads();
         LZ4AMD_PSTAMP(0);
@@ -298,18 +304,25 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         for (uint32_t trip = 0;; trip++) {
             const bool run = okind == OUT_NONE;
             if (!__any(run)) break;
-            if (run) {
-                const bool at_tok = s.mode == 0;
-                if (at_tok && s.p >= sp1) { okind = OUT_EXIT; opos = s.p; }
-                else if (at_tok && ((bm[bm_word((s.p - sp0) >> 5)] >> ((s.p - sp0) & 31)) & 1u)) { okind = OUT_MERGE; opos = s.p; }
-                else if (trip >= kBridgeTrips) { okind = OUT_EXIT; opos = at_tok ? s.p : s.tok; }   // (a token either way: the next span starts there)
-                else if (s.p >= csize) { okind = OUT_STOP; opos = at_tok ? s.p : s.tok; }
-                else {
-                    nb += at_tok ? 1u : 0u;
-                    walk_step(s, win_byte(W, src, csize, s.p), csize);
-                    if (s.dead) { okind = OUT_STOP; opos = s.tok; }
-                }
-            }
+            const bool at_tok = s.mode == 0;
+            const bool c_exit = at_tok && s.p >= sp1;
+            uint32_t bit = 0;
+            if (run && at_tok && !c_exit) bit = (bm[bm_word((s.p - sp0) >> 5)] >> ((s.p - sp0) & 31)) & 1u;
+            const bool c_merge = bit != 0;
+            const bool c_trips = trip >= kBridgeTrips;                       // (a token either way: the next span starts there)
+            const bool c_end = s.p >= csize;
+            const bool go = run && !c_exit && !c_merge && !c_trips && !c_end;
+            if (go && s.p - W.base >= 16u) { W.base = s.p; W.v = load_granule(src, csize, s.p); }
+            WalkState t = s;
+            walk_step(t, chunk_byte(W.v, (s.p - W.base) & 15u), csize);
+            const uint32_t here = at_tok ? s.p : s.tok;
+            const uint32_t kind_stop = c_exit ? OUT_EXIT : c_merge ? OUT_MERGE : c_trips ? OUT_EXIT : OUT_STOP;
+            const uint32_t pos_stop = (c_exit || c_merge) ? s.p : here;
+            okind = !run ? okind : (go ? (t.dead ? OUT_STOP : OUT_NONE) : kind_stop);
+            opos = !run ? opos : (go ? (t.dead ? t.tok : opos) : pos_stop);
+            nb += go && at_tok ? 1u : 0u;
+            s.tok = go ? t.tok : s.tok; s.dead = go ? t.dead : s.dead; s.acc = go ? t.acc : s.acc; s.mlf = go ? t.mlf : s.mlf;
+            s.cnt = go ? t.cnt : s.cnt; s.mode = go ? t.mode : s.mode; s.p = go ? t.p : s.p;
         }
         // ---- P3: which threads are on the true chain?  (merge links, pointer doubling)
         __syncthreads();
@@ -355,10 +368,15 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
             win_init(W);
             uint32_t left = active ? nb : 0;
             while (__any(left != 0)) {
-                if (left) {
-                    if (b.mode == 0) { if (b.p < tend && b.p < sp1) atomicOr(&bm[bm_word((b.p - sp0) >> 5)], 1u << ((b.p - sp0) & 31)); left--; }
-                    if (left) walk_step(b, win_byte(W, src, csize, b.p), csize);
-                }
+                const bool at_tok = b.mode == 0;
+                if (left && at_tok && b.p < tend && b.p < sp1) atomicOr(&bm[bm_word((b.p - sp0) >> 5)], 1u << ((b.p - sp0) & 31));
+                left -= left && at_tok ? 1u : 0u;
+                const bool go = left != 0;
+                if (go && b.p - W.base >= 16u) { W.base = b.p; W.v = load_granule(src, csize, b.p); }
+                WalkState t = b;
+                walk_step(t, chunk_byte(W.v, (b.p - W.base) & 15u), csize);
+                b.tok = go ? t.tok : b.tok; b.dead = go ? t.dead : b.dead; b.acc = go ? t.acc : b.acc; b.mlf = go ? t.mlf : b.mlf;
+                b.cnt = go ? t.cnt : b.cnt; b.mode = go ? t.mode : b.mode; b.p = go ? t.p : b.p;
             }
         }
         __syncthreads();
