@@ -346,21 +346,21 @@ __device__ __forceinline__ U32x4 ring_read16(const RegionCtx& C, uint32_t pos) {
 enum : uint32_t { kKeyAlways = 0xFFFFFFFFu };
 __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint32_t d, uint32_t lo, uint32_t n,
                                            const SeqRec& rec, uint32_t ms, bool own_ok, U32x4& v, uint32_t& key) {
+    // Literal pieces and match pieces sit side by side in a wave, so both address computations run for every lane anyway:
+    // they are written straight-line and end in ONE 16-byte LDS read at the selected address (compressed ring or output
+    // ring) instead of one predicated read per kind.
     key = kKeyAlways;
-    if (is_lit) {
-        const uint32_t A = rec.litpos + (d - rec.outpos);
-        if (A + n > C.chi) return false;
-        uint32_t a = C.crW + (A - C.lp0) - lo + kCrBytes;
-        a = cr_fold(cr_fold(a));
-        v = lds_read16_at((const uint8_t*)(C.smem + kOffCr), a);
-        return true;
-    }
+    // -- a literal piece: stream bytes [A, A + n)
+    const uint32_t A = rec.litpos + (d - rec.outpos);
+    const uint32_t a = cr_fold(cr_fold(C.crW + (A - C.lp0) - lo + kCrBytes));
+    const bool lit_ok = A + n <= C.chi;
+    // -- a match piece: output bytes [s, s + n)
     uint32_t dist = rec.off;
     const uint32_t into = d - ms;
 #ifdef LZ4AMD_TRACE
-    if (dist == 0) { fprintf(stderr, "ZERO OFFSET item: R=%u d=%u lo=%u n=%u rec{%u,%u,%u,%u} ms=%u j0=%u nrec=%u\n", C.R, d, lo, n, rec.outpos, rec.litpos, rec.ll, rec.off, ms, C.j0, C.nrec); return false; }
+    if (!is_lit && dist == 0) { fprintf(stderr, "ZERO OFFSET item: R=%u d=%u lo=%u n=%u rec{%u,%u,%u,%u} ms=%u j0=%u nrec=%u\n", C.R, d, lo, n, rec.outpos, rec.litpos, rec.ll, rec.off, ms, C.j0, C.nrec); return false; }
 #endif
-    if (into >= dist) {
+    if (!is_lit && into >= dist) {
         // the source lies inside this very match (it overlaps itself): every earlier period holds the same
         // bytes; read the farthest one the 64 KB window holds, long final, instead of the bytes just written
         uint32_t k = into / dist + 1;
@@ -373,19 +373,26 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     // offset < 16 + lo) are in once every lower piece of the chunk is
     const uint32_t cstart = d - lo;
     const uint32_t se = n <= dist ? s + n - 1 : d - 1;                       // last source byte
-    if (s < cstart && !range_is_final(C, s, se < cstart ? se : cstart - 1)) { if (n <= dist && se < cstart) key = s; return false; }
-    if (se >= cstart && !own_ok) return false;
-    if (n <= dist) {
-        v = ring_read16(C, s - lo);
-        return true;
+    const bool below = s < cstart;
+    bool src_final = true;
+    if (!is_lit && below) src_final = range_is_final(C, s, se < cstart ? se : cstart - 1);
+    const bool wait_own = src_final && se >= cstart && !own_ok;
+    if (!is_lit && !src_final && n <= dist && se < cstart) key = s;
+    const bool ready = is_lit ? lit_ok : (src_final && !wait_own);
+    const bool plain = is_lit || n <= dist;
+    if (ready && plain) {
+        const uint32_t addr = is_lit ? kOffCr + a : kOffRing + ring_fold(s - lo - C.ringB);
+        v = lds_read16_at((const uint8_t*)C.smem, addr);
     }
-    // period < n <= 16: bytes [s, d) are the pattern
-    const U32x4 pat = ring_read16(C, s);
-    v[0] = v[1] = v[2] = v[3] = 0;
-    uint32_t k = 0;
+    if (ready && !plain) {
+        // period < n <= 16: bytes [s, d) are the pattern
+        const U32x4 pat = ring_read16(C, s);
+        v[0] = v[1] = v[2] = v[3] = 0;
+        uint32_t k = 0;
 #pragma nounroll
-    for (uint32_t i = 0; i < n; i++) { chunk_set_byte(v, lo + i, chunk_byte(pat, k)); if (++k == dist) k = 0; }
-    return true;
+        for (uint32_t i = 0; i < n; i++) { chunk_set_byte(v, lo + i, chunk_byte(pat, k)); if (++k == dist) k = 0; }
+    }
+    return ready;
 }
 
 __device__ __forceinline__ void lds_or16(char* smem, uint32_t off, const U32x4& v) {
