@@ -86,7 +86,8 @@ static_assert(kSlots == 96, "slot = region mod 96 is computed with a multiply");
 // LDS carve-up of stage B (bytes); stage A uses the same memory before (lz4_preparse_kernel.h)
 enum : uint32_t {
     kOffMisc = 0,                                            // u32[64] control words
-    kOffFin = kOffMisc + 64 * 4,                             // u32[16] regions completed per copy wave
+    kOffMaskTab = kOffMisc + 64 * 4,                         // U32x4[17]: byte masks, entry n selects bytes [0, n) of a chunk
+    kOffFin = kOffMaskTab + 17 * 16 + 16,                    // u32[16] regions completed per copy wave
     kOffBits = kOffFin + 16 * 4,                             // DoneEnt[kSlots]
     kOffIdx = kOffBits + kSlots * 16,                        // u16[kIdxRing]
     kOffPend = kOffIdx + kIdxRing * 2,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
@@ -122,13 +123,18 @@ __device__ __forceinline__ uint32_t low_bytes_mask(uint32_t n, uint32_t k) {
     const int32_t r = (int32_t)n - 4 * (int32_t)k;
     return r >= 4 ? 0xFFFFFFFFu : (r <= 0 ? 0u : ((1u << (8 * r)) - 1u));
 }
-// v restricted to bytes [lo, hi)
-__device__ __forceinline__ U32x4 keep_bytes(const U32x4& v, uint32_t lo, uint32_t hi) {
+// v restricted to bytes [lo, hi): two rows of the LDS mask table (computing the eight dword masks took ~60 instructions
+// per call, three calls per region - a fifth of the copy stage's instruction count)
+__device__ __forceinline__ U32x4 keep_bytes(const char* smem, const U32x4& v, uint32_t lo, uint32_t hi) {
+    const U32x4 mh = *(const U32x4*)(smem + kOffMaskTab + 16 * hi), ml = *(const U32x4*)(smem + kOffMaskTab + 16 * lo);
     U32x4 r;
-    r[0] = v[0] & low_bytes_mask(hi, 0) & ~low_bytes_mask(lo, 0);
-    r[1] = v[1] & low_bytes_mask(hi, 1) & ~low_bytes_mask(lo, 1);
-    r[2] = v[2] & low_bytes_mask(hi, 2) & ~low_bytes_mask(lo, 2);
-    r[3] = v[3] & low_bytes_mask(hi, 3) & ~low_bytes_mask(lo, 3);
+    r[0] = v[0] & mh[0] & ~ml[0]; r[1] = v[1] & mh[1] & ~ml[1]; r[2] = v[2] & mh[2] & ~ml[2]; r[3] = v[3] & mh[3] & ~ml[3];
+    return r;
+}
+__device__ __forceinline__ U32x4 keep_low_bytes(const char* smem, const U32x4& v, uint32_t hi) {
+    const U32x4 mh = *(const U32x4*)(smem + kOffMaskTab + 16 * hi);
+    U32x4 r;
+    r[0] = v[0] & mh[0]; r[1] = v[1] & mh[1]; r[2] = v[2] & mh[2]; r[3] = v[3] & mh[3];
     return r;
 }
 // 16 bytes starting at ANY byte a of an LDS array of dwords (the arrays are padded: a + 20 is in range)
@@ -491,7 +497,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
         uint32_t keyA = kKeyAlways, keyB0 = kKeyAlways, packB0 = 0;    // what my pending pieces wait for (round A; round B, first trip: + lo / n / chunk)
         if (actA) {
             ready = item_fetch(C, alit, c0, 0, an, arec, ams, true, v, keyA);
-            v = ready ? keep_bytes(v, 0, an) : U32x4{0, 0, 0, 0};
+            v = ready ? keep_low_bytes(smem, v, an) : U32x4{0, 0, 0, 0};
             slot_write16(C, lane, v);
         }
         uint64_t pendA = __ballot(actA && !ready);
@@ -505,7 +511,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                 U32x4 bv;
                 uint32_t kb;
                 rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, false, bv, kb);
-                if (rdy) slot_or16(C, it.chunk, keep_bytes(bv, it.lo, it.lo + it.n));
+                if (rdy) slot_or16(C, it.chunk, keep_bytes(smem, bv, it.lo, it.lo + it.n));
                 else if (t == 0) { keyB0 = kb; packB0 = it.lo | (it.n << 4) | (it.chunk << 9); }
             }
             const unsigned long long pm = __ballot(it.valid && !rdy);
@@ -537,13 +543,13 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                     const unsigned long long pb0 = pend[1];
                     const bool sa_ = ((pendA >> lane) & 1ull) && keyA != kKeyAlways;
                     bool rdyA = false;
-                    if (sa_ && range_is_final(C, keyA, keyA + an - 1)) { slot_or16(C, lane, keep_bytes(ring_read16(C, keyA), 0, an)); rdyA = true; }
+                    if (sa_ && range_is_final(C, keyA, keyA + an - 1)) { slot_or16(C, lane, keep_low_bytes(smem, ring_read16(C, keyA), an)); rdyA = true; }
                     const unsigned long long doneA = __ballot(rdyA);
                     const bool sb_ = ((pb0 >> lane) & 1ull) && keyB0 != kKeyAlways;
                     bool rdyB = false;
                     if (sb_) {
                         const uint32_t blo = packB0 & 15u, bn = (packB0 >> 4) & 31u, bch = packB0 >> 9;
-                        if (range_is_final(C, keyB0, keyB0 + bn - 1)) { slot_or16(C, bch, keep_bytes(ring_read16(C, keyB0 - blo), blo, blo + bn)); rdyB = true; }
+                        if (range_is_final(C, keyB0, keyB0 + bn - 1)) { slot_or16(C, bch, keep_bytes(smem, ring_read16(C, keyB0 - blo), blo, blo + bn)); rdyB = true; }
                     }
                     const unsigned long long doneB = __ballot(rdyB);
                     pendA &= ~doneA;
@@ -566,7 +572,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                     if (mine) {
                         U32x4 av;
                         rdy = item_fetch(C, alit, c0, 0, an, arec, ams, true, av, keyA);
-                        if (rdy) slot_or16(C, lane, keep_bytes(av, 0, an));
+                        if (rdy) slot_or16(C, lane, keep_low_bytes(smem, av, an));
                     }
                     pendA &= ~__ballot(rdy);
                 }
@@ -587,7 +593,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                         uint32_t kb;
                         rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, own_ok, bv, kb);
                         if (!rdy && t == 0) { keyB0 = kb; packB0 = it.lo | (it.n << 4) | (it.chunk << 9); }
-                        if (rdy) slot_or16(C, it.chunk, keep_bytes(bv, it.lo, it.lo + it.n));
+                        if (rdy) slot_or16(C, it.chunk, keep_bytes(smem, bv, it.lo, it.lo + it.n));
                     }
                     const unsigned long long left = pm & ~__ballot(rdy);
                     if (lane == 0) pend[1 + t] = left;
@@ -686,6 +692,7 @@ __device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz
     // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
     if (tid == 0) { misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_EMIT] = kBias; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
     if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
+    if (tid < 17) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid, k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
     if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
     if (prefix) {
         uint8_t* ring = (uint8_t*)(smem + kOffRing);
