@@ -386,7 +386,8 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     if (!is_lit && !src_final && n <= dist && se < cstart) key = s;
     const bool ready = is_lit ? lit_ok : (src_final && !wait_own);
     const bool plain = is_lit || n <= dist;
-    if (ready && plain) {
+    {   // (read whether or not the piece is ready: the address is always inside its ring, and the read then does not wait
+        //  for the done bits' own trip to LDS)
         const uint32_t addr = is_lit ? kOffCr + a : kOffRing + ring_fold(s - lo - C.ringB);
         v = lds_read16_at((const uint8_t*)C.smem, addr);
     }
