@@ -496,6 +496,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
         U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
         bool ready = false;
         uint32_t keyA = kKeyAlways, keyB0 = kKeyAlways, packB0 = 0;    // what my pending pieces wait for (round A; round B, first trip: + lo / n / chunk)
+        const BItem it0 = b_item(C, 0);                // round B's first trip reads its records while round A's reads are in flight
         if (actA) {
             ready = item_fetch(C, alit, c0, 0, an, arec, ams, true, v, keyA);
             v = ready ? keep_low_bytes(smem, v, an) : U32x4{0, 0, 0, 0};
@@ -506,7 +507,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
         const uint32_t trips = (C.nrec + 31) / 32;
         uint64_t pendBc = 0;                           // chunks with a pending round-B piece
         for (uint32_t t = 0; t < trips; t++) {
-            const BItem it = b_item(C, t);
+            const BItem it = t == 0 ? it0 : b_item(C, t);
             bool rdy = false;
             if (it.valid) {
                 U32x4 bv;
