@@ -572,20 +572,26 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         }
         // -- ... while everybody inserts the tile into the table (positions that may start a match):
         //    8 consecutive positions per thread, hashed out of four aligned dwords
-        if (n >= kMfLimit + 1) {
+        //    Wave 0 is the critical path of this interval (overruns + offsets), so the other fifteen waves take its share:
+        //    thread j of them takes positions 8j .. 8j+7, the last 512 positions of a full tile go to wave 8 as a second group.
+        if (n >= kMfLimit + 1 && tid >= 64) {
             const uint32_t last_q = n - kMfLimit;
-            const uint32_t q0 = t0 + 8 * tid;                       // t0 is a multiple of 1024; tiles are at most 8 * kCmpThreads long
-            if (q0 < t1 && q0 <= last_q) {
-                const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
-                const uint32_t* a = (const uint32_t*)(ring + o);
-                uint32_t dw[4];
+            const uint32_t j = tid - 64;
 #pragma unroll
-                for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
+            for (uint32_t g = 0; g < 2; g++) {
+                const uint32_t q0 = g == 0 ? t0 + 8 * j : t0 + 8 * (kCmpThreads - 64) + 8 * (j - 448);     // t0 is a multiple of 1024; tiles are at most 8 * kCmpThreads long
+                if ((g == 0 || (j >= 448 && j < 512)) && q0 < t1 && q0 <= last_q) {
+                    const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
+                    const uint32_t* a = (const uint32_t*)(ring + o);
+                    uint32_t dw[4];
 #pragma unroll
-                for (uint32_t i = 0; i < 8; i++) {
-                    const uint32_t q = q0 + i;
-                    const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
-                    if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos32(lo, hi, small)], q);
+                    for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; i++) {
+                        const uint32_t q = q0 + i;
+                        const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
+                        if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos32(lo, hi, small)], q);
+                    }
                 }
             }
         }
