@@ -77,7 +77,7 @@ enum : uint32_t {
     kCOffRing = kCOffEncp + 2 * kCmpWaves * kRecsPerStrip * 2,
     kCmpLdsBytes = kCOffRing + kSrcRing + kSrcPad,
 };
-enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3 };
+enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4 };      // CM_READY: tiles whose output offsets are fixed
 enum : uint32_t { S_N = 0, S_ENC = 1, S_LL0 = 2, S_TAIL = 3, S_OUT = 4, S_CARRY = 5,
                   S_END = 6,      // where the strip's last match ends when it runs past the strip (else 0)
                   S_FIRST = 7,    // first record that is emitted (the ones before it were covered by an earlier strip's match)
@@ -483,6 +483,9 @@ __device__ __forceinline__ StripTotals strip_offsets(uint32_t* strip, uint32_t n
     return r;
 }
 
+// a control word every lane of the wave agrees on
+__device__ __forceinline__ uint32_t uload_cm(const uint32_t* w) { return __builtin_amdgcn_readfirstlane(lds_load_acquire(w)); }
+
 // ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t b, char* smem) {
     const uint32_t tid = threadIdx.x, w = wave_id();
@@ -512,7 +515,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const bool small = n < kSmallBlockLimit;
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
-    if (tid == 0) { misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; }
+    if (tid == 0) { misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; }
     // first tile straight into the ring; later tiles are prefetched one tile ahead
     uint32_t t0 = 0, tile_len, strip_len;
     tile_geometry(pre ? kTileMax * 4 : 0, small, tile_len, strip_len);
@@ -525,12 +528,14 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         for (uint32_t Pp = 16 * tid; Pp < hi; Pp += 16 * kCmpThreads) ring_commit16(ring, Pp, load_src16(src, n, Pp));
         loaded = (hi + 15) & ~15u;
     }
-    // Two barriers per tile.  Interval A: every wave parses its strip of tile k, then writes out its
-    // strip of tile k-1 (whose output offsets were fixed in the previous interval B).  Interval B:
-    // wave 0 turns the strips' sizes of tile k into output offsets while everybody inserts tile k
-    // into the table.  Records and strip summaries are double buffered for that.
+    // Two barriers per tile.  Interval A: wave 0 first settles tile k-1 (overrunning matches, then the strips' sizes
+    // into output offsets: ~3.5 K cycles of one wave's dependent work, which used to sit between the barriers with
+    // fifteen waves waiting) and says so in CM_READY; every wave parses its strip of tile k, then - once CM_READY
+    // covers tile k-1, which it long does by then - writes out its strip of tile k-1.  Interval B: everybody inserts
+    // tile k into the table.  Records and strip summaries are double buffered for that.
     uint32_t par = 0;                                       // buffer parity of tile k
-    uint32_t prev_t0 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
+    uint32_t prev_t0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
+    uint32_t tiles_parsed = 0;                              // tiles whose strips were matched so far (CM_READY counts up to it)
     while (t0 < n) {
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
         uint32_t* strip_k = strip + par * kStripFields * kCmpWaves;
@@ -546,6 +551,16 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 16 * kCmpThreads
         __syncthreads();                                       // ring, table and tile k-1's offsets ready
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
+        // -- A0: wave 0 settles tile k-1
+        if (w == 0 && prev_nstrips) {
+            resolve_overruns(strip_p, recs_p - w * kRecsPerStrip, ends + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip,
+                             encp + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n);
+            wave_lds_fence();
+            const StripTotals t = strip_offsets(strip_p, prev_nstrips, misc[CM_OUT], misc[CM_CARRY], misc[CM_FAIL], cap);
+            if (lane_id() == 0) { misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; }
+            wave_lds_fence();
+            if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
+        }
         // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
         const bool parse = t0 >= pre;
         const uint32_t nstrips = parse ? (t1 - t0 + strip_len - 1) / strip_len : 0;
@@ -557,41 +572,30 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: emit tile k-1
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
-        if (w < prev_nstrips && !misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
-            emit_strip(ring, recs_p + strip_p[S_FIRST * kCmpWaves + w], strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
+        if (w < prev_nstrips) {
+            while (uload_cm(&misc[CM_READY]) < tiles_parsed) spin_pause();
+            if (!misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
+                emit_strip(ring, recs_p + strip_p[S_FIRST * kCmpWaves + w], strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
+        }
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
-        // -- B: offsets (wave 0) ...
-        if (w == 0 && parse) {
-            resolve_overruns(strip_k, recs_k - w * kRecsPerStrip, ends + par * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip,
-                             encp + par * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip, nstrips, t0, strip_len, t1, n);
-            wave_lds_fence();
-            const StripTotals t = strip_offsets(strip_k, nstrips, misc[CM_OUT], misc[CM_CARRY], misc[CM_FAIL], cap);
-            if (lane_id() == 0) { misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; }
-        }
-        // -- ... while everybody inserts the tile into the table (positions that may start a match):
+        // -- B: everybody inserts the tile into the table (positions that may start a match):
         //    8 consecutive positions per thread, hashed out of four aligned dwords
-        //    Wave 0 is the critical path of this interval (overruns + offsets), so the other fifteen waves take its share:
-        //    thread j of them takes positions 8j .. 8j+7, the last 512 positions of a full tile go to wave 8 as a second group.
-        if (n >= kMfLimit + 1 && tid >= 64) {
+        if (n >= kMfLimit + 1) {
             const uint32_t last_q = n - kMfLimit;
-            const uint32_t j = tid - 64;
+            const uint32_t q0 = t0 + 8 * tid;                       // t0 is a multiple of 1024; tiles are at most 8 * kCmpThreads long
+            if (q0 < t1 && q0 <= last_q) {
+                const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
+                const uint32_t* a = (const uint32_t*)(ring + o);
+                uint32_t dw[4];
 #pragma unroll
-            for (uint32_t g = 0; g < 2; g++) {
-                const uint32_t q0 = g == 0 ? t0 + 8 * j : t0 + 8 * (kCmpThreads - 64) + 8 * (j - 448);     // t0 is a multiple of 1024; tiles are at most 8 * kCmpThreads long
-                if ((g == 0 || (j >= 448 && j < 512)) && q0 < t1 && q0 <= last_q) {
-                    const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
-                    const uint32_t* a = (const uint32_t*)(ring + o);
-                    uint32_t dw[4];
+                for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
 #pragma unroll
-                    for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; i++) {
-                        const uint32_t q = q0 + i;
-                        const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
-                        if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos32(lo, hi, small)], q);
-                    }
+                for (uint32_t i = 0; i < 8; i++) {
+                    const uint32_t q = q0 + i;
+                    const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
+                    if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos32(lo, hi, small)], q);
                 }
             }
         }
@@ -599,14 +603,23 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
         if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
-        prev_t0 = t0; prev_strip_len = strip_len; prev_nstrips = nstrips; par ^= 1;
+        prev_t0 = t0; prev_t1 = t1; prev_strip_len = strip_len; prev_nstrips = nstrips; par ^= 1;
+        if (nstrips) tiles_parsed++;
         t0 = t1; tile_len = nt_len; strip_len = nt_strip;
     }
     __syncthreads();
-    // -- the last tile's sequences
+    // -- the last tile's sequences (settled by wave 0 first)
     {
-        const uint32_t* strip_p = strip + (par ^ 1) * kStripFields * kCmpWaves;
-        const MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
+        uint32_t* strip_p = strip + (par ^ 1) * kStripFields * kCmpWaves;
+        MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
+        if (w == 0 && prev_nstrips) {
+            resolve_overruns(strip_p, recs_p - w * kRecsPerStrip, ends + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip,
+                             encp + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n);
+            wave_lds_fence();
+            const StripTotals t = strip_offsets(strip_p, prev_nstrips, misc[CM_OUT], misc[CM_CARRY], misc[CM_FAIL], cap);
+            if (lane_id() == 0) { misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; }
+        }
+        __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         if (w < prev_nstrips && !misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
             emit_strip(ring, recs_p + strip_p[S_FIRST * kCmpWaves + w], strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
