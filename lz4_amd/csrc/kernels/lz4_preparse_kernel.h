@@ -153,8 +153,8 @@ __device__ __forceinline__ TokInfo tok_decode(lz4amd_gsrc g, uint32_t csize, uin
 // The walkers' view of the chain: one stream byte per trip, no branches.  A thread is at a token (mode 0), inside a
 // literal-length field (mode 1) or inside a match-length field (mode 2).  It stops (dead, at the token `tok`) where
 // tok_decode says "slow path" - and, off the true chain, wherever the bytes make no sense.
-struct WalkState { uint32_t p, tok, acc, mode, cnt; bool mlf, dead; };
-__device__ __forceinline__ void walk_init(WalkState& s, uint32_t p) { s.p = p; s.tok = p; s.acc = 0; s.mode = 0; s.cnt = 0; s.mlf = false; s.dead = false; }
+struct WalkState { uint32_t p, tok, acc, mode, cnt, mlf, dead; };       // (mlf, dead: 0 / 1 - loop-carried bools cost scalar mask merges every trip)
+__device__ __forceinline__ void walk_init(WalkState& s, uint32_t p) { s.p = p; s.tok = p; s.acc = 0; s.mode = 0; s.cnt = 0; s.mlf = 0; s.dead = 0; }
 // consume byte b = stream[s.p] (the caller checked s.p < csize)
 __device__ __forceinline__ void walk_step(WalkState& s, uint32_t b, uint32_t csize) {
     const bool m0 = s.mode == 0, m1 = s.mode == 1, m2 = s.mode == 2;
@@ -164,14 +164,14 @@ __device__ __forceinline__ void walk_step(WalkState& s, uint32_t b, uint32_t csi
     const bool litdone = (m0 && !ext0) || (m1 && !is255);                  // the literal length is complete with this byte
     const uint32_t ll = m0 ? ll0 : s.acc + b;
     const uint32_t m = s.p + 1 + ll;                                        // first byte after the literals
-    const bool mlf = m0 ? (b & 15) == 15 : s.mlf;
+    const bool mlf = m0 ? (b & 15) == 15 : s.mlf != 0;
     const bool cont = (m0 && ext0) || ((m1 || m2) && is255);               // the length field goes on
     const uint32_t cnt = m0 ? 0u : s.cnt + 1;
     const bool stop = (litdone && (m + 8 > csize || m < s.p)) || (cont && cnt >= kExtMax);
     s.tok = m0 ? s.p : s.tok;
-    s.dead = stop;
+    s.dead = stop ? 1u : 0u;
     s.acc = m0 ? 15u : s.acc + b;
-    s.mlf = mlf;
+    s.mlf = mlf ? 1u : 0u;
     s.cnt = litdone ? 0u : cnt;
     s.mode = litdone ? (mlf ? 2u : 0u) : (cont ? (m2 ? 2u : 1u) : 0u);
     s.p = litdone ? m + 2 : s.p + 1;
@@ -292,7 +292,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
             WalkState t = s;
             walk_step(t, chunk_byte(W.v, (s.p - W.base) & 15u), csize);
             s.tok = go ? t.tok : (act && at_tok ? s.p : s.tok);
-            s.dead = go ? t.dead : (s.dead || act);
+            s.dead = go ? t.dead : (s.dead | (act ? 1u : 0u));
             s.acc = go ? t.acc : s.acc; s.mlf = go ? t.mlf : s.mlf; s.cnt = go ? t.cnt : s.cnt;
             s.mode = go ? t.mode : s.mode; s.p = go ? t.p : s.p;
         }
