@@ -355,8 +355,16 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
         const bool shortrun = have && tl <= kShortRun;
         if (shortrun && tl) {
             if (my_i >= ring_lo) {
+                // four bytes per trip (two aligned LDS dwords + a byte alignment, one dword store), then the 0-3 left over
                 const uint32_t o = src_ring_off(my_i);
-                for (uint32_t i = 0; i < tl; i++) dst[lit_dst + i] = ring[ring_fwd(o, i)];
+                const uint32_t quads = tl & ~3u;
+                for (uint32_t i = 0; i < quads; i += 4) {
+                    const uint32_t a = ring_fwd(o, i);
+                    const uint32_t* r32 = (const uint32_t*)(ring + (a & ~3u));        // (the ring's pad covers the read past its end)
+                    const uint32_t v = align_bytes(r32[1], r32[0], a & 3u);
+                    __builtin_memcpy(dst + lit_dst + i, &v, 4);
+                }
+                for (uint32_t i = quads; i < tl; i++) dst[lit_dst + i] = ring[ring_fwd(o, i)];
             } else {
                 for (uint32_t i = 0; i < tl; i++) dst[lit_dst + i] = src[my_i + i];
             }
