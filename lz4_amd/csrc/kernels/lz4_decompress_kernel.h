@@ -534,11 +534,10 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                 if (!pendchunks) break;
                 n_iter++;
                 {
-                    const uint32_t ab = lds_load_acquire(&misc[M_ABORT]), chi = lds_load_acquire(&misc[M_CHI]);
-                    if (__builtin_amdgcn_readfirstlane(ab)) return;
-                    C.chi = __builtin_amdgcn_readfirstlane(chi);
+                    const Ctl c = ctl_snapshot(smem);          // abort, stream bytes resident, first open region: one look
+                    if (c.abort_) return;
+                    C.chi = c.chi; C.g = c.open;
                 }
-                C.g = first_open_region(smem);
                 wave_lds_fence();                      // (pend[] of the last pass)
                 {
                     // the cheap way first: plain matches that only waited for their source chunks (one poll, one ring read)

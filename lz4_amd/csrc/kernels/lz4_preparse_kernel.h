@@ -105,14 +105,10 @@ __device__ __forceinline__ uint32_t win_byte(Win& W, lz4amd_gsrc g, uint32_t csi
     return chunk_byte(W.v, p - W.base);
 }
 
-// index in [from, 16) of the chunk's first byte that is not 255; 16 when there is none (from = 1 or 2)
+// index in [from, 16) of the chunk's first byte that is not 255; 16 when there is none (from = 1 or 2).
+// (the lowest set bit of ~chunk lies in the lowest byte that is not 255: no per-byte test needed)
 __device__ __forceinline__ uint32_t first_not255(const U32x4& a, uint32_t from) {
-    uint64_t lo = 0, hi = 0;
-    {   const uint32_t t0 = ~a[0], t1 = ~a[1], t2 = ~a[2], t3 = ~a[3];          // a byte that was 255 is 0 now
-        const uint32_t n0 = (((t0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t0) & 0x80808080u, n1 = (((t1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t1) & 0x80808080u;
-        const uint32_t n2 = (((t2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t2) & 0x80808080u, n3 = (((t3 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t3) & 0x80808080u;
-        lo = (uint64_t)n0 | ((uint64_t)n1 << 32); hi = (uint64_t)n2 | ((uint64_t)n3 << 32);
-    }
+    uint64_t lo = (uint64_t)(~a[0]) | ((uint64_t)(~a[1]) << 32), hi = (uint64_t)(~a[2]) | ((uint64_t)(~a[3]) << 32);
     lo &= ~0ull << (8 * from);
     if (lo) return ((uint32_t)__ffsll((long long)lo) - 1) >> 3;
     if (hi) return 8 + (((uint32_t)__ffsll((long long)hi) - 1) >> 3);
