@@ -44,6 +44,11 @@ typedef enum {
 int         lz4amd_ctx_create(lz4amd_ctx** out, int device);
 void        lz4amd_ctx_destroy(lz4amd_ctx* ctx);
 const char* lz4amd_last_error(void);
+/* Arguments the reference acts on and this library accepts without acting on them are not errors, but they are not silent
+ * either: the call records a notice (thread local, like the error text; "" when the last such call had nothing to say).
+ * Today: LZ4_compress_fast* with acceleration > 1 (lz4.c:1389: the GPU parse has no speed / ratio knob) and
+ * LZ4_compress_HC* with compressionLevel > 9 (lz4hc.c:92-106: levels 10-12 run the level-9 search, no optimal parser). */
+const char* lz4amd_last_notice(void);
 int         lz4amd_device_cus(const lz4amd_ctx* ctx);
 
 /* LZ4_compressBound (lz4.h:226) - pure arithmetic, usable without a device */

@@ -12,7 +12,7 @@
  * every block as history (lz4hc_api.c).
  *
  * Not provided (SURVEY.md section 8f "next"): LZ4_compress_HC_destSize, LZ4_attach_HC_dictionary, and the
- * optimal parser of levels 10-12 (those levels run the level-9 search).
+ * optimal parser of levels 10-12 (those levels run the level-9 search; lz4amd_last_notice() says so after such a call).
  */
 #ifndef LZ4_AMD_LZ4HC_H
 #define LZ4_AMD_LZ4HC_H

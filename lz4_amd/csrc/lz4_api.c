@@ -142,7 +142,7 @@ int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int ds
  * so the value is accepted and ignored (any value yields a valid block). */
 int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration)
 {
-    (void)acceleration;
+    lz4amd_set_notice(acceleration > 1 ? "LZ4_compress_fast: acceleration > 1 is accepted and ignored (the block is parsed as with acceleration 1)" : "");
     if (srcSize < 0 || (unsigned)srcSize > (unsigned)LZ4_MAX_INPUT_SIZE) return 0;   /* lz4.c:1360 */
     if (dst == NULL || dstCapacity <= 0) return 0;
     if (src == NULL && srcSize != 0) return 0;

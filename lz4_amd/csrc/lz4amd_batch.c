@@ -21,6 +21,9 @@ void lz4amd_set_error(const char* msg)
     snprintf(g_last_error, sizeof g_last_error, "%s", msg ? msg : "");
 }
 const char* lz4amd_last_error(void) { return g_last_error; }
+static __thread char g_last_notice[160] = "";
+void lz4amd_set_notice(const char* msg) { snprintf(g_last_notice, sizeof g_last_notice, "%s", msg ? msg : ""); }
+const char* lz4amd_last_notice(void) { return g_last_notice; }
 
 int lz4amd_compress_bound(int n)
 {   /* lz4.h:214-215 LZ4_COMPRESSBOUND */

@@ -29,6 +29,7 @@ struct lz4amd_plan {
 };
 
 void lz4amd_set_error(const char* msg);
+void lz4amd_set_notice(const char* msg);     /* an argument that was accepted and not acted on (include/lz4amd.h) */
 
 /* a one-block plan kept by a thread: new sizes (and HC level) for its only row, sent on `stream` before the launch */
 int lz4amd_plan_set_row0(lz4amd_plan* p, int src_size, int dst_cap, int level, void* stream);

@@ -102,3 +102,23 @@ def test_bounds_match_the_reference(libpath, reflib):
     assert L.LZ4F_compressionLevel_max() == reflib.LZ4F_compressionLevel_max() == 12
     assert L.LZ4_sizeofStateHC() == reflib.LZ4_sizeofStateHC()
     assert L.LZ4_sizeofState() == reflib.LZ4_sizeofState()
+
+
+def test_ignored_arguments_leave_a_notice():
+    """acceleration > 1 and HC levels > 9 are accepted and not acted on; the ABI says so (lz4amd_last_notice), also
+    without a device: the notice is recorded before the block is touched."""
+    import ctypes
+    import lz4_amd
+    L = lz4_amd.lib()
+    L.lz4amd_last_notice.restype = ctypes.c_char_p
+    L.LZ4_compress_fast.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.LZ4_compress_HC.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    dst = ctypes.create_string_buffer(64)
+    L.LZ4_compress_fast(b"abc", dst, -1, 64, 8)                      # invalid size: returns 0 at once, notice still set
+    assert b"acceleration" in L.lz4amd_last_notice()
+    L.LZ4_compress_fast(b"abc", dst, -1, 64, 1)
+    assert L.lz4amd_last_notice() == b""
+    L.LZ4_compress_HC(b"abc", dst, -1, 64, 12)
+    assert b"level-9" in L.lz4amd_last_notice()
+    L.LZ4_compress_HC(b"abc", dst, -1, 64, 9)
+    assert L.lz4amd_last_notice() == b""
