@@ -604,10 +604,14 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
             t_retry += clock_ticks() - tr0;
         }
     }
-    // ---- the region is complete: to HBM, then tell the other waves
+    // ---- the region is complete: its bytes into registers, tell the other waves (they read the ring, not HBM: a region
+    //      that waits for this one need not wait for the store as well), then to HBM
     wave_lds_fence();
+    U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
+    if (actA) v = *(const U32x4*)(smem + slot_off + kChunk * lane);
+    wave_lds_fence();                                   // (the slot is not read again: whoever recycles it may)
+    if (lane == 0) lds_store_release64(&ents[C.slot].mask, ~0ull);
     if (actA) {
-        const U32x4 v = *(const U32x4*)(smem + slot_off + kChunk * lane);
         const uint32_t c1 = c0 + kChunk < C.x1 ? c0 + kChunk : C.x1;
         if (c1 - c0 == kChunk) st_global16(dst + (c0 - kBias), v);
         else {
@@ -615,8 +619,6 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
             for (uint32_t i = 0; i < c1 - c0; i++) dst[c0 - kBias + i] = (uint8_t)chunk_byte(v, i);
         }
     }
-    wave_lds_fence();
-    if (lane == 0) lds_store_release64(&ents[C.slot].mask, ~0ull);
 }
 
 __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* smem, uint64_t* prof) {
