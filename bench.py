@@ -33,6 +33,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -417,9 +418,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # developer aid: LZ4AMD_BENCH_LOOPBACK=1 runs the N > 1 code path on a box with ONE GPU (every rank on cuda:0,
+        # gloo instead of RCCL) - a functional check of this file, not a measurement
+        loopback = os.environ.get("LZ4AMD_BENCH_LOOPBACK") == "1"
+        if loopback:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if loopback:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -488,25 +497,12 @@ def main():
     d_total /= args.steps
     assert torch.equal(out, data), "round trip is not bit exact after the timed loop"
 
-    # ---- N > 1: the movement configs[4] names, over RCCL (not part of `value`, which stays the kernel-only rate)
-    dp = None
-    if world > 1 and not args.no_data_path:
-        try:
-            r = data_path(dist, torch, dev, rank, world, data, comp, csizes)
-            ok = bool(torch.equal(r["received"], data)) if rank == 0 else True       # rank 0 scattered copies of its own shard
-            if rank == 0:                                    # every gathered block of rank 0 is byte-identical to its slot
-                ok = ok and all(bool(torch.equal(r["blocks"][i], comp[i, :csizes[i]])) for i in range(0, nb, max(1, nb // 16)))
-                ok = ok and len(r["blocks"]) == world * nb
-            dp = {k: aggregate(dist, r[k], 0, device=dev)[0] for k in ("scatter_s", "sizes_s", "gather_s")}
-            dp.update({"ok": ok, "scatter_bytes": r["scatter_bytes"], "gather_bytes": r["gather_bytes"]})
-        except Exception as e:
-            dp = {"error": str(e)}
-
     # ---- not part of the step: the batched XXH32 kernel (frame block checksums) over the same blocks
     xplan = lz4_amd.Plan(ctx, lz4_amd.OP_XXH32, lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb, [0] * nb, [0] * nb))
     xplan.launch(stream); xplan.results(stream)
     x_ms = sum(xplan.launch_timed(stream)[1] for _ in range(3)) / 3
 
+    result = None
     if rank == 0:
         copy_gbps = stream_copy_gbps(ctx, lz4_amd, torch, 1 << 30, stream)
         alg = {"compress": U + C, "decompress": U + C}        # U read + C written / C read + U written
@@ -539,12 +535,39 @@ def main():
             "extras": {"xxh32_batch_GBps": round(U / (x_ms * 1e-3) / 1e9, 1), "xxh32_batch_ms": round(x_ms, 3),
                        "note": "XXH32 (seed 0) of every 4 MiB block, one wave per block; not in `value`"},
         }
+    # ---- N > 1: the movement configs[4] names, over RCCL (not part of `value`, which stays the kernel-only rate)
+    dp = None
+    if world > 1 and not args.no_data_path:
+        # a collective that never returns must not cost the bench line: after 120 s rank 0 prints what it has and every rank leaves
+        def bail():
+            if rank == 0:
+                result["data_path"] = {"error": "the scatter / all_gather / gather phase did not finish within 120 s"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(120.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            r = data_path(dist, torch, dev, rank, world, data, comp, csizes)
+            ok = bool(torch.equal(r["received"], data)) if rank == 0 else True       # rank 0 scattered copies of its own shard
+            if rank == 0:                                    # every gathered block of rank 0 is byte-identical to its slot
+                ok = ok and all(bool(torch.equal(r["blocks"][i], comp[i, :csizes[i]])) for i in range(0, nb, max(1, nb // 16)))
+                ok = ok and len(r["blocks"]) == world * nb
+            dp = {k: aggregate(dist, r[k], 0, device=dev)[0] for k in ("scatter_s", "sizes_s", "gather_s")}
+            dp.update({"ok": ok, "scatter_bytes": r["scatter_bytes"], "gather_bytes": r["gather_bytes"]})
+        except Exception as e:
+            dp = {"error": str(e)}
+        finally:
+            watchdog.cancel()
+
+    if rank == 0:
         if dp is not None:
             if "error" not in dp:
                 move_s = dp["scatter_s"] + dp["sizes_s"] + dp["gather_s"]
                 step_s = t_max / args.steps
-                dp = {"collectives": "RCCL over xGMI: scatter of %d x %.2f GiB from rank 0, all_gather of int32 csize[%d], gather of the packed payloads"
-                                     % (world - 1, U / 2**30, nb),
+                dp = {"collectives": "%s: scatter of %d x %.2f GiB from rank 0, all_gather of int32 csize[%d], gather of the packed payloads"
+                                     % ("RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend() + " (loopback check, not a measurement)",
+                                        world - 1, U / 2**30, nb),
                       "scatter_s": round(dp["scatter_s"], 5), "sizes_s": round(dp["sizes_s"], 5), "gather_s": round(dp["gather_s"], 5),
                       "scatter_GBps": round(dp["scatter_bytes"] / dp["scatter_s"] / 1e9, 2) if dp["scatter_s"] > 0 else None,
                       "end_to_end_GBps": round(U * world / (step_s + move_s) / 1e9, 3), "kernel_only_GBps": round(bytes_all / t_max / 1e9, 3),
