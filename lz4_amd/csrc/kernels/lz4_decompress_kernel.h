@@ -100,7 +100,7 @@ enum : uint32_t {
 static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0, "LDS alignment");
 
-enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_FIN, M_CHI, M_EMIT, M_HEAD, M_CLO, M_NEXT, M_OPEN };      // (word 1 is the pre-parse's error word)
+enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_FIN, M_CHI, M_CLO, M_HEAD, M_EMIT, M_NEXT, M_OPEN };      // (M_HEAD, M_EMIT: one aligned 64-bit word, published together)      // (word 1 is the pre-parse's error word)
 
 // scratch of one workgroup: the sequence-record table of the block it is decoding
 __host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize) { return pre::scratch_bytes(max_csize); }
@@ -157,8 +157,8 @@ __device__ __forceinline__ Ctl ctl_snapshot(const char* smem) {
     lds_load_pair16(w, a, b);
     Ctl c;
     c.abort_ = __builtin_amdgcn_readfirstlane(a[0]); c.fin = __builtin_amdgcn_readfirstlane(a[1]);
-    c.chi = __builtin_amdgcn_readfirstlane(a[2]); c.emit = __builtin_amdgcn_readfirstlane(a[3]);
-    c.head = __builtin_amdgcn_readfirstlane(b[0]); c.clo = __builtin_amdgcn_readfirstlane(b[1]);
+    c.chi = __builtin_amdgcn_readfirstlane(a[2]); c.clo = __builtin_amdgcn_readfirstlane(a[3]);
+    c.head = __builtin_amdgcn_readfirstlane(b[0]); c.emit = __builtin_amdgcn_readfirstlane(b[1]);
     c.next = __builtin_amdgcn_readfirstlane(b[2]); c.open = __builtin_amdgcn_readfirstlane(b[3]);
     return c;
 }
@@ -228,8 +228,8 @@ __device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab
     uint32_t plen = 0, pn = nseq < 64 ? nseq : 64;
     if (lane < pn) { prec = rectab[lane]; plen = rectab[lane + 1].outpos - prec.outpos; }
     uint32_t pc_off = 0;                               // a long record is fed in pieces: output bytes of it already fed
-    bool fin_sent = false;
-    uint32_t clo_sent = 0;
+    bool fin_sent = false, last_progress = false;
+    uint32_t clo_sent = 0, trip = 0, g = kFirstRegion, tail = 0;
     for (;;) {
         bool progress = false;
         // ---- the next batch of the record table, when the last one is out (it was requested a batch ago)
@@ -243,17 +243,23 @@ __device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab
             } else { prec.outpos = prec.litpos = prec.ll = prec.off = 0; plen = 0; }
             progress = true;
         }
-        // ---- what the copy still needs: first open region g, first record in use, first literal byte in use
-        const uint32_t g = first_open_region(smem);
-        uint32_t tail = head, need;
-        if ((g << kRegionShift) < obase) {
-            const uint32_t t16 = idx[g & kIdxMask];
-            tail = head - ((head - t16) & 0xFFFFu);
-            const SeqRec r = recs[tail & kRecMask];
-            uint32_t d = (g << kRegionShift) - r.outpos; if (d > r.ll) d = r.ll;
-            need = r.litpos + d;
-        } else need = bdone < bn ? wave_readlane(brec.litpos, bdone) : csize;   // nothing published is in use
-        if (need != clo_sent) { clo_sent = need; if (lane == 0) lds_store_release(&misc[M_CLO], need); }   // what the loader may overwrite
+        // ---- what the copy still needs: first open region g, first record in use, first literal byte in use.  Looked up every
+        //      fourth trip or when the last trip got nowhere: both only ever move forward, so stale values are merely careful
+        //      (less room, a nearer horizon), and the lookup is a chain of three LDS round trips on the one wave that feeds fourteen
+        if ((trip & 3u) == 0 || !last_progress) {
+            g = first_open_region(smem);
+            uint32_t need;
+            tail = head;
+            if ((g << kRegionShift) < obase) {
+                const uint32_t t16 = idx[g & kIdxMask];
+                tail = head - ((head - t16) & 0xFFFFu);
+                const SeqRec r = recs[tail & kRecMask];
+                uint32_t d = (g << kRegionShift) - r.outpos; if (d > r.ll) d = r.ll;
+                need = r.litpos + d;
+            } else need = bdone < bn ? wave_readlane(brec.litpos, bdone) : csize;   // nothing published is in use
+            if (need != clo_sent) { clo_sent = need; if (lane == 0) lds_store_release(&misc[M_CLO], need); }   // what the loader may overwrite
+        }
+        trip++;
         if (bdone < bn) {
             const uint32_t room = kRecCap - 1 - (head - tail);           // rows free, one kept for the sentinel
             const bool islong = blen > 2 * kPieceSpan;
@@ -272,7 +278,7 @@ __device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab
                     const uint32_t g1 = ((o + kRegion - 1) >> kRegionShift) + lane;
                     if ((g1 << kRegionShift) < o + n) idx[g1 & kIdxMask] = (uint16_t)head;
                     wave_lds_fence();
-                    if (lane == 0) { lds_store_release(&misc[M_HEAD], head + 1); lds_store_release(&misc[M_EMIT], o + n); }
+                    if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(head + 1) | ((uint64_t)(o + n) << 32));
                     head += 1; obase = o + n; pc_off += n;
                     if (pc_off >= len) { bdone++; pc_off = 0; }
                     progress = true;
@@ -293,7 +299,7 @@ __device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab
                     }
                     const uint32_t oend = wave_readlane(o + blen, bdone + npub - 1);
                     wave_lds_fence();
-                    if (lane == 0) { lds_store_release(&misc[M_HEAD], head + npub); lds_store_release(&misc[M_EMIT], oend); }
+                    if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(head + npub) | ((uint64_t)oend << 32));
                     head += npub; obase = oend; bdone += npub;
                     progress = true;
                 }
@@ -305,6 +311,7 @@ __device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab
             fin_sent = true;
         }
         if (fin_sent && uload(&misc[M_CHI]) >= csize) break;     // (the loader may still be behind: keep telling it what the copy has consumed)
+        last_progress = progress;
         if (!progress) spin_pause();
     }
 }
