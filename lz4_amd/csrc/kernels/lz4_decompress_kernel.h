@@ -635,7 +635,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
     const uint32_t lane = lane_id();
     uint32_t k = 0;
     uint64_t t_rec = 0, t_lead = 0, t_work = 0, t_retry = 0;
-    uint32_t n_iters = 0, n_retried = 0;
+    uint32_t n_iters = 0, n_retried = 0, n_lead = 0, n_cov = 0;
     for (;;) {
         // regions are handed out in order to whichever wave is free: a slow region does not hold up its wave's next ones
         uint32_t R = 0;
@@ -660,9 +660,12 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
                 covered = true;
             }
             if (covered && C.g + kMaxLead >= R) break;
+            if (covered) n_lead++; else n_cov++;               // (developer profile: what the wait was for)
             spin_pause();
         }
-        { const uint64_t t = clock_ticks(); t_rec += t - ts; ts = t; }
+        {   const uint64_t t = clock_ticks(), dt = t - ts;
+            const uint64_t lead_part = (n_lead + n_cov) ? dt * n_lead / (n_lead + n_cov) : 0;
+            t_lead += lead_part; t_rec += dt - lead_part; ts = t; n_lead = n_cov = 0; }
         {
             const uint32_t i0 = idx[R & kIdxMask], i1 = idx[(R + 1) & kIdxMask];
             C.j0 = i0;
