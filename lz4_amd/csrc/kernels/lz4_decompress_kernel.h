@@ -17,12 +17,12 @@
 //       between the first and the last byte of the block:
 //       LOADER (wave 14)  streams the compressed block into a 32 KB LDS ring (coalesced 16-byte
 //           loads, the next 4 KB in flight while the last is written).
-//       FEEDER (wave 15)  streams the record table into a 1024-row LDS ring, 64 records at a
+//       FEEDER (wave 15)  streams the record table into a 2048-row LDS ring, 64 records at a
 //           time, noting for every 1 KB REGION of output the record that holds its first byte;
 //           records longer than 16 KB of output are cut in pieces.
 //       (both run as far ahead as the rings allow)
 //       COPY (waves 0-13)  output-stationary: wave w owns regions w, w+14, ... .  A region is
-//           composed in its slot of a 96 KB LDS ring that always holds the 64 KB LZ4 window, from
+//           composed in its slot of a 80 KB LDS ring that always holds the 64 KB LZ4 window, from
 //           PIECES (the literal run or the match of a record, cut at 16-byte chunk borders) in two
 //           lane-uniform rounds: round A, lane = chunk, writes the piece that covers the chunk's
 //           first byte; round B, lane = piece, ORs in the head of every piece that starts inside a
@@ -62,14 +62,14 @@ enum : uint32_t {
     kChunk = 16,                                // output bytes composed at a time
     kRegionShift = 10,
     kRegion = 1u << kRegionShift,               // 64 chunks
-    kSlots = 96,                                // output ring slots (regions): 64 KB window + regions in flight
+    kSlots = 80,                                // output ring slots (regions): 64 KB window + regions in flight (96 before: the 16 KB went to the record ring)
     kRingBytes = kSlots * kRegion,
     kRingPad = 32,                              // mirror of the first bytes: reads never wrap
     kMaxLead = kSlots - 64 - 1,                 // a wave may lead the first unfinished region by this many
     kCrBytes = 32u << 10,                       // compressed ring (direct mapped: position mod 32 K)
     kCrPad = 32,
     kLoadBatch = 4096,                          // bytes the feeder moves per step
-    kRecCap = 1024,                             // sequence-record ring
+    kRecCap = 2048,                             // sequence-record ring (1024 rows filled up on many-sequence data: HC-compressed 256 KiB blocks waited for room)
     kRecMask = kRecCap - 1,
     kIdxRing = 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
@@ -81,7 +81,6 @@ enum : uint32_t {
     kNone = 0xFFFFFFFFu,
 };
 static_assert(kMaxLead + 1 >= kCopyWaves, "every copy wave must be able to work at once");
-static_assert(kSlots == 96, "slot = region mod 96 is computed with a multiply");
 
 // LDS carve-up of stage B (bytes); stage A uses the same memory before (lz4_preparse_kernel.h)
 enum : uint32_t {
@@ -210,7 +209,7 @@ __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, cha
 }
 
 // ------------------------------------------------------------------------------ FEEDER
-// The record table -> the 1024-row LDS ring, 64 records at a time (the next batch is on its way from memory while
+// The record table -> the 2048-row LDS ring, 64 records at a time (the next batch is on its way from memory while
 // one is published), with the first record of every region noted; it also tells the loader which stream bytes the
 // copy has left behind.  Nothing here blocks on the copy: whatever does not fit now is tried again on the next trip.
 __device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab, uint32_t nseq, char* smem) {
@@ -641,11 +640,11 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
         uint32_t R = 0;
         if (lane == 0) R = atomicAdd(&misc[M_NEXT], 1u);
         R = __builtin_amdgcn_readfirstlane(R);
-        const uint32_t slot = R - (uint32_t)(((uint64_t)R * 0xAAAAAAABull) >> 38) * kSlots;          // R mod 96
+        const uint32_t slot = R % kSlots;
         RegionCtx C; C.smem = smem; C.R = R; C.slot = slot;
         C.x0 = R << kRegionShift;
         // ---- wait until the records cover the region (or the block ends inside / before it) and its ring slot is free:
-        //      region R takes the slot of region R-96, which regions up to R-32 may still read
+        //      region R takes the slot of region R-80, which regions up to R-16 may still read
         uint64_t ts = clock_ticks();
         uint32_t oe, head;
         for (;;) {
@@ -684,7 +683,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
         // move the first-open-region word over every complete region in front of it (mine included)
         for (;;) {
             const uint32_t g = uload(&misc[M_OPEN]);
-            const uint32_t gs = g - (uint32_t)(((uint64_t)g * 0xAAAAAAABull) >> 38) * kSlots;
+            const uint32_t gs = g % kSlots;
             uint32_t tag; uint64_t mask;
             lds_load_tag_mask(&ents[gs].tag, &ents[gs].mask, tag, mask);
             const bool complete = tag == g + kSlots && mask == ~0ull;
