@@ -39,10 +39,6 @@
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
 
-#ifndef LZ4AMD_SHORT_RUN
-#define LZ4AMD_SHORT_RUN 16
-#endif
-
 namespace lz4amd {
 
 using CompBatch = ::lz4amd_comp_params;   // argument block (lz4amd_params.h)
@@ -61,7 +57,7 @@ enum : uint32_t {
     kHashBits = 13,
     kRecsPerStrip = 64,                // matches a strip may take (the rest of it becomes literals)
     kLaneLenCap = 24,                  // match bytes a lane measures on its own
-    kShortRun = LZ4AMD_SHORT_RUN,                    // literal runs up to this long are copied by the sequence's own lane
+    kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane (4 / 8 / 32 measured: no better)
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
     kStripFields = 9,
@@ -185,9 +181,6 @@ __device__ __forceinline__ void tile_geometry(uint32_t t0, bool small, uint32_t&
     strip_len = t / kCmpWaves; if (strip_len < kStripMin) strip_len = kStripMin;
 }
 
-#ifndef LZ4AMD_PROBE_SH
-#define LZ4AMD_PROBE_SH 1
-#endif
 // ------------------------------------------------------------------------------ match (one strip)
 __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
                                             uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend) {
@@ -201,8 +194,9 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t cs_off = src_ring_off(cs);
         // big blocks probe every second position (the backward extension recovers the odd starts):
-        // half the work for about 4 % of the matches, which the larger table more than pays for
-        const uint32_t sh = small ? 0u : (uint32_t)LZ4AMD_PROBE_SH, span = 64u << sh, smask = (1u << sh) - 1u;
+        // half the work for about 4 % of the matches, which the larger table more than pays for (every 4th position
+        // was simulated: +5 % size at P60, +15 % at P90)
+        const uint32_t sh = small ? 0u : 1u, span = 64u << sh, smask = (1u << sh) - 1u;
         uint32_t p = cs, cur = cs;                             // cur: first position not yet covered
         while (p < ce && p <= last_q && nseq < kRecsPerStrip) {
             const uint32_t q = p + (lane << sh);

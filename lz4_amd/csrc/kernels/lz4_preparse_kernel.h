@@ -26,12 +26,6 @@
 #pragma once
 #include "lz4_common.h"
 
-#ifndef LZ4AMD_SEG_MIN
-#define LZ4AMD_SEG_MIN 64
-#endif
-#ifndef LZ4AMD_BRIDGE_TRIPS
-#define LZ4AMD_BRIDGE_TRIPS 192
-#endif
 namespace lz4amd { namespace pre {
 
 struct alignas(16) SeqRec { uint32_t outpos, litpos, ll, off; };
@@ -39,8 +33,8 @@ struct alignas(16) SeqRec { uint32_t outpos, litpos, ll, off; };
 enum : uint32_t {
     kThreads = 1024,
     kSpanMax = 1u << 20,                        // stream bytes per span
-    kSegMin = LZ4AMD_SEG_MIN,                              // a thread's segment is at least this long (short blocks use fewer threads; 256 -> 64: 64 KiB blocks decode 12 % faster)
-    kBridgeTrips = LZ4AMD_BRIDGE_TRIPS,                         // lockstep trips of the bridge walk
+    kSegMin = 64,                              // a thread's segment is at least this long (short blocks use fewer threads; 256 -> 64: 64 KiB blocks decode 12 % faster)
+    kBridgeTrips = 192,                         // lockstep trips of the bridge walk (96: more spans cut short, 4 MiB blocks 25 % slower; 384: no change)
     kExtMax = 64,                               // longer length fields take the slow path
     kBias = 65536,                              // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kNone = 0xFFFFFFFFu,
