@@ -52,12 +52,13 @@ enum : uint32_t {
     kTileMaxSmall = 2048,              // smaller blocks (4-byte hash, like the reference: lz4.c:1389)
     kTileMin = 1024,
     kStripMin = 256,
-    kSrcRing = 100u << 10,
+    kSrcRing = 84u << 10,              // the 64 KB window + the tile + the prefetched next tile + 4 KB
     kSrcPad = 32,                      // mirror of the ring's first bytes: unaligned reads never wrap
     kHashBits = 13,
     kRecsPerStrip = 64,                // matches a strip may take (the rest of it becomes literals)
-    kLaneLenCap = 24,                  // match bytes a lane measures on its own
-    kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane (4 / 8 / 32 measured: no better)
+    kCandPerPass = 64,                 // match candidates (runs of probe positions with one distance) measured at a time
+    kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane
+    kStageBytes = 12288,               // a tile's encoded bytes are composed here (LDS) and leave with 16-byte stores
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
     kStripFields = 9,
@@ -70,10 +71,19 @@ enum : uint32_t {
     kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kCmpWaves][kRecsPerStrip]
     kCOffEnds = kCOffRecs + 2 * kCmpWaves * kRecsPerStrip * 8,      // u16[2][kCmpWaves][kRecsPerStrip] where a record's match ends (from the strip's start)
     kCOffEncp = kCOffEnds + 2 * kCmpWaves * kRecsPerStrip * 2,      // u16[2][kCmpWaves][kRecsPerStrip] encoded bytes of the strip's records before it
-    kCOffRing = kCOffEncp + 2 * kCmpWaves * kRecsPerStrip * 2,
+    kCOffCandS = kCOffEncp + 2 * kCmpWaves * kRecsPerStrip * 2,     // u32[kCmpWaves][kCandPerPass] a candidate's first probe position | distance << 9
+    kCOffCandE = kCOffCandS + kCmpWaves * kCandPerPass * 4,         // u16[kCmpWaves][kCandPerPass] its last probe position
+    kCOffCarry = kCOffCandE + kCmpWaves * kCandPerPass * 2,         // u8[2][16]: encoded bytes of the 16-byte chunk a tile's output ends in (they leave with the next tile)
+    kCOffStage = kCOffCarry + 32,                                   // u8[kStageBytes]
+    kCOffRing = kCOffStage + kStageBytes,
     kCmpLdsBytes = kCOffRing + kSrcRing + kSrcPad,
 };
-enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4 };      // CM_READY: tiles whose output offsets are fixed
+static_assert(kCmpLdsBytes <= 160u * 1024u, "LDS budget");
+static_assert(kCOffRing % 16 == 0 && kCOffStage % 16 == 0 && kCOffCarry % 16 == 0 && kSrcRing % 16 == 0, "LDS alignment");
+enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4,     // CM_READY: tiles whose output offsets are fixed
+                  CM_TILE = 8 };       // u32[2][4] per tile in flight: { first output position, end, written directly (not staged),
+                                       //   first pending byte of its carry chunk }
+enum : uint32_t { T_OUT0 = 0, T_OUT1 = 1, T_DIRECT = 2, T_CFROM = 3 };
 enum : uint32_t { S_N = 0, S_ENC = 1, S_LL0 = 2, S_TAIL = 3, S_OUT = 4, S_CARRY = 5,
                   S_END = 6,      // where the strip's last match ends when it runs past the strip (else 0)
                   S_FIRST = 7,    // first record that is emitted (the ones before it were covered by an earlier strip's match)
@@ -182,121 +192,228 @@ __device__ __forceinline__ void tile_geometry(uint32_t t0, bool small, uint32_t&
 }
 
 // ------------------------------------------------------------------------------ match (one strip)
+// 8 bytes at ring offset o (any alignment) as two dwords: three ALIGNED dword reads and two v_alignbyte (a misaligned LDS
+// access of any width is serialised lane by lane on gfx950: 64 cycles instead of ~3, tools/exp/lds_prims.hip)
+struct Pair32 { uint32_t lo, hi; };
+__device__ __forceinline__ Pair32 ring_ld8_32(const uint8_t* ring, uint32_t o) {
+    const uint32_t* a = (const uint32_t*)(ring + (o & ~3u));
+    const uint32_t sh = o & 3u;
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2];
+    Pair32 r; r.lo = align_bytes(d1, d0, sh); r.hi = align_bytes(d2, d1, sh);
+    return r;
+}
+
+// One wave parses one strip.  SH = 1: every second position is probed (blocks >= 64 KB + 11), SH = 0: every position.
+//   probe     a lane owns 4 << SH consecutive source bytes = four probe positions: its bytes come out of ONE aligned
+//             read, the four hashes out of registers, each candidate is checked for its first four bytes only;
+//   runs      consecutive probe positions that hit with the SAME distance are one match seen several times: only the
+//             first and the last probe of such a run matter (where the match may start, up to where it is known to
+//             hold).  Run starts / ends are numbered by a wave scan and written to a 64-entry list;
+//   measure   lane = run: how far does it go on behind its last probe (8 bytes on its own; the rare longer ones are
+//             finished by the whole wave when the run is taken), how far back before its first probe (lz4.c:1105-1109);
+//   select    greedy in position order (a run that starts inside the match taken before it is cut to start at that
+//             match's end - the reference would probe there and find the same distance), scalar bookkeeping only;
+//   records   the taken lanes write {literals, offset, length} and their encoded sizes side by side.
+#ifdef LZ4AMD_PROF_MATCH
+#define MPROF(k) do { const uint64_t t_ = clock_ticks(); mtp[k] += t_ - mtq; mtq = t_; } while (0)
+#define MPROF_ARGS , uint64_t* mtp
+#define MPROF_PASS , mtp
+#else
+#define MPROF(k) do {} while (0)
+#define MPROF_ARGS
+#define MPROF_PASS
+#endif
+template <uint32_t SH>
 __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
-                                            uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend) {
+                                            uint32_t* candS, uint16_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend MPROF_ARGS) {
     const uint32_t lane = lane_id();
-    const bool small = n < kSmallBlockLimit;
-    uint32_t nseq = 0, enc = 0, ll0 = 0, anchor = cs;
-    // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= ce
+#ifdef LZ4AMD_PROF_MATCH
+    uint64_t mtq = clock_ticks();
+#endif
+    constexpr bool small = SH == 0;
+    constexpr uint32_t kSpan = 256u << SH, kLaneBytes = 4u << SH;
+    uint32_t nseq = 0, enc = 0, ll0 = 0, cur = cs;             // cur: end of the last match taken (first byte not yet covered)
+    // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= tend
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
-        const uint32_t last_q = n - kMfLimit;                  // inclusive; q + 8 <= n - 4 holds for all probes
+        const uint32_t last_q = n - kMfLimit;                  // inclusive
         // a match may run past the strip up to the tile's end: the strips it covers give way (resolve_overruns)
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t cs_off = src_ring_off(cs);
-        // big blocks probe every second position (the backward extension recovers the odd starts):
-        // half the work for about 4 % of the matches, which the larger table more than pays for (every 4th position
-        // was simulated: +5 % size at P60, +15 % at P90)
-        const uint32_t sh = small ? 0u : 1u, span = 64u << sh, smask = (1u << sh) - 1u;
-        uint32_t p = cs, cur = cs;                             // cur: first position not yet covered
-        while (p < ce && p <= last_q && nseq < kRecsPerStrip) {
-            const uint32_t q = p + (lane << sh);
-            const bool valid = q < ce && q <= last_q && q != 0;
-            const uint32_t qo = ring_fwd(cs_off, q - cs);
-            uint32_t c = 0, len = 0, back = 0;
-            bool f = false;
-            if (valid) {
-                // stage 1: my bytes q-8 .. q+24 (independent of the table)
-                const Win32 v = ring_window32(ring, qo);
-                // stage 2: the candidate
-                c = tab[hash_pos32(v.f0, v.f1, small)];
+        for (uint32_t p = cs; p < ce && p <= last_q && nseq < kRecsPerStrip; p += kSpan) {
+            if (cur >= p + kSpan) continue;                    // all of it is covered already
+            // ---- probe: four positions per lane
+            const uint32_t q0 = p + lane * kLaneBytes;
+            const uint32_t o0 = ring_fwd(cs_off, q0 - cs);     // multiple of kLaneBytes; o0 + 12 <= ring + pad
+            uint32_t R0, R1, R2 = 0;
+            if (SH) { const uint64_t v = *(const uint64_t*)(ring + o0); R0 = (uint32_t)v; R1 = (uint32_t)(v >> 32); R2 = *(const uint32_t*)(ring + o0 + 8); }
+            else { R0 = *(const uint32_t*)(ring + o0); R1 = *(const uint32_t*)(ring + o0 + 4); }
+            uint32_t dd[4];                                    // distance of the candidate that holds at slot j, 0: none
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t q = q0 + (j << SH);
+                uint32_t f0, f4 = 0;
+                if (SH) {
+                    f0 = j == 0 ? R0 : j == 1 ? align_bytes(R1, R0, 2) : j == 2 ? R1 : align_bytes(R2, R1, 2);
+                    f4 = j == 0 ? R1 : j == 1 ? R1 >> 16 : j == 2 ? R2 : R2 >> 16;
+                } else f0 = j == 0 ? R0 : align_bytes(R1, R0, j);
+                const uint32_t c = tab[hash_pos32(f0, f4, small)];
                 const uint32_t d = q - c;
-                if (c < q && d <= kMaxDistance) {
-                    // stage 3: its bytes c-8 .. c+24
-                    const Win32 k = ring_window32(ring, ring_back(qo, d));
-                    len = equal_bytes8_32(v.f0, v.f1, k.f0, k.f1);
-                    if (len == 8) { len += equal_bytes8_32(v.f2, v.f3, k.f2, k.f3); if (len == 16) len += equal_bytes8_32(v.f4, v.f5, k.f4, k.f5); }
-                    f = len >= kMinMatch;
+                const bool ok = q < ce && q <= last_q && c < q && d <= kMaxDistance;
+                const uint32_t co = ok ? ring_back(o0 + (j << SH), d) : 0u;
+                const uint32_t* a = (const uint32_t*)(ring + (co & ~3u));
+                const uint32_t x = align_bytes(a[1], a[0], co & 3u);
+                dd[j] = (ok && x == f0) ? d : 0u;
+            }
+            MPROF(0);
+            // ---- runs: first / last probe of every stretch of hits with one distance
+            const uint32_t pv = wave_prev_u32(dd[3]), nx = wave_next_u32(dd[0]);
+            const uint32_t sb = ((dd[0] && dd[0] != pv) ? 1u : 0u) | ((dd[1] && dd[1] != dd[0]) ? 2u : 0u) |
+                                ((dd[2] && dd[2] != dd[1]) ? 4u : 0u) | ((dd[3] && dd[3] != dd[2]) ? 8u : 0u);
+            const uint32_t eb = ((dd[0] && dd[0] != dd[1]) ? 1u : 0u) | ((dd[1] && dd[1] != dd[2]) ? 2u : 0u) |
+                                ((dd[2] && dd[2] != dd[3]) ? 4u : 0u) | ((dd[3] && dd[3] != nx) ? 8u : 0u);
+            const uint32_t cnt = (uint32_t)__popc(sb) | ((uint32_t)__popc(eb) << 16);
+            const uint32_t incl = wave_incl_sum(cnt);
+            const uint32_t total = wave_readlane(incl, 63) & 0xFFFFu;          // runs in this span (as many ends as starts)
+            const uint32_t baseS = (incl - cnt) & 0xFFFFu, baseE = (incl - cnt) >> 16;
+            MPROF(1);
+            for (uint32_t lo = 0; lo < total && nseq < kRecsPerStrip; lo += kCandPerPass) {
+                // ---- the runs [lo, lo + 64) into the list (nearly always all of them; a lane seldom holds more than one start)
+                {
+                    uint32_t s = sb, e2 = eb, iS = baseS - lo, iE = baseE - lo;     // (indices below lo wrap and are dropped)
+                    while (__any((s | e2) != 0)) {
+                        if (s) {
+                            const uint32_t j = (uint32_t)__ffs((int)s) - 1; s &= s - 1;
+                            const uint32_t dj = j == 0 ? dd[0] : j == 1 ? dd[1] : j == 2 ? dd[2] : dd[3];
+                            if (iS < kCandPerPass) candS[iS] = ((q0 - p) + (j << SH)) | (dj << 9);
+                            iS++;
+                        }
+                        if (e2) {
+                            const uint32_t j = (uint32_t)__ffs((int)e2) - 1; e2 &= e2 - 1;
+                            if (iE < kCandPerPass) candE[iE] = (uint16_t)((q0 - p) + (j << SH));
+                            iE++;
+                        }
+                    }
+                }
+                wave_lds_fence();
+                MPROF(2);
+                // ---- measure: lane = run
+                const uint32_t nc = total - lo < kCandPerPass ? total - lo : kCandPerPass;
+                const bool have = lane < nc;
+                uint32_t qs = 0, d = 1, e = 0, back = 0, more = 0;
+                if (have) {
+                    const uint32_t S = candS[lane], E = candE[lane];
+                    qs = p + (S & 511u); d = S >> 9;
+                    const uint32_t a = p + E + kMinMatch;                    // first byte the probes did not compare
+                    e = mlimit;
+                    if (a < mlimit) {
+                        // the next 24 bytes on the lane's own (seven aligned dwords per side)
+                        const uint32_t ao = ring_fwd(cs_off, a - cs), ko = ring_back(ao, d);
+                        const uint32_t* xa = (const uint32_t*)(ring + (ao & ~3u));
+                        const uint32_t* ya = (const uint32_t*)(ring + (ko & ~3u));
+                        uint32_t xd[7], yd[7];
+#pragma unroll
+                        for (uint32_t i = 0; i < 7; i++) { xd[i] = xa[i]; yd[i] = ya[i]; }
+                        uint32_t same = 24;
+#pragma unroll
+                        for (int i = 5; i >= 0; i--) {
+                            const uint32_t z = align_bytes(xd[i + 1], xd[i], ao & 3u) ^ align_bytes(yd[i + 1], yd[i], ko & 3u);
+                            same = z ? 4 * (uint32_t)i + ((uint32_t)(__ffs((int)z) - 1) >> 3) : same;
+                        }
+                        more = (same == 24 && a + 24 < mlimit) ? 1u : 0u;
+                        if (same > mlimit - a) same = mlimit - a;
+                        e = a + same;
+                    }
                     // how far back, over literals that may still be pending (lz4.c:1105-1109)?
-                    if (c >= 8) {
-                        const uint32_t x1 = v.b1 ^ k.b1, x0 = v.b0 ^ k.b0;
+                    if (qs - d >= 8) {
+                        const uint32_t bo = ring_back(ring_fwd(cs_off, qs - cs), 8);
+                        const Pair32 v = ring_ld8_32(ring, bo), k = ring_ld8_32(ring, ring_back(bo, d));
+                        const uint32_t x1 = v.hi ^ k.hi, x0 = v.lo ^ k.lo;
                         back = x1 ? (uint32_t)__clz((int)x1) >> 3 : (x0 ? 4 + ((uint32_t)__clz((int)x0) >> 3) : 8u);
                     }
                 }
-            }
-            // Which matches are taken is a serial question (a match starts where the previous one ended) but a
-            // cheap one: the walk below only follows "first candidate at or after the end of the last one" and
-            // tells every taken lane where its predecessor ended.  Everything per match - backward extension over
-            // the pending literals, record, encoded size - is then done by the taken lanes side by side.
-            uint32_t e = q + len;                                  // where my match ends (no lane-side length beyond the cap)
-            if (e > mlimit) e = mlimit;
-            uint32_t prev_end = 0;                                 // end of the match taken before mine (taken lanes only)
-            unsigned long long m = __ballot(f && q + kMinMatch <= mlimit);
-            unsigned long long taken = 0;
-            uint32_t ntaken = 0, wend = anchor;                    // wend: end of the last match taken so far
-            while (m) {
-                // candidates that start inside what is already covered are out
-                if (cur > p) { const uint32_t k = (cur - p + smask) >> sh; if (k >= 64) break; m &= ~0ull << k; if (!m) break; }
-                const uint32_t l = (uint32_t)__ffsll((long long)m) - 1;
-                m &= m - 1;
-                uint32_t el = wave_readlane(e, l);
-                const uint32_t qm = p + (l << sh);
-                uint32_t ml = wave_readlane(len, l);
-                if (ml >= kLaneLenCap && qm + ml < mlimit) {
+                wave_lds_fence();                                            // (the list may be rewritten by the next pass)
+                MPROF(3);
+                // ---- select: a run is taken when it still holds a minimal match behind everything that ends before it - the
+                //      running maximum of the ends of the runs in front of it (a wave scan: no serial walk over the matches; a
+                //      run that is not taken ends less than 4 bytes behind a taken one, so the maximum over all runs is the end
+                //      of the last taken match give or take 3 bytes).  A taken run that went on matching for more than the 24
+                //      bytes its lane compared is finished by the whole wave, and the scan is repeated with its real end.
+                const bool sv = have && e >= qs + kMinMatch;
+                unsigned long long taken;
+                for (;;) {
+                    uint32_t pmx = wave_prev_u32(wave_incl_max(sv ? e : 0u));
+                    if (pmx < cur) pmx = cur;
+                    const uint32_t st = qs > pmx ? qs : pmx;
+                    bool tk = sv && e >= st + kMinMatch && st <= last_q;
+                    taken = __ballot(tk);
+                    const uint32_t room = kRecsPerStrip - nseq;
+                    if ((uint32_t)__popcll(taken) > room) taken = __ballot(tk && lanes_below(taken) < room);
+                    const unsigned long long mm = taken & __ballot(more != 0);
+                    if (!mm) break;
                     // long match: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
-                    const uint32_t cm = wave_readlane(c, l);
-                    const uint32_t qmo = ring_fwd(cs_off, qm - cs), cmo = ring_back(qmo, qm - cm);
+                    const uint32_t l = (uint32_t)__ffsll((long long)mm) - 1;
+                    uint32_t el = wave_readlane(e, l);
+                    const uint32_t eo = ring_fwd(cs_off, el - cs), ko = ring_back(eo, wave_readlane(d, l));
+                    uint32_t ext = 0;
                     for (;;) {
-                        const uint32_t a = qm + ml + 8 * lane;
+                        const uint32_t a = el + ext + 8 * lane;
                         uint32_t same = 0;
                         if (a < mlimit) {
-                            same = equal_bytes8(ring_ld8(ring, ring_fwd(qmo, ml + 8 * lane)), ring_ld8(ring, ring_fwd(cmo, ml + 8 * lane)));
+                            same = equal_bytes8(ring_ld8(ring, ring_fwd(eo, ext + 8 * lane)), ring_ld8(ring, ring_fwd(ko, ext + 8 * lane)));
                             if (same > mlimit - a) same = mlimit - a;
                         }
                         const unsigned long long brk = __ballot(same < 8);
                         if (brk) {
                             const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
-                            ml += 8 * fl + wave_readlane(same, fl);
+                            ext += 8 * fl + wave_readlane(same, fl);
                             break;
                         }
-                        ml += 512;
+                        ext += 512;
                     }
-                    el = qm + ml; if (el > mlimit) el = mlimit;
+                    el += ext;
                     e = lane == l ? el : e;
+                    more = lane == l ? 0u : more;
                 }
-                prev_end = lane == l ? wend : prev_end;
-                taken |= 1ull << l;
-                ntaken++;
-                wend = cur = el;
-                if (nseq + ntaken >= kRecsPerStrip) break;
-            }
-            if (taken) {
-                const bool mine = (taken >> lane) & 1;
-                uint32_t my_enc = 0, my_ll = 0;
-                if (mine) {
-                    uint32_t bk = back; if (bk > q - prev_end) bk = q - prev_end;     // lz4.c:1105-1109 over the pending literals
-                    const uint32_t qs = q - bk;
-                    my_ll = qs - prev_end;
-                    const uint32_t mlen = e - qs;
-                    MatchRec r; r.ll = my_ll; r.mo = (q - c) | ((mlen - kMinMatch) << 16);
-                    recs[nseq + lanes_below(taken)] = r;
-                    my_enc = enc_size(my_ll, mlen - kMinMatch);
+                const uint32_t ntaken = (uint32_t)__popcll(taken);
+                uint32_t prev_end = 0;                                       // end of the match taken before mine (taken lanes)
+                if (taken) {
+                    const uint32_t pt = wave_incl_max(((taken >> lane) & 1) ? e : 0u);
+                    prev_end = wave_prev_u32(pt);
+                    if (prev_end < cur) prev_end = cur;
+                    const uint32_t last_e = wave_readlane(pt, 63);
+                    if (last_e > cur) cur = last_e;
                 }
-                if (nseq == 0) ll0 = wave_readlane(my_ll, (uint32_t)__ffsll((long long)taken) - 1);
-                const uint32_t enc_incl = wave_incl_sum(my_enc);
-                if (mine) { const uint32_t i = nseq + lanes_below(taken); ends[i] = (uint16_t)(e - cs); encp[i] = (uint16_t)(enc + enc_incl - my_enc); }
-                enc += wave_readlane(enc_incl, 63);
-                nseq += ntaken;
-                anchor = wend;
+                MPROF(4);
+                // ---- records
+                if (taken) {
+                    const bool mine = (taken >> lane) & 1;
+                    const uint32_t ri = nseq + lanes_below(taken);
+                    uint32_t my_enc = 0, my_ll = 0;
+                    if (mine) {
+                        uint32_t start = prev_end;
+                        if (qs > prev_end) { uint32_t bk = back; if (bk > qs - prev_end) bk = qs - prev_end; start = qs - bk; }
+                        my_ll = start - prev_end;
+                        const uint32_t mlen = e - start;
+                        MatchRec r; r.ll = my_ll; r.mo = d | ((mlen - kMinMatch) << 16);
+                        recs[ri] = r;
+                        my_enc = enc_size(my_ll, mlen - kMinMatch);
+                    }
+                    if (nseq == 0) ll0 = wave_readlane(my_ll, (uint32_t)__ffsll((long long)taken) - 1);
+                    const uint32_t enc_incl = wave_incl_sum(my_enc);
+                    if (mine) { ends[ri] = (uint16_t)(e - cs); encp[ri] = (uint16_t)(enc + enc_incl - my_enc); }
+                    enc += wave_readlane(enc_incl, 63);
+                    nseq += ntaken;
+                }
+                MPROF(5);
             }
-            p = cur > p + span ? (cur + smask) & ~smask : p + span;
         }
     }
     if (lane == 0) {
         strip[S_N * kCmpWaves + w] = nseq;
         strip[S_ENC * kCmpWaves + w] = enc;
         strip[S_LL0 * kCmpWaves + w] = ll0;
-        strip[S_TAIL * kCmpWaves + w] = anchor < ce ? ce - anchor : 0;
-        strip[S_END * kCmpWaves + w] = anchor > ce ? anchor : 0;
+        strip[S_TAIL * kCmpWaves + w] = cur < ce ? ce - cur : 0;
+        strip[S_END * kCmpWaves + w] = cur > ce ? cur : 0;
     }
 }
 
@@ -372,6 +489,99 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
         opos += wave_readlane(e_incl, 63);
         ipos += wave_readlane(a_incl, 63);
     }
+}
+
+// ------------------------------------------------------------------------------ emit into the staging buffer (one strip)
+// The same sequences as emit_strip, composed in LDS: `stage` holds the tile's encoded bytes, stage[0] = output position
+// dbase (the 16-byte chunk of the output the tile starts in).  Byte-granular LDS writes cost what dword writes cost
+// (tools/exp/lds_prims.hip); the bytes then leave for HBM as whole aligned 16-byte chunks (flush_tile).  Literals always
+// come out of the source ring here: a staged tile's literals are at most kStageBytes old.
+__device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchRec* recs, const uint32_t* strip, uint32_t w,
+                                               uint8_t* stage, uint32_t dbase, uint32_t cs) {
+    const uint32_t lane = lane_id();
+    const uint32_t nk = strip[S_N * kCmpWaves + w];
+    const uint32_t carry = strip[S_CARRY * kCmpWaves + w];
+    const uint32_t cs_off = src_ring_off(cs);
+    uint32_t ipos = 0;             // source position of the next sequence's own literals, from cs
+    uint32_t opos = strip[S_OUT * kCmpWaves + w] - dbase;      // staging offset of the next sequence's token
+    for (uint32_t base = 0; base < nk; base += 64) {
+        const uint32_t i = base + lane;
+        const bool have = i < nk;
+        uint32_t ll = 0, mlm4 = 0, off = 0, extra = 0;
+        if (have) { const MatchRec r = recs[i]; ll = r.ll; off = r.mo & 0xFFFFu; mlm4 = r.mo >> 16; }
+        if (i == 0) extra = carry;                       // literals inherited from earlier strips
+        const uint32_t e = have ? enc_size(ll + extra, mlm4) : 0;
+        const uint32_t adv = have ? ll + mlm4 + kMinMatch : 0;
+        const uint32_t e_incl = wave_incl_sum(e), a_incl = wave_incl_sum(adv);
+        const uint32_t tl = ll + extra;
+        const uint32_t rel = ipos + a_incl - adv;        // my own literals start here (from cs); the carried ones lie before
+        const uint32_t so = rel >= extra ? ring_fwd(cs_off, rel - extra) : ring_back(cs_off, extra - rel);
+        uint32_t lit_d = 0;
+        if (have) {
+            uint32_t o = opos + e_incl - e;
+            const uint32_t tok_ll = tl >= 15 ? 15u : tl, tok_ml = mlm4 >= 15 ? 15u : mlm4;
+            stage[o++] = (uint8_t)((tok_ll << 4) | tok_ml);
+            if (tl >= 15) { uint32_t rest = tl - 15; while (rest >= 255) { stage[o++] = 255; rest -= 255; } stage[o++] = (uint8_t)rest; }
+            lit_d = o; o += tl;
+            stage[o] = (uint8_t)off; stage[o + 1] = (uint8_t)(off >> 8); o += 2;
+            if (mlm4 >= 15) { uint32_t rest = mlm4 - 15; while (rest >= 255) { stage[o++] = 255; rest -= 255; } stage[o++] = (uint8_t)rest; }
+        }
+        // literal runs: the short ones byte by byte by the lane that owns the sequence, all lanes at once (the ring's pad
+        // covers a short run that crosses the ring's end); the long ones one sequence at a time with the whole wave copying
+        if (have && tl <= kShortRun) for (uint32_t k = 0; k < tl; k++) stage[lit_d + k] = ring[so + k];
+        unsigned long long longm = __ballot(have && tl > kShortRun);
+        while (longm) {
+            const uint32_t j = (uint32_t)__ffsll((long long)longm) - 1;
+            longm &= longm - 1;
+            const uint32_t d0 = wave_readlane(lit_d, j), s0 = wave_readlane(so, j), len = wave_readlane(tl, j);
+            for (uint32_t k = lane; k < len; k += 64) stage[d0 + k] = ring[ring_fwd(s0, k)];
+        }
+        opos += wave_readlane(e_incl, 63);
+        ipos += wave_readlane(a_incl, 63);
+    }
+}
+
+// ------------------------------------------------------------------------------ flush (all threads)
+// The staged tile leaves for HBM: every thread stores one ALIGNED 16-byte chunk (the output's own 16-byte grid: a0 is
+// dst's misalignment).  The chunk the tile starts in begins with the last bytes of the tile before: they wait in the
+// carry chunk (two of them, by tile parity) and leave now; the bytes behind the tile's last whole chunk wait in turn.
+// cfrom: first byte of the carry chunk that is pending (bytes below it left already, or lie before dst).
+__device__ __forceinline__ void flush_tile(char* smem, uint32_t pp, lz4amd_gdst dst, uint32_t a0) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
+    const uint32_t* T = misc + CM_TILE + 4 * pp;
+    const uint32_t out0 = T[T_OUT0], out1 = T[T_OUT1], direct = T[T_DIRECT], cfrom = T[T_CFROM];
+    uint32_t* Tn = misc + CM_TILE + 4 * (pp ^ 1);
+    const uint8_t* C = (const uint8_t*)(smem + kCOffCarry) + 16 * pp;
+    uint8_t* Cn = (uint8_t*)(smem + kCOffCarry) + 16 * (pp ^ 1);
+    const uint32_t V0 = out0 + a0, V1 = out1 + a0, dbase = V0 & ~15u, h = V0 - dbase;
+    if (direct) {
+        // the tile went to HBM byte by byte (emit_strip): only the pending bytes before it are left to write
+        if (tid >= cfrom && tid < h) dst[dbase - a0 + tid] = C[tid];
+        if (tid == 0) Tn[T_CFROM] = V1 & 15u;
+        return;
+    }
+    const uint32_t nfull = (V1 - dbase) >> 4, r = (V1 - dbase) & 15u;
+    for (uint32_t i = tid; i <= nfull; i += kCmpThreads) {
+        if (i == nfull && r == 0) break;
+        U32x4 v = *(const U32x4*)(smem + kCOffStage + 16 * i);
+        if (i == 0 && h) {
+            const U32x4 c = *(const U32x4*)C;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const int32_t rr = (int32_t)h - 4 * (int32_t)k;
+                const uint32_t m = rr >= 4 ? 0xFFFFFFFFu : (rr <= 0 ? 0u : ((1u << (8 * rr)) - 1u));
+                v[k] = (c[k] & m) | (v[k] & ~m);
+            }
+        }
+        if (i < nfull) {
+            if (i == 0 && cfrom) {
+#pragma nounroll
+                for (uint32_t k = cfrom; k < 16; k++) dst[dbase - a0 + k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+            } else st_global16(dst + (dbase - a0 + 16 * i), v);
+        } else *(U32x4*)Cn = v;
+    }
+    if (tid == 0) Tn[T_CFROM] = nfull ? 0u : cfrom;
 }
 
 // ------------------------------------------------------------------------------ offsets (one wave)
@@ -488,6 +698,38 @@ __device__ __forceinline__ StripTotals strip_offsets(uint32_t* strip, uint32_t n
 // a control word every lane of the wave agrees on
 __device__ __forceinline__ uint32_t uload_cm(const uint32_t* w) { return __builtin_amdgcn_readfirstlane(lds_load_acquire(w)); }
 
+// ------------------------------------------------------------------------------ one tile settled / written (helpers of one block)
+// wave 0: tile (parity pp) gets its output offsets; whether it is composed in LDS or - when its encoded bytes do not fit
+// the staging buffer, i.e. when it ends a literal run of more than a few KB - written to HBM directly
+__device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t nstrips, uint32_t t0, uint32_t strip_len, uint32_t t1,
+                                            uint32_t n, uint32_t cap, uint32_t a0) {
+    uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
+    uint32_t* strip_p = (uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
+    resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kCmpWaves * kRecsPerStrip, (const uint16_t*)(smem + kCOffEnds) + pp * kCmpWaves * kRecsPerStrip,
+                     (const uint16_t*)(smem + kCOffEncp) + pp * kCmpWaves * kRecsPerStrip, nstrips, t0, strip_len, t1, n);
+    wave_lds_fence();
+    const uint32_t out0 = misc[CM_OUT];
+    const StripTotals t = strip_offsets(strip_p, nstrips, out0, misc[CM_CARRY], misc[CM_FAIL], cap);
+    if (lane_id() == 0) {
+        misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail;
+        uint32_t* T = misc + CM_TILE + 4 * pp;
+        T[T_OUT0] = out0; T[T_OUT1] = t.out;
+        T[T_DIRECT] = (t.out + a0) - ((out0 + a0) & ~15u) > kStageBytes - 16 ? 1u : 0u;
+    }
+    wave_lds_fence();
+}
+// every wave: its strip of the settled tile (parity pp), into the staging buffer or straight to HBM
+__device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo) {
+    const uint32_t* misc = (const uint32_t*)(smem + kCOffMisc);
+    const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
+    if (misc[CM_FAIL] || !strip_p[S_N * kCmpWaves + w]) return;
+    const uint8_t* ring = (const uint8_t*)(smem + kCOffRing);
+    const MatchRec* recs_w = (const MatchRec*)(smem + kCOffRecs) + (pp * kCmpWaves + w) * kRecsPerStrip + strip_p[S_FIRST * kCmpWaves + w];
+    const uint32_t* T = misc + CM_TILE + 4 * pp;
+    if (T[T_DIRECT]) emit_strip(ring, recs_w, strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
+    else emit_strip_lds(ring, recs_w, strip_p, w, (uint8_t*)(smem + kCOffStage), ((T[T_OUT0] + a0) & ~15u) - a0, strip_p[S_P * kCmpWaves + w]);    // (stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
+}
+
 // ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t b, char* smem) {
     const uint32_t tid = threadIdx.x, w = wave_id();
@@ -497,13 +739,16 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + w * kRecsPerStrip;      // + parity * kCmpWaves * kRecsPerStrip
     uint16_t* ends = (uint16_t*)(smem + kCOffEnds) + w * kRecsPerStrip;
     uint16_t* encp = (uint16_t*)(smem + kCOffEncp) + w * kRecsPerStrip;
+    uint32_t* candS = (uint32_t*)(smem + kCOffCandS) + w * kCandPerPass;
+    uint16_t* candE = (uint16_t*)(smem + kCOffCandE) + w * kCandPerPass;
     uint8_t* ring = (uint8_t*)(smem + kCOffRing);
 
     // history (linked blocks, lz4io.c:741-744 / LZ4_compress_fast_continue in prefix mode lz4.c:1707): the
-    // `pre` bytes right before the block are parsed into the table but not emitted.  Whole tiles only.
+    // `pre` bytes right before the block are parsed into the table but not emitted (all but up to 15 of them: the
+    // block starts on the 16-byte grid of the positions).
     uint32_t pre = P.prefix ? (uint32_t)P.prefix[b] : 0u;
     if (pre > kMaxDistance + 1) pre = kMaxDistance + 1;
-    pre &= ~(kTileMax - 1);
+    pre &= ~15u;
     const lz4amd_gsrc src = LZ4AMD_TO_GSRC(P.src[b]) - pre;          // position 0 = start of the history
     const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
     const int32_t n_i = P.src_size[b];
@@ -515,15 +760,22 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }      // lz4.c:1361-1371
     const uint32_t n = (uint32_t)n_i + pre, cap = (uint32_t)cap_i;
     const bool small = n < kSmallBlockLimit;
+    const uint32_t a0 = (uint32_t)((uintptr_t)P.dst[b] & 15u);        // dst's place on HBM's 16-byte grid
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
-    if (tid == 0) { misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; }
+    if (tid == 0) {
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0;
+        misc[CM_TILE + T_CFROM] = a0; misc[CM_TILE + 4 + T_CFROM] = a0;     // nothing of the first chunk is pending: the bytes before dst are not ours
+    }
     // first tile straight into the ring; later tiles are prefetched one tile ahead
     uint32_t t0 = 0, tile_len, strip_len;
     tile_geometry(pre ? kTileMax * 4 : 0, small, tile_len, strip_len);
     uint32_t loaded = 0;                                  // ring holds [.., loaded)
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
+#ifdef LZ4AMD_PROF_MATCH
+    uint64_t mtp[6] = {0, 0, 0, 0, 0, 0};
+#endif
     if (prof) tq = clock_ticks();
     {
         uint32_t hi = tile_len + 16; if (hi > n) hi = n;
@@ -533,17 +785,17 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     // Two barriers per tile.  Interval A: wave 0 first settles tile k-1 (overrunning matches, then the strips' sizes
     // into output offsets: ~3.5 K cycles of one wave's dependent work, which used to sit between the barriers with
     // fifteen waves waiting) and says so in CM_READY; every wave parses its strip of tile k, then - once CM_READY
-    // covers tile k-1, which it long does by then - writes out its strip of tile k-1.  Interval B: everybody inserts
-    // tile k into the table.  Records and strip summaries are double buffered for that.
+    // covers tile k-1, which it long does by then - composes its strip of tile k-1 in the staging buffer.  Interval B:
+    // everybody inserts tile k into the table and stores one 16-byte chunk of tile k-1's bytes.  Records and strip
+    // summaries are double buffered for that.
     uint32_t par = 0;                                       // buffer parity of tile k
     uint32_t prev_t0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
     uint32_t tiles_parsed = 0;                              // tiles whose strips were matched so far (CM_READY counts up to it)
     while (t0 < n) {
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
+        if (t0 < pre && t1 > pre) t1 = pre;                    // the block's first tile starts where the history ends
         uint32_t* strip_k = strip + par * kStripFields * kCmpWaves;
-        uint32_t* strip_p = strip + (par ^ 1) * kStripFields * kCmpWaves;
         MatchRec* recs_k = recs + par * kCmpWaves * kRecsPerStrip;
-        MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
         tile_geometry(pre ? kTileMax * 4 : t1, small, nt_len, nt_strip);
@@ -555,12 +807,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
         // -- A0: wave 0 settles tile k-1
         if (w == 0 && prev_nstrips) {
-            resolve_overruns(strip_p, recs_p - w * kRecsPerStrip, ends + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip,
-                             encp + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n);
-            wave_lds_fence();
-            const StripTotals t = strip_offsets(strip_p, prev_nstrips, misc[CM_OUT], misc[CM_CARRY], misc[CM_FAIL], cap);
-            if (lane_id() == 0) { misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; }
-            wave_lds_fence();
+            settle_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
             if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
         }
         // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
@@ -569,24 +816,25 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (w < nstrips) {
             const uint32_t cs = t0 + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
-            match_strip(ring, tab, recs_k, ends + par * kCmpWaves * kRecsPerStrip, encp + par * kCmpWaves * kRecsPerStrip, strip_k, w, n, cs, ce, t1);
+            if (small) match_strip<0>(ring, tab, recs_k, ends + par * kCmpWaves * kRecsPerStrip, encp + par * kCmpWaves * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
+            else match_strip<1>(ring, tab, recs_k, ends + par * kCmpWaves * kRecsPerStrip, encp + par * kCmpWaves * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: emit tile k-1
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         if (w < prev_nstrips) {
             while (uload_cm(&misc[CM_READY]) < tiles_parsed) spin_pause();
-            if (!misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
-                emit_strip(ring, recs_p + strip_p[S_FIRST * kCmpWaves + w], strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
+            emit_tile_strip(smem, par ^ 1, w, src, dst, a0, ring_lo);
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
-        // -- B: everybody inserts the tile into the table (positions that may start a match):
+        // -- B: tile k-1's bytes leave; everybody inserts tile k into the table (positions that may start a match):
         //    8 consecutive positions per thread, hashed out of four aligned dwords
+        if (prev_nstrips && !misc[CM_FAIL]) flush_tile(smem, par ^ 1, dst, a0);
         if (n >= kMfLimit + 1) {
             const uint32_t last_q = n - kMfLimit;
-            const uint32_t q0 = t0 + 8 * tid;                       // t0 is a multiple of 1024; tiles are at most 8 * kCmpThreads long
+            const uint32_t q0 = t0 + 8 * tid;                       // t0 is a multiple of 16; tiles are at most 8 * kCmpThreads long
             if (q0 < t1 && q0 <= last_q) {
                 const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
                 const uint32_t* a = (const uint32_t*)(ring + o);
@@ -601,7 +849,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 }
             }
         }
-        // the prefetched granules go into ring slots that hold bytes more than a window + two tiles old
+        // the prefetched granules go into ring slots that hold bytes more than a window + a tile old
         if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
         if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
@@ -611,36 +859,38 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     }
     __syncthreads();
     // -- the last tile's sequences (settled by wave 0 first)
-    {
-        uint32_t* strip_p = strip + (par ^ 1) * kStripFields * kCmpWaves;
-        MatchRec* recs_p = recs + (par ^ 1) * kCmpWaves * kRecsPerStrip;
-        if (w == 0 && prev_nstrips) {
-            resolve_overruns(strip_p, recs_p - w * kRecsPerStrip, ends + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip,
-                             encp + (par ^ 1) * kCmpWaves * kRecsPerStrip - w * kRecsPerStrip, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n);
-            wave_lds_fence();
-            const StripTotals t = strip_offsets(strip_p, prev_nstrips, misc[CM_OUT], misc[CM_CARRY], misc[CM_FAIL], cap);
-            if (lane_id() == 0) { misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; }
-        }
+    if (prev_nstrips) {
+        if (w == 0) settle_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
         __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
-        if (w < prev_nstrips && !misc[CM_FAIL] && strip_p[S_N * kCmpWaves + w])
-            emit_strip(ring, recs_p + strip_p[S_FIRST * kCmpWaves + w], strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
+        if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, src, dst, a0, ring_lo);
+        __syncthreads();
+        if (!misc[CM_FAIL]) flush_tile(smem, par ^ 1, dst, a0);
     }
     __syncthreads();
     if (prof) {
         // developer aid: match + emit time of every wave (spread between the strips of a tile)
-        if (lane_id() == 0) misc[8 + w] = (uint32_t)((tp[1] + tp[4]) >> 4);
+        if (lane_id() == 0) misc[16 + w] = (uint32_t)((tp[1] + tp[4]) >> 4);
         __syncthreads();
         if (tid == 0) {
             uint64_t mx = 0, mn = ~0ull, sm = 0;
-            for (uint32_t i = 0; i < kCmpWaves; i++) { const uint64_t v = (uint64_t)misc[8 + i] << 4; mx = v > mx ? v : mx; mn = v < mn ? v : mn; sm += v; }
+            for (uint32_t i = 0; i < kCmpWaves; i++) { const uint64_t v = (uint64_t)misc[16 + i] << 4; mx = v > mx ? v : mx; mn = v < mn ? v : mn; sm += v; }
             prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = tp[4]; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
+#ifdef LZ4AMD_PROF_MATCH
+            // developer build: wave 0's match time by phase (probe, runs, list, measure, select, records)
+            prof[2] = mtp[0]; prof[3] = mtp[1]; prof[5] = mtp[2]; prof[6] = mtp[3]; prof[7] = mtp[4]; prof[0] = mtp[5];
+#endif
         }
     }
-    // -- final literal run (lz4.c:1302-1329)
+    // -- the pending bytes of the last chunk, then the final literal run (lz4.c:1302-1329)
     const uint32_t out = misc[CM_OUT], run = misc[CM_CARRY];
     const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;
     if (misc[CM_FAIL] || total > cap) { if (tid == 0) P.result[b] = 0; return; }
+    {
+        const uint32_t r = (out + a0) & 15u, cfrom = misc[CM_TILE + 4 * par + T_CFROM];
+        const uint8_t* Cn = (const uint8_t*)(smem + kCOffCarry) + 16 * par;
+        if (tid >= cfrom && tid < r) dst[out - r + tid] = Cn[tid];
+    }
     const uint32_t lit_dst = out + 1 + lit_hdr_ext(run);
     if (tid == 0) {
         lz4amd_gdst p = dst + out;

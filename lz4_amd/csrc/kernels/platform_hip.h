@@ -117,6 +117,9 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
     t = LZ4AMD_DPP(0, v, 0x143, 0xc); v = t > v ? t : v;
     return v;
 }
+// value of the lane below / above (0 for lane 0 / lane 63): wave_shr:1 / wave_shl:1 on the DPP lanes
+__device__ __forceinline__ uint32_t wave_prev_u32(uint32_t v) { return LZ4AMD_DPP(0, v, 0x138, 0xf); }
+__device__ __forceinline__ uint32_t wave_next_u32(uint32_t v) { return LZ4AMD_DPP(0, v, 0x130, 0xf); }
 // minimum over each row of 16 lanes, in every lane of the row (row_ror 8,4,2,1)
 __device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
     uint32_t t;

@@ -48,6 +48,8 @@ static inline uint32_t wave_incl_max_u32(uint32_t v) {
     for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(v, d); if (lane >= d && y > v) v = y; }
     return v;
 }
+static inline uint32_t wave_prev_u32(uint32_t v) { const uint32_t lane = simt::cur()->tid & 63u; const uint32_t y = __shfl_up(v, 1u); return lane ? y : 0u; }
+static inline uint32_t wave_next_u32(uint32_t v) { const uint32_t lane = simt::cur()->tid & 63u; const uint32_t y = __shfl_down(v, 1u); return lane < 63u ? y : 0u; }
 static inline uint32_t row16_min_u32(uint32_t v) {
     for (int d = 8; d >= 1; d >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)v, d); if (y < v) v = y; }
     return v;
