@@ -55,6 +55,8 @@ enum : uint32_t {
     kSrcRing = 84u << 10,              // the 64 KB window + the tile + the prefetched next tile + 4 KB
     kSrcPad = 32,                      // mirror of the ring's first bytes: unaligned reads never wrap
     kHashBits = 13,
+    kStrips = 16,                      // strips of a tile, one wave each
+    kSettleWave = 0,                   // the wave that settles a tile (overrunning matches, strip sizes -> offsets)
     kRecsPerStrip = 64,                // matches a strip may take (the rest of it becomes literals)
     kCandPerPass = 64,                 // match candidates (runs of probe positions with one distance) measured at a time
     kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane
@@ -68,12 +70,12 @@ enum : uint32_t {
     kCOffMisc = 0,                                        // u32[32]
     kCOffStrip = kCOffMisc + 32 * 4,                      // u32[2][kStripFields][16] per-strip summaries (two tiles in flight)
     kCOffTab = kCOffStrip + 2 * kStripFields * kCmpWaves * 4,   // u32[1 << kHashBits]
-    kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kCmpWaves][kRecsPerStrip]
-    kCOffEnds = kCOffRecs + 2 * kCmpWaves * kRecsPerStrip * 8,      // u16[2][kCmpWaves][kRecsPerStrip] where a record's match ends (from the strip's start)
-    kCOffEncp = kCOffEnds + 2 * kCmpWaves * kRecsPerStrip * 2,      // u16[2][kCmpWaves][kRecsPerStrip] encoded bytes of the strip's records before it
-    kCOffCandS = kCOffEncp + 2 * kCmpWaves * kRecsPerStrip * 2,     // u32[kCmpWaves][kCandPerPass] a candidate's first probe position | distance << 9
-    kCOffCandE = kCOffCandS + kCmpWaves * kCandPerPass * 4,         // u16[kCmpWaves][kCandPerPass] its last probe position
-    kCOffCarry = kCOffCandE + kCmpWaves * kCandPerPass * 2,         // u8[2][16]: encoded bytes of the 16-byte chunk a tile's output ends in (they leave with the next tile)
+    kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kStrips][kRecsPerStrip]
+    kCOffEnds = kCOffRecs + 2 * kStrips * kRecsPerStrip * 8,        // u16[2][kStrips][kRecsPerStrip] where a record's match ends (from the strip's start)
+    kCOffEncp = kCOffEnds + 2 * kStrips * kRecsPerStrip * 2,        // u16[2][kStrips][kRecsPerStrip] encoded bytes of the strip's records before it
+    kCOffCandS = kCOffEncp + 2 * kStrips * kRecsPerStrip * 2,       // u32[kStrips][kCandPerPass] a candidate's first probe position | distance << 10
+    kCOffCandE = kCOffCandS + kStrips * kCandPerPass * 4,           // u16[kStrips][kCandPerPass] its last probe position
+    kCOffCarry = kCOffCandE + kStrips * kCandPerPass * 2,         // u8[2][16]: encoded bytes of the 16-byte chunk a tile's output ends in (they leave with the next tile)
     kCOffStage = kCOffCarry + 32,                                   // u8[kStageBytes]
     kCOffRing = kCOffStage + kStageBytes,
     kCmpLdsBytes = kCOffRing + kSrcRing + kSrcPad,
@@ -107,12 +109,13 @@ template <class Ptr> __device__ __forceinline__ Ptr put_len_ext(Ptr p, uint32_t 
 }
 
 // 13-bit hashes of the 4 (blocks < 64 KB + 11, lz4.c:777-783) or 5 (lz4.c:785-795) bytes at a position.
-// The 5-byte one is not the reference's 64-bit multiply (four quarter-rate 32-bit multiplies on this
-// chip) but two 32-bit multiplicative hashes of the same bytes added up; any well mixed function of
-// the 5 bytes gives the same matches up to table collisions.
+// Not the reference's 32- / 64-bit multiplies (v_mul_lo_u32 runs at a quarter of the VALU rate on this chip) but
+// full-rate 24-bit multiply-adds over the overlapping byte triples of the same bytes; any well mixed function of the
+// bytes gives the same matches up to table collisions.
 __device__ __forceinline__ uint32_t hash_pos32(uint32_t lo, uint32_t hi, bool small) {
-    const uint32_t h4 = lo * 2654435761u;
-    return (small ? h4 : h4 + (hi & 0xFFu) * 0x85EBCA77u) >> (32 - kHashBits);
+    uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(lo >> 8, 0x85EBCBu);
+    if (!small) h += __umul24(hi & 0xFFu, 0xC2B2AFu);
+    return h >> (32 - kHashBits);
 }
 __device__ __forceinline__ uint32_t hash_pos(uint64_t v8, bool small) { return hash_pos32((uint32_t)v8, (uint32_t)(v8 >> 32), small); }
 
@@ -127,8 +130,8 @@ __device__ __forceinline__ uint32_t equal_bytes8(uint64_t x, uint64_t y) {
 // ring offset of block position pos
 __device__ __forceinline__ uint32_t src_ring_off(uint32_t pos) { return pos % kSrcRing; }
 // offset `d` bytes before / after ring offset o (d < kSrcRing)
-__device__ __forceinline__ uint32_t ring_back(uint32_t o, uint32_t d) { return o >= d ? o - d : o + kSrcRing - d; }
-__device__ __forceinline__ uint32_t ring_fwd(uint32_t o, uint32_t d) { const uint32_t x = o + d; return x >= kSrcRing ? x - kSrcRing : x; }
+__device__ __forceinline__ uint32_t ring_back(uint32_t o, uint32_t d) { const uint32_t x = o - d, y = x + kSrcRing; return x < y ? x : y; }      // (x wraps when o < d)
+__device__ __forceinline__ uint32_t ring_fwd(uint32_t o, uint32_t d) { const uint32_t x = o + d, y = x - kSrcRing; return x < y ? x : y; }
 // 8 bytes at ring offset o, any alignment: two ALIGNED 8-byte reads and a funnel shift (a misaligned
 // ds_read_b64 costs about five aligned ones on gfx950; the pad covers the read past the ring's end)
 __device__ __forceinline__ uint64_t funnel8(uint64_t lo, uint64_t hi, uint32_t byte_shift) {
@@ -188,7 +191,7 @@ __device__ __forceinline__ void tile_geometry(uint32_t t0, bool small, uint32_t&
     uint32_t t = kTileMin;
     while (t < tmax && t * 4 <= t0) t <<= 1;
     tile_len = t;
-    strip_len = t / kCmpWaves; if (strip_len < kStripMin) strip_len = kStripMin;
+    strip_len = t / kStrips; if (strip_len < kStripMin) strip_len = kStripMin;
 }
 
 // ------------------------------------------------------------------------------ match (one strip)
@@ -223,6 +226,64 @@ __device__ __forceinline__ Pair32 ring_ld8_32(const uint8_t* ring, uint32_t o) {
 #define MPROF_ARGS
 #define MPROF_PASS
 #endif
+// one probe round: the four positions of a lane's kLaneBytes source bytes from p + lane * kLaneBytes on
+struct Round { uint32_t dd[4]; uint32_t sb, eb; };      // distance of the candidate that holds at slot j (0: none); run starts / ends
+template <uint32_t SH>
+__device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi) {
+    constexpr bool small = SH == 0;
+    Round R;
+    uint32_t R0, R1, R2 = 0;
+    if (SH) { const uint64_t v = *(const uint64_t*)(ring + o0); R0 = (uint32_t)v; R1 = (uint32_t)(v >> 32); R2 = *(const uint32_t*)(ring + o0 + 8); }
+    else { R0 = *(const uint32_t*)(ring + o0); R1 = *(const uint32_t*)(ring + o0 + 4); }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t q = q0 + (j << SH);
+        uint32_t f0, f4 = 0;
+        if (SH) {
+            f0 = j == 0 ? R0 : j == 1 ? align_bytes(R1, R0, 2) : j == 2 ? R1 : align_bytes(R2, R1, 2);
+            f4 = j == 0 ? R1 : j == 1 ? R1 >> 16 : j == 2 ? R2 : R2 >> 16;
+        } else f0 = j == 0 ? R0 : align_bytes(R1, R0, j);
+        const uint32_t c = tab[hash_pos32(f0, f4, small)];
+        const uint32_t d = q - c;
+        const bool ok = q <= q_hi && d - 1u < kMaxDistance;             // c < q, q - c <= 65535 (d - 1 wraps for c >= q)
+        const uint32_t co = ok ? ring_back(o0 + (j << SH), d) : 0u;
+        const uint32_t* a = (const uint32_t*)(ring + (co & ~3u));
+        const uint32_t x = align_bytes(a[1], a[0], co & 3u);
+        R.dd[j] = (ok && x == f0) ? d : 0u;
+    }
+    // runs: first / last probe of every stretch of hits with one distance
+    const uint32_t pv = wave_prev_u32(R.dd[3]), nx = wave_next_u32(R.dd[0]);
+    R.sb = ((R.dd[0] && R.dd[0] != pv) ? 1u : 0u) | ((R.dd[1] && R.dd[1] != R.dd[0]) ? 2u : 0u) |
+           ((R.dd[2] && R.dd[2] != R.dd[1]) ? 4u : 0u) | ((R.dd[3] && R.dd[3] != R.dd[2]) ? 8u : 0u);
+    R.eb = ((R.dd[0] && R.dd[0] != R.dd[1]) ? 1u : 0u) | ((R.dd[1] && R.dd[1] != R.dd[2]) ? 2u : 0u) |
+           ((R.dd[2] && R.dd[2] != R.dd[3]) ? 4u : 0u) | ((R.dd[3] && R.dd[3] != nx) ? 8u : 0u);
+    return R;
+}
+// the runs of one round whose numbers fall into [0, kCandPerPass) (iS / iE: number of the lane's first start / end, already
+// relative to the pass) into the list; rel: the lane's first probe position from the strip's start
+// slot number / distance of the lowest run start or end in a 4-bit mask, by bit tests (an index computed with ffs makes
+// the compiler keep dd[] in scratch memory and load from it: a trip to HBM in the middle of the match)
+__device__ __forceinline__ uint32_t slot_of(uint32_t low) { return (low >> 1) - (low >> 3); }           // 1, 2, 4, 8 -> 0, 1, 2, 3
+__device__ __forceinline__ uint32_t dist_of(const Round& R, uint32_t low) { return (low & 1u) ? R.dd[0] : (low & 2u) ? R.dd[1] : (low & 4u) ? R.dd[2] : R.dd[3]; }
+template <uint32_t SH>
+__device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t iE, uint32_t rel, uint32_t* candS, uint16_t* candE) {
+    uint32_t s = R.sb, e2 = R.eb;
+    {   // a lane's first start and first end (nearly always its only ones) without a trip around the loop
+        const uint32_t ls = s & (0u - s), le = e2 & (0u - e2);
+        if (s && iS < kCandPerPass) candS[iS] = (rel + (slot_of(ls) << SH)) | (dist_of(R, ls) << 10);
+        if (e2 && iE < kCandPerPass) candE[iE] = (uint16_t)(rel + (slot_of(le) << SH));
+        iS += s ? 1u : 0u; iE += e2 ? 1u : 0u;
+        s ^= ls; e2 ^= le;
+    }
+    while (__any((s | e2) != 0)) {
+        const uint32_t ls = s & (0u - s), le = e2 & (0u - e2);
+        if (s && iS < kCandPerPass) candS[iS] = (rel + (slot_of(ls) << SH)) | (dist_of(R, ls) << 10);
+        if (e2 && iE < kCandPerPass) candE[iE] = (uint16_t)(rel + (slot_of(le) << SH));
+        iS += s ? 1u : 0u; iE += e2 ? 1u : 0u;
+        s ^= ls; e2 ^= le;
+    }
+}
+
 template <uint32_t SH>
 __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
                                             uint32_t* candS, uint16_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend MPROF_ARGS) {
@@ -230,8 +291,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
 #ifdef LZ4AMD_PROF_MATCH
     uint64_t mtq = clock_ticks();
 #endif
-    constexpr bool small = SH == 0;
-    constexpr uint32_t kSpan = 256u << SH, kLaneBytes = 4u << SH;
+    constexpr uint32_t kSpan = 256u << SH, kLaneBytes = 4u << SH;      // a round covers kSpan bytes; a strip is at most two rounds long
     uint32_t nseq = 0, enc = 0, ll0 = 0, cur = cs;             // cur: end of the last match taken (first byte not yet covered)
     // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= tend
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
@@ -239,61 +299,33 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
         // a match may run past the strip up to the tile's end: the strips it covers give way (resolve_overruns)
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t cs_off = src_ring_off(cs);
-        for (uint32_t p = cs; p < ce && p <= last_q && nseq < kRecsPerStrip; p += kSpan) {
-            if (cur >= p + kSpan) continue;                    // all of it is covered already
-            // ---- probe: four positions per lane
-            const uint32_t q0 = p + lane * kLaneBytes;
-            const uint32_t o0 = ring_fwd(cs_off, q0 - cs);     // multiple of kLaneBytes; o0 + 12 <= ring + pad
-            uint32_t R0, R1, R2 = 0;
-            if (SH) { const uint64_t v = *(const uint64_t*)(ring + o0); R0 = (uint32_t)v; R1 = (uint32_t)(v >> 32); R2 = *(const uint32_t*)(ring + o0 + 8); }
-            else { R0 = *(const uint32_t*)(ring + o0); R1 = *(const uint32_t*)(ring + o0 + 4); }
-            uint32_t dd[4];                                    // distance of the candidate that holds at slot j, 0: none
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t q = q0 + (j << SH);
-                uint32_t f0, f4 = 0;
-                if (SH) {
-                    f0 = j == 0 ? R0 : j == 1 ? align_bytes(R1, R0, 2) : j == 2 ? R1 : align_bytes(R2, R1, 2);
-                    f4 = j == 0 ? R1 : j == 1 ? R1 >> 16 : j == 2 ? R2 : R2 >> 16;
-                } else f0 = j == 0 ? R0 : align_bytes(R1, R0, j);
-                const uint32_t c = tab[hash_pos32(f0, f4, small)];
-                const uint32_t d = q - c;
-                const bool ok = q < ce && q <= last_q && c < q && d <= kMaxDistance;
-                const uint32_t co = ok ? ring_back(o0 + (j << SH), d) : 0u;
-                const uint32_t* a = (const uint32_t*)(ring + (co & ~3u));
-                const uint32_t x = align_bytes(a[1], a[0], co & 3u);
-                dd[j] = (ok && x == f0) ? d : 0u;
-            }
-            MPROF(0);
-            // ---- runs: first / last probe of every stretch of hits with one distance
-            const uint32_t pv = wave_prev_u32(dd[3]), nx = wave_next_u32(dd[0]);
-            const uint32_t sb = ((dd[0] && dd[0] != pv) ? 1u : 0u) | ((dd[1] && dd[1] != dd[0]) ? 2u : 0u) |
-                                ((dd[2] && dd[2] != dd[1]) ? 4u : 0u) | ((dd[3] && dd[3] != dd[2]) ? 8u : 0u);
-            const uint32_t eb = ((dd[0] && dd[0] != dd[1]) ? 1u : 0u) | ((dd[1] && dd[1] != dd[2]) ? 2u : 0u) |
-                                ((dd[2] && dd[2] != dd[3]) ? 4u : 0u) | ((dd[3] && dd[3] != nx) ? 8u : 0u);
-            const uint32_t cnt = (uint32_t)__popc(sb) | ((uint32_t)__popc(eb) << 16);
-            const uint32_t incl = wave_incl_sum(cnt);
-            const uint32_t total = wave_readlane(incl, 63) & 0xFFFFu;          // runs in this span (as many ends as starts)
-            const uint32_t baseS = (incl - cnt) & 0xFFFFu, baseE = (incl - cnt) >> 16;
-            MPROF(1);
-            for (uint32_t lo = 0; lo < total && nseq < kRecsPerStrip; lo += kCandPerPass) {
-                // ---- the runs [lo, lo + 64) into the list (nearly always all of them; a lane seldom holds more than one start)
+        const uint32_t q_hi = ce - 1 < last_q ? ce - 1 : last_q;   // last position of the strip that may start a match
+        {
+            const uint32_t p = cs;
+            const uint32_t rel0 = lane * kLaneBytes, rel1 = kSpan + lane * kLaneBytes;
+            const bool two = cs + kSpan <= q_hi;               // strips of two rounds
+            uint32_t total = 0;
+            for (uint32_t lo = 0; nseq < kRecsPerStrip; lo += kCandPerPass) {
+                // ---- probe, round by round (four positions per lane), the runs [lo, lo + 64) into the list.  Runs are numbered in
+                //      position order: round A's, then round B's.  More than 64 runs in a strip are rare: the rounds are simply
+                //      probed again for the next 64 (the table is frozen: same answers), which keeps one round's registers live.
                 {
-                    uint32_t s = sb, e2 = eb, iS = baseS - lo, iE = baseE - lo;     // (indices below lo wrap and are dropped)
-                    while (__any((s | e2) != 0)) {
-                        if (s) {
-                            const uint32_t j = (uint32_t)__ffs((int)s) - 1; s &= s - 1;
-                            const uint32_t dj = j == 0 ? dd[0] : j == 1 ? dd[1] : j == 2 ? dd[2] : dd[3];
-                            if (iS < kCandPerPass) candS[iS] = ((q0 - p) + (j << SH)) | (dj << 9);
-                            iS++;
-                        }
-                        if (e2) {
-                            const uint32_t j = (uint32_t)__ffs((int)e2) - 1; e2 &= e2 - 1;
-                            if (iE < kCandPerPass) candE[iE] = (uint16_t)((q0 - p) + (j << SH));
-                            iE++;
-                        }
-                    }
+                    const Round A = probe_round<SH>(ring, tab, ring_fwd(cs_off, rel0), cs + rel0, q_hi);
+                    const uint32_t cntA = (uint32_t)__popc(A.sb) | ((uint32_t)__popc(A.eb) << 16);
+                    const uint32_t inclA = wave_incl_sum(cntA), exA = inclA - cntA;
+                    total = wave_readlane(inclA, 63);
+                    list_round<SH>(A, (exA & 0xFFFFu) - lo, (exA >> 16) - lo, rel0, candS, candE);      // (indices below lo wrap and are dropped)
                 }
+                if (two) {
+                    const Round B = probe_round<SH>(ring, tab, ring_fwd(cs_off, rel1), cs + rel1, q_hi);
+                    const uint32_t cntB = (uint32_t)__popc(B.sb) | ((uint32_t)__popc(B.eb) << 16);
+                    const uint32_t inclB = wave_incl_sum(cntB), exB = inclB - cntB + total;
+                    total += wave_readlane(inclB, 63);
+                    list_round<SH>(B, (exB & 0xFFFFu) - lo, (exB >> 16) - lo, rel1, candS, candE);
+                }
+                total &= 0xFFFFu;
+                MPROF(0);
+                if (lo >= total) break;
                 wave_lds_fence();
                 MPROF(2);
                 // ---- measure: lane = run
@@ -302,7 +334,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                 uint32_t qs = 0, d = 1, e = 0, back = 0, more = 0;
                 if (have) {
                     const uint32_t S = candS[lane], E = candE[lane];
-                    qs = p + (S & 511u); d = S >> 9;
+                    qs = p + (S & 1023u); d = S >> 10;
                     const uint32_t a = p + E + kMinMatch;                    // first byte the probes did not compare
                     e = mlimit;
                     if (a < mlimit) {
@@ -337,7 +369,8 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                 //      running maximum of the ends of the runs in front of it (a wave scan: no serial walk over the matches; a
                 //      run that is not taken ends less than 4 bytes behind a taken one, so the maximum over all runs is the end
                 //      of the last taken match give or take 3 bytes).  A taken run that went on matching for more than the 24
-                //      bytes its lane compared is finished by the whole wave, and the scan is repeated with its real end.
+                //      bytes its lane compared is finished by the whole wave, and the scan is repeated with its real end
+                //      (finishing every such run before the scan was measured: slower, most of them end up covered).
                 const bool sv = have && e >= qs + kMinMatch;
                 unsigned long long taken;
                 for (;;) {
@@ -359,7 +392,8 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                         const uint32_t a = el + ext + 8 * lane;
                         uint32_t same = 0;
                         if (a < mlimit) {
-                            same = equal_bytes8(ring_ld8(ring, ring_fwd(eo, ext + 8 * lane)), ring_ld8(ring, ring_fwd(ko, ext + 8 * lane)));
+                            const Pair32 x = ring_ld8_32(ring, ring_fwd(eo, ext + 8 * lane)), y = ring_ld8_32(ring, ring_fwd(ko, ext + 8 * lane));
+                            same = equal_bytes8_32(x.lo, x.hi, y.lo, y.hi);
                             if (same > mlimit - a) same = mlimit - a;
                         }
                         const unsigned long long brk = __ballot(same < 8);
@@ -405,6 +439,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                     nseq += ntaken;
                 }
                 MPROF(5);
+                if (lo + kCandPerPass >= total) break;
             }
         }
     }
@@ -491,13 +526,43 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
     }
 }
 
+// ------------------------------------------------------------------------------ emit straight to HBM, the plain way (one strip)
+// For the rare tile whose encoded bytes do not fit the staging buffer (it ends a literal run of many KB): one sequence
+// after the other, lane 0 writes the token / length / offset bytes, the wave copies the literals from the source in HBM.
+// Small and slow on purpose: it must not cost the staged path registers.
+__device__ __forceinline__ void emit_strip_plain(const MatchRec* recs, const uint32_t* strip, uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t cs) {
+    const uint32_t lane = lane_id();
+    const uint32_t nk = strip[S_N * kCmpWaves + w];
+    uint32_t ipos = cs - strip[S_CARRY * kCmpWaves + w];      // source position of the next sequence's literals (the first one's include the carried ones)
+    uint32_t opos = strip[S_OUT * kCmpWaves + w];
+#pragma nounroll
+    for (uint32_t i = 0; i < nk; i++) {
+        const MatchRec r = recs[i];
+        const uint32_t mlm4 = r.mo >> 16, off = r.mo & 0xFFFFu;
+        const uint32_t tl = i == 0 ? cs + r.ll - ipos : r.ll;
+        const uint32_t lit_d = opos + 1 + lit_hdr_ext(tl);
+        if (lane == 0) {
+            lz4amd_gdst p = dst + opos;
+            *p++ = (uint8_t)(((tl >= 15 ? 15u : tl) << 4) | (mlm4 >= 15 ? 15u : mlm4));
+            if (tl >= 15) p = put_len_ext(p, tl - 15);
+            p = dst + lit_d + tl;
+            p[0] = (uint8_t)off; p[1] = (uint8_t)(off >> 8); p += 2;
+            if (mlm4 >= 15) p = put_len_ext(p, mlm4 - 15);
+        }
+#pragma nounroll
+        for (uint32_t k = lane; k < tl; k += 64) dst[lit_d + k] = src[ipos + k];
+        opos = lit_d + tl + 2 + (mlm4 >= 15 ? len_ext_bytes(mlm4 - 15) : 0u);
+        ipos += tl + mlm4 + kMinMatch;
+    }
+}
+
 // ------------------------------------------------------------------------------ emit into the staging buffer (one strip)
 // The same sequences as emit_strip, composed in LDS: `stage` holds the tile's encoded bytes, stage[0] = output position
 // dbase (the 16-byte chunk of the output the tile starts in).  Byte-granular LDS writes cost what dword writes cost
-// (tools/exp/lds_prims.hip); the bytes then leave for HBM as whole aligned 16-byte chunks (flush_tile).  Literals always
+// (tools/exp/lds_prims.hip); the bytes then leave for HBM as whole aligned 16-byte chunks (flush_begin, flush_end).  Literals always
 // come out of the source ring here: a staged tile's literals are at most kStageBytes old.
 __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchRec* recs, const uint32_t* strip, uint32_t w,
-                                               uint8_t* stage, uint32_t dbase, uint32_t cs) {
+                                               uint8_t* stage, uint32_t dbase, uint32_t cs, uint32_t* scr) {
     const uint32_t lane = lane_id();
     const uint32_t nk = strip[S_N * kCmpWaves + w];
     const uint32_t carry = strip[S_CARRY * kCmpWaves + w];
@@ -510,31 +575,47 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
         uint32_t ll = 0, mlm4 = 0, off = 0, extra = 0;
         if (have) { const MatchRec r = recs[i]; ll = r.ll; off = r.mo & 0xFFFFu; mlm4 = r.mo >> 16; }
         if (i == 0) extra = carry;                       // literals inherited from earlier strips
-        const uint32_t e = have ? enc_size(ll + extra, mlm4) : 0;
+        const uint32_t tl = ll + extra;
+        const uint32_t lhdr = 1 + lit_hdr_ext(tl);       // token + the literal length's extension bytes
+        const uint32_t e = have ? lhdr + tl + 2 + (mlm4 >= 15 ? len_ext_bytes(mlm4 - 15) : 0u) : 0u;
         const uint32_t adv = have ? ll + mlm4 + kMinMatch : 0;
         const uint32_t e_incl = wave_incl_sum(e), a_incl = wave_incl_sum(adv);
-        const uint32_t tl = ll + extra;
         const uint32_t rel = ipos + a_incl - adv;        // my own literals start here (from cs); the carried ones lie before
         const uint32_t so = rel >= extra ? ring_fwd(cs_off, rel - extra) : ring_back(cs_off, extra - rel);
-        uint32_t lit_d = 0;
+        const uint32_t my_o = opos + e_incl - e, lit_d = my_o + lhdr;
+        // ---- the literal runs, in pieces of 8 bytes, lane = piece: pieces are numbered by a wave scan, a piece finds its
+        //      sequence through a scatter of the sequences' first piece numbers + a running maximum (no walk over the
+        //      sequences: a wave that hands itself one sequence after the other spends its time on LDS round trips)
+        const uint32_t cnt = have ? (tl + 7) >> 3 : 0u;
+        const uint32_t p_incl = wave_incl_sum(cnt), pbase = p_incl - cnt, npieces = wave_readlane(p_incl, 63);
+        for (uint32_t W = 0; W < npieces; W += 64) {
+            scr[lane] = 0;
+            wave_lds_fence();
+            if (cnt && pbase < W + 64 && pbase + cnt > W) scr[pbase > W ? pbase - W : 0u] = lane + 1;
+            wave_lds_fence();
+            const uint32_t own = wave_incl_max(scr[lane]);
+            wave_lds_fence();
+            const uint32_t ol = own ? own - 1 : 0u;
+            const uint32_t o_so = (uint32_t)__shfl((int)so, (int)ol), o_d = (uint32_t)__shfl((int)lit_d, (int)ol);
+            const uint32_t o_tl = (uint32_t)__shfl((int)tl, (int)ol), o_pb = (uint32_t)__shfl((int)pbase, (int)ol);
+            const uint32_t c8 = 8 * (W + lane - o_pb);
+            const uint32_t nb = (own && W + lane < npieces) ? (o_tl - c8 < 8 ? o_tl - c8 : 8u) : 0u;
+            const uint32_t sa = nb ? ring_fwd(o_so, c8) : 0u;          // (the ring's pad covers the 8 bytes of a piece that crosses its end)
+            uint32_t bytes[8];
+#pragma unroll
+            for (uint32_t m = 0; m < 8; m++) bytes[m] = ring[sa + m];
+#pragma unroll
+            for (uint32_t m = 0; m < 8; m++) if (m < nb) stage[o_d + c8 + m] = (uint8_t)bytes[m];
+        }
+        // ---- token, length bytes, offset
         if (have) {
-            uint32_t o = opos + e_incl - e;
+            uint32_t o = my_o;
             const uint32_t tok_ll = tl >= 15 ? 15u : tl, tok_ml = mlm4 >= 15 ? 15u : mlm4;
             stage[o++] = (uint8_t)((tok_ll << 4) | tok_ml);
             if (tl >= 15) { uint32_t rest = tl - 15; while (rest >= 255) { stage[o++] = 255; rest -= 255; } stage[o++] = (uint8_t)rest; }
-            lit_d = o; o += tl;
+            o = lit_d + tl;
             stage[o] = (uint8_t)off; stage[o + 1] = (uint8_t)(off >> 8); o += 2;
             if (mlm4 >= 15) { uint32_t rest = mlm4 - 15; while (rest >= 255) { stage[o++] = 255; rest -= 255; } stage[o++] = (uint8_t)rest; }
-        }
-        // literal runs: the short ones byte by byte by the lane that owns the sequence, all lanes at once (the ring's pad
-        // covers a short run that crosses the ring's end); the long ones one sequence at a time with the whole wave copying
-        if (have && tl <= kShortRun) for (uint32_t k = 0; k < tl; k++) stage[lit_d + k] = ring[so + k];
-        unsigned long long longm = __ballot(have && tl > kShortRun);
-        while (longm) {
-            const uint32_t j = (uint32_t)__ffsll((long long)longm) - 1;
-            longm &= longm - 1;
-            const uint32_t d0 = wave_readlane(lit_d, j), s0 = wave_readlane(so, j), len = wave_readlane(tl, j);
-            for (uint32_t k = lane; k < len; k += 64) stage[d0 + k] = ring[ring_fwd(s0, k)];
         }
         opos += wave_readlane(e_incl, 63);
         ipos += wave_readlane(a_incl, 63);
@@ -546,42 +627,50 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
 // dst's misalignment).  The chunk the tile starts in begins with the last bytes of the tile before: they wait in the
 // carry chunk (two of them, by tile parity) and leave now; the bytes behind the tile's last whole chunk wait in turn.
 // cfrom: first byte of the carry chunk that is pending (bytes below it left already, or lie before dst).
-__device__ __forceinline__ void flush_tile(char* smem, uint32_t pp, lz4amd_gdst dst, uint32_t a0) {
+struct FlushCtx { U32x4 v; uint32_t dbase, h, nfull, r, cfrom, direct, pp; };
+static_assert(kStageBytes / 16 <= kCmpThreads, "one staged chunk per thread");
+// first half: the tile's numbers and my chunk of the staging buffer into registers (the table inserts run while they arrive)
+__device__ __forceinline__ FlushCtx flush_begin(const char* smem, uint32_t pp, uint32_t a0) {
+    const uint32_t* T = (const uint32_t*)(smem + kCOffMisc) + CM_TILE + 4 * pp;
+    FlushCtx f;
+    const uint32_t out0 = T[T_OUT0], out1 = T[T_OUT1];
+    f.direct = T[T_DIRECT]; f.cfrom = T[T_CFROM]; f.pp = pp;
+    const uint32_t V0 = out0 + a0, V1 = out1 + a0;
+    f.dbase = V0 & ~15u; f.h = V0 - f.dbase;
+    f.nfull = (V1 - f.dbase) >> 4; f.r = (V1 - f.dbase) & 15u;
+    f.v = *(const U32x4*)(smem + kCOffStage + 16 * threadIdx.x);       // (threads behind the tile's last chunk read bytes nobody uses)
+    return f;
+}
+__device__ __forceinline__ void flush_end(char* smem, const FlushCtx& f, lz4amd_gdst dst, uint32_t a0) {
     const uint32_t tid = threadIdx.x;
-    uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
-    const uint32_t* T = misc + CM_TILE + 4 * pp;
-    const uint32_t out0 = T[T_OUT0], out1 = T[T_OUT1], direct = T[T_DIRECT], cfrom = T[T_CFROM];
-    uint32_t* Tn = misc + CM_TILE + 4 * (pp ^ 1);
-    const uint8_t* C = (const uint8_t*)(smem + kCOffCarry) + 16 * pp;
-    uint8_t* Cn = (uint8_t*)(smem + kCOffCarry) + 16 * (pp ^ 1);
-    const uint32_t V0 = out0 + a0, V1 = out1 + a0, dbase = V0 & ~15u, h = V0 - dbase;
-    if (direct) {
+    uint32_t* Tn = (uint32_t*)(smem + kCOffMisc) + CM_TILE + 4 * (f.pp ^ 1);
+    const uint8_t* C = (const uint8_t*)(smem + kCOffCarry) + 16 * f.pp;
+    uint8_t* Cn = (uint8_t*)(smem + kCOffCarry) + 16 * (f.pp ^ 1);
+    if (f.direct) {
         // the tile went to HBM byte by byte (emit_strip): only the pending bytes before it are left to write
-        if (tid >= cfrom && tid < h) dst[dbase - a0 + tid] = C[tid];
-        if (tid == 0) Tn[T_CFROM] = V1 & 15u;
+        if (tid >= f.cfrom && tid < f.h) dst[f.dbase - a0 + tid] = C[tid];
+        if (tid == 0) Tn[T_CFROM] = (f.dbase + 16 * f.nfull + f.r) & 15u;
         return;
     }
-    const uint32_t nfull = (V1 - dbase) >> 4, r = (V1 - dbase) & 15u;
-    for (uint32_t i = tid; i <= nfull; i += kCmpThreads) {
-        if (i == nfull && r == 0) break;
-        U32x4 v = *(const U32x4*)(smem + kCOffStage + 16 * i);
-        if (i == 0 && h) {
+    if (tid < f.nfull || (tid == f.nfull && f.r)) {
+        U32x4 v = f.v;
+        if (tid == 0 && f.h) {
             const U32x4 c = *(const U32x4*)C;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
-                const int32_t rr = (int32_t)h - 4 * (int32_t)k;
+                const int32_t rr = (int32_t)f.h - 4 * (int32_t)k;
                 const uint32_t m = rr >= 4 ? 0xFFFFFFFFu : (rr <= 0 ? 0u : ((1u << (8 * rr)) - 1u));
                 v[k] = (c[k] & m) | (v[k] & ~m);
             }
         }
-        if (i < nfull) {
-            if (i == 0 && cfrom) {
+        if (tid < f.nfull) {
+            if (tid == 0 && f.cfrom) {
 #pragma nounroll
-                for (uint32_t k = cfrom; k < 16; k++) dst[dbase - a0 + k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
-            } else st_global16(dst + (dbase - a0 + 16 * i), v);
+                for (uint32_t k = f.cfrom; k < 16; k++) dst[f.dbase - a0 + k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+            } else st_global16(dst + (f.dbase - a0 + 16 * tid), v);
         } else *(U32x4*)Cn = v;
     }
-    if (tid == 0) Tn[T_CFROM] = nfull ? 0u : cfrom;
+    if (tid == 0) Tn[T_CFROM] = f.nfull ? 0u : f.cfrom;
 }
 
 // ------------------------------------------------------------------------------ offsets (one wave)
@@ -633,9 +722,16 @@ __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs
     if (mine) {
         uint32_t first = 0, nk2 = nk, enc = strip[S_ENC * kCmpWaves + lane], ll0 = strip[S_LL0 * kCmpWaves + lane], tail = strip[S_TAIL * kCmpWaves + lane];
         if (P > cs) {
-            uint32_t lo = 0, hi = nk;                         // first record whose match ends behind P
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cs + ek[mid] > P) hi = mid; else lo = mid + 1; }
-            uint32_t f = lo;
+            // first record whose match ends behind P: nearly always the first or the second one (an overrun covers a few
+            // bytes of the next strip), or none (a long match covers the whole strip): look there before searching
+            uint32_t f;
+            if (nk == 0 || cs + ek[nk - 1] <= P) f = nk;
+            else if (cs + ek[0] > P) f = 0;
+            else {
+                uint32_t lo = 1, hi = nk - 1;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cs + ek[mid] > P) hi = mid; else lo = mid + 1; }
+                f = lo;
+            }
             first = nk; nk2 = 0; enc = 0; ll0 = 0; tail = ce > P ? ce - P : 0;
             if (f < nk) {
                 MatchRec r = rk[f];
@@ -705,9 +801,15 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
                                             uint32_t n, uint32_t cap, uint32_t a0) {
     uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
     uint32_t* strip_p = (uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
-    resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kCmpWaves * kRecsPerStrip, (const uint16_t*)(smem + kCOffEnds) + pp * kCmpWaves * kRecsPerStrip,
-                     (const uint16_t*)(smem + kCOffEncp) + pp * kCmpWaves * kRecsPerStrip, nstrips, t0, strip_len, t1, n);
+#ifdef LZ4AMD_PROF_TILE
+    const uint64_t ts0 = clock_ticks();
+#endif
+    resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kStrips * kRecsPerStrip, (const uint16_t*)(smem + kCOffEnds) + pp * kStrips * kRecsPerStrip,
+                     (const uint16_t*)(smem + kCOffEncp) + pp * kStrips * kRecsPerStrip, nstrips, t0, strip_len, t1, n);
     wave_lds_fence();
+#ifdef LZ4AMD_PROF_TILE
+    const uint64_t ts1 = clock_ticks();
+#endif
     const uint32_t out0 = misc[CM_OUT];
     const StripTotals t = strip_offsets(strip_p, nstrips, out0, misc[CM_CARRY], misc[CM_FAIL], cap);
     if (lane_id() == 0) {
@@ -717,6 +819,9 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
         T[T_DIRECT] = (t.out + a0) - ((out0 + a0) & ~15u) > kStageBytes - 16 ? 1u : 0u;
     }
     wave_lds_fence();
+#ifdef LZ4AMD_PROF_TILE
+    { const uint64_t ts2 = clock_ticks(); if (lane_id() == 0) { ((uint64_t*)(smem + kCOffMisc))[12] += ts1 - ts0; ((uint64_t*)(smem + kCOffMisc))[13] += ts2 - ts1; } }
+#endif
 }
 // every wave: its strip of the settled tile (parity pp), into the staging buffer or straight to HBM
 __device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo) {
@@ -724,10 +829,11 @@ __device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_
     const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
     if (misc[CM_FAIL] || !strip_p[S_N * kCmpWaves + w]) return;
     const uint8_t* ring = (const uint8_t*)(smem + kCOffRing);
-    const MatchRec* recs_w = (const MatchRec*)(smem + kCOffRecs) + (pp * kCmpWaves + w) * kRecsPerStrip + strip_p[S_FIRST * kCmpWaves + w];
+    const MatchRec* recs_w = (const MatchRec*)(smem + kCOffRecs) + (pp * kStrips + w) * kRecsPerStrip + strip_p[S_FIRST * kCmpWaves + w];
     const uint32_t* T = misc + CM_TILE + 4 * pp;
-    if (T[T_DIRECT]) emit_strip(ring, recs_w, strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], ring_lo);
-    else emit_strip_lds(ring, recs_w, strip_p, w, (uint8_t*)(smem + kCOffStage), ((T[T_OUT0] + a0) & ~15u) - a0, strip_p[S_P * kCmpWaves + w]);    // (stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
+    if (T[T_DIRECT]) emit_strip_plain(recs_w, strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w]);
+    else emit_strip_lds(ring, recs_w, strip_p, w, (uint8_t*)(smem + kCOffStage), ((T[T_OUT0] + a0) & ~15u) - a0, strip_p[S_P * kCmpWaves + w],
+                        (uint32_t*)(smem + kCOffCandS) + w * kCandPerPass);    // (scratch: the wave's candidate list, idle now; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
 }
 
 // ------------------------------------------------------------------------------ one block
@@ -736,11 +842,12 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
     uint32_t* strip = (uint32_t*)(smem + kCOffStrip);
     uint32_t* tab = (uint32_t*)(smem + kCOffTab);
-    MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + w * kRecsPerStrip;      // + parity * kCmpWaves * kRecsPerStrip
-    uint16_t* ends = (uint16_t*)(smem + kCOffEnds) + w * kRecsPerStrip;
-    uint16_t* encp = (uint16_t*)(smem + kCOffEncp) + w * kRecsPerStrip;
-    uint32_t* candS = (uint32_t*)(smem + kCOffCandS) + w * kCandPerPass;
-    uint16_t* candE = (uint16_t*)(smem + kCOffCandE) + w * kCandPerPass;
+    const uint32_t sw = w;
+    MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + sw * kRecsPerStrip;      // + parity * kStrips * kRecsPerStrip
+    uint16_t* ends = (uint16_t*)(smem + kCOffEnds) + sw * kRecsPerStrip;
+    uint16_t* encp = (uint16_t*)(smem + kCOffEncp) + sw * kRecsPerStrip;
+    uint32_t* candS = (uint32_t*)(smem + kCOffCandS) + sw * kCandPerPass;
+    uint16_t* candE = (uint16_t*)(smem + kCOffCandE) + sw * kCandPerPass;
     uint8_t* ring = (uint8_t*)(smem + kCOffRing);
 
     // history (linked blocks, lz4io.c:741-744 / LZ4_compress_fast_continue in prefix mode lz4.c:1707): the
@@ -765,6 +872,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (tid == 0) {
         misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0;
+#ifdef LZ4AMD_PROF_TILE
+        for (uint32_t i = 24; i < 30; i++) misc[i] = 0;
+#endif
         misc[CM_TILE + T_CFROM] = a0; misc[CM_TILE + 4 + T_CFROM] = a0;     // nothing of the first chunk is pending: the bytes before dst are not ours
     }
     // first tile straight into the ring; later tiles are prefetched one tile ahead
@@ -795,7 +905,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
         if (t0 < pre && t1 > pre) t1 = pre;                    // the block's first tile starts where the history ends
         uint32_t* strip_k = strip + par * kStripFields * kCmpWaves;
-        MatchRec* recs_k = recs + par * kCmpWaves * kRecsPerStrip;
+        MatchRec* recs_k = recs + par * kStrips * kRecsPerStrip;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
         tile_geometry(pre ? kTileMax * 4 : t1, small, nt_len, nt_strip);
@@ -803,25 +913,25 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         const uint32_t Pp = loaded + 16 * tid;
         U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;
         if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 16 * kCmpThreads
-        __syncthreads();                                       // ring, table and tile k-1's offsets ready
+        __syncthreads();                                       // ring, table and tile k-1's records ready
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
-        // -- A0: wave 0 settles tile k-1
-        if (w == 0 && prev_nstrips) {
+        const bool parse = t0 >= pre;
+        const uint32_t nstrips = parse ? (t1 - t0 + strip_len - 1) >> (31 - __clz((int)strip_len)) : 0;      // (strip lengths are powers of two)
+        const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
+        // -- A0: one wave settles tile k-1 first
+        if (w == kSettleWave && prev_nstrips) {
             settle_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
             if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
         }
         // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
-        const bool parse = t0 >= pre;
-        const uint32_t nstrips = parse ? (t1 - t0 + strip_len - 1) / strip_len : 0;
         if (w < nstrips) {
             const uint32_t cs = t0 + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
-            if (small) match_strip<0>(ring, tab, recs_k, ends + par * kCmpWaves * kRecsPerStrip, encp + par * kCmpWaves * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
-            else match_strip<1>(ring, tab, recs_k, ends + par * kCmpWaves * kRecsPerStrip, encp + par * kCmpWaves * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
+            if (small) match_strip<0>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
+            else match_strip<1>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
-        // -- A2: emit tile k-1
-        const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
+        // -- A2: write out tile k-1 (into the staging buffer)
         if (w < prev_nstrips) {
             while (uload_cm(&misc[CM_READY]) < tiles_parsed) spin_pause();
             emit_tile_strip(smem, par ^ 1, w, src, dst, a0, ring_lo);
@@ -831,7 +941,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
         // -- B: tile k-1's bytes leave; everybody inserts tile k into the table (positions that may start a match):
         //    8 consecutive positions per thread, hashed out of four aligned dwords
-        if (prev_nstrips && !misc[CM_FAIL]) flush_tile(smem, par ^ 1, dst, a0);
+        const bool do_flush = prev_nstrips && !misc[CM_FAIL];
+        FlushCtx fc;
+        if (do_flush) fc = flush_begin(smem, par ^ 1, a0);
         if (n >= kMfLimit + 1) {
             const uint32_t last_q = n - kMfLimit;
             const uint32_t q0 = t0 + 8 * tid;                       // t0 is a multiple of 16; tiles are at most 8 * kCmpThreads long
@@ -849,9 +961,14 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 }
             }
         }
-        // the prefetched granules go into ring slots that hold bytes more than a window + a tile old
+#ifdef LZ4AMD_PROF_TILE
+        if (prof) { const uint64_t t = clock_ticks(); if (tid == 0) ((uint64_t*)(smem + kCOffMisc))[14] += t - tq; }
+#endif
+        // the prefetched granules go into ring slots that hold bytes more than a window + a tile old (before the flush's store:
+        // the wait for the load would wait for the store's acknowledgement as well - the counter is in order)
         if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
+        if (do_flush) flush_end(smem, fc, dst, a0);
         if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
         prev_t0 = t0; prev_t1 = t1; prev_strip_len = strip_len; prev_nstrips = nstrips; par ^= 1;
         if (nstrips) tiles_parsed++;
@@ -860,22 +977,28 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     __syncthreads();
     // -- the last tile's sequences (settled by wave 0 first)
     if (prev_nstrips) {
-        if (w == 0) settle_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
+        if (w == kSettleWave) settle_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
         __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, src, dst, a0, ring_lo);
         __syncthreads();
-        if (!misc[CM_FAIL]) flush_tile(smem, par ^ 1, dst, a0);
+        if (!misc[CM_FAIL]) { const FlushCtx fc = flush_begin(smem, par ^ 1, a0); flush_end(smem, fc, dst, a0); }
     }
     __syncthreads();
     if (prof) {
         // developer aid: match + emit time of every wave (spread between the strips of a tile)
+        if (w == 0 && lane_id() == 0) misc[6] = (uint32_t)(tp[4] >> 4);
+#ifndef LZ4AMD_PROF_TILE
         if (lane_id() == 0) misc[16 + w] = (uint32_t)((tp[1] + tp[4]) >> 4);
+#endif
         __syncthreads();
         if (tid == 0) {
             uint64_t mx = 0, mn = ~0ull, sm = 0;
             for (uint32_t i = 0; i < kCmpWaves; i++) { const uint64_t v = (uint64_t)misc[16 + i] << 4; mx = v > mx ? v : mx; mn = v < mn ? v : mn; sm += v; }
-            prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = tp[4]; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
+#ifdef LZ4AMD_PROF_TILE
+            { const uint64_t* m64 = (const uint64_t*)(smem + kCOffMisc); mx = m64[12]; mn = m64[13]; sm = m64[14] * kCmpWaves; }
+#endif
+            prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = (uint64_t)misc[6] << 4; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
 #ifdef LZ4AMD_PROF_MATCH
             // developer build: wave 0's match time by phase (probe, runs, list, measure, select, records)
             prof[2] = mtp[0]; prof[3] = mtp[1]; prof[5] = mtp[2]; prof[6] = mtp[3]; prof[7] = mtp[4]; prof[0] = mtp[5];

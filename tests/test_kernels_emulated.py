@@ -34,15 +34,17 @@ def emu_decompress(emu, blocks, caps, grid=0, align=0):
     return outs
 
 
-def emu_compress(emu, datas, caps=None, sub=0):
+def emu_compress(emu, datas, caps=None, sub=0, align=None):
     n = len(datas)
     caps = caps or [len(d) + len(d) // 255 + 16 for d in datas]
     srcs = [ctypes.create_string_buffer(d, len(d)) if d else ctypes.create_string_buffer(1) for d in datas]
-    dsts = [ctypes.create_string_buffer(max(c, 0) + 64) for c in caps]
+    dsts = [ctypes.create_string_buffer(max(c, 0) + 96) for c in caps]
     for d in dsts:
         ctypes.memset(d, CANARY, len(d))
+    # dst at byte `align` of the 16-byte grid (default: blocks take turns through 0..15, the compressor stores aligned chunks)
+    ptr = lambda i: ((ctypes.addressof(dsts[i]) + 15) & ~15) + ((i * 5) % 16 if align is None else align)
     sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs])
-    dp = (ctypes.c_void_p * n)(*[ctypes.addressof(d) for d in dsts])
+    dp = (ctypes.c_void_p * n)(*[ptr(i) for i in range(n)])
     ss = (ctypes.c_int32 * n)(*[len(d) for d in datas])
     dc = (ctypes.c_int32 * n)(*caps)
     res = (ctypes.c_int32 * n)()
@@ -50,9 +52,11 @@ def emu_compress(emu, datas, caps=None, sub=0):
     outs = []
     for i in range(n):
         raw = dsts[i].raw
+        off = ptr(i) - ctypes.addressof(dsts[i])
         cap = max(caps[i], 0)
-        assert raw[cap:cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
-        outs.append((res[i], raw[:max(res[i], 0)]))
+        assert raw[off + cap:off + cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
+        assert raw[:off] == bytes([CANARY]) * off, f"block {i}: wrote before dst"
+        outs.append((res[i], raw[off:off + max(res[i], 0)]))
     return outs
 
 
@@ -63,6 +67,11 @@ def corpus(datagen):
     datas = [datagen(*s) for s in specs]
     datas += [b"\x00" * 300000, b"abcd" * 70000, b"a" * 40000 + os.urandom(3000) + b"a" * 40000,
               os.urandom(70000), b"ab" * 9, b"x" * 64, b"x" * 65]
+    # literal runs longer than the compressor's staging buffer, ended by matches (the tile is written to HBM directly),
+    # twice in a row and next to ordinary tiles
+    rnd = random.Random(5)
+    noise = lambda n: bytes(rnd.getrandbits(8) for _ in range(n))
+    datas += [noise(20000) + b"abcd" * 3000 + noise(30011) + datagen(50000, 60, 7) + noise(13000) + b"xyz" * 5000]
     return datas
 
 
@@ -389,9 +398,11 @@ def emu_compress_hc(emu, datas, level=9, caps=None, grid=0):
     outs = []
     for i in range(n):
         raw = dsts[i].raw
+        off = ptr(i) - ctypes.addressof(dsts[i])
         cap = max(caps[i], 0)
-        assert raw[cap:cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
-        outs.append((res[i], raw[:max(res[i], 0)]))
+        assert raw[off + cap:off + cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
+        assert raw[:off] == bytes([CANARY]) * off, f"block {i}: wrote before dst"
+        outs.append((res[i], raw[off:off + max(res[i], 0)]))
     return outs
 
 
