@@ -19,9 +19,13 @@
  *    when decode speed matters.
  *  - compressionLevel >= 2 selects the HC kernel (lz4frame.c:943-958), lower values the fast one; negative
  *    "acceleration" levels are served by the fast kernel as level 0.
- *  - LZ4F_decompress buffers the frame and decodes it when it is complete; the bytes delivered and
- *    the return convention (0 = frame done, else a hint > 0, errors per LZ4F_isError) are the
- *    reference's, the pacing is not.
+ *  - LZ4F_decompress is a streaming state machine like the reference's (lz4frame.c:1613-2060): input is taken item by
+ *    item, never past the frame; the complete blocks it holds are decoded as one table on the device as soon as the
+ *    caller's input runs dry, the end mark shows up or a batch is full (64 MiB of input, 1024 blocks or 256 MiB of
+ *    output), and their bytes are delivered before more input is read.  Return values are the reference's size hints.
+ *    One deviation: a block is delivered when it is complete - a stored block is not streamed through in parts as
+ *    lz4frame.c:1790-1830 does - so on truncated or slowly arriving input fewer bytes may have been delivered than
+ *    by the reference for the same input consumed.
  *  - The streaming compression context (LZ4F_compressBegin / Update / flush / End, lz4frame_stream_api.c) sends
  *    one block per call to the device; LZ4F_compressFrame sends the whole frame at once.
  * Not provided: dictionaries (LZ4F_CDict, LZ4F_compressBegin_usingDict).

@@ -879,7 +879,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     }
     // first tile straight into the ring; later tiles are prefetched one tile ahead
     uint32_t t0 = 0, tile_len, strip_len;
-    tile_geometry(pre ? kTileMax * 4 : 0, small, tile_len, strip_len);
+    tile_geometry(pre ? kTileMax * 4 : 0, small, tile_len, strip_len);      // (the history goes in in the largest tiles; the block itself starts with small ones)
     uint32_t loaded = 0;                                  // ring holds [.., loaded)
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
@@ -908,7 +908,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         MatchRec* recs_k = recs + par * kStrips * kRecsPerStrip;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
-        tile_geometry(pre ? kTileMax * 4 : t1, small, nt_len, nt_strip);
+        tile_geometry(t1 >= pre ? t1 - pre : kTileMax * 4, small, nt_len, nt_strip);
         uint32_t pf_hi = loaded + nt_len; if (pf_hi > n || pf_hi < loaded) pf_hi = n;     // stays 16 bytes ahead of the tile
         const uint32_t Pp = loaded + 16 * tid;
         U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;

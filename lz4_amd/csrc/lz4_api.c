@@ -107,7 +107,9 @@ int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int ds
     if (!ctx || lz4amd_hip_use_device(ctx->device)) return fail;
     t = slot_get();
     if (!t) return fail;
-    if (in_bytes + 16 > t->in_cap || out_bytes + 16 > t->out_cap) {
+    if (in_bytes + 16 > t->in_cap || out_bytes + 16 > t->out_cap || in_bytes + 16 > t->hin_cap || out_bytes + 16 > t->hout_cap) {
+        /* (the page-locked buffers are part of the condition: a failed allocation must not leave a NULL staging pointer behind
+         *  device buffers that look large enough to the next call) */
         /* the buffers grow: the plans bound to them go (rare: sizes settle after the first blocks) */
         for (i = 0; i < 3; i++) { lz4amd_plan_destroy(t->plan[i]); t->plan[i] = NULL; }
         if (stage_reserve(&t->d_in, &t->in_cap, in_bytes + 16) || stage_reserve(&t->d_out, &t->out_cap, out_bytes + 16)) return fail;

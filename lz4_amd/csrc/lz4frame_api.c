@@ -7,7 +7,7 @@
  * checksum, per-block size fields, end mark, content checksum.  LZ4F_compressFrame sends all blocks
  * of the frame to the device in ONE block table (lz4amd_batch.c); LZ4F_decompress is a streaming
  * state machine that decodes the complete blocks it holds as one table whenever the caller's input
- * runs dry, the frame ends or a batch (64 MiB / 1024 blocks) is full, and delivers their bytes
+ * runs dry, the frame ends or a batch (64 MiB of input / 1024 blocks / 256 MiB of output) is full, and delivers their bytes
  * before taking more input - memory is bounded by a batch, not by the frame.  The content checksum
  * is one serial XXH32 over the content (xxhash.c:352-389; the recurrence cannot be split), computed
  * on the calling thread.  There is no CPU codec here: a compressed block needs a HIP device (stored
@@ -226,6 +226,8 @@ finish_frame:
 enum { ST_HEADER = 0, ST_SKIP, ST_BLOCKS, ST_TAIL, ST_DONE };
 enum { kBatchBlocks = 1024 };
 static const size_t kBatchBytes = (size_t)64 << 20;
+static const size_t kBatchDecoded = (size_t)256 << 20;     /* decoded bytes a batch may need (its blocks x the frame's block size): a
+                                                             * few MB of highly compressible 4 MiB blocks must not ask for GBs of memory */
 struct LZ4F_dctx_s {
     int stage;
     uint8_t* in; size_t in_size, in_cap;          /* bytes of the item(s) being collected */
@@ -307,6 +309,7 @@ static size_t parse_header(const uint8_t* p, size_t n, LZ4F_frameInfo_t* info, s
 static size_t header_want(const uint8_t* p, size_t n)
 {
     if (n >= 4 && (rd32(p) & 0xFFFFFFF0u) == MAGIC_SKIP) return 8;
+    if (n >= 4 && rd32(p) != MAGIC) return 4;    /* not a frame: parse_header says so at once (lz4frame.c:1375), before FLG is believed */
     if (n < 7) return 7;                         /* the smallest header; the smallest frame is 11 bytes, so this never reads past one */
     return 7 + ((p[4] & 8) ? 8 : 0) + ((p[4] & 1) ? 4 : 0);
 }
@@ -572,7 +575,7 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
         /* -- ST_BLOCKS: collect whole blocks, decode them when there is no reason to wait for more */
         {   const size_t tail = d->info.blockChecksumFlag == LZ4F_blockChecksumEnabled ? 4 : 0;
             int starved = 0;
-            while (!d->end_seen && d->nready < (size_t)kBatchBlocks && d->scan_pos < kBatchBytes) {
+            while (!d->end_seen && d->nready < (size_t)kBatchBlocks && d->scan_pos < kBatchBytes && (d->nready + 1) * d->block_max <= kBatchDecoded) {
                 uint32_t f;
                 if (!take_input(d, d->scan_pos + 4, src, avail, &used, &err)) { if (err) goto fail; starved = 1; break; }
                 f = rd32(d->in + d->scan_pos);

@@ -151,6 +151,19 @@ def test_decompress_hostile_input_against_the_real_reference(ctx, ocodec, reflib
     assert stricter <= len(muts) // 50, stricter          # a handful at most (none on this seed set so far)
 
 
+def test_decompress_rejects_offset_zero(ctx):
+    """A deliberate, documented deviation (include/lz4.h): a sequence with offset 0 is malformed here.
+    The reference's safe decoder only checks `match < lowPrefix` (lz4.c:2356) and copies the four (uninitialised)
+    bytes at the output position onto themselves - its result for such a stream is undefined bytes, ours is an error.
+    The block format document forbids offset 0; nothing the reference compresses contains one."""
+    blk = bytes([0x10, ord("a"), 0x00, 0x00, 0xC0]) + b"0123456789AB"   # literal 'a', match(offset 0, length 4), 12 final literals
+    (r, _), = gpu_decompress(ctx, [blk], [17])
+    assert r < 0
+    ok = bytes([0x10, ord("a"), 0x01, 0x00, 0xC0]) + b"0123456789AB"    # the same with offset 1 is fine
+    (r, o), = gpu_decompress(ctx, [ok], [17])
+    assert r == 17 and o == b"aaaaa0123456789AB"
+
+
 def test_decompress_long_overlapping_matches(ctx, ocodec):
     """Periodic runs longer than the output ring (see tests/test_kernels_emulated.py): reference-compressed,
     decoded on the GPU, compared byte for byte."""
@@ -163,13 +176,13 @@ def test_decompress_long_overlapping_matches(ctx, ocodec):
 
 def test_compress_ratio_window_grid(ctx, reflib, datagen):
     """The fast compressor's size against the reference's on datagen P20 / P50 / P90 at 64 KiB, 256 KiB and 4 MiB
-    blocks (BASELINE north_star: +-3 % of reference ratio), and every block decodes.  Inside +-3 % everywhere except
-    highly compressible data in SMALL blocks: the hash table is frozen while a tile is parsed, so matches whose
-    source lies in the same 1-2 KB tile are not found, and at the start of a block most sources are that near.
-    Those two cells carry their measured bounds (P90: +9.4 % at 64 KiB, +3.7 % at 256 KiB) so that they cannot
-    get worse unnoticed."""
+    blocks (BASELINE north_star: within 3 % of the reference's ratio), and every block decodes.  No cell is larger
+    than the reference by more than 3 % (round 2 carried +9.4 % / +3.7 % at P90 on small blocks; the round-3 matcher
+    measures runs of equal distance once and takes them by a wave scan, which finds more).  On highly compressible
+    data in big blocks the output is SMALLER than the reference's by more than 3 % (P90 at 4 MiB: about -5 %): every
+    position is inserted into the 13-bit table and matches are extended backwards over pending literals; that side
+    of the window is only bounded loosely (a size 15 % under the reference's would be a bug in the measurement)."""
     import lz4_amd
-    bound = {(90, 65536): 0.11, (90, 262144): 0.045}
     for pct in (20, 50, 90):
         for bs, nb in ((65536, 32), (262144, 8), (4 << 20, 2)):
             data = datagen(bs * nb, pct, 7)
@@ -182,7 +195,7 @@ def test_compress_ratio_window_grid(ctx, reflib, datagen):
                 cb = ctypes.create_string_buffer(cap)
                 ref_total += reflib.LZ4_compress_default(blk, cb, bs, cap)
             ours = sum(cs)
-            assert abs(ours - ref_total) <= bound.get((pct, bs), 0.03) * ref_total, (pct, bs, ours, ref_total)
+            assert 0.85 * ref_total <= ours <= 1.03 * ref_total, (pct, bs, ours, ref_total)
             out, res, _ = lz4_amd.decompress_blocks(ctx, comp, cs, bs, bs * nb)
             assert res == [bs] * nb and torch.equal(out, t)
 
