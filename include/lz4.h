@@ -99,6 +99,46 @@ int                 LZ4_decoderRingBufferSize(int maxBlockSize);                
 int                 LZ4_decompress_safe_continue(LZ4_streamDecode_t* LZ4_streamDecode, const char* src, char* dst,
                                                  int srcSize, int dstCapacity);   /* lz4.h:531 */
 
+/* ---- the long tail (lz4_amd/csrc/lz4_compat_api.c): what the reference's own tests and CLI link against besides the
+ * hot path.  Device-backed unless marked "host": */
+int  LZ4_compress_fast_extState_fastReset(void* state, const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:611 */
+void LZ4_attach_dictionary(LZ4_stream_t* workingStream, const LZ4_stream_t* dictionaryStream);      /* lz4.h:640; lz4.c:1658 */
+int  LZ4_loadDictSlow(LZ4_stream_t* streamPtr, const char* dictionary, int dictSize);               /* lz4.h:380 */
+/* lz4.h:568, lz4.c:1506: as much of src as fits targetDstSize; *srcSizePtr = bytes consumed.  Found by compressing
+ * prefixes on the device (bisection), so a call costs ~log2(srcSize) launches when the input does not fit whole. */
+int  LZ4_compress_destSize(const char* src, char* dst, int* srcSizePtr, int targetDstSize);
+int  LZ4_compress_destSize_extState(void* state, const char* src, char* dst, int* srcSizePtr, int targetDstSize, int acceleration);   /* lz4.h:582 */
+int  LZ4_decompress_safe_withPrefix64k(const char* src, char* dst, int compressedSize, int maxDstSize);       /* lz4.c:2479 */
+/* host (no device kernel: the caller does not say how large the block's output is), written from the block format document: */
+int  LZ4_decompress_safe_partial(const char* src, char* dst, int srcSize, int targetOutputSize, int dstCapacity);   /* lz4.h:291; lz4.c:2459 */
+int  LZ4_decompress_safe_partial_usingDict(const char* src, char* dst, int compressedSize, int targetOutputSize, int maxOutputSize,
+                                           const char* dictStart, int dictSize);                                   /* lz4.h:553 */
+/* deprecated and host (lz4.h:806-826: the input's size is unknown, the caller vouches for it): */
+int  LZ4_decompress_fast(const char* src, char* dst, int originalSize);
+int  LZ4_decompress_fast_continue(LZ4_streamDecode_t* LZ4_streamDecode, const char* src, char* dst, int originalSize);
+int  LZ4_decompress_fast_usingDict(const char* src, char* dst, int originalSize, const char* dictStart, int dictSize);
+int  LZ4_decompress_fast_withPrefix64k(const char* src, char* dst, int originalSize);
+/* deprecated names, thin wrappers (lz4.h:784-845) */
+int  LZ4_compress(const char* src, char* dest, int srcSize);
+int  LZ4_compress_limitedOutput(const char* src, char* dest, int srcSize, int maxOutputSize);
+int  LZ4_compress_withState(void* state, const char* source, char* dest, int inputSize);
+int  LZ4_compress_limitedOutput_withState(void* state, const char* source, char* dest, int inputSize, int maxOutputSize);
+int  LZ4_compress_continue(LZ4_stream_t* LZ4_streamPtr, const char* source, char* dest, int inputSize);
+int  LZ4_compress_limitedOutput_continue(LZ4_stream_t* LZ4_streamPtr, const char* source, char* dest, int inputSize, int maxOutputSize);
+int  LZ4_uncompress(const char* source, char* dest, int outputSize);
+int  LZ4_uncompress_unknownOutputSize(const char* source, char* dest, int isize, int maxOutputSize);
+void* LZ4_create(char* inputBuffer);
+int   LZ4_sizeofStreamState(void);
+int   LZ4_resetStreamState(void* state, char* inputBuffer);
+char* LZ4_slideInputBuffer(void* state);
+/* in-place (de)compression (lz4.h:637-678): both work here as in the reference - a block is staged through the device,
+ * so the source is read completely before the first output byte is written */
+#define LZ4_DISTANCE_MAX 65535
+#define LZ4_DECOMPRESS_INPLACE_MARGIN(compressedSize)          (((compressedSize) >> 8) + 32)
+#define LZ4_DECOMPRESS_INPLACE_BUFFER_SIZE(decompressedSize)   ((decompressedSize) + LZ4_DECOMPRESS_INPLACE_MARGIN(decompressedSize))
+#define LZ4_COMPRESS_INPLACE_MARGIN                           (LZ4_DISTANCE_MAX + 32)
+#define LZ4_COMPRESS_INPLACE_BUFFER_SIZE(maxCompressedSize)   ((maxCompressedSize) + LZ4_COMPRESS_INPLACE_MARGIN)
+
 #ifdef __cplusplus
 }
 #endif

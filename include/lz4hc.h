@@ -45,7 +45,8 @@ int LZ4_compress_HC_extStateHC(void* stateHC, const char* src, char* dst, int sr
 /* ---- streaming (reference lz4hc.h:98-180, 275, 356-389) */
 typedef union LZ4_streamHC_u {
     char minStateSize[LZ4_STREAMHC_MINSIZE];                /* lz4hc.h:252-256: the size is ABI */
-    struct { const char* dictionary; unsigned dictSize; int compressionLevel; } internal_donotuse;
+    struct { const char* dictionary; unsigned dictSize; int compressionLevel;
+             signed char favorDecSpeed, dirty; /* (named as in lz4hc.h:246-248; a context here is never dirty: nothing survives a failed call) */ } internal_donotuse;
 } LZ4_streamHC_t;
 LZ4_streamHC_t* LZ4_createStreamHC(void);                                          /* lz4hc.h:109 */
 int             LZ4_freeStreamHC(LZ4_streamHC_t* streamHCPtr);                     /* lz4hc.h:110 */
@@ -57,6 +58,32 @@ int             LZ4_loadDictHC(LZ4_streamHC_t* streamHCPtr, const char* dictiona
 int             LZ4_compress_HC_continue(LZ4_streamHC_t* streamHCPtr, const char* src, char* dst,
                                          int srcSize, int maxDstSize);             /* lz4hc.h:160 */
 int             LZ4_saveDictHC(LZ4_streamHC_t* streamHCPtr, char* safeBuffer, int maxDictSize);      /* lz4hc.h:178 */
+
+/* ---- the long tail (lz4_amd/csrc/lz4_compat_api.c) */
+int  LZ4_compress_HC_extStateHC_fastReset(void* state, const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel);   /* lz4hc.h:397 */
+void LZ4_attach_HC_dictionary(LZ4_streamHC_t* working_stream, const LZ4_streamHC_t* dictionary_stream);      /* lz4hc.h:403 */
+void LZ4_favorDecompressionSpeed(LZ4_streamHC_t* LZ4_streamHCPtr, int favor);    /* lz4hc.h:364: accepted, not acted on (lz4amd_last_notice) */
+/* lz4hc.h:89, 170: as much of src as fits targetDstSize (prefixes compressed on the device, bisection) */
+int  LZ4_compress_HC_destSize(void* stateHC, const char* src, char* dst, int* srcSizePtr, int targetDstSize, int compressionLevel);
+int  LZ4_compress_HC_continue_destSize(LZ4_streamHC_t* LZ4_streamHCPtr, const char* src, char* dst, int* srcSizePtr, int targetDstSize);
+/* deprecated names, thin wrappers (lz4hc.h:290-352) */
+int  LZ4_compressHC(const char* source, char* dest, int inputSize);
+int  LZ4_compressHC_limitedOutput(const char* source, char* dest, int inputSize, int maxOutputSize);
+int  LZ4_compressHC2(const char* source, char* dest, int inputSize, int compressionLevel);
+int  LZ4_compressHC2_limitedOutput(const char* source, char* dest, int inputSize, int maxOutputSize, int compressionLevel);
+int  LZ4_compressHC_withStateHC(void* state, const char* source, char* dest, int inputSize);
+int  LZ4_compressHC_limitedOutput_withStateHC(void* state, const char* source, char* dest, int inputSize, int maxOutputSize);
+int  LZ4_compressHC2_withStateHC(void* state, const char* source, char* dest, int inputSize, int compressionLevel);
+int  LZ4_compressHC2_limitedOutput_withStateHC(void* state, const char* source, char* dest, int inputSize, int maxOutputSize, int compressionLevel);
+int  LZ4_compressHC_continue(LZ4_streamHC_t* LZ4_streamHCPtr, const char* source, char* dest, int inputSize);
+int  LZ4_compressHC_limitedOutput_continue(LZ4_streamHC_t* LZ4_streamHCPtr, const char* source, char* dest, int inputSize, int maxOutputSize);
+void* LZ4_createHC(const char* inputBuffer);
+int   LZ4_freeHC(void* LZ4HC_Data);
+char* LZ4_slideInputBufferHC(void* LZ4HC_Data);
+int   LZ4_compressHC2_continue(void* LZ4HC_Data, const char* source, char* dest, int inputSize, int compressionLevel);
+int   LZ4_compressHC2_limitedOutput_continue(void* LZ4HC_Data, const char* source, char* dest, int inputSize, int maxOutputSize, int compressionLevel);
+int   LZ4_sizeofStreamStateHC(void);
+int   LZ4_resetStreamStateHC(void* state, char* inputBuffer);
 
 #ifdef __cplusplus
 }

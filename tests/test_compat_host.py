@@ -1,0 +1,112 @@
+"""The host-side entry points of the ABI's long tail (lz4_amd/csrc/lz4_compat_api.c) that need no device:
+LZ4_decompress_safe_partial*, the deprecated LZ4_decompress_fast* family and the LZ4_XXH32 / LZ4_XXH64 exports,
+compared call by call with the real reference (oracle/_ref) on reference-compressed blocks."""
+import ctypes
+import os
+import random
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+vp, ci = ctypes.c_void_p, ctypes.c_int
+
+
+@pytest.fixture(scope="module")
+def ours():
+    so = os.path.join(ROOT, "lz4_amd", "liblz4_amd.so")
+    if not os.path.exists(so):
+        pytest.skip("liblz4_amd.so not built")
+    L = ctypes.CDLL(so)
+    L.LZ4_XXH32.restype = ctypes.c_uint32
+    L.LZ4_XXH32.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+    L.LZ4_XXH64.restype = ctypes.c_uint64
+    L.LZ4_XXH64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
+    return L
+
+
+def _blocks(reflib, datagen):
+    rnd = random.Random(3)
+    datas = [datagen(n, p, s) for n, p, s in ((70000, 50, 1), (3000, 80, 2), (200, 30, 3), (65536, 95, 4), (40000, 0, 5))]
+    datas += [b"a" * 5000, b"abcdefgh" * 900 + bytes(rnd.getrandbits(8) for _ in range(700)), b"x" * 13]
+    out = []
+    for d in datas:
+        cap = reflib.LZ4_compressBound(len(d))
+        cb = ctypes.create_string_buffer(cap)
+        n = reflib.LZ4_compress_default(d, cb, len(d), cap)
+        assert n > 0
+        out.append((d, cb.raw[:n]))
+    return out
+
+
+def test_partial_decode_matches_the_reference(ours, reflib, datagen):
+    for d, c in _blocks(reflib, datagen):
+        for target in sorted({0, 1, 5, len(d) // 3, len(d) - 1, len(d), len(d) + 10}):
+            for cut in (len(c), max(1, len(c) * 2 // 3)):            # whole block, truncated input
+                a = ctypes.create_string_buffer(len(d) + 64); b = ctypes.create_string_buffer(len(d) + 64)
+                ra = ours.LZ4_decompress_safe_partial(c[:cut], a, cut, target, len(d) + 10)
+                rb = reflib.LZ4_decompress_safe_partial(c[:cut], b, cut, target, len(d) + 10)
+                if rb >= 0:
+                    assert ra == rb, (len(d), target, cut, ra, rb)
+                    assert a.raw[:ra] == b.raw[:rb] == d[:ra]
+                    assert a.raw[ra:ra + 16] == b"\x00" * 16          # nothing written behind what was asked for
+                else:
+                    assert ra < 0
+
+
+def test_partial_decode_with_dictionary(ours, reflib, datagen):
+    data = datagen(90000, 60, 8)
+    dict_, body = data[:30000], data[30000:]
+    s = reflib.LZ4_createStream
+    reflib.LZ4_createStream.restype = vp
+    st = reflib.LZ4_createStream()
+    reflib.LZ4_loadDict.argtypes = [vp, ctypes.c_char_p, ci]
+    reflib.LZ4_compress_fast_continue.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ci, ci, ci]
+    dbuf = ctypes.create_string_buffer(dict_, len(dict_))
+    reflib.LZ4_loadDict(st, dbuf, len(dict_))
+    cap = reflib.LZ4_compressBound(len(body)); cb = ctypes.create_string_buffer(cap)
+    n = reflib.LZ4_compress_fast_continue(st, body, cb, len(body), cap, 1)
+    assert n > 0
+    for target in (100, 20000, len(body)):
+        a = ctypes.create_string_buffer(len(body) + 16)
+        r = ours.LZ4_decompress_safe_partial_usingDict(cb.raw[:n], a, n, target, len(body), dbuf, len(dict_))
+        assert r == target and a.raw[:r] == body[:r]
+
+
+def test_deprecated_fast_decoders(ours, reflib, datagen):
+    for d, c in _blocks(reflib, datagen):
+        if len(d) < 14:
+            continue
+        a = ctypes.create_string_buffer(len(d) + 16)
+        assert ours.LZ4_decompress_fast(c, a, len(d)) == len(c)      # returns the input bytes read
+        assert a.raw[:len(d)] == d and a.raw[len(d)] == 0
+        a = ctypes.create_string_buffer(len(d) + 16)
+        assert ours.LZ4_decompress_fast(c, a, len(d) - 1) < 0        # fuzzer.c:532-542
+        assert a.raw[len(d) - 1] == 0
+        assert ours.LZ4_decompress_fast(c, a, len(d) + 1) < 0
+        assert ours.LZ4_uncompress(c, a, len(d)) == len(c)
+
+
+def test_xxh_exports(ours, reflib):
+    reflib.LZ4_XXH32.restype = ctypes.c_uint32
+    reflib.LZ4_XXH32.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+    reflib.LZ4_XXH64.restype = ctypes.c_uint64
+    reflib.LZ4_XXH64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
+    rnd = random.Random(1)
+    for n in (0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 63, 64, 100, 1000, 65537):
+        b = bytes(rnd.getrandbits(8) for _ in range(n))
+        for seed in (0, 1, 0x9E3779B1):
+            assert ours.LZ4_XXH32(b, n, seed) == reflib.LZ4_XXH32(b, n, seed)
+            assert ours.LZ4_XXH64(b, n, seed) == reflib.LZ4_XXH64(b, n, seed)
+    # streaming states
+    ours.LZ4_XXH64_createState.restype = vp
+    st = ours.LZ4_XXH64_createState()
+    ours.LZ4_XXH64_reset.argtypes = [vp, ctypes.c_uint64]
+    ours.LZ4_XXH64_update.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    ours.LZ4_XXH64_digest.argtypes = [vp]; ours.LZ4_XXH64_digest.restype = ctypes.c_uint64
+    ours.LZ4_XXH64_freeState.argtypes = [vp]
+    b = bytes(rnd.getrandbits(8) for _ in range(5000))
+    ours.LZ4_XXH64_reset(st, 7)
+    for i in range(0, 5000, 37):
+        ours.LZ4_XXH64_update(st, b[i:i + 37], len(b[i:i + 37]))
+    assert ours.LZ4_XXH64_digest(st) == reflib.LZ4_XXH64(b, 5000, 7)
+    ours.LZ4_XXH64_freeState(st)

@@ -368,6 +368,24 @@ def test_reference_round_trip_driver_linked_against_the_library(ctx, datagen, tm
             assert r.returncode == 0, (size, pct, level, r.stdout[-300:], r.stderr[-300:])
 
 
+def test_reference_fuzzer_linked_against_the_library(ctx):
+    """The reference's own tests/fuzzer.c, unmodified, compiled against include/ and linked against liblz4_amd.so
+    (oracle/Makefile: _ref/fuzzer_amd, link pattern of tests/Makefile:116-118).  FUZ_test (fuzzer.c:317-1076) drives every
+    block-level entry point - one-shot fast / HC, extState, destSize, in-place, partial and deprecated decoders,
+    dictionaries as prefix / external / attached, streaming contexts - with random sizes and checks sizes, canaries
+    and checksums.  It runs with a seed: without one the program first runs FUZ_unitTests, whose known-answer anchors
+    pin the REFERENCE compressor's exact output sizes (fuzzer.c:1175 `cSize == sampleSize-1`, 1385 == 4116: SURVEY
+    section 8c lists them as anchors that do not transfer to another compressor)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "fuzzer_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/fuzzer_amd not built (needs /root/reference at build time)")
+    for seed in ("3", "20260923"):
+        r = subprocess.run([exe, "-s" + seed, "-T8s"], capture_output=True, text=True, timeout=100)
+        out = r.stdout + r.stderr
+        assert r.returncode == 0 and "all tests completed successfully" in out, out[-600:]
+
+
 def test_full_size_roundtrip_properties(ctx, golden, datagen, ocodec):
     """BASELINE config 2 shape at 256 MiB: independent 4 MiB datagen -P60 blocks, device resident."""
     import lz4_amd
