@@ -28,7 +28,8 @@
  *    by the reference for the same input consumed.
  *  - The streaming compression context (LZ4F_compressBegin / Update / flush / End, lz4frame_stream_api.c) sends
  *    one block per call to the device; LZ4F_compressFrame sends the whole frame at once.
- * Not provided: dictionaries (LZ4F_CDict, LZ4F_compressBegin_usingDict).
+ *  - Dictionaries (LZ4F_CDict, *_usingDict, lz4frame.h:560-640): a frame begun with a dictionary compresses its first block
+ *    (every block, when blocks are independent) with the dictionary's last 64 KB as history, one block per launch.
  */
 #ifndef LZ4_AMD_LZ4FRAME_H
 #define LZ4_AMD_LZ4FRAME_H
@@ -67,6 +68,8 @@ typedef struct {
     unsigned favorDecSpeed;
     unsigned reserved[3];
 } LZ4F_preferences_t;
+#define LZ4F_INIT_FRAMEINFO   { LZ4F_max64KB, LZ4F_blockLinked, LZ4F_noContentChecksum, LZ4F_frame, 0ULL, 0U, LZ4F_noBlockChecksum }   /* lz4frame.h:185 */
+#define LZ4F_INIT_PREFERENCES { LZ4F_INIT_FRAMEINFO, 0, 0u, 0u, { 0u, 0u, 0u } }                                                       /* lz4frame.h:200 */
 
 #define LZ4F_VERSION 100                                            /* lz4frame.h:256 */
 unsigned LZ4F_getVersion(void);                                     /* lz4frame.h:257 */
@@ -112,6 +115,40 @@ size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* frameInfoPtr, const 
  * bytes written / consumed. */
 size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr,
                        const void* srcBuffer, size_t* srcSizePtr, const LZ4F_decompressOptions_t* dOptPtr);
+
+/* ---- the long tail (lz4frame.h:505-747; what tests/frametest.c links besides the calls above) */
+size_t LZ4F_getBlockSize(LZ4F_blockSizeID_t blockSizeID);                                          /* lz4frame.h:702; lz4frame.c:333 */
+size_t LZ4F_headerSize(const void* src, size_t srcSize);                                           /* lz4frame.h:429; lz4frame.c:1441 */
+#define LZ4F_HEADER_SIZE_MIN  7
+#define LZ4F_HEADER_SIZE_MAX 19
+#define LZ4F_MIN_SIZE_TO_KNOW_HEADER_LENGTH 5
+#define LZ4F_BLOCK_HEADER_SIZE 4
+#define LZ4F_BLOCK_CHECKSUM_SIZE 4
+#define LZ4F_CONTENT_CHECKSUM_SIZE 4
+#define LZ4F_ENDMARK_SIZE 4
+#define LZ4F_MAGICNUMBER 0x184D2204U
+#define LZ4F_MAGIC_SKIPPABLE_START 0x184D2A50U
+/* lz4frame.h:716 - bytes added to the frame as stored blocks (independent blocks only) */
+size_t LZ4F_uncompressedUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                               const LZ4F_compressOptions_t* cOptPtr);
+/* dictionaries (lz4frame.h:560-640) */
+typedef struct LZ4F_CDict_s LZ4F_CDict;
+LZ4F_CDict* LZ4F_createCDict(const void* dictBuffer, size_t dictSize);
+void        LZ4F_freeCDict(LZ4F_CDict* CDict);
+size_t LZ4F_compressFrame_usingCDict(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                     const LZ4F_CDict* cdict, const LZ4F_preferences_t* preferencesPtr);
+size_t LZ4F_compressBegin_usingCDict(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_CDict* cdict, const LZ4F_preferences_t* prefsPtr);
+size_t LZ4F_compressBegin_usingDict(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* dictBuffer, size_t dictSize, const LZ4F_preferences_t* prefsPtr);
+size_t LZ4F_decompress_usingDict(LZ4F_dctx* dctxPtr, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                                 const void* dict, size_t dictSize, const LZ4F_decompressOptions_t* decompressOptionsPtr);
+/* custom memory (lz4frame.h:712-747) */
+typedef void* (*LZ4F_AllocFunction)(void* opaqueState, size_t size);
+typedef void* (*LZ4F_CallocFunction)(void* opaqueState, size_t size);
+typedef void  (*LZ4F_FreeFunction)(void* opaqueState, void* address);
+typedef struct { LZ4F_AllocFunction customAlloc; LZ4F_CallocFunction customCalloc; LZ4F_FreeFunction customFree; void* opaqueState; } LZ4F_CustomMem;
+LZ4F_cctx*  LZ4F_createCompressionContext_advanced(LZ4F_CustomMem customMem, unsigned version);
+LZ4F_dctx*  LZ4F_createDecompressionContext_advanced(LZ4F_CustomMem customMem, unsigned version);
+LZ4F_CDict* LZ4F_createCDict_advanced(LZ4F_CustomMem customMem, const void* dictBuffer, size_t dictSize);
 
 /* lz4frame.h:656-686: error codes, in the reference's order */
 typedef enum {

@@ -866,7 +866,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     }
     if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }      // lz4.c:1361-1371
     const uint32_t n = (uint32_t)n_i + pre, cap = (uint32_t)cap_i;
-    const bool small = n < kSmallBlockLimit;
+    const bool small = (uint32_t)n_i < kSmallBlockLimit;       // (the block's own size: a small block is probed at every position whatever history precedes it)
     const uint32_t a0 = (uint32_t)((uintptr_t)P.dst[b] & 15u);        // dst's place on HBM's 16-byte grid
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;

@@ -757,7 +757,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
             return;
         }
         if (csize_i <= 0) { if (tid == 0) P.result[b] = -1; return; }
-    } else ok = src != nullptr && csize_i > 0 && cap_i > 0 && !(stored && csize_i > cap_i);
+    } else ok = src != nullptr && (csize_i > 0 || (stored && csize_i == 0)) && cap_i > 0 && !(stored && csize_i > cap_i);    // (a stored block may be empty: tests/frametest.c:1237 inserts such blocks)
     const uint32_t csize = (uint32_t)csize_i, cap = (uint32_t)cap_i;
     // a dependent block is pre-parsed against the largest history there can be; what is really there is checked below
     uint32_t prefix = chained ? kBias : (P.prefix ? (uint32_t)P.prefix[b] : 0u); if (prefix > kBias) prefix = kBias;

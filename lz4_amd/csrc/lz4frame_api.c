@@ -19,6 +19,7 @@
 #include "lz4amd_ffi.h"
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -239,6 +240,9 @@ struct LZ4F_dctx_s {
     unsigned long long total_out, skip_left;
     xxh32_state xxh;
     uint8_t* hist; size_t hist_len;               /* linked frames: the 64 KB before the next batch */
+    LZ4F_CustomMem cmem; int has_cmem;            /* LZ4F_createDecompressionContext_advanced: who allocated the context */
+    int skipc, skipc_call;                        /* skipChecksums: once asked for it holds for the rest of the frame (lz4frame.c:1634) */
+    const uint8_t* dict; size_t dict_len;         /* LZ4F_decompress_usingDict: what the frame's first bytes (every block of an independent-block frame) may reference */
     /* the content checksum of a batch runs on a helper thread while its bytes are delivered and the next input is taken */
     int hashing; pthread_t hthread; size_t hash_n;
 };
@@ -263,8 +267,21 @@ void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
 }
 LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* d)
 {
-    if (d) { dctx_hash_join(d); free(d->in); free(d->out); free(d->hist); free(d); }
+    if (d) {
+        dctx_hash_join(d); free(d->in); free(d->out); free(d->hist);
+        if (d->has_cmem && d->cmem.customFree) d->cmem.customFree(d->cmem.opaqueState, d); else free(d);
+    }
     return 0;
+}
+LZ4F_dctx* LZ4F_createDecompressionContext_advanced(LZ4F_CustomMem customMem, unsigned version)
+{   /* lz4frame.c:1267-1279 (the context itself comes from the caller's allocator; the batch buffers are the library's) */
+    LZ4F_dctx* d = NULL;
+    (void)version;
+    if (customMem.customCalloc) d = (LZ4F_dctx*)customMem.customCalloc(customMem.opaqueState, sizeof *d);
+    else if (customMem.customAlloc) { d = (LZ4F_dctx*)customMem.customAlloc(customMem.opaqueState, sizeof *d); if (d) memset(d, 0, sizeof *d); }
+    else d = (LZ4F_dctx*)calloc(1, sizeof *d);
+    if (d) { d->cmem = customMem; d->has_cmem = customMem.customFree != NULL; }
+    return d;
 }
 
 /* parse the header at p (n bytes available).  Returns header size, 0 if more bytes are needed, or an error. */
@@ -318,6 +335,11 @@ static void enter_frame(LZ4F_dctx* d, size_t block_max)
     d->block_max = block_max;
     d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
     d->total_out = 0; d->hist_len = 0;
+    d->skipc = d->skipc_call;                    /* a new frame: only what the current call asks for */
+    if (d->dict_len && d->info.frameType == LZ4F_frame && d->info.blockMode == LZ4F_blockLinked) {
+        /* lz4frame.c:1904-1912: a linked frame's first block sees the dictionary as the output before it */
+        if (d->hist || (d->hist = (uint8_t*)malloc(65536))) { memcpy(d->hist, d->dict, d->dict_len); d->hist_len = d->dict_len; }
+    }
     xxh32_reset(&d->xxh);
     if (d->info.frameType == LZ4F_skippableFrame) { d->skip_left = d->info.contentSize; d->stage = d->skip_left ? ST_SKIP : ST_DONE; }
     else d->stage = ST_BLOCKS;
@@ -420,11 +442,29 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         if (lz4amd_plan_create_decompress_chained(ctx, &dplan, (int)nb, d_src, sizes, (char*)g_stage.out + h0, caps, st, (int)h0)
             || lz4amd_plan_launch(dplan, NULL) || lz4amd_plan_results(dplan, res, NULL)) { free(st); goto done; }
         free(st);
-        for (i = 0; i < nb; i++) { if (res[i] < 0) { result = ERR(decompressionFailed); goto done; } o += (size_t)res[i]; }
+        for (i = 0; i < nb; i++) {
+            if (res[i] < 0) {
+                result = ERR(decompressionFailed); goto done;
+            }
+            o += (size_t)res[i];
+        }
         out_total = o - h0;
     } else {
+        const size_t dl = d->dict_len, slot = d->block_max + (dl ? 65536 : 0);
+        if (dl) {
+            /* LZ4F_decompress_usingDict on independent blocks (lz4frame.c:1904): the dictionary goes in front of every slot
+             * (one upload, one gather launch), the decoder's prefix mode does the rest */
+            lz4amd_plan* cp = NULL;
+            int* dls = (int*)malloc(nb * sizeof *dls);
+            int ok = dls != NULL && !stage_fit(&g_stage.out, &g_stage.out_cap, nb * slot + 64) && !stage_fit(&g_stage.pack, &g_stage.pack_cap, dl + 64)
+                     && !lz4amd_hip_h2d(g_stage.pack, d->dict, dl, NULL);
+            for (i = 0; ok && i < nb; i++) { d_src[i] = g_stage.pack; dls[i] = (int)dl; d_dst[i] = (char*)g_stage.out + i * slot + (65536 - dl); }
+            ok = ok && !lz4amd_plan_create(ctx, &cp, LZ4AMD_OP_GATHER, (int)nb, d_src, dls, d_dst, dls, 0) && !lz4amd_plan_launch(cp, NULL);
+            lz4amd_plan_destroy(cp); free(dls);
+            if (!ok) { result = ERR(allocation_failed); goto done; }
+        }
         for (i = 0; i < nb; i++) {
-            d_dst[i] = (char*)g_stage.out + i * d->block_max;
+            d_dst[i] = (char*)g_stage.out + i * slot + (dl ? 65536 : 0);
             if (raw[i]) {
                 if ((size_t)sizes[i] > d->block_max) { result = ERR(decompressionFailed); goto done; }
                 res[i] = sizes[i];
@@ -437,7 +477,9 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
             void** dd = (void**)malloc(ncomp * sizeof *dd); int* rr = (int*)malloc(ncomp * sizeof *rr);
             if (!dd || !rr) { free(dd); free(rr); result = ERR(allocation_failed); goto done; }
             for (i = 0; i < ncomp; i++) dd[i] = d_dst[prefix[i]];
-            if (lz4amd_plan_create(ctx, &dplan, LZ4AMD_OP_DECOMPRESS, (int)ncomp, d_src, sums, dd, caps, 0) ||
+            for (i = 0; dl && i < ncomp; i++) rr[i] = (int)dl;              /* (prefix lengths; rr[] takes the results afterwards) */
+            if ((dl ? lz4amd_plan_create_prefix(ctx, &dplan, (int)ncomp, d_src, sums, dd, caps, rr)
+                    : lz4amd_plan_create(ctx, &dplan, LZ4AMD_OP_DECOMPRESS, (int)ncomp, d_src, sums, dd, caps, 0)) ||
                 lz4amd_plan_launch(dplan, NULL) || lz4amd_plan_results(dplan, rr, NULL)) { free(dd); free(rr); goto done; }
             for (i = 0; i < ncomp; i++) {
                 if (rr[i] < 0) { free(dd); free(rr); result = ERR(decompressionFailed); goto done; }
@@ -454,6 +496,7 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
          * (stored blocks are then laid over their slots from the input); ragged tables go block by block */
         size_t o = 0;
         int dense = 1;
+        if (d->dict_len) dense = 0;                  /* (the slots are 64 KB apart then) */
         for (i = 0; i + 1 < nb; i++) if ((size_t)res[i] != d->block_max) { dense = 0; break; }
         if (dense && out_total && lz4amd_hip_d2h(d->out, g_stage.out, out_total, NULL)) goto done;
         for (i = 0; i < nb; i++) {
@@ -530,8 +573,9 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
     const uint8_t* src = (const uint8_t*)srcBuffer;
     uint8_t* dst = (uint8_t*)dstBuffer;
     size_t avail, used = 0, dcap, given = 0, err = 0;
-    const int skipc = opt && opt->skipChecksums;
     if (!d || !dstSizePtr || !srcSizePtr) return ERR(parameter_null);
+    d->skipc_call = opt && opt->skipChecksums;
+    d->skipc |= d->skipc_call;
     avail = src ? *srcSizePtr : 0; dcap = dst ? *dstSizePtr : 0;
     *srcSizePtr = 0; *dstSizePtr = 0;
 
@@ -568,7 +612,7 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
         if (d->stage == ST_TAIL) {                                           /* content checksum, lz4frame.c:2005-2030 */
             if (!take_input(d, 4, src, avail, &used, &err)) { if (err) goto fail; break; }
             dctx_hash_join(d);
-            if (!skipc && rd32(d->in) != xxh32_digest(&d->xxh)) { err = ERR(contentChecksum_invalid); goto fail; }
+            if (!d->skipc && rd32(d->in) != xxh32_digest(&d->xxh)) { err = ERR(contentChecksum_invalid); goto fail; }
             d->in_size = 0; d->stage = ST_DONE;
             continue;
         }
@@ -585,7 +629,7 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
                 d->scan_pos += 4 + (f & 0x7FFFFFFFu) + tail; d->nready++;
             }
             if (d->nready) {                                                 /* starved, end of frame or a full batch */
-                const size_t r = decode_batch(d, d->nready, d->scan_pos, skipc);
+                const size_t r = decode_batch(d, d->nready, d->scan_pos, d->skipc);
                 if (LZ4F_isError(r)) { err = r; goto fail; }
                 memmove(d->in, d->in + d->scan_pos, d->in_size - d->scan_pos);
                 d->in_size -= d->scan_pos; d->scan_pos = 0; d->nready = 0;
@@ -609,4 +653,33 @@ fail:
     LZ4F_resetDecompressionContext(d);                                       /* lz4frame.c:2034: an error leaves the context reusable */
     *srcSizePtr = used; *dstSizePtr = given;
     return err;
+}
+
+
+/* ---------------------------------------------------------------- the frame API's long tail (what tests/frametest.c links) */
+size_t LZ4F_getBlockSize(LZ4F_blockSizeID_t blockSizeID)
+{   /* lz4frame.c:333-341 */
+    const size_t bs = block_size_of((unsigned)blockSizeID);
+    return bs ? bs : ERR(maxBlockSize_invalid);
+}
+size_t LZ4F_headerSize(const void* src, size_t srcSize)
+{   /* lz4frame.c:1441-1462 */
+    const uint8_t* p = (const uint8_t*)src;
+    if (src == NULL) return ERR(srcPtr_wrong);
+    if (srcSize < 5) return ERR(frameHeader_incomplete);                    /* LZ4F_MIN_SIZE_TO_KNOW_HEADER_LENGTH */
+    if ((rd32(p) & 0xFFFFFFF0u) == MAGIC_SKIP) return 8;
+    if (rd32(p) != MAGIC) return ERR(frameType_unknown);
+    return 7 + ((p[4] & 8) ? 8 : 0) + ((p[4] & 1) ? 4 : 0);
+}
+size_t LZ4F_decompress_usingDict(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                                 const void* dict, size_t dictSize, const LZ4F_decompressOptions_t* decompressOptionsPtr)
+{   /* lz4frame.c:2070-2083: the dictionary counts when a frame starts; it must stay in place while the frame is decoded */
+    if (dctx == NULL) return ERR(parameter_null);
+    if (dctx->stage == ST_HEADER || dctx->stage == ST_DONE) {
+        if (dict && dictSize) {
+            if (dictSize > 65536) { dict = (const uint8_t*)dict + (dictSize - 65536); dictSize = 65536; }
+            dctx->dict = (const uint8_t*)dict; dctx->dict_len = dictSize;
+        } else { dctx->dict = NULL; dctx->dict_len = 0; }
+    }
+    return LZ4F_decompress(dctx, dstBuffer, dstSizePtr, srcBuffer, srcSizePtr, decompressOptionsPtr);
 }

@@ -40,24 +40,71 @@ struct LZ4F_cctx_s {
     size_t hist, fill;          /* valid history bytes (end at win + WINDOW), bytes gathered */
     uint64_t total_in;
     xxh32_state xxh;
+    LZ4F_CustomMem cmem;        /* lz4frame.h:712-727: the context and its buffer come from the caller's allocator when one is given */
+    uint8_t* dict; size_t dict_len;     /* compressBegin_usingDict / usingCDict: the last 64 KB of the dictionary (a copy) */
+    int fill_raw;               /* the gathered bytes came through LZ4F_uncompressedUpdate: they leave as a stored block */
 };
+struct LZ4F_CDict_s { LZ4F_CustomMem cmem; uint8_t* content; size_t size; };
+
+static void* cm_alloc(const LZ4F_CustomMem* m, size_t n, int zero)
+{
+    if (m->customCalloc && zero) return m->customCalloc(m->opaqueState, n);
+    if (m->customAlloc) { void* p = m->customAlloc(m->opaqueState, n); if (p && zero) memset(p, 0, n); return p; }
+    return zero ? calloc(1, n) : malloc(n);
+}
+static void cm_free(const LZ4F_CustomMem* m, void* p)
+{
+    if (!p) return;
+    if (m->customFree) m->customFree(m->opaqueState, p); else free(p);
+}
 
 int LZ4F_compressionLevel_max(void) { return LZ4HC_CLEVEL_MAX; }
 
+LZ4F_cctx* LZ4F_createCompressionContext_advanced(LZ4F_CustomMem customMem, unsigned version)
+{   /* lz4frame.c:604-617 */
+    LZ4F_cctx* const c = (LZ4F_cctx*)cm_alloc(&customMem, sizeof *c, 1);
+    if (!c) return NULL;
+    c->cmem = customMem;
+    c->version = version;
+    return c;
+}
 LZ4F_errorCode_t LZ4F_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned version)
 {   /* lz4frame.c:626-639 */
-    LZ4F_cctx* c;
+    LZ4F_CustomMem none;
     if (cctxPtr == NULL) return ERR(parameter_null);
-    c = (LZ4F_cctx*)calloc(1, sizeof *c);
-    if (!c) return ERR(allocation_failed);
-    c->version = version;
-    *cctxPtr = c;
-    return 0;
+    memset(&none, 0, sizeof none);
+    *cctxPtr = LZ4F_createCompressionContext_advanced(none, version);
+    return *cctxPtr ? 0 : ERR(allocation_failed);
 }
 LZ4F_errorCode_t LZ4F_freeCompressionContext(LZ4F_cctx* c)
 {
-    if (c) { free(c->win); free(c); }
+    if (c) { const LZ4F_CustomMem m = c->cmem; cm_free(&m, c->win); cm_free(&m, c->dict); cm_free(&m, c); }
     return 0;
+}
+
+/* ---- dictionaries (lz4frame.c:531-594, 690-826): a CDict is the dictionary's last 64 KB; a frame that starts with one
+ * compresses its first block (every block, when blocks are independent) with those bytes as history */
+LZ4F_CDict* LZ4F_createCDict_advanced(LZ4F_CustomMem cmem, const void* dictBuffer, size_t dictSize)
+{
+    LZ4F_CDict* const cd = (LZ4F_CDict*)cm_alloc(&cmem, sizeof *cd, 1);
+    if (!cd) return NULL;
+    cd->cmem = cmem;
+    if (dictSize > WINDOW) { dictBuffer = (const uint8_t*)dictBuffer + (dictSize - WINDOW); dictSize = WINDOW; }
+    cd->content = (uint8_t*)cm_alloc(&cmem, dictSize ? dictSize : 1, 0);
+    if (!cd->content) { cm_free(&cmem, cd); return NULL; }
+    if (dictSize) memcpy(cd->content, dictBuffer, dictSize);
+    cd->size = dictSize;
+    return cd;
+}
+LZ4F_CDict* LZ4F_createCDict(const void* dictBuffer, size_t dictSize)
+{
+    LZ4F_CustomMem none;
+    memset(&none, 0, sizeof none);
+    return LZ4F_createCDict_advanced(none, dictBuffer, dictSize);
+}
+void LZ4F_freeCDict(LZ4F_CDict* cd)
+{
+    if (cd) { const LZ4F_CustomMem m = cd->cmem; cm_free(&m, cd->content); cm_free(&m, cd); }
 }
 
 static size_t bound_internal(size_t srcSize, const LZ4F_preferences_t* prefsPtr, size_t alreadyBuffered)
@@ -83,7 +130,20 @@ size_t LZ4F_compressBound(size_t srcSize, const LZ4F_preferences_t* prefsPtr)
     return bound_internal(srcSize, prefsPtr, (size_t)-1);
 }
 
+static size_t begin_internal(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const void* dict, size_t dictSize, const LZ4F_preferences_t* prefsPtr);
 size_t LZ4F_compressBegin(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* prefsPtr)
+{
+    return begin_internal(c, dstBuffer, dstCapacity, NULL, 0, prefsPtr);
+}
+size_t LZ4F_compressBegin_usingDict(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const void* dictBuffer, size_t dictSize, const LZ4F_preferences_t* prefsPtr)
+{   /* lz4frame.c:838-845 */
+    return begin_internal(c, dstBuffer, dstCapacity, dictBuffer, dictSize, prefsPtr);
+}
+size_t LZ4F_compressBegin_usingCDict(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const LZ4F_CDict* cdict, const LZ4F_preferences_t* prefsPtr)
+{   /* lz4frame.c:862-868 */
+    return begin_internal(c, dstBuffer, dstCapacity, cdict ? cdict->content : NULL, cdict ? cdict->size : 0, prefsPtr);
+}
+static size_t begin_internal(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const void* dict, size_t dictSize, const LZ4F_preferences_t* prefsPtr)
 {   /* lz4frame.c:690-826 */
     uint8_t* op = (uint8_t*)dstBuffer;
     if (c == NULL || dstBuffer == NULL) return ERR(parameter_null);
@@ -92,10 +152,18 @@ size_t LZ4F_compressBegin(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, con
     if (c->prefs.frameInfo.blockSizeID == 0) c->prefs.frameInfo.blockSizeID = LZ4F_max64KB;
     c->block_size = block_size_of(c->prefs.frameInfo.blockSizeID);
     if (!c->block_size) return ERR(maxBlockSize_invalid);
-    {   uint8_t* const w = (uint8_t*)realloc(c->win, WINDOW + c->block_size);
-        if (!w) return ERR(allocation_failed);
-        c->win = w; }
-    c->hist = c->fill = 0; c->total_in = 0;
+    cm_free(&c->cmem, c->win);
+    c->win = (uint8_t*)cm_alloc(&c->cmem, WINDOW + c->block_size, 0);
+    if (!c->win) return ERR(allocation_failed);
+    c->hist = c->fill = 0; c->total_in = 0; c->fill_raw = 0;
+    cm_free(&c->cmem, c->dict); c->dict = NULL; c->dict_len = 0;
+    if (dict && dictSize) {
+        if (dictSize > WINDOW) { dict = (const uint8_t*)dict + (dictSize - WINDOW); dictSize = WINDOW; }
+        c->dict = (uint8_t*)cm_alloc(&c->cmem, dictSize, 0);
+        if (!c->dict) return ERR(allocation_failed);
+        memcpy(c->dict, dict, dictSize); c->dict_len = dictSize;
+        memcpy(c->win + WINDOW - dictSize, dict, dictSize); c->hist = dictSize;      /* the first block's history */
+    }
     xxh32_reset(&c->xxh);
     /* header (lz4frame.c:779-813) */
     wr32(op, 0x184D2204u); op += 4;
@@ -119,11 +187,15 @@ static size_t put_block(LZ4F_cctx* c, uint8_t* op)
     uint8_t* const blk = c->win + WINDOW;
     const int linked = c->prefs.frameInfo.blockMode == LZ4F_blockLinked;
     uint8_t* const start = op;
-    int cs;
-    /* lz4frame.c:943-958: levels >= LZ4HC_CLEVEL_MIN take the HC compressor; linked blocks see the 64 KB before them */
-    cs = lz4amd_compress_with_history(linked && c->hist ? (const char*)blk - c->hist : NULL, (int)c->hist,
-                                      (const char*)blk, (char*)op + BH, (int)n, (int)n - 1,
-                                      c->prefs.compressionLevel >= LZ4HC_CLEVEL_MIN ? c->prefs.compressionLevel : 0);
+    int cs = 0;
+    /* lz4frame.c:943-958: levels >= LZ4HC_CLEVEL_MIN take the HC compressor; linked blocks see the 64 KB before them, the
+     * blocks of an independent-block frame that was begun with a dictionary see the dictionary (lz4frame.c:917-943) */
+    if (!linked && c->dict_len) { memcpy(c->win + WINDOW - c->dict_len, c->dict, c->dict_len); c->hist = c->dict_len; }
+    if (!c->fill_raw)
+        cs = lz4amd_compress_with_history(c->hist ? (const char*)blk - c->hist : NULL, (int)c->hist,
+                                          (const char*)blk, (char*)op + BH, (int)n, (int)n - 1,
+                                          c->prefs.compressionLevel >= LZ4HC_CLEVEL_MIN ? c->prefs.compressionLevel : 0);
+    c->fill_raw = 0;
     if (cs <= 0 || (size_t)cs >= n) {                            /* lz4frame.c:896-899: stored raw */
         wr32(op, (uint32_t)n | 0x80000000u); memcpy(op + BH, blk, n); cs = (int)n;
     } else wr32(op, (uint32_t)cs);
@@ -134,7 +206,7 @@ static size_t put_block(LZ4F_cctx* c, uint8_t* op)
         const size_t total = c->hist + n, keep = total < WINDOW ? total : WINDOW;
         memmove(c->win + WINDOW - keep, blk + n - keep, keep);
         c->hist = keep;
-    }
+    } else c->hist = 0;
     c->fill = 0;
     return (size_t)(op - start);
 }
@@ -148,6 +220,7 @@ size_t LZ4F_compressUpdate(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, co
     if (c == NULL || dstBuffer == NULL || (srcBuffer == NULL && srcSize)) return ERR(parameter_null);
     if (c->stage != 1) return ERR(compressionState_uninitialized);
     if (dstCapacity < bound_internal(srcSize, &c->prefs, c->fill)) return ERR(dstMaxSize_tooSmall);
+    if (c->fill && c->fill_raw) op += put_block(c, op);          /* lz4frame.c:1013-1018: the kind of block changes: what was gathered leaves first */
     if (c->prefs.frameInfo.contentChecksumFlag) xxh32_update(&c->xxh, ip, srcSize);
     c->total_in += srcSize;
     while (srcSize) {
@@ -158,6 +231,60 @@ size_t LZ4F_compressUpdate(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, co
     }
     if (c->prefs.autoFlush && c->fill) op += put_block(c, op);
     return (size_t)(op - (uint8_t*)dstBuffer);
+}
+
+size_t LZ4F_uncompressedUpdate(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                               const LZ4F_compressOptions_t* cOptPtr)
+{   /* lz4frame.c:1139-1147: the bytes go into the frame as stored blocks (independent blocks only: a stored block leaves no
+     * compression history behind) */
+    const uint8_t* ip = (const uint8_t*)srcBuffer;
+    uint8_t* op = (uint8_t*)dstBuffer;
+    (void)cOptPtr;
+    if (c == NULL || dstBuffer == NULL || (srcBuffer == NULL && srcSize)) return ERR(parameter_null);
+    if (c->stage != 1) return ERR(compressionState_uninitialized);
+    if (c->prefs.frameInfo.blockMode != LZ4F_blockIndependent) return ERR(blockMode_invalid);
+    if (dstCapacity < bound_internal(srcSize, &c->prefs, c->fill)) return ERR(dstMaxSize_tooSmall);
+    if (c->fill && !c->fill_raw) op += put_block(c, op);         /* what was gathered for compression leaves first */
+    if (c->prefs.frameInfo.contentChecksumFlag) xxh32_update(&c->xxh, ip, srcSize);
+    c->total_in += srcSize;
+    while (srcSize) {
+        const size_t room = c->block_size - c->fill, take = srcSize < room ? srcSize : room;
+        memcpy(c->win + WINDOW + c->fill, ip, take);
+        c->fill += take; ip += take; srcSize -= take; c->fill_raw = 1;
+        if (c->fill == c->block_size) op += put_block(c, op);
+    }
+    if (c->prefs.autoFlush && c->fill) op += put_block(c, op);
+    return (size_t)(op - (uint8_t*)dstBuffer);
+}
+
+size_t LZ4F_compressFrame_usingCDict(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                                     const LZ4F_CDict* cdict, const LZ4F_preferences_t* preferencesPtr)
+{   /* lz4frame.c:433-477: one frame through the streaming calls with autoFlush, the block size that fits the input and the
+     * content size corrected; without a dictionary this is LZ4F_compressFrame (all blocks in one launch) */
+    LZ4F_preferences_t prefs;
+    uint8_t* const dst = (uint8_t*)dstBuffer;
+    uint8_t* op = dst;
+    size_t r;
+    if (cdict == NULL || cdict->size == 0) return LZ4F_compressFrame(dstBuffer, dstCapacity, srcBuffer, srcSize, preferencesPtr);
+    if (cctx == NULL) return ERR(parameter_null);
+    if (preferencesPtr) prefs = *preferencesPtr; else memset(&prefs, 0, sizeof prefs);
+    if (prefs.frameInfo.contentSize != 0) prefs.frameInfo.contentSize = (unsigned long long)srcSize;
+    {   unsigned id = prefs.frameInfo.blockSizeID ? (unsigned)prefs.frameInfo.blockSizeID : LZ4F_max64KB, proposed = LZ4F_max64KB;
+        while (id > proposed) { if (srcSize <= block_size_of(proposed)) { id = proposed; break; } proposed++; }    /* lz4frame.c:388-398 */
+        prefs.frameInfo.blockSizeID = (LZ4F_blockSizeID_t)id; }
+    prefs.autoFlush = 1;
+    if (srcSize <= block_size_of(prefs.frameInfo.blockSizeID)) prefs.frameInfo.blockMode = LZ4F_blockIndependent;   /* lz4frame.c:441-442 */
+    if (dstCapacity < LZ4F_compressFrameBound(srcSize, &prefs)) return ERR(dstMaxSize_tooSmall);
+    r = LZ4F_compressBegin_usingCDict(cctx, op, dstCapacity, cdict, &prefs);
+    if (LZ4F_isError(r)) return r;
+    op += r;
+    r = LZ4F_compressUpdate(cctx, op, dstCapacity - (size_t)(op - dst), srcBuffer, srcSize, NULL);
+    if (LZ4F_isError(r)) return r;
+    op += r;
+    r = LZ4F_compressEnd(cctx, op, dstCapacity - (size_t)(op - dst), NULL);
+    if (LZ4F_isError(r)) return r;
+    op += r;
+    return (size_t)(op - dst);
 }
 
 size_t LZ4F_flush(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* cOptPtr)

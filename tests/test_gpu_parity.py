@@ -386,6 +386,24 @@ def test_reference_fuzzer_linked_against_the_library(ctx):
         assert r.returncode == 0 and "all tests completed successfully" in out, out[-600:]
 
 
+def test_reference_frametest_linked_against_the_library(ctx):
+    """The reference's own tests/frametest.c, unmodified, compiled against include/lz4frame.h and linked against
+    liblz4_amd.so (oracle/Makefile: _ref/frametest_amd; tests/Makefile:119-121): its unit tests (frametest.c:279-968:
+    frame sizes and errors, byte-by-byte and random-segment decoding, block / content checksums, content size, dictID,
+    LZ4F_CDict and *_usingDict on linked and independent blocks, custom allocators, skippable frames, getBlockSize) and
+    its fuzzer (frametest.c:1117-1330: random preferences, random update / flush / uncompressedUpdate sequences, empty
+    stored blocks spliced in, decoding in random segments into contiguous / gapped / overwritten output with random
+    stableDst / skipChecksums, corrupted frames)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "frametest_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/frametest_amd not built (needs /root/reference at build time)")
+    for args in (["-T10s"], ["-s1234", "-T8s"]):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=200)
+        out = r.stdout + r.stderr
+        assert r.returncode == 0 and "Basic tests completed" in out and "All tests completed" in out, out[-600:]
+
+
 def test_full_size_roundtrip_properties(ctx, golden, datagen, ocodec):
     """BASELINE config 2 shape at 256 MiB: independent 4 MiB datagen -P60 blocks, device resident."""
     import lz4_amd
