@@ -347,39 +347,59 @@ def _sync(torch, dev):
         torch.cuda.synchronize()
 
 
-def data_path(dist, torch, dev, rank, world, data, comp, csizes):
-    """configs[4]'s movement with torch.distributed collectives (backend nccl = RCCL over xGMI on the GPU
-    box, gloo in the CPU test): scatter of the input shards from rank 0, all-gather of the compressed sizes, gather of
-    the payloads (packed per rank) to rank 0.  Returns seconds per phase and, on rank 0, the gathered payloads
-    re-ordered by (rank, block) with the help of the sizes table."""
+def pack_python(torch, dev, comp, csizes):
+    """The used part of every slot, one behind the other (the CPU test's packer; the GPU job packs with LZ4AMD_OP_GATHER)."""
+    packed = torch.empty(sum(csizes), dtype=torch.uint8, device=dev)
+    off = 0
+    for i, c in enumerate(csizes):
+        packed[off:off + c] = comp[i, :c]
+        off += c
+    return packed
+
+
+def data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=None):
+    """configs[4]'s movement with torch.distributed (backend nccl = RCCL over xGMI on the GPU box, gloo in
+    the CPU test).  Setup, untimed: the corpus lives on the root, so rank 0 first collects every rank's shard (each
+    rank generated its own, `datagen -s<rank>`).  Timed: (1) scatter of the DISTINCT shards from rank 0, (2) all_gather
+    of the int32 compressed sizes, (3) the payloads, packed per rank (`pack`), to rank 0 with exact-length point-to-point
+    transfers (no padding to the largest rank).  Returns seconds per phase, what this rank received and - on rank 0 -
+    every shard and the payloads cut back into (rank, block) order with the sizes table."""
     U = data.numel()
+    pack = pack or (lambda c, z: pack_python(torch, dev, c, z))
+    shards = [torch.empty_like(data) for _ in range(world)] if rank == 0 else None
+    dist.gather(data, gather_list=shards, dst=0)                       # setup: the root holds the whole corpus
     recv = torch.empty_like(data)
-    shards = [data] + [data.clone() for _ in range(world - 1)] if rank == 0 else None      # rank 0 holds every shard
     _sync(torch, dev); dist.barrier()
     t0 = time.perf_counter()
     dist.scatter(recv, scatter_list=shards, src=0)
     _sync(torch, dev); dist.barrier()
     t_scatter = time.perf_counter() - t0
-    del shards
     # compressed sizes of every block of every rank
     mine = torch.tensor(list(csizes), dtype=torch.int32, device=dev)
     allsz = [torch.empty_like(mine) for _ in range(world)]
+    _sync(torch, dev); dist.barrier()
     t0 = time.perf_counter()
     dist.all_gather(allsz, mine)
     _sync(torch, dev)
     t_sizes = time.perf_counter() - t0
-    # payloads: the used part of every slot, packed per rank, gathered on a fixed stride (the largest packed size)
     totals = [int(t.sum().item()) for t in allsz]
-    slot = max(totals)
-    packed = torch.zeros(slot, dtype=torch.uint8, device=dev)
-    off = 0
-    for i, c in enumerate(csizes):
-        packed[off:off + c] = comp[i, :c]
-        off += c
+    # payloads: packed on the device, then exact lengths to the root
     _sync(torch, dev); dist.barrier()
     t0 = time.perf_counter()
-    gl = [torch.empty(slot, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-    dist.gather(packed, gather_list=gl, dst=0)
+    packed = pack(comp, list(csizes))
+    _sync(torch, dev)
+    t_pack = time.perf_counter() - t0
+    dist.barrier()
+    t0 = time.perf_counter()
+    bufs = None
+    if rank == 0:
+        bufs = [packed] + [torch.empty(totals[r], dtype=torch.uint8, device=dev) for r in range(1, world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(1, world) if totals[r]]
+    else:
+        ops = [dist.P2POp(dist.isend, packed, 0)] if totals[rank] else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     _sync(torch, dev); dist.barrier()
     t_gather = time.perf_counter() - t0
     blocks = None
@@ -388,10 +408,10 @@ def data_path(dist, torch, dev, rank, world, data, comp, csizes):
         for r in range(world):
             o = 0
             for c in allsz[r].tolist():
-                blocks.append(gl[r][o:o + c])
+                blocks.append(bufs[r][o:o + c])
                 o += c
-    return {"scatter_s": t_scatter, "sizes_s": t_sizes, "gather_s": t_gather, "received": recv,
-            "scatter_bytes": U * (world - 1), "gather_bytes": sum(totals), "blocks": blocks, "sizes": [t.tolist() for t in allsz]}
+    return {"scatter_s": t_scatter, "sizes_s": t_sizes, "pack_s": t_pack, "gather_s": t_gather, "received": recv, "shards": shards,
+            "scatter_bytes": U * (world - 1), "gather_bytes": sum(totals) - totals[0], "blocks": blocks, "sizes": [t.tolist() for t in allsz]}
 
 
 def main():
@@ -399,7 +419,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=256, help="blocks per GPU (256 x 4 MiB = 1 GiB)")
+    ap.add_argument("--blocks", type=int, default=None,
+                    help="blocks per GPU; default 256 x 4 MiB = 1 GiB at N = 1 (configs[1]), 2048 x 4 MiB = 8 GiB per GPU at N > 1 (configs[4])")
     ap.add_argument("--block-bytes", type=int, default=4 << 20)
     ap.add_argument("--pct", type=int, default=60, help="datagen -P compressibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -433,6 +454,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
+    if args.blocks is None:
+        args.blocks = 256 if world == 1 else 2048
     ctx = lz4_amd.Context(dev.index)                     # raises loudly without the HIP library / GPU
     plan_s = shard_plan(args.blocks, rank, world)
     bs, nb = args.block_bytes, plan_s["n_blocks"]
@@ -522,8 +545,8 @@ def main():
             "ms_per_step": round(t_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (datagen -P%d restated in tools/datagen.c, md5-pinned to the reference tool)" % args.pct,
-            "config": {"workload": "configs[1]: %d independent %d-byte blocks per GPU (%.2f GiB), datagen -P%d -s<rank>, block compress + decompress, device resident"
-                                   % (nb, bs, U / 2**30, args.pct),
+            "config": {"workload": "%s: %d independent %d-byte blocks per GPU (%.2f GiB), datagen -P%d -s<rank>, block compress + decompress, device resident"
+                                   % ("configs[1]" if world == 1 else "configs[4] (%d GPUs)" % world, nb, bs, U / 2**30, args.pct),
                        "blocks_per_gpu": nb, "block_bytes": bs, "parallelism": "blocks sharded over %d GPU(s), no collective inside the codec" % world},
             "compress_GBps": round(U / (c_total * 1e-3) / 1e9, 2),
             "decompress_GBps": round(U / (d_total * 1e-3) / 1e9, 2),
@@ -548,13 +571,40 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            r = data_path(dist, torch, dev, rank, world, data, comp, csizes)
-            ok = bool(torch.equal(r["received"], data)) if rank == 0 else True       # rank 0 scattered copies of its own shard
-            if rank == 0:                                    # every gathered block of rank 0 is byte-identical to its slot
-                ok = ok and all(bool(torch.equal(r["blocks"][i], comp[i, :csizes[i]])) for i in range(0, nb, max(1, nb // 16)))
+            def pack_gpu(comp_, cs_):
+                # LZ4AMD_OP_GATHER: one launch copies the used part of every slot to its place in the packed payload
+                packed = torch.empty(sum(cs_), dtype=torch.uint8, device=dev)
+                offs, o = [], 0
+                for c in cs_:
+                    offs.append(o); o += c
+                gt = lz4_amd.BlockTable([comp_.data_ptr() + i * stride for i in range(nb)], cs_,
+                                        [packed.data_ptr() + off for off in offs], cs_)
+                gp = lz4_amd.Plan(ctx, lz4_amd.OP_GATHER, gt)
+                gp.launch(stream)
+                assert gp.results(stream) == cs_, "gather op failed"
+                return packed
+            r = data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=pack_gpu)
+            ok = bool(torch.equal(r["received"], data))               # every rank got its own shard back from the root
+            if rank == 0:
+                # the root decodes a sample of EVERY rank's gathered blocks with its own decoder and compares with the shard it holds
                 ok = ok and len(r["blocks"]) == world * nb
-            dp = {k: aggregate(dist, r[k], 0, device=dev)[0] for k in ("scatter_s", "sizes_s", "gather_s")}
-            dp.update({"ok": ok, "scatter_bytes": r["scatter_bytes"], "gather_bytes": r["gather_bytes"]})
+                sample = list(range(0, nb, max(1, nb // 8)))
+                for rr in range(world):
+                    blks = [r["blocks"][rr * nb + i] for i in sample]
+                    cs = [int(b.numel()) for b in blks]
+                    so = torch.empty(len(sample) * bs, dtype=torch.uint8, device=dev)
+                    vt = lz4_amd.BlockTable([b.data_ptr() for b in blks], cs, [so.data_ptr() + k * bs for k in range(len(sample))], [bs] * len(sample))
+                    vp = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, vt)
+                    vp.launch(stream)
+                    ok = ok and vp.results(stream) == [bs] * len(sample)
+                    for k, i in enumerate(sample):
+                        ok = ok and bool(torch.equal(so[k * bs:(k + 1) * bs], r["shards"][rr][i * bs:(i + 1) * bs]))
+            dp = {k: aggregate(dist, r[k], 0, device=dev)[0] for k in ("scatter_s", "sizes_s", "pack_s", "gather_s")}
+            okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            names = [None] * world
+            dist.all_gather_object(names, torch.cuda.get_device_name(dev))
+            dp.update({"ok": bool(okt.item() == 1.0), "scatter_bytes": r["scatter_bytes"], "gather_bytes": r["gather_bytes"], "devices": names})
         except Exception as e:
             dp = {"error": str(e)}
         finally:
@@ -563,16 +613,24 @@ def main():
     if rank == 0:
         if dp is not None:
             if "error" not in dp:
-                move_s = dp["scatter_s"] + dp["sizes_s"] + dp["gather_s"]
+                move_s = dp["scatter_s"] + dp["sizes_s"] + dp["pack_s"] + dp["gather_s"]
                 step_s = t_max / args.steps
-                dp = {"collectives": "%s: scatter of %d x %.2f GiB from rank 0, all_gather of int32 csize[%d], gather of the packed payloads"
-                                     % ("RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend() + " (loopback check, not a measurement)",
-                                        world - 1, U / 2**30, nb),
-                      "scatter_s": round(dp["scatter_s"], 5), "sizes_s": round(dp["sizes_s"], 5), "gather_s": round(dp["gather_s"], 5),
+                e2e = U * world / (step_s + move_s) / 1e9
+                backend = dist.get_backend()
+                dp = {"experiment": "configs[4]: %d GPUs x %d blocks of %d bytes (%.1f GiB per GPU, %.1f GiB in all), shards datagen -s0..%d held by rank 0"
+                                    % (world, nb, bs, U / 2**30, U * world / 2**30, world - 1),
+                      "world_size": dist.get_world_size(), "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (loopback check of the code path, not a measurement)"),
+                      "devices": dp["devices"],
+                      "collectives": "scatter of the %d distinct shards from rank 0; all_gather of int32 csize[%d]; payloads packed by LZ4AMD_OP_GATHER and sent to rank 0 with their exact lengths" % (world, nb),
+                      "scatter_s": round(dp["scatter_s"], 5), "sizes_s": round(dp["sizes_s"], 5), "pack_s": round(dp["pack_s"], 5), "gather_s": round(dp["gather_s"], 5),
                       "scatter_GBps": round(dp["scatter_bytes"] / dp["scatter_s"] / 1e9, 2) if dp["scatter_s"] > 0 else None,
-                      "end_to_end_GBps": round(U * world / (step_s + move_s) / 1e9, 3), "kernel_only_GBps": round(bytes_all / t_max / 1e9, 3),
                       "gather_GBps": round(dp["gather_bytes"] / dp["gather_s"] / 1e9, 2) if dp["gather_s"] > 0 else None,
-                      "payloads_reassembled": dp["ok"], "note": "one scatter + one compress/decompress step + one gather; unmeasured on hardware until a SCALE record exists"}
+                      "kernel_only_GBps": round(bytes_all / t_max / 1e9, 3),
+                      "kernel_only_frac_of_hbm_peak": round((U + C) * 2 * world / step_s / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                      "end_to_end_GBps": round(e2e, 3),
+                      "end_to_end_note": "uncompressed bytes of all ranks / (scatter + one compress+decompress step + sizes + pack + gather); the movement is bound by rank 0's xGMI links, not by HBM",
+                      "payloads_reassembled_and_decoded": dp["ok"],
+                      "note": "unmeasured on multi-GPU hardware until a SCALE record exists"}
             result["data_path"] = dp
         if world == 1 and not args.no_hc and U % (256 << 10) == 0:
             try:

@@ -1,8 +1,9 @@
 """The N>1 path of bench.py on CPU: world size 2 over gloo.  Blocks shard across ranks; the codec has no
 collective; the movement of BASELINE configs[4] (scatter of the input from rank 0, all-gather of the compressed
-sizes, gather of the payloads - bench.data_path, the very function the GPU job runs over RCCL) is exercised with real
-bytes: every rank's blocks are compressed by the oracle (the CPU stand-in for the kernels here), gathered, put back in
-(rank, block) order from the sizes table and decoded."""
+sizes, exact-length gather of the packed payloads - bench.data_path, the very function the GPU job runs over RCCL) is
+exercised with real bytes: every rank brings its own shard, the root collects the corpus and scatters the distinct shards,
+every rank's blocks are compressed by the oracle (the CPU stand-in for the kernels here), gathered, put back in
+(rank, block) order from the sizes table and decoded against the shard they came from."""
 import ctypes
 import os
 import socket
@@ -46,39 +47,36 @@ def _worker(rank, world, port, out):
     dist.all_reduce(owned)
     t_max, b_sum = bench.aggregate(dist, 1.0 + rank, 1000 * (rank + 1))
 
-    # ---- real bytes through the scatter / all-gather / gather path
+    # ---- real bytes through the gather-to-root / scatter / all-gather / exact-length gather path
     orc = _oracle()
     dev = torch.device("cpu")
-    # rank 0 is the only one with the corpus: what the other ranks hold before the scatter is scratch
-    host = bench.gen_data(NB * BS, 60 - 10 * rank, 3) if rank == 0 else bench.gen_data(NB * BS, 90, 99)
+    # every rank generates its own shard (datagen -s<rank>, different compressibility: ragged sizes); the root collects the corpus
+    host = bench.gen_data(NB * BS, 60 - 10 * rank, plan["seed"])
     data = torch.from_numpy(host.copy())
     stride = orc.lz4o_compress_bound(BS)
-    # (the scatter hands every rank a copy of rank 0's shard list entry; see bench.data_path)
     comp = torch.zeros((NB, stride), dtype=torch.uint8)
     csizes = []
-    # compress AFTER the scatter in the real job; here the scatter result is checked first, then the received bytes are compressed
-    recv_probe = bench.data_path(dist, torch, dev, rank, world, data, comp, [1] * NB)["received"]
-    src = recv_probe.numpy()
     for i in range(NB):
-        blk = src[i * BS:(i + 1) * BS].tobytes()
+        blk = host[i * BS:(i + 1) * BS].tobytes()
         dst = ctypes.create_string_buffer(stride)
         c = orc.lz4o_compress_default(blk, dst, BS, stride)
         assert c > 0
         comp[i, :c] = torch.frombuffer(bytearray(dst.raw[:c]), dtype=torch.uint8)
         csizes.append(c)
-    r = bench.data_path(dist, torch, dev, rank, world, torch.from_numpy(src.copy()), comp, csizes)
+    r = bench.data_path(dist, torch, dev, rank, world, data, comp, csizes)
+    scattered_ok = bool(torch.equal(r["received"], data))      # the root sent every rank ITS shard, not a copy of its own
     ok_blocks = None
     if rank == 0:
         ok_blocks = 0
-        for k, blk in enumerate(r["blocks"]):               # every gathered block decodes to the block it came from
+        assert len(r["shards"]) == world and not torch.equal(r["shards"][0], r["shards"][1])
+        for k, blk in enumerate(r["blocks"]):               # every gathered block decodes to the block of the shard it came from
             cbytes = blk.numpy().tobytes()
             dst = ctypes.create_string_buffer(BS)
             n = orc.lz4o_decompress_safe(cbytes, dst, len(cbytes), BS)
-            i = k % NB
-            if n == BS and dst.raw == host[i * BS:(i + 1) * BS].tobytes():
+            rr, i = divmod(k, NB)
+            if n == BS and dst.raw == r["shards"][rr][i * BS:(i + 1) * BS].numpy().tobytes():
                 ok_blocks += 1
-    out[rank] = (plan, int(owned.min()), int(owned.max()), t_max, b_sum,
-                 bool(torch.equal(recv_probe, torch.from_numpy(bench.gen_data(NB * BS, 60, 3)))), r["sizes"], ok_blocks)
+    out[rank] = (plan, int(owned.min()), int(owned.max()), t_max, b_sum, scattered_ok, r["sizes"], ok_blocks, csizes)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -90,11 +88,12 @@ def test_two_rank_sharding_movement_and_aggregation():
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         res = dict(out)
     assert set(res) == {0, 1}
-    for rank, (plan, omin, omax, t_max, b_sum, scattered_ok, sizes, ok_blocks) in res.items():
+    for rank, (plan, omin, omax, t_max, b_sum, scattered_ok, sizes, ok_blocks, csizes) in res.items():
         assert plan["rank"] == rank and plan["world"] == world and plan["seed"] == rank
         assert omin == 1 and omax == 1                     # a partition: every block exactly once
         assert t_max == 2.0                                # max over ranks
         assert b_sum == 3000.0                             # sum over ranks
-        assert scattered_ok                                # every rank received rank 0's bytes
-        assert len(sizes) == world and all(len(s) == NB for s in sizes) and sizes[0] == sizes[1]   # same input -> same sizes, known everywhere
+        assert scattered_ok                                # every rank received its own shard from the root
+        assert len(sizes) == world and all(len(s) == NB for s in sizes) and sizes[rank] == csizes   # every rank knows every size
+        assert sizes[0] != sizes[1]                        # distinct shards: ragged payloads, exact-length transfers
     assert res[0][7] == world * NB                         # rank 0 put every payload back in order and decoded it
