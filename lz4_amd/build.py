@@ -51,7 +51,8 @@ def build_product(force=False):
     dev_o = os.path.join(objdir, "lz4amd_device.o")
     _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
           os.path.join(CSRC, "lz4amd_device.hip"), "-o", dev_o])
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_o] + objs + ["-lpthread"])
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_o] + objs +
+         ["-lpthread", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])
     return LIB
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
 # bench line (default flags) into gpurun_out/<tag>_bench.json
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
-tag=${1:-r02}
+tag=${1:-r03}
 timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 3000 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err
