@@ -22,5 +22,6 @@ B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-hc --no-extras
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_hc -o ${tag}hc -- python $R/tools/prof_hc.py 4096 262144 60 9 > $R/gpurun_out/${tag}_prof_hc.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/${tag}_pmc_fetch_hc -o ${tag}hf -- python $R/tools/prof_hc.py 4096 262144 60 9 > /dev/null 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/${tag}_pmc_write_hc -o ${tag}hw -- python $R/tools/prof_hc.py 4096 262144 60 9 > /dev/null 2>&1 )
+( timeout 120 python tools/stress_gpu.py 30 5 2>&1 | tail -1 ) > gpurun_out/${tag}_stress.log; cat gpurun_out/${tag}_stress.log
 for db in $(find gpurun_out -name "${tag}*results.db"); do python tools/rocprof_summary.py $db > ${db%.db}.txt 2>&1; tail -n 12 ${db%.db}.txt; done
 du -sh gpurun_out
