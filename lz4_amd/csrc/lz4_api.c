@@ -22,9 +22,6 @@ pthread_mutex_t lz4amd_default_lock = PTHREAD_MUTEX_INITIALIZER;   /* shared wit
 #define g_lock lz4amd_default_lock
 static lz4amd_ctx* g_ctx = NULL;
 static int g_ctx_failed = 0;
-/* grow-only device staging buffers of the default context (guarded by g_lock) */
-static void* g_stage_in = NULL;  static size_t g_stage_in_cap = 0;
-static void* g_stage_out = NULL; static size_t g_stage_out_cap = 0;
 
 lz4amd_ctx* lz4amd_default_ctx(void)
 {   /* caller holds g_lock */
@@ -92,13 +89,20 @@ static lz4amd_thread_slot* slot_get(void)
     return t;
 }
 
-int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail)
+/* History (LZ4_decompress_safe_usingDict, the streaming contexts): up to 64 KB that sit in front of the block in device
+ * memory - before the SOURCE for the compressors (lz4.c:1707), before the OUTPUT for the decoder (lz4.c:2719-2732: prefix
+ * mode; a dictionary elsewhere in host memory needs no separate code path on the device).  The thread's buffers keep 64 KB of
+ * room in front of the block for it and its plans carry a history column, so a call with history costs what one without does:
+ * no lock, no device allocation, no plan construction. */
+#define HIST_ROOM 65536u
+static int run_one_hist(lz4amd_op op, const char* hist, int histSize, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail)
 {
     lz4amd_ctx* ctx;
     lz4amd_thread_slot* t;
     int result = fail, i;
     size_t in_bytes = srcSize > 0 ? (size_t)srcSize : 0;
     size_t out_bytes = dstCapacity > 0 ? (size_t)dstCapacity : 0;
+    const size_t pre = (hist && histSize > 0) ? ((size_t)histSize > HIST_ROOM ? HIST_ROOM : (size_t)histSize) : 0;
     if ((int)op < 0 || (int)op > 2) return fail;
 
     pthread_mutex_lock(&g_lock);                     /* (only the first call creates the context) */
@@ -107,36 +111,51 @@ int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int ds
     if (!ctx || lz4amd_hip_use_device(ctx->device)) return fail;
     t = slot_get();
     if (!t) return fail;
-    if (in_bytes + 16 > t->in_cap || out_bytes + 16 > t->out_cap || in_bytes + 16 > t->hin_cap || out_bytes + 16 > t->hout_cap) {
-        /* (the page-locked buffers are part of the condition: a failed allocation must not leave a NULL staging pointer behind
+    if (HIST_ROOM + in_bytes + 16 > t->in_cap || HIST_ROOM + out_bytes + 16 > t->out_cap || HIST_ROOM + in_bytes + 16 > t->hin_cap || HIST_ROOM + out_bytes + 16 > t->hout_cap) {
+        /* the buffers grow: the plans bound to them go (rare: sizes settle after the first blocks).
+         * (the page-locked buffers are part of the condition: a failed allocation must not leave a NULL staging pointer behind
          *  device buffers that look large enough to the next call) */
-        /* the buffers grow: the plans bound to them go (rare: sizes settle after the first blocks) */
         for (i = 0; i < 3; i++) { lz4amd_plan_destroy(t->plan[i]); t->plan[i] = NULL; }
-        if (stage_reserve(&t->d_in, &t->in_cap, in_bytes + 16) || stage_reserve(&t->d_out, &t->out_cap, out_bytes + 16)) return fail;
+        if (stage_reserve(&t->d_in, &t->in_cap, HIST_ROOM + in_bytes + 16) || stage_reserve(&t->d_out, &t->out_cap, HIST_ROOM + out_bytes + 16)) return fail;
         if (t->in_cap > t->hin_cap) { lz4amd_hip_host_free(t->h_in); t->h_in = (char*)lz4amd_hip_host_alloc(t->in_cap); t->hin_cap = t->h_in ? t->in_cap : 0; }
         if (t->out_cap > t->hout_cap) { lz4amd_hip_host_free(t->h_out); t->h_out = (char*)lz4amd_hip_host_alloc(t->out_cap); t->hout_cap = t->h_out ? t->out_cap : 0; }
         if (!t->h_in || !t->h_out) return fail;
     }
     if (!t->plan[op]) {
         /* sized for the largest block the buffers take (decoder / HC scratch follow the source size) */
-        const void* dsrc = t->d_in; void* ddst = t->d_out;
-        int smax = t->in_cap - 16 > 0x7E000000u ? 0x7E000000 : (int)(t->in_cap - 16), cmax = t->out_cap - 16 > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)(t->out_cap - 16);
-        if (lz4amd_plan_create(ctx, &t->plan[op], op, 1, &dsrc, &smax, &ddst, &cmax, level)) return fail;
+        const void* dsrc = (char*)t->d_in + HIST_ROOM; void* ddst = (char*)t->d_out + HIST_ROOM;
+        const size_t smax_z = t->in_cap - HIST_ROOM - 16, cmax_z = t->out_cap - HIST_ROOM - 16;
+        int smax = smax_z > 0x7E000000u ? 0x7E000000 : (int)smax_z, cmax = cmax_z > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)cmax_z, pmax = (int)HIST_ROOM;
+        int rc = op == LZ4AMD_OP_DECOMPRESS ? lz4amd_plan_create_prefix(ctx, &t->plan[op], 1, &dsrc, &smax, &ddst, &cmax, &pmax)
+               : op == LZ4AMD_OP_COMPRESS   ? lz4amd_plan_create_compress_prefix(ctx, &t->plan[op], 1, &dsrc, &smax, &ddst, &cmax, &pmax)
+                                            : lz4amd_plan_create_compress_hc_prefix(ctx, &t->plan[op], 1, &dsrc, &smax, &ddst, &cmax, &pmax, level);
+        if (rc) return fail;
         if (lz4amd_plan_bind_host_row(t->plan[op], t->rows + 4 * (int)op)) return fail;
     }
     {
         int* row = t->rows + 4 * (int)op;
-        row[0] = srcSize; row[1] = dstCapacity; row[2] = fail;
+        row[0] = srcSize; row[1] = dstCapacity; row[2] = fail; row[3] = (int)pre;
         lz4amd_plan_set_level(t->plan[op], level);
-        if (in_bytes) { memcpy(t->h_in, src, in_bytes); if (lz4amd_hip_h2d(t->d_in, t->h_in, in_bytes, t->stream)) return fail; }
+        if (op == LZ4AMD_OP_DECOMPRESS) {
+            if (pre) { memcpy(t->h_out + HIST_ROOM - pre, hist + ((size_t)histSize - pre), pre); if (lz4amd_hip_h2d((char*)t->d_out + HIST_ROOM - pre, t->h_out + HIST_ROOM - pre, pre, t->stream)) return fail; }
+            if (in_bytes) { memcpy(t->h_in + HIST_ROOM, src, in_bytes); if (lz4amd_hip_h2d((char*)t->d_in + HIST_ROOM, t->h_in + HIST_ROOM, in_bytes, t->stream)) return fail; }
+        } else {
+            if (pre) memcpy(t->h_in + HIST_ROOM - pre, hist + ((size_t)histSize - pre), pre);
+            if (in_bytes) memcpy(t->h_in + HIST_ROOM, src, in_bytes);
+            if (pre + in_bytes && lz4amd_hip_h2d((char*)t->d_in + HIST_ROOM - pre, t->h_in + HIST_ROOM - pre, pre + in_bytes, t->stream)) return fail;
+        }
         if (lz4amd_plan_launch(t->plan[op], t->stream) || lz4amd_hip_sync(t->stream)) return fail;
         result = row[2];
         if (result > 0 && (size_t)result <= out_bytes) {
-            if (lz4amd_hip_d2h(t->h_out, t->d_out, (size_t)result, t->stream) || lz4amd_hip_sync(t->stream)) return fail;
-            memcpy(dst, t->h_out, (size_t)result);
+            if (lz4amd_hip_d2h(t->h_out + HIST_ROOM, (char*)t->d_out + HIST_ROOM, (size_t)result, t->stream) || lz4amd_hip_sync(t->stream)) return fail;
+            memcpy(dst, t->h_out + HIST_ROOM, (size_t)result);
         }
     }
     return result;
+}
+int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int dstCapacity, int level, int fail)
+{
+    return run_one_hist(op, NULL, 0, src, dst, srcSize, dstCapacity, level, fail);
 }
 
 /* lz4.c:1453 LZ4_compress_fast: `acceleration` trades ratio for speed in the reference's serial
@@ -179,32 +198,9 @@ int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstC
 int LZ4_decompress_safe_usingDict(const char* src, char* dst, int compressedSize, int dstCapacity,
                                   const char* dictStart, int dictSize)
 {
-    lz4amd_ctx* ctx;
-    lz4amd_plan* plan = NULL;
-    int result = -1, pre;
-    const void* dsrc; void* ddst;
-    size_t in_bytes, out_bytes;
     if (src == NULL || dstCapacity < 0 || compressedSize < 0) return -1;
     if (dictStart == NULL || dictSize <= 0) return LZ4_decompress_safe(src, dst, compressedSize, dstCapacity);
-    pre = dictSize > 65536 ? 65536 : dictSize;
-    in_bytes = (size_t)compressedSize; out_bytes = (size_t)dstCapacity;
-    pthread_mutex_lock(&g_lock);
-    ctx = lz4amd_default_ctx();
-    if (!ctx) goto done;
-    if (stage_reserve(&g_stage_in, &g_stage_in_cap, in_bytes + 16) ||
-        stage_reserve(&g_stage_out, &g_stage_out_cap, out_bytes + 65536 + 16)) goto done;
-    if (in_bytes && lz4amd_hip_h2d(g_stage_in, src, in_bytes, NULL)) goto done;
-    if (lz4amd_hip_h2d((char*)g_stage_out + (65536 - pre), dictStart + (dictSize - pre), (size_t)pre, NULL)) goto done;
-    dsrc = g_stage_in; ddst = (char*)g_stage_out + 65536;
-    if (lz4amd_plan_create_prefix(ctx, &plan, 1, &dsrc, &compressedSize, &ddst, &dstCapacity, &pre)) goto done;
-    if (lz4amd_plan_launch(plan, NULL) || lz4amd_plan_results(plan, &result, NULL)) { result = -1; goto done; }
-    if (result > 0 && (size_t)result <= out_bytes) {
-        if (lz4amd_hip_d2h(dst, ddst, (size_t)result, NULL) || lz4amd_hip_sync(NULL)) result = -1;
-    }
-done:
-    lz4amd_plan_destroy(plan);
-    pthread_mutex_unlock(&g_lock);
-    return result;
+    return run_one_hist(LZ4AMD_OP_DECOMPRESS, dictStart, dictSize, src, dst, compressedSize, dstCapacity, 0, -1);
 }
 
 /* One block with up to 64 KB of history (the bytes a streaming compressor may reference, lz4.c:1707
@@ -212,33 +208,7 @@ done:
  * is compressed with the history as its prefix (include/lz4amd.h lz4amd_plan_create_compress_prefix). */
 int lz4amd_compress_with_history(const char* hist, int histSize, const char* src, char* dst, int srcSize, int dstCapacity, int hc_level)
 {   /* hc_level 0: LZ4_compress_default semantics; > 0: LZ4_compress_HC at that level */
-    lz4amd_ctx* ctx;
-    lz4amd_plan* plan = NULL;
-    int result = 0, pre;
-    const void* dsrc; void* ddst;
-    size_t in_bytes, out_bytes;
     if (srcSize < 0 || (unsigned)srcSize > (unsigned)LZ4_MAX_INPUT_SIZE || dst == NULL || dstCapacity <= 0) return 0;
     if (src == NULL && srcSize != 0) return 0;
-    if (hist == NULL || histSize <= 0)
-        return lz4amd_run_one(hc_level > 0 ? LZ4AMD_OP_COMPRESS_HC : LZ4AMD_OP_COMPRESS, src, dst, srcSize, dstCapacity, hc_level, 0);
-    pre = histSize > 65536 ? 65536 : histSize;
-    in_bytes = (size_t)srcSize; out_bytes = (size_t)dstCapacity;
-    pthread_mutex_lock(&g_lock);
-    ctx = lz4amd_default_ctx();
-    if (!ctx) goto done;
-    if (stage_reserve(&g_stage_in, &g_stage_in_cap, in_bytes + 65536 + 16) ||
-        stage_reserve(&g_stage_out, &g_stage_out_cap, out_bytes + 16)) goto done;
-    if (lz4amd_hip_h2d((char*)g_stage_in + (65536 - pre), hist + (histSize - pre), (size_t)pre, NULL)) goto done;
-    if (in_bytes && lz4amd_hip_h2d((char*)g_stage_in + 65536, src, in_bytes, NULL)) goto done;
-    dsrc = (char*)g_stage_in + 65536; ddst = g_stage_out;
-    if (hc_level > 0 ? lz4amd_plan_create_compress_hc_prefix(ctx, &plan, 1, &dsrc, &srcSize, &ddst, &dstCapacity, &pre, hc_level)
-                     : lz4amd_plan_create_compress_prefix(ctx, &plan, 1, &dsrc, &srcSize, &ddst, &dstCapacity, &pre)) goto done;
-    if (lz4amd_plan_launch(plan, NULL) || lz4amd_plan_results(plan, &result, NULL)) { result = 0; goto done; }
-    if (result > 0 && (size_t)result <= out_bytes) {
-        if (lz4amd_hip_d2h(dst, g_stage_out, (size_t)result, NULL) || lz4amd_hip_sync(NULL)) result = 0;
-    }
-done:
-    lz4amd_plan_destroy(plan);
-    pthread_mutex_unlock(&g_lock);
-    return result;
+    return run_one_hist(hc_level > 0 ? LZ4AMD_OP_COMPRESS_HC : LZ4AMD_OP_COMPRESS, hist, histSize, src, dst, srcSize, dstCapacity, hc_level, 0);
 }

@@ -367,9 +367,10 @@ void lz4amd_plan_set_level(lz4amd_plan* p, int level) { if (p && p->op == LZ4AMD
 int lz4amd_plan_bind_host_row(lz4amd_plan* p, int* row)
 {
     if (!p || p->n != 1 || !row) return LZ4AMD_E_ARG;
-    if (p->op == LZ4AMD_OP_DECOMPRESS) { p->dec.src_size = row; p->dec.dst_cap = row + 1; p->dec.result = row + 2; }
-    else if (p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.src_size = row; p->hc.dst_cap = row + 1; p->hc.result = row + 2; }
-    else if (p->op == LZ4AMD_OP_COMPRESS) { p->comp.src_size = row; p->comp.dst_cap = row + 1; p->comp.result = row + 2; }
+    /* (a plan made with a history column reads the history's length from row[3]) */
+    if (p->op == LZ4AMD_OP_DECOMPRESS) { p->dec.src_size = row; p->dec.dst_cap = row + 1; p->dec.result = row + 2; if (p->dec.prefix) p->dec.prefix = row + 3; }
+    else if (p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.src_size = row; p->hc.dst_cap = row + 1; p->hc.result = row + 2; if (p->hc.prefix) p->hc.prefix = row + 3; }
+    else if (p->op == LZ4AMD_OP_COMPRESS) { p->comp.src_size = row; p->comp.dst_cap = row + 1; p->comp.result = row + 2; if (p->comp.prefix) p->comp.prefix = row + 3; }
     else return LZ4AMD_E_ARG;
     p->d_results = row + 2;
     return LZ4AMD_OK;
