@@ -194,6 +194,17 @@ __device__ __forceinline__ void tile_geometry(uint32_t t0, bool small, uint32_t&
     strip_len = t / kStrips; if (strip_len < kStripMin) strip_len = kStripMin;
 }
 
+// Where the strips of a tile lie: strip w covers [g0 + w * strip_len, g0 + (w + 1) * strip_len) cut to the tile [t0, t1); g0 is the
+// tile's start.  (Measured and dropped: a grid that starts half a strip earlier in the largest tiles, so that the wave which also
+// settles the tile before gets a half strip - a half strip costs nearly what a whole one does, 4.24 -> 4.46 ms per GiB.)
+__device__ __forceinline__ uint32_t strip_origin(uint32_t t0, uint32_t tile_len, uint32_t strip_len) {
+    (void)tile_len; (void)strip_len;
+    return t0;
+}
+__device__ __forceinline__ uint32_t strip_lo(uint32_t g0, uint32_t t0, uint32_t w, uint32_t strip_len) {
+    const uint32_t c = g0 + w * strip_len; return c > t0 ? c : t0;
+}
+
 // ------------------------------------------------------------------------------ match (one strip)
 // 8 bytes at ring offset o (any alignment) as two dwords: three ALIGNED dword reads and two v_alignbyte (a misaligned LDS
 // access of any width is serialised lane by lane on gfx950: 64 cycles instead of ~3, tools/exp/lds_prims.hip)
@@ -600,12 +611,23 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
             const uint32_t o_tl = (uint32_t)__shfl((int)tl, (int)ol), o_pb = (uint32_t)__shfl((int)pbase, (int)ol);
             const uint32_t c8 = 8 * (W + lane - o_pb);
             const uint32_t nb = (own && W + lane < npieces) ? (o_tl - c8 < 8 ? o_tl - c8 : 8u) : 0u;
-            const uint32_t sa = nb ? ring_fwd(o_so, c8) : 0u;          // (the ring's pad covers the 8 bytes of a piece that crosses its end)
-            uint32_t bytes[8];
-#pragma unroll
-            for (uint32_t m = 0; m < 8; m++) bytes[m] = ring[sa + m];
-#pragma unroll
-            for (uint32_t m = 0; m < 8; m++) if (m < nb) stage[o_d + c8 + m] = (uint8_t)bytes[m];
+            if (nb) {
+                // 8 source bytes out of three aligned dwords, cut to the piece's length, shifted to the destination's place in its
+                // dwords and OR-ed in (the staging buffer is zero between tiles; the token / length / offset bytes of other lanes in
+                // the same dwords are byte writes, which the OR of zero bytes leaves alone): no byte loop, no per-byte predicate
+                const uint32_t sa = ring_fwd(o_so, c8);                    // (the ring's pad covers the bytes of a piece that crosses its end)
+                const uint32_t* s32 = (const uint32_t*)(ring + (sa & ~3u));
+                const uint32_t s0 = s32[0], s1 = s32[1], s2 = s32[2];
+                uint32_t lo = align_bytes(s1, s0, sa & 3u), hi = align_bytes(s2, s1, sa & 3u);
+                lo &= nb >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * nb));
+                hi &= nb >= 8 ? 0xFFFFFFFFu : (nb > 4 ? ~(0xFFFFFFFFu << (8 * (nb - 4))) : 0u);
+                const uint32_t da = o_d + c8, sh = 8 * (da & 3u);
+                const uint64_t v = ((uint64_t)lo | ((uint64_t)hi << 32)) << sh;
+                uint32_t* d32 = (uint32_t*)(stage + (da & ~3u));
+                atomicOr(&d32[0], (uint32_t)v);
+                atomicOr(&d32[1], (uint32_t)(v >> 32));
+                atomicOr(&d32[2], sh ? hi >> (32 - sh) : 0u);
+            }
         }
         // ---- token, length bytes, offset
         if (have) {
@@ -630,7 +652,7 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
 struct FlushCtx { U32x4 v; uint32_t dbase, h, nfull, r, cfrom, direct, pp; };
 static_assert(kStageBytes / 16 <= kCmpThreads, "one staged chunk per thread");
 // first half: the tile's numbers and my chunk of the staging buffer into registers (the table inserts run while they arrive)
-__device__ __forceinline__ FlushCtx flush_begin(const char* smem, uint32_t pp, uint32_t a0) {
+__device__ __forceinline__ FlushCtx flush_begin(char* smem, uint32_t pp, uint32_t a0) {
     const uint32_t* T = (const uint32_t*)(smem + kCOffMisc) + CM_TILE + 4 * pp;
     FlushCtx f;
     const uint32_t out0 = T[T_OUT0], out1 = T[T_OUT1];
@@ -639,6 +661,7 @@ __device__ __forceinline__ FlushCtx flush_begin(const char* smem, uint32_t pp, u
     f.dbase = V0 & ~15u; f.h = V0 - f.dbase;
     f.nfull = (V1 - f.dbase) >> 4; f.r = (V1 - f.dbase) & 15u;
     f.v = *(const U32x4*)(smem + kCOffStage + 16 * threadIdx.x);       // (threads behind the tile's last chunk read bytes nobody uses)
+    if (16 * threadIdx.x < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * threadIdx.x) = z; }   // the next tile ORs its literals into zeros
     return f;
 }
 __device__ __forceinline__ void flush_end(char* smem, const FlushCtx& f, lz4amd_gdst dst, uint32_t a0) {
@@ -684,11 +707,11 @@ __device__ __forceinline__ void flush_end(char* smem, const FlushCtx& f, lz4amd_
 // brought up to date.  One wave: a short serial walk over the strips settles where each one starts (a strip's own
 // overrun counts only if its last match survives), then lane k puts strip k right (binary search in the record ends).
 __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs_tile, const uint16_t* ends_tile, const uint16_t* encp_tile,
-                                                 uint32_t nstrips, uint32_t t0, uint32_t strip_len, uint32_t t1, uint32_t n) {
+                                                 uint32_t nstrips, uint32_t g0, uint32_t t0, uint32_t strip_len, uint32_t t1, uint32_t n) {
     const uint32_t lane = lane_id();
     const bool mine = lane < nstrips;
-    const uint32_t cs = t0 + lane * strip_len;
-    uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
+    const uint32_t cs = strip_lo(g0, t0, lane, strip_len);
+    uint32_t ce = g0 + (lane + 1) * strip_len; if (ce > t1) ce = t1;
     const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, own_end = mine ? strip[S_END * kCmpWaves + lane] : 0;
     MatchRec* rk = recs_tile + lane * kRecsPerStrip;
     const uint16_t* ek = ends_tile + lane * kRecsPerStrip;
@@ -710,7 +733,7 @@ __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs
         if (__any(mine && !survives)) {
             cover = 0;
             for (uint32_t k = 0; k < nstrips; k++) {
-                const uint32_t cs_k = t0 + k * strip_len, Pk = cover > cs_k ? cover : cs_k;
+                const uint32_t cs_k = strip_lo(g0, t0, k, strip_len), Pk = cover > cs_k ? cover : cs_k;
                 if (lane == k) P = Pk;
                 const uint32_t e_k = wave_readlane(own_end, k), q_k = wave_readlane(q_last, k);
                 const bool sv = e_k != 0 && (Pk <= q_k || (e_k >= Pk + kMinMatch && Pk <= n - kMfLimit));
@@ -797,7 +820,7 @@ __device__ __forceinline__ uint32_t uload_cm(const uint32_t* w) { return __built
 // ------------------------------------------------------------------------------ one tile settled / written (helpers of one block)
 // wave 0: tile (parity pp) gets its output offsets; whether it is composed in LDS or - when its encoded bytes do not fit
 // the staging buffer, i.e. when it ends a literal run of more than a few KB - written to HBM directly
-__device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t nstrips, uint32_t t0, uint32_t strip_len, uint32_t t1,
+__device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t nstrips, uint32_t g0, uint32_t t0, uint32_t strip_len, uint32_t t1,
                                             uint32_t n, uint32_t cap, uint32_t a0) {
     uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
     uint32_t* strip_p = (uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
@@ -805,7 +828,7 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
     const uint64_t ts0 = clock_ticks();
 #endif
     resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kStrips * kRecsPerStrip, (const uint16_t*)(smem + kCOffEnds) + pp * kStrips * kRecsPerStrip,
-                     (const uint16_t*)(smem + kCOffEncp) + pp * kStrips * kRecsPerStrip, nstrips, t0, strip_len, t1, n);
+                     (const uint16_t*)(smem + kCOffEncp) + pp * kStrips * kRecsPerStrip, nstrips, g0, t0, strip_len, t1, n);
     wave_lds_fence();
 #ifdef LZ4AMD_PROF_TILE
     const uint64_t ts1 = clock_ticks();
@@ -870,6 +893,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const uint32_t a0 = (uint32_t)((uintptr_t)P.dst[b] & 15u);        // dst's place on HBM's 16-byte grid
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
+    if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
         misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0;
 #ifdef LZ4AMD_PROF_TILE
@@ -899,7 +923,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     // everybody inserts tile k into the table and stores one 16-byte chunk of tile k-1's bytes.  Records and strip
     // summaries are double buffered for that.
     uint32_t par = 0;                                       // buffer parity of tile k
-    uint32_t prev_t0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
+    uint32_t prev_t0 = 0, prev_g0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
     uint32_t tiles_parsed = 0;                              // tiles whose strips were matched so far (CM_READY counts up to it)
     while (t0 < n) {
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
@@ -916,17 +940,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         __syncthreads();                                       // ring, table and tile k-1's records ready
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
         const bool parse = t0 >= pre;
-        const uint32_t nstrips = parse ? (t1 - t0 + strip_len - 1) >> (31 - __clz((int)strip_len)) : 0;      // (strip lengths are powers of two)
+        const uint32_t g0 = strip_origin(t0, tile_len, strip_len);
+        const uint32_t nstrips = parse ? (t1 - g0 + strip_len - 1) >> (31 - __clz((int)strip_len)) : 0;      // (strip lengths are powers of two)
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         // -- A0: one wave settles tile k-1 first
         if (w == kSettleWave && prev_nstrips) {
-            settle_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
+            settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
             if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
         }
         // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
         if (w < nstrips) {
-            const uint32_t cs = t0 + w * strip_len;
-            uint32_t ce = cs + strip_len; if (ce > t1) ce = t1;
+            const uint32_t cs = strip_lo(g0, t0, w, strip_len);
+            uint32_t ce = g0 + (w + 1) * strip_len; if (ce > t1) ce = t1;
             if (small) match_strip<0>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
             else match_strip<1>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
         }
@@ -953,11 +978,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 uint32_t dw[4];
 #pragma unroll
                 for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
+                uint32_t h[8];
 #pragma unroll
                 for (uint32_t i = 0; i < 8; i++) {
-                    const uint32_t q = q0 + i;
                     const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
-                    if (q < t1 && q <= last_q) atomicMax(&tab[hash_pos32(lo, hi, small)], q);
+                    h[i] = hash_pos32(lo, hi, small);
+                }
+                if (q0 + 7 < t1 && q0 + 7 <= last_q) {                  // every thread but the ones at a block's very end: no per-position test
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; i++) atomicMax(&tab[h[i]], q0 + i);
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; i++) if (q0 + i < t1 && q0 + i <= last_q) atomicMax(&tab[h[i]], q0 + i);
                 }
             }
         }
@@ -970,14 +1002,14 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
         if (do_flush) flush_end(smem, fc, dst, a0);
         if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
-        prev_t0 = t0; prev_t1 = t1; prev_strip_len = strip_len; prev_nstrips = nstrips; par ^= 1;
+        prev_t0 = t0; prev_g0 = g0; prev_t1 = t1; prev_strip_len = strip_len; prev_nstrips = nstrips; par ^= 1;
         if (nstrips) tiles_parsed++;
         t0 = t1; tile_len = nt_len; strip_len = nt_strip;
     }
     __syncthreads();
     // -- the last tile's sequences (settled by wave 0 first)
     if (prev_nstrips) {
-        if (w == kSettleWave) settle_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
+        if (w == kSettleWave) settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
         __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, src, dst, a0, ring_lo);
