@@ -18,6 +18,8 @@ enum : uint32_t {
 __device__ __forceinline__ int err_at(uint32_t pos) { return -(int)(pos & 0x7FFFFFFFu) - 1; }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// ... computed where it is asked for (see opaque_u32 in the platform header): the decoder's roles use this one
+__device__ __forceinline__ uint32_t lane_here() { return opaque_u32(threadIdx.x) & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
 
 __device__ __forceinline__ uint32_t ld_u8(const uint8_t* p) { return *p; }

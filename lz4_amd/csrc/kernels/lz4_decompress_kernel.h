@@ -17,9 +17,9 @@
 //       between the first and the last byte of the block:
 //       LOADER (wave 14)  streams the compressed block into a 32 KB LDS ring (coalesced 16-byte
 //           loads, the next 4 KB in flight while the last is written).
-//       FEEDER (wave 15)  streams the record table into a 2048-row LDS ring, 64 records at a
-//           time, noting for every 1 KB REGION of output the record that holds its first byte;
-//           records longer than 16 KB of output are cut in pieces.
+//       FEEDER (wave 15)  a plain mover: the record table -> a 2048-row LDS ring, 256 rows at a
+//           time, and the pre-parse's region index (for every 1 KB REGION of output the record that
+//           holds its first byte) -> a 512-entry LDS ring.  No per-record work.
 //       (both run as far ahead as the rings allow)
 //       COPY (waves 0-13)  output-stationary: wave w owns regions w, w+14, ... .  A region is
 //           composed in its slot of a 80 KB LDS ring that always holds the 64 KB LZ4 window, from
@@ -32,8 +32,9 @@
 //           Sources still in flight on another wave are waited for through per-chunk done bits;
 //           finished regions go to HBM with one 16-byte store per lane (1 KB contiguous per wave).
 //
-// HBM/L2 traffic per block: compressed bytes read by the pre-parse and once more by the feeder,
-// the record table written and read once (16 B per sequence), output written once; matches and
+// HBM/L2 traffic per block: compressed bytes read by the pre-parse and once more by the loader,
+// the record table written and read once (16 B per sequence) and the region index (4 B per KB of
+// output), output written once; matches and
 // literals never touch HBM during the copy.  No MFMA: byte moves.
 #pragma once
 #include "lz4_common.h"
@@ -41,7 +42,7 @@
 #include "lz4_preparse_kernel.h"
 
 #ifdef LZ4AMD_TRACE
-#define DTRACE(...) do { if (lane_id() == 0) { fprintf(stderr, "[w%u] ", wave_id()); fprintf(stderr, __VA_ARGS__); } } while (0)
+#define DTRACE(...) do { if (lane_here() == 0) { fprintf(stderr, "[w%u] ", wave_id()); fprintf(stderr, __VA_ARGS__); } } while (0)
 #else
 #define DTRACE(...) do {} while (0)
 #endif
@@ -73,8 +74,7 @@ enum : uint32_t {
     kRecMask = kRecCap - 1,
     kIdxRing = 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
-    kOutAhead = 480,                            // records are published at most this many regions ahead of the copy
-    kPieceSpan = 8192,                          // records of more than 2 * kPieceSpan output bytes are fed in pieces of this size
+    kFeedRows = 256,                            // table rows the feeder moves per trip
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
     kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kFirstRegion = kBias >> kRegionShift,
@@ -88,8 +88,8 @@ enum : uint32_t {
     kOffMaskTab = kOffMisc + 64 * 4,                         // U32x4[17]: byte masks, entry n selects bytes [0, n) of a chunk
     kOffFin = kOffMaskTab + 17 * 16 + 16,                    // u32[16] regions completed per copy wave
     kOffBits = kOffFin + 16 * 4,                             // DoneEnt[kSlots]
-    kOffIdx = kOffBits + kSlots * 16,                        // u16[kIdxRing]
-    kOffPend = kOffIdx + kIdxRing * 2,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
+    kOffIdx = kOffBits + kSlots * 16,                        // u32[kIdxRing]
+    kOffPend = kOffIdx + kIdxRing * 4,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
     kOffRecs = (kOffPend + kCopyWaves * (kMaxTrips + 2) * 8 + 15) & ~15u,   // SeqRec[kRecCap]
     kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
     kOffRing = kOffCr + kCrBytes + kCrPad,                   // output ring + pad
@@ -99,10 +99,10 @@ enum : uint32_t {
 static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0, "LDS alignment");
 
-enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_FIN, M_CHI, M_CLO, M_HEAD, M_EMIT, M_NEXT, M_OPEN };      // (M_HEAD, M_EMIT: one aligned 64-bit word, published together)      // (word 1 is the pre-parse's error word)
+enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_SPARE, M_CHI, M_CLO, M_HEAD, M_IHEAD, M_NEXT, M_OPEN };      // (M_HEAD, M_IHEAD: one aligned 64-bit word, published together: table rows resident, region index entries resident)      // (word 1 is the pre-parse's error word)
 
-// scratch of one workgroup: the sequence-record table of the block it is decoding
-__host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize) { return pre::scratch_bytes(max_csize); }
+// scratch of one workgroup: the sequence-record table of the block it is decoding, the pre-parse's token list, the region index
+__host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize, uint32_t max_out) { return pre::scratch_bytes(max_csize, max_out); }
 
 // ------------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -149,17 +149,30 @@ __device__ __forceinline__ U32x4 lds_read16_at(const uint8_t* base, uint32_t a) 
 
 // The control words M_ABORT .. M_OPEN (8 consecutive dwords) in one look: two 16-byte LDS reads issued together, so a
 // wave pays one LDS round trip instead of one per word.
-struct Ctl { uint32_t abort_, fin, chi, emit, head, clo, next, open; };
+struct Ctl { uint32_t abort_, chi, ihead, head, clo, next, open; };
+__device__ __forceinline__ Ctl ctl_unpack(const U32x4& a, const U32x4& b) {
+    Ctl c;
+    c.abort_ = __builtin_amdgcn_readfirstlane(a[0]);
+    c.chi = __builtin_amdgcn_readfirstlane(a[2]); c.clo = __builtin_amdgcn_readfirstlane(a[3]);
+    c.head = __builtin_amdgcn_readfirstlane(b[0]); c.ihead = __builtin_amdgcn_readfirstlane(b[1]);
+    c.next = __builtin_amdgcn_readfirstlane(b[2]); c.open = __builtin_amdgcn_readfirstlane(b[3]);
+    return c;
+}
 __device__ __forceinline__ Ctl ctl_snapshot(const char* smem) {
     const U32x4* w = (const U32x4*)(smem + kOffMisc + 4 * M_ABORT);
     U32x4 a, b;
     lds_load_pair16(w, a, b);
-    Ctl c;
-    c.abort_ = __builtin_amdgcn_readfirstlane(a[0]); c.fin = __builtin_amdgcn_readfirstlane(a[1]);
-    c.chi = __builtin_amdgcn_readfirstlane(a[2]); c.clo = __builtin_amdgcn_readfirstlane(a[3]);
-    c.head = __builtin_amdgcn_readfirstlane(b[0]); c.emit = __builtin_amdgcn_readfirstlane(b[1]);
-    c.next = __builtin_amdgcn_readfirstlane(b[2]); c.open = __builtin_amdgcn_readfirstlane(b[3]);
-    return c;
+    return ctl_unpack(a, b);
+}
+// ... and in the same look the region index entries of regions R and R + 1 (read AFTER the control words: they are
+// valid if the control words say so)
+__device__ __forceinline__ Ctl ctl_snapshot_region(const char* smem, uint32_t R, uint32_t& i0, uint32_t& i1) {
+    const U32x4* w = (const U32x4*)(smem + kOffMisc + 4 * M_ABORT);
+    const uint32_t* idx = (const uint32_t*)(smem + kOffIdx);
+    U32x4 a, b;
+    lds_load_pair16_then2(w, a, b, &idx[R & kIdxMask], &idx[(R + 1) & kIdxMask], i0, i1);
+    i0 = __builtin_amdgcn_readfirstlane(i0); i1 = __builtin_amdgcn_readfirstlane(i1);
+    return ctl_unpack(a, b);
 }
 static_assert(M_OPEN == M_ABORT + 7 && (kOffMisc + 4 * M_ABORT) % 16 == 0, "control word layout");
 
@@ -175,7 +188,7 @@ __device__ __forceinline__ uint32_t first_open_region(const char* smem) {
 __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, char* smem) {
     uint8_t* cr = (uint8_t*)(smem + kOffCr);
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_here();
     U32x4 cur[4], nxt[4];
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) { const uint32_t P = 16 * (lane + 64 * i); if (P < csize) cur[i] = load_granule(src, csize, P); }
@@ -185,7 +198,7 @@ __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, cha
         for (;;) {
             const uint32_t clo = uload(&misc[M_CLO]);
             if (L + kLoadBatch <= clo + kCrBytes) break;
-            spin_pause();
+            spin_pause_long();
         }
         const uint32_t nL = L + kLoadBatch;
 #pragma unroll
@@ -209,109 +222,79 @@ __device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, cha
 }
 
 // ------------------------------------------------------------------------------ FEEDER
-// The record table -> the 2048-row LDS ring, 64 records at a time (the next batch is on its way from memory while
-// one is published), with the first record of every region noted; it also tells the loader which stream bytes the
-// copy has left behind.  Nothing here blocks on the copy: whatever does not fit now is tried again on the next trip.
-__device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab, uint32_t nseq, char* smem) {
+// A plain mover: the record table -> the 2048-row LDS ring, 256 rows a trip (the next 256 on their way from memory
+// meanwhile), and the pre-parse's region index (first record of every 1 KB region of output) -> its LDS ring, 64
+// regions a trip.  No per-record work: whatever the copy needs to know about a region it reads from those two rings.
+// It also tells the loader which stream bytes the copy has left behind.  Nothing here blocks on the copy: whatever
+// does not fit now is tried again on the next trip.
+__device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t rend, char* smem) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    uint16_t* idx = (uint16_t*)(smem + kOffIdx);
+    uint32_t* idx = (uint32_t*)(smem + kOffIdx);
     SeqRec* recs = (SeqRec*)(smem + kOffRecs);
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_here();
     wave_priority_high();                              // fifteen waves wait for what this one produces
-    // ---- record state: the batch in registers (lane i: record rix + i), how much of it is published
-    uint32_t rix = 0, bn = 0, bdone = 0, head = 0, obase = kBias;
-    SeqRec brec; brec.outpos = brec.litpos = brec.ll = brec.off = 0;
-    uint32_t blen = 0;
-    // the batch after it, on its way from the table (lane i: record rix + bn + i)
-    SeqRec prec; prec.outpos = prec.litpos = prec.ll = prec.off = 0;
-    uint32_t plen = 0, pn = nseq < 64 ? nseq : 64;
-    if (lane < pn) { prec = rectab[lane]; plen = rectab[lane + 1].outpos - prec.outpos; }
-    uint32_t pc_off = 0;                               // a long record is fed in pieces: output bytes of it already fed
-    bool fin_sent = false, last_progress = false;
-    uint32_t clo_sent = 0, trip = 0, g = kFirstRegion, tail = 0;
+    const uint32_t nrows = nseq + 1;                   // (the table ends with a sentinel row: where the block's output ends)
+    uint32_t head = 0, ihead = kFirstRegion, tail = 0, clo_sent = 0;
+    // the next batch of rows, in registers / on its way from memory: [head, head + 256)
+    SeqRec pa[kFeedRows / 64];
+#pragma unroll
+    for (uint32_t k = 0; k < kFeedRows / 64; k++) {
+        pa[k].outpos = pa[k].litpos = pa[k].ll = pa[k].off = 0;
+        if (64 * k + lane < nrows) pa[k] = rectab[64 * k + lane];
+    }
+    uint32_t pidx = 0, icarry = 0;
+    if (ihead + lane < rend) pidx = ridx[lane];
     for (;;) {
+        const Ctl c = ctl_snapshot(smem);
+        if (c.abort_) break;
+        const uint32_t g = c.open;
         bool progress = false;
-        // ---- the next batch of the record table, when the last one is out (it was requested a batch ago)
-        if (bdone == bn && pn) {
-            brec = prec; blen = plen; bn = pn; bdone = 0; pc_off = 0;
-            rix += bn;
-            pn = nseq - rix < 64 ? nseq - rix : 64;
-            if (lane < pn) {
-                prec = rectab[rix + lane];
-                plen = rectab[rix + lane + 1].outpos - prec.outpos;      // (the table ends with a sentinel row)
-            } else { prec.outpos = prec.litpos = prec.ll = prec.off = 0; plen = 0; }
-            progress = true;
-        }
-        // ---- what the copy still needs: first open region g, first record in use, first literal byte in use.  Looked up every
-        //      fourth trip or when the last trip got nowhere: both only ever move forward, so stale values are merely careful
-        //      (less room, a nearer horizon), and the lookup is a chain of three LDS round trips on the one wave that feeds fourteen
-        if ((trip & 3u) == 0 || !last_progress) {
-            g = first_open_region(smem);
-            uint32_t need;
-            tail = head;
-            if ((g << kRegionShift) < obase) {
-                const uint32_t t16 = idx[g & kIdxMask];
-                tail = head - ((head - t16) & 0xFFFFu);
-                const SeqRec r = recs[tail & kRecMask];
-                uint32_t d = (g << kRegionShift) - r.outpos; if (d > r.ll) d = r.ll;
-                need = r.litpos + d;
-            } else need = bdone < bn ? wave_readlane(brec.litpos, bdone) : csize;   // nothing published is in use
-            if (need != clo_sent) { clo_sent = need; if (lane == 0) lds_store_release(&misc[M_CLO], need); }   // what the loader may overwrite
-        }
-        trip++;
-        if (bdone < bn) {
-            const uint32_t room = kRecCap - 1 - (head - tail);           // rows free, one kept for the sentinel
-            const bool islong = blen > 2 * kPieceSpan;
-            if (wave_readlane(islong ? 1u : 0u, bdone)) {
-                // one piece of a long record: literals first ({position, source, n, 0}), then the match ({position, -, 0, offset})
-                const uint32_t o0 = wave_readlane(brec.outpos, bdone), ll = wave_readlane(brec.ll, bdone), len = wave_readlane(blen, bdone);
-                const uint32_t lp = wave_readlane(brec.litpos, bdone), off = wave_readlane(brec.off, bdone);
-                const bool inlit = pc_off < ll;
-                const uint32_t left = inlit ? ll - pc_off : len - pc_off;
-                const uint32_t n = left < kPieceSpan ? left : kPieceSpan;
-                const uint32_t o = o0 + pc_off;
-                if (room >= 1 && ((o + n) >> kRegionShift) < g + kOutAhead) {
-                    SeqRec rec; rec.outpos = o; rec.litpos = inlit ? lp + pc_off : lp + ll; rec.ll = inlit ? n : 0u; rec.off = inlit ? 0u : off;
-                    // (a match piece points at the end of its record's literals: literal sources never go back)
-                    if (lane == 0) { recs[head & kRecMask] = rec; recs[(head + 1) & kRecMask].outpos = o + n; }
-                    const uint32_t g1 = ((o + kRegion - 1) >> kRegionShift) + lane;
-                    if ((g1 << kRegionShift) < o + n) idx[g1 & kIdxMask] = (uint16_t)head;
-                    wave_lds_fence();
-                    if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(head + 1) | ((uint64_t)(o + n) << 32));
-                    head += 1; obase = o + n; pc_off += n;
-                    if (pc_off >= len) { bdone++; pc_off = 0; }
-                    progress = true;
-                }
-            } else {
-                const uint32_t o = brec.outpos, er = (o + blen - 1) >> kRegionShift;
-                const unsigned long long okm = __ballot(lane >= bdone && lane < bn && !islong && (blen == 0 || er < g + kOutAhead));
-                const unsigned long long run = ~(okm >> bdone);
-                uint32_t npub = run ? (uint32_t)__ffsll((long long)run) - 1 : 64u;
-                if (npub > bn - bdone) npub = bn - bdone;
-                if (npub > room) npub = room;
-                if (npub) {
-                    if (lane >= bdone && lane < bdone + npub) {
-                        const uint32_t j = head + (lane - bdone);
-                        recs[j & kRecMask] = brec;
-                        for (uint32_t g1 = (o + kRegion - 1) >> kRegionShift; (g1 << kRegionShift) < o + blen; g1++) idx[g1 & kIdxMask] = (uint16_t)j;
-                        if (lane == bdone + npub - 1) recs[(j + 1) & kRecMask].outpos = o + blen;      // sentinel: where the next record starts
-                    }
-                    const uint32_t oend = wave_readlane(o + blen, bdone + npub - 1);
-                    wave_lds_fence();
-                    if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(head + npub) | ((uint64_t)oend << 32));
-                    head += npub; obase = oend; bdone += npub;
-                    progress = true;
-                }
+        // ---- the region index: regions [ihead, ihead + 64), once the ring has let go of the regions 512 below them
+        if (ihead < rend) {
+            const uint32_t n = rend - ihead < 64 ? rend - ihead : 64;
+            if (ihead + n <= g + kIdxRing) {
+                // (a sequence that covers several region starts noted only the first: holes take the entry before them)
+                const uint32_t filled = wave_incl_max_u32(pidx > icarry ? pidx : icarry);
+                icarry = wave_readlane(filled, 63);
+                if (lane < n) idx[(ihead + lane) & kIdxMask] = filled - 1;
+                ihead += n;
+                pidx = 0;
+                if (ihead + lane < rend) pidx = ridx[ihead - kFirstRegion + lane];
+                progress = true;
             }
         }
-        if (!fin_sent && pn == 0 && bdone == bn) {            // every record is out: the copy may run to the end
-            wave_lds_fence();
-            if (lane == 0) lds_store_release(&misc[M_FIN], 1u);
-            fin_sent = true;
+        wave_lds_fence();
+        // ---- what the copy still needs: the first record and the first literal byte of the first open region g (both only
+        //      ever move forward, so stale values are merely careful: less room)
+        uint32_t need = clo_sent;
+        if (g >= rend) need = csize;
+        else if (g < ihead) {
+            tail = __builtin_amdgcn_readfirstlane(idx[g & kIdxMask]);
+            if (tail < head) {
+                const SeqRec r = recs[tail & kRecMask];
+                uint32_t d = (g << kRegionShift) - r.outpos; if (d > r.ll) d = r.ll;
+                need = __builtin_amdgcn_readfirstlane(r.litpos + d);
+            }
         }
-        if (fin_sent && uload(&misc[M_CHI]) >= csize) break;     // (the loader may still be behind: keep telling it what the copy has consumed)
-        last_progress = progress;
-        if (!progress) spin_pause();
+        if (need != clo_sent) { clo_sent = need; if (lane == 0) lds_store_release(&misc[M_CLO], need); }   // what the loader may overwrite
+        // ---- records: rows [head, head + 256)
+        if (head < nrows) {
+            const uint32_t n = nrows - head < kFeedRows ? nrows - head : kFeedRows;
+            if (head + n - tail <= kRecCap) {
+#pragma unroll
+                for (uint32_t k = 0; k < kFeedRows / 64; k++) if (64 * k + lane < n) recs[(head + 64 * k + lane) & kRecMask] = pa[k];
+                head += n;
+#pragma unroll
+                for (uint32_t k = 0; k < kFeedRows / 64; k++) if (head + 64 * k + lane < nrows) pa[k] = rectab[head + 64 * k + lane];
+                progress = true;
+            }
+        }
+        if (progress) {
+            wave_lds_fence();
+            if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)head | ((uint64_t)ihead << 32));
+        }
+        if (head == nrows && ihead == rend && c.chi >= csize && need == csize) break;     // (the loader may still be behind: keep telling it what the copy has consumed)
+        if (!progress) { spin_pause_long(); spin_pause_long(); }      // (the rings hold tens of thousands of cycles of work: a look every ~1000 is plenty, and every look takes issue slots from the copy waves of this SIMD)
     }
 }
 
@@ -321,7 +304,6 @@ struct RegionCtx {
     uint32_t R, x0, x1, slot;       // region, its output range, its ring slot
     uint32_t g;                     // regions below g are final
     uint32_t chi;                   // compressed bytes resident
-    uint32_t crW, lp0;              // ring address / stream position of the region's first literal source
     uint32_t ringB;                 // output position of ring address 0 two laps below the region
     uint32_t j0, nrec;              // records that overlap the region
     uint64_t mydone;                // chunks of this region that are final
@@ -364,7 +346,7 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     key = kKeyAlways;
     // -- a literal piece: stream bytes [A, A + n)
     const uint32_t A = rec.litpos + (d - rec.outpos);
-    const uint32_t a = cr_fold(cr_fold(C.crW + (A - C.lp0) - lo + kCrBytes));
+    const uint32_t a = mod_cr(A - lo);                                       // (the ring is direct mapped; below position 0 only masked-off bytes)
     const bool lit_ok = A + n <= C.chi;
     // -- a match piece: output bytes [s, s + n)
     uint32_t dist = rec.off;
@@ -439,7 +421,7 @@ __device__ __forceinline__ uint64_t chunks_of(unsigned long long pm, uint32_t ch
 struct BItem { SeqRec rec; uint32_t ms, d, lo, n, chunk; bool is_lit, valid; };
 __device__ __forceinline__ BItem b_item(const RegionCtx& C, uint32_t t) {
     const SeqRec* recs = (const SeqRec*)(C.smem + kOffRecs);
-    const uint32_t l = lane_id(), r = 32 * t + (l >> 1);
+    const uint32_t l = lane_here(), r = 32 * t + (l >> 1);
     BItem it; it.valid = false; it.is_lit = !(l & 1);
     it.rec.outpos = it.rec.litpos = it.rec.ll = it.rec.off = 0; it.ms = it.d = it.lo = it.n = it.chunk = 0;
     if (r < C.nrec) {
@@ -464,12 +446,11 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
     DoneEnt* ents = (DoneEnt*)(smem + kOffBits);
     unsigned long long* pend = (unsigned long long*)(smem + kOffPend) + w * (kMaxTrips + 2);     // [0] scratch, [1..] trips
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_here();
     const uint32_t slot_off = kOffRing + (C.slot << kRegionShift);
     // the slot is mine now: no chunk of region R is done (mask first, then the tag)
     if (lane == 0) { lds_store_release64(&ents[C.slot].mask, 0ull); lds_store_release(&ents[C.slot].tag, C.R + kSlots); }
     C.mydone = 0;
-    C.lp0 = recs[C.j0 & kRecMask].litpos; C.crW = mod_cr(C.lp0);
     C.ringB = (C.R - C.slot - kSlots) << kRegionShift;
     // ---- round A: which record covers the first byte of each chunk?  (scratch: the slot itself)
     uint32_t* fs = (uint32_t*)(smem + slot_off);
@@ -627,11 +608,10 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     }
 }
 
-__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* smem, uint64_t* prof) {
+__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, uint32_t nseq, uint32_t total, uint32_t rend, char* smem, uint64_t* prof) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    const uint16_t* idx = (const uint16_t*)(smem + kOffIdx);
     const DoneEnt* ents = (const DoneEnt*)(smem + kOffBits);
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_here();
     uint32_t k = 0;
     uint64_t t_rec = 0, t_lead = 0, t_work = 0, t_retry = 0;
     uint32_t n_iters = 0, n_retried = 0, n_lead = 0, n_cov = 0;
@@ -640,39 +620,37 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
         uint32_t R = 0;
         if (lane == 0) R = atomicAdd(&misc[M_NEXT], 1u);
         R = __builtin_amdgcn_readfirstlane(R);
+        if (R >= rend) break;
         const uint32_t slot = R % kSlots;
         RegionCtx C; C.smem = smem; C.R = R; C.slot = slot;
         C.x0 = R << kRegionShift;
-        // ---- wait until the records cover the region (or the block ends inside / before it) and its ring slot is free:
-        //      region R takes the slot of region R-80, which regions up to R-16 may still read
-        uint64_t ts = clock_ticks();
-        uint32_t oe, head;
+        C.x1 = C.x0 + kRegion < kBias + total ? C.x0 + kRegion : kBias + total;
+        // ---- wait until the region's records are in the ring and its ring slot is free: region R takes the slot of
+        //      region R-80, which regions up to R-16 may still read
+        uint64_t ts = prof ? clock_ticks() : 0;
+        const uint32_t iwant = R + 2 < rend ? R + 2 : rend;        // index entries of R and R + 1
         for (;;) {
-            const Ctl c = ctl_snapshot(smem);
-            oe = c.emit; head = c.head; C.g = c.open; C.chi = c.chi;
+            uint32_t i0, i1;
+            const Ctl c = ctl_snapshot_region(smem, R, i0, i1);
+            C.g = c.open; C.chi = c.chi;
             if (c.abort_) goto out;
-            bool covered = oe >= C.x0 + kRegion;
-            C.x1 = C.x0 + kRegion;
-            if (!covered && c.fin) {
-                if (C.x0 >= oe) goto out;
-                C.x1 = oe < C.x0 + kRegion ? oe : C.x0 + kRegion;
-                covered = true;
+            bool covered = c.ihead >= iwant;
+            if (covered) {
+                C.j0 = i0;
+                const uint32_t jl = R + 1 < rend ? i1 : nseq - 1;
+                uint32_t nrec = jl - C.j0 + 1;
+                if (nrec > 32 * kMaxTrips) nrec = 32 * kMaxTrips;             // (more than 258 records never overlap a region)
+                C.nrec = nrec;
+                covered = c.head >= jl + 2;                                    // (row jl + 1 says where record jl ends)
             }
             if (covered && C.g + kMaxLead >= R) break;
             if (covered) n_lead++; else n_cov++;               // (developer profile: what the wait was for)
             spin_pause();
         }
-        {   const uint64_t t = clock_ticks(), dt = t - ts;
-            const uint64_t lead_part = (n_lead + n_cov) ? dt * n_lead / (n_lead + n_cov) : 0;
-            t_lead += lead_part; t_rec += dt - lead_part; ts = t; n_lead = n_cov = 0; }
-        {
-            const uint32_t i0 = idx[R & kIdxMask], i1 = idx[(R + 1) & kIdxMask];
-            C.j0 = i0;
-            const uint32_t jl = (C.x1 < oe) ? i1 : head - 1;
-            uint32_t nrec = ((jl - C.j0) & 0xFFFFu) + 1;
-            if (nrec > 32 * kMaxTrips) nrec = 32 * kMaxTrips;             // (more than 258 records never overlap a region)
-            C.nrec = nrec;
-        }
+        if (prof) {   // (the clock reads and this bookkeeping only under the developer profile: they were ~5 % of a region's time)
+            const uint64_t t = clock_ticks(), dt = t - ts;
+            if (n_lead > n_cov) t_lead += dt; else t_rec += dt;
+            ts = t; n_lead = n_cov = 0; }
         uint64_t tr = 0; uint32_t ni = 0;
         DTRACE("region R=%u x0=%u x1=%u j0=%u nrec=%u g=%u\n", R, C.x0, C.x1, C.j0, C.nrec, C.g);
         copy_region(C, dst, w, tr, ni);
@@ -690,7 +668,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, char* sme
             if (!__builtin_amdgcn_readfirstlane(complete ? 1u : 0u)) break;
             if (lane == 0) atomicCAS(&misc[M_OPEN], g, g + 1);
         }
-        { const uint64_t t = clock_ticks(); t_work += t - ts - tr; t_retry += tr; }
+        if (prof) { const uint64_t t = clock_ticks(); t_work += t - ts - tr; t_retry += tr; }
     }
 out:
     if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[5] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); }
@@ -698,11 +676,11 @@ out:
 
 // ------------------------------------------------------------------------------ stage B of one block
 __device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, uint32_t prefix,
-                                             const SeqRec* rectab, uint32_t nseq, char* smem, uint64_t* prof) {
+                                             const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t total, char* smem, uint64_t* prof) {
     const uint32_t tid = threadIdx.x, w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
-    if (tid == 0) { misc[M_ABORT] = 0; misc[M_FIN] = 0; misc[M_CHI] = 0; misc[M_EMIT] = kBias; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
+    if (tid == 0) { misc[M_ABORT] = 0; misc[M_SPARE] = 0; misc[M_CHI] = 0; misc[M_IHEAD] = kFirstRegion; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
     if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
     if (tid < 17) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid, k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
     if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
@@ -719,9 +697,10 @@ __device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz
     }
     __syncthreads();
 
-    if (w == kFeedWave) feeder_role(csize, rectab, nseq, smem);
+    const uint32_t rend = (kBias + total + kRegion - 1) >> kRegionShift;          // regions [kFirstRegion, rend)
+    if (w == kFeedWave) feeder_role(csize, rectab, ridx, nseq, rend, smem);
     else if (w == kLoadWave) loader_role(src, csize, smem);
-    else copy_role(w, dst, smem, prof);
+    else copy_role(w, dst, nseq, total, rend, smem, prof);
 
 }
 
@@ -769,7 +748,8 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
 
     // ---- stage A: the record table (a malformed block ends here, nothing written)
     uint32_t nseq = 0, total = stored ? csize : 0u;
-    if (ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof)) {
+    uint32_t* ridx = nullptr;
+    if (ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx)) {
         if (!chained) { if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]); return; }
         ok = false;
     }
@@ -783,10 +763,10 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
         if (tid == 0) {
             long long s;
             while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
-            misc[M_CHI] = (uint32_t)(unsigned long long)s; misc[M_EMIT] = (uint32_t)((unsigned long long)s >> 32);
+            misc[M_CHI] = (uint32_t)(unsigned long long)s; misc[M_SPARE] = (uint32_t)((unsigned long long)s >> 32);
         }
         __syncthreads();
-        start = (long long)((unsigned long long)misc[M_CHI] | ((unsigned long long)misc[M_EMIT] << 32));
+        start = (long long)((unsigned long long)misc[M_CHI] | ((unsigned long long)misc[M_SPARE] << 32));
         __syncthreads();                                       // (stage B re-initialises those words)
         const unsigned long long before = (unsigned long long)(start < 0 ? 0 : start) + (P.prefix ? (unsigned long long)(uint32_t)P.prefix[0] : 0ull);
         prefix = before < kBias ? (uint32_t)before : kBias;
@@ -800,7 +780,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
         if (stored) for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
     }
 
-    if (!stored) stream_block(src, csize, dst, prefix, rectab, nseq, smem, prof);
+    if (!stored) stream_block(src, csize, dst, prefix, rectab, ridx, nseq, total, smem, prof);
 
     __syncthreads();
     if (tid == 0) {

@@ -58,9 +58,20 @@ enum : uint32_t { M_ERR = 1, M_MINREF = 2, M_TERM = 8, M_NX, M_OBASE, M_NREC, M_
 // scratch of one workgroup: the record table (every sequence but the last takes >= 3 stream bytes; +1 last, +1 sentinel)
 // followed by the token list of one span
 __host__ __device__ inline uint64_t table_bytes(uint32_t max_csize) { return ((uint64_t)max_csize / 3 + 4) * sizeof(SeqRec); }
-__host__ __device__ inline uint64_t scratch_bytes(uint32_t max_csize) {
-    const uint32_t span = max_csize < kSpanMax ? max_csize : kSpanMax;
-    return table_bytes(max_csize) + ((uint64_t)span / 3 + 8) * 4;
+__host__ __device__ inline uint64_t toks_bytes(uint32_t csize) {
+    const uint32_t span = csize < kSpanMax ? csize : kSpanMax;
+    return (((uint64_t)span / 3 + 8) * 4 + 15) & ~15ull;
+}
+// ... and behind the token list the REGION INDEX: for every 1 KB region of the block's output the record that holds the region's
+// first byte (u32 per region): the copy stage of the decoder finds a region's records through it, straight from the table
+enum : uint32_t { kRegionShiftPre = 10 };
+__host__ __device__ inline uint64_t max_regions(uint32_t max_csize, uint32_t max_out) {
+    const uint64_t most = (uint64_t)max_csize * 255 + 64;                // the format's largest expansion
+    const uint64_t out = max_out < most ? max_out : most;
+    return (out >> kRegionShiftPre) + 4;
+}
+__host__ __device__ inline uint64_t scratch_bytes(uint32_t max_csize, uint32_t max_out) {
+    return table_bytes(max_csize) + toks_bytes(max_csize) + max_regions(max_csize, max_out) * 4;
 }
 
 // 16 bytes as four dwords; byte i of the chunk is byte (i & 3) of dword (i >> 2).
@@ -178,9 +189,17 @@ enum : uint32_t { OUT_NONE = 0, OUT_MERGE = 1, OUT_EXIT = 2, OUT_STOP = 3, OUT_I
 // SLOW PATH (wave 0, every lane the same values; length fields are scanned 64 bytes at a time): the sequence whose
 // token is at p, whatever its size, with the reference's rules; its record goes to rectab[nrec].
 // Returns 0: go on at nx, 1: that was the block's last sequence, 2: malformed (position in errpos).
+// The region index: record rec covers output [o, oe); if the first byte of a 1 KB region lies in there, the FIRST such
+// region notes rec + 1 (0 = nothing noted: the index is zeroed before, and a sequence that covers several region
+// starts leaves holes behind the first, which the reader fills with a running maximum - entries only ever grow)
+__device__ __forceinline__ void region_note(uint32_t* ridx, uint32_t o, uint32_t oe, uint32_t rec, bool on) {
+    const uint32_t g = (o + (1u << kRegionShiftPre) - 1) >> kRegionShiftPre;
+    if (on && (g << kRegionShiftPre) < oe) ridx[g - (kBias >> kRegionShiftPre)] = rec + 1;
+}
+
 __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_t capB, uint32_t low, uint32_t p,
-                                          uint32_t& obase, uint32_t& nrec, SeqRec* rectab, uint32_t& nx_out, uint32_t& errpos, uint32_t& minref) {
-    const uint32_t lane = lane_id();
+                                          uint32_t& obase, uint32_t& nrec, SeqRec* rectab, uint32_t* ridx, uint32_t& nx_out, uint32_t& errpos, uint32_t& minref) {
+    const uint32_t lane = lane_here();
     errpos = p < csize ? p : (csize ? csize - 1 : 0);
     if (p >= csize) return 2;
     const uint32_t t = g[p];
@@ -204,6 +223,7 @@ __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_
     if (last) {
         if (rem != ll || room < ll) return 2;                               // lz4.c:2312-2318
         if (lane == 0) { SeqRec r; r.outpos = obase; r.litpos = q; r.ll = ll; r.off = 0; rectab[nrec] = r; }
+        region_note(ridx, obase, obase + ll, nrec, lane == 0);
         nrec++; obase += ll;
         return 1;
     }
@@ -229,6 +249,7 @@ __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_
     if (ms - off < minref) minref = ms - off;
     if (capB - ms < ml + kLastLiterals) return 2;                           // lz4.c:2423
     if (lane == 0) { SeqRec r; r.outpos = obase; r.litpos = q; r.ll = ll; r.off = off; rectab[nrec] = r; }
+    region_note(ridx, obase, ms + ml, nrec, lane == 0);
     nrec++; obase = ms + ml;
     nx_out = nx;
     return 0;
@@ -238,7 +259,7 @@ __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_
 // Returns false (uniformly) when the block is malformed (position in misc[M_ERR]); nseq_out / total_out otherwise.
 __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix,
                                                SeqRec* rectab, char* smem, uint64_t table_size,
-                                               uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof = nullptr) {
+                                               uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof = nullptr, uint32_t** ridx_out = nullptr) {
     uint64_t pt[6] = {0, 0, 0, 0, 0, 0}, pq = prof ? clock_ticks() : 0;       // developer profile: cycles in P1, P2, P3, P4, list, P5
 #define LZ4AMD_PSTAMP(i) do { if (prof) { const uint64_t t_ = clock_ticks(); pt[i] += t_ - pq; pq = t_; } } while (0)
     const uint32_t tid = threadIdx.x;
@@ -251,8 +272,11 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     uint8_t* mark = (uint8_t*)(smem + kOffMark);
     uint32_t* bm = (uint32_t*)(smem + kOffBitmap);
     uint32_t* toks = (uint32_t*)((char*)rectab + table_size);
+    uint32_t* ridx = (uint32_t*)((char*)toks + toks_bytes(csize));       // region (from the block's first) -> record
+    if (ridx_out) *ridx_out = ridx;
     const uint32_t capB = cap + kBias, low = kBias - prefix;
     if (tid == 0) { misc[M_ERR] = kNone; misc[M_MINREF] = kNone; }
+    for (uint32_t i = tid, n = (uint32_t)max_regions(csize, cap); i < n; i += kThreads) ridx[i] = 0;    // (ordered before P5's notes by the barriers between)
 
     uint32_t e = 0, obase = kBias, nrec = 0;          // uniform: next true token, output position, records written
     for (;;) {
@@ -464,7 +488,10 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
                           || capB - (o + ti[j].ll) < ti[j].ml + kLastLiterals;          // lz4.c:2279 (a sequence here is never the last), 2356, 2423
                     if (b) { atomicMin(&misc[M_ERR], tp[j]); bad = 1; }
                     else if (o + ti[j].ll - ti[j].off < kBias) atomicMin(&misc[M_MINREF], o + ti[j].ll - ti[j].off);    // reaches into the history
-                    if (!b) { SeqRec r; r.outpos = o; r.litpos = ti[j].q; r.ll = ti[j].ll; r.off = ti[j].off; rectab[nrec + i0 + 64 * j] = r; }
+                    if (!b) {
+                        SeqRec r; r.outpos = o; r.litpos = ti[j].q; r.ll = ti[j].ll; r.off = ti[j].off; rectab[nrec + i0 + 64 * j] = r;
+                        region_note(ridx, o, o + ti[j].ll + ti[j].ml, nrec + i0 + 64 * j, true);
+                    }
                 }
             }
             if (__syncthreads_or(bad)) return false;
@@ -476,7 +503,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         if (stop) {
             if (tid < 64) {
                 uint32_t nx = 0, ep = 0, mr = kNone;
-                const int rc = slow_token(src, csize, capB, low, tend, obase, nrec, rectab, nx, ep, mr);
+                const int rc = slow_token(src, csize, capB, low, tend, obase, nrec, rectab, ridx, nx, ep, mr);
                 if (tid == 0 && mr < misc[M_MINREF]) misc[M_MINREF] = mr;
                 if (tid == 0) { misc[M_RC] = (uint32_t)rc; misc[M_NX] = nx; misc[M_OBASE] = obase; misc[M_NREC] = nrec; if (rc == 2) misc[M_ERR] = ep; }
             }

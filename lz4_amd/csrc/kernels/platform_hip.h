@@ -57,6 +57,15 @@ __device__ __forceinline__ void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u3
     a = q[0]; b = q[1];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// ... followed, in this order and in the same trip to the LDS, by two dwords (the DS unit serves one wave's reads in
+// issue order: what the two dwords hold was published before the words in a and b were)
+__device__ __forceinline__ void lds_load_pair16_then2(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b, const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) {
+    const volatile __attribute__((address_space(3))) lz4amd_u32x4* q = (const volatile __attribute__((address_space(3))) lz4amd_u32x4*)p;
+    a = q[0]; b = q[1];
+    v0 = *(const volatile __attribute__((address_space(3))) uint32_t*)p0;
+    v1 = *(const volatile __attribute__((address_space(3))) uint32_t*)p1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // LDS operations of one wave are issued and serviced in program order; this only keeps the
 // compiler from moving LDS accesses of the wave across the point (the CPU interpreter used by the
 // unit tests needs a real rendezvous here, because its lanes do not run in lockstep).
@@ -78,6 +87,10 @@ __device__ __forceinline__ void lds_store_relaxed(uint32_t* w, uint32_t v) {
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// x, unknown to the optimiser from here on: whatever is computed from it is computed HERE, not at the top of the kernel.
+// (Everything derived from the thread index is loop invariant for the whole kernel; hoisted there, dozens of such
+// values stay live through every phase of every block and push the phases' own values out to scratch memory.)
+__device__ __forceinline__ uint32_t opaque_u32(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8); }
 __device__ __forceinline__ void chain_wait_pause() { __builtin_amdgcn_s_sleep(32); }      // waiting for another workgroup

@@ -105,10 +105,11 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
     p->d_results = (int*)dres;
 
     if (op == LZ4AMD_OP_DECOMPRESS) {
-        unsigned max_c = 0, grid;
+        unsigned max_c = 0, max_cap = 0, grid;
         lz4amd_dec_params* q = &p->dec;
         for (i = 0; i < n; i++) {
             if (src_sizes[i] > 0 && (unsigned)src_sizes[i] > max_c) max_c = (unsigned)src_sizes[i];
+            if (dst_caps[i] > 0 && (unsigned)dst_caps[i] > max_cap) max_cap = (unsigned)dst_caps[i];
         }
         /* one 1024-thread workgroup owns a CU's LDS; blocks are pulled from a ticket counter */
         grid = (unsigned)ctx->n_cus;
@@ -118,7 +119,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
         q->prefix = NULL;
-        q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c) + 255) & ~(uint64_t)255;
+        q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c, max_cap) + 255) & ~(uint64_t)255;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase timestamps */
             q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));

@@ -94,7 +94,7 @@ extern "C" float lz4amd_hip_event_ms(void* a, void* b) {
     return ms;
 }
 
-extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize) { return (size_t)dec_scratch_bytes(max_csize); }
+extern "C" size_t lz4amd_hip_dec_scratch_bytes(unsigned max_csize, unsigned max_out) { return (size_t)dec_scratch_bytes(max_csize, max_out); }
 extern "C" size_t lz4amd_hip_hc_scratch_bytes(unsigned max_src) { return (size_t)hc_scratch_bytes(max_src); }
 extern "C" int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned grid, void* s) {
     if (!p->n_blocks || !grid) return 0;

@@ -30,7 +30,7 @@ int         lz4amd_hip_event_sync(void* ev);
 float       lz4amd_hip_event_ms(void* start, void* stop);
 
 /* kernel geometry facts the host needs for sizing */
-size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize);
+size_t      lz4amd_hip_dec_scratch_bytes(unsigned max_csize, unsigned max_out);
 size_t      lz4amd_hip_hc_scratch_bytes(unsigned max_src);
 
 /* launches (asynchronous on `stream`) */

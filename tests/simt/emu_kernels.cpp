@@ -24,8 +24,10 @@ extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int3
     uint32_t max_c = 0;
     for (uint32_t i = 0; i < n; i++)
         if (src_size[i] > 0 && (uint32_t)src_size[i] > max_c) max_c = src_size[i];
+    uint32_t max_cap = 0;
+    for (uint32_t i = 0; i < n; i++) if (dst_cap[i] > 0 && (uint32_t)dst_cap[i] > max_cap) max_cap = dst_cap[i];
     if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
-    uint64_t stride = (dec_scratch_bytes(max_c) + 15) & ~15ull;
+    uint64_t stride = (dec_scratch_bytes(max_c, max_cap) + 15) & ~15ull;
     std::vector<uint8_t> scratch((size_t)(stride * grid + 64));
     uint32_t ticket = 0;
     DecBatch P;
@@ -42,8 +44,10 @@ extern "C" int emu_decompress_chained(const uint8_t* const* src, const int32_t* 
     using namespace lz4amd;
     uint32_t max_c = 0;
     for (uint32_t i = 0; i < n; i++) if (src_size[i] > 0 && (uint32_t)src_size[i] > max_c) max_c = src_size[i];
+    uint32_t max_cap = 0;
+    for (uint32_t i = 0; i < n; i++) if (dst_cap[i] > 0 && (uint32_t)dst_cap[i] > max_cap) max_cap = dst_cap[i];
     if (grid == 0) grid = n < 4 ? (n ? n : 1) : 4;
-    uint64_t stride = (dec_scratch_bytes(max_c) + 15) & ~15ull;
+    uint64_t stride = (dec_scratch_bytes(max_c, max_cap) + 15) & ~15ull;
     std::vector<uint8_t> scratch((size_t)(stride * grid + 64));
     std::vector<uint8_t*> dsts(n ? n : 1, dst0);
     std::vector<long long> chain(n + 1, -1); chain[0] = 0;

@@ -22,6 +22,7 @@ static inline void wave_lds_fence() { (void)__ballot(1); }
 static inline void wave_lds_order() { (void)__ballot(1); }
 static inline void lds_store_relaxed(uint32_t* w, uint32_t v) { *(volatile uint32_t*)w = v; }
 static inline uint32_t lanes_below(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << (simt::cur()->tid & 63u)) - 1)); }
+static inline uint32_t opaque_u32(uint32_t x) { return x; }
 static inline void spin_pause() { simt::yield_to_sched(); }
 static inline long long chain_load_acquire(const long long* w) { return __atomic_load_n(w, __ATOMIC_ACQUIRE); }
 static inline void chain_store_release(long long* w, long long v) { __atomic_store_n(w, v, __ATOMIC_RELEASE); }
@@ -33,6 +34,10 @@ static inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
 }
 typedef uint32_t lz4amd_u32x4 __attribute__((vector_size(16)));
 static inline void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b) { memcpy(&a, (const void*)p, 16); memcpy(&b, (const void*)(p + 1), 16); }
+static inline void lds_load_pair16_then2(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b, const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) {
+    lds_load_pair16(p, a, b);
+    v0 = *(const volatile uint32_t*)p0; v1 = *(const volatile uint32_t*)p1;
+}
 static inline lz4amd_u32x4 ld_global16_raw(const uint8_t* p) { lz4amd_u32x4 v; memcpy(&v, p, 16); return v; }
 static inline void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { memcpy(p, &v, 16); }
 static inline uint64_t clock_ticks() { return 0; }

@@ -1,7 +1,7 @@
 """Developer aid: role breakdown of the streaming decompress kernel (LZ4AMD_PROF stamps). GPU only.
 usage: prof_dec.py [n_blocks] [block_bytes] [P] [hc_level]"""
 import ctypes, os, sys, statistics
-os.environ["LZ4AMD_PROF"] = "1"
+if not os.environ.get("NOPROF"): os.environ["LZ4AMD_PROF"] = "1"        # NOPROF=1: kernel time only, without the stamps
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, lz4_amd
@@ -22,7 +22,7 @@ U, C = nb * bs, sum(csizes)
 print("decoder %s: %d x %d B P%d%s  kernel ms %.3f  GB/s out %.1f  (U+C)/t %.1f GB/s = %.3f of 8 TB/s" % (
     "v4", nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
 assert torch.equal(out, data), "decode mismatch"
-if True:
+if not os.environ.get("NOPROF"):
     L = lz4_amd.lib()
     w = (ctypes.c_ulonglong * (256 * 8))()
     n = L.lz4amd_plan_profile(plan._h, w, len(w))
