@@ -3,8 +3,10 @@
 // Replaces, for a whole batch of independent blocks resident in HBM, what the reference does per
 // block in LZ4_decompress_safe (lib/lz4.c:2451 -> LZ4_decompress_generic lz4.c:2023-2445; length
 // fields: read_variable_length lz4.c:1979-2014; end-of-block rules lz4.c:2276-2330, 2421-2429).
-// Accepts ANY legal LZ4 block, rejects what the reference's safe loop rejects, never reads outside
-// src[0,csize) nor writes outside dst[0,cap).  Not a port: the reference decoder is one serial
+// Accepts ANY legal LZ4 block, rejects what the reference's safe loop rejects, never writes outside
+// dst[0,cap) and never uses a byte outside src[0,csize) (the stream stage fetches the block in the
+// aligned 16-byte granules of its memory: the first and the last granule may reach up to 15 bytes
+// beyond the block, inside the granule, hence the page, that holds its first / last byte).  Not a port: the reference decoder is one serial
 // token chain per block.  Here ONE 1024-thread workgroup (16 waves, one CU, ~150 KB of its LDS)
 // decodes a block in two stages:
 //
@@ -15,13 +17,12 @@
 //
 //   B STREAM     a dataflow pipeline through LDS rings and counters only - no workgroup barrier
 //       between the first and the last byte of the block:
-//       LOADER (wave 14)  streams the compressed block into a 32 KB LDS ring (coalesced 16-byte
-//           loads, the next 4 KB in flight while the last is written).
-//       FEEDER (wave 15)  a plain mover: the record table -> a 2048-row LDS ring, 256 rows at a
-//           time, and the pre-parse's region index (for every 1 KB REGION of output the record that
-//           holds its first byte) -> a 512-entry LDS ring.  No per-record work.
-//       (both run as far ahead as the rings allow)
-//       COPY (waves 0-13)  output-stationary: wave w owns regions w, w+14, ... .  A region is
+//       MOVER (wave 15)  moves everything the copy reads into LDS and does nothing else: the
+//           compressed block -> a 32 KB ring (coalesced 16-byte loads, 4 KB a trip), the record
+//           table -> a 2048-row ring (256 rows a trip), the pre-parse's region index (for every
+//           1 KB REGION of output the record that holds its first byte) -> a 512-entry ring; the
+//           next batch of each is in flight while the copy works; as far ahead as the rings allow.
+//       COPY (waves 0-14)  output-stationary: regions are handed out in order to whichever wave is free.  A region is
 //           composed in its slot of a 80 KB LDS ring that always holds the 64 KB LZ4 window, from
 //           PIECES (the literal run or the match of a record, cut at 16-byte chunk borders) in two
 //           lane-uniform rounds: round A, lane = chunk, writes the piece that covers the chunk's
@@ -32,7 +33,7 @@
 //           Sources still in flight on another wave are waited for through per-chunk done bits;
 //           finished regions go to HBM with one 16-byte store per lane (1 KB contiguous per wave).
 //
-// HBM/L2 traffic per block: compressed bytes read by the pre-parse and once more by the loader,
+// HBM/L2 traffic per block: compressed bytes read by the pre-parse and once more by the mover,
 // the record table written and read once (16 B per sequence) and the region index (4 B per KB of
 // output), output written once; matches and
 // literals never touch HBM during the copy.  No MFMA: byte moves.
@@ -57,9 +58,8 @@ struct alignas(16) DoneEnt { uint64_t mask; uint32_t tag, pad; };
 enum : uint32_t {
     kDecThreads = 1024,
     kDecWaves = kDecThreads / 64,
-    kFeedWave = kDecWaves - 1,                  // sequence records -> LDS
-    kLoadWave = kDecWaves - 2,                  // compressed stream -> LDS
-    kCopyWaves = kDecWaves - 2,                 // waves 0 .. kCopyWaves-1
+    kMoveWave = kDecWaves - 1,                  // compressed stream, sequence records, region index -> LDS
+    kCopyWaves = kDecWaves - 1,                 // waves 0 .. kCopyWaves-1
     kChunk = 16,                                // output bytes composed at a time
     kRegionShift = 10,
     kRegion = 1u << kRegionShift,               // 64 chunks
@@ -69,12 +69,11 @@ enum : uint32_t {
     kMaxLead = kSlots - 64 - 1,                 // a wave may lead the first unfinished region by this many
     kCrBytes = 32u << 10,                       // compressed ring (direct mapped: position mod 32 K)
     kCrPad = 32,
-    kLoadBatch = 4096,                          // bytes the feeder moves per step
     kRecCap = 2048,                             // sequence-record ring (1024 rows filled up on many-sequence data: HC-compressed 256 KiB blocks waited for room)
     kRecMask = kRecCap - 1,
     kIdxRing = 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
-    kFeedRows = 256,                            // table rows the feeder moves per trip
+    kDmaDepth = 16,                             // LDS-DMA instructions (1 KB each) the mover keeps in flight
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
     kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kFirstRegion = kBias >> kRegionShift,
@@ -108,6 +107,8 @@ __host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize, uint32
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // position in the compressed ring
 __device__ __forceinline__ uint32_t mod_cr(uint32_t x) { return x & (kCrBytes - 1); }
+// the compressed block's misalignment in memory
+__device__ __forceinline__ uint32_t stream_misalign(lz4amd_gsrc src) { return (uint32_t)(uintptr_t)src & 15u; }
 static_assert((kCrBytes & (kCrBytes - 1)) == 0, "ring size");
 __device__ __forceinline__ uint32_t cr_fold(uint32_t a) { return umin32(a, a - kCrBytes); }        // [0, 2*32K) -> [0, 32K)
 __device__ __forceinline__ uint32_t ring_fold(uint32_t a) { return umin32(a, a - kRingBytes); }
@@ -182,66 +183,32 @@ __device__ __forceinline__ uint32_t first_open_region(const char* smem) {
     return uload((const uint32_t*)(smem + kOffMisc) + M_OPEN);
 }
 
-// ------------------------------------------------------------------------------ LOADER
-// The compressed block -> the 32 KB LDS ring the copy reads its literals from (coalesced 16-byte loads, the next
-// 4 KB in flight while the last is written); it runs as far ahead as the ring allows.
-__device__ __forceinline__ void loader_role(lz4amd_gsrc src, uint32_t csize, char* smem) {
-    uint8_t* cr = (uint8_t*)(smem + kOffCr);
-    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    const uint32_t lane = lane_here();
-    U32x4 cur[4], nxt[4];
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) { const uint32_t P = 16 * (lane + 64 * i); if (P < csize) cur[i] = load_granule(src, csize, P); }
-    uint32_t L = 0;
-    while (L < csize) {
-        // bytes [L, L + batch) may be written once nobody needs the bytes 32 K below them
-        for (;;) {
-            const uint32_t clo = uload(&misc[M_CLO]);
-            if (L + kLoadBatch <= clo + kCrBytes) break;
-            spin_pause_long();
-        }
-        const uint32_t nL = L + kLoadBatch;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) { const uint32_t P = nL + 16 * (lane + 64 * i); if (P < csize) nxt[i] = load_granule(src, csize, P); }
-        const uint32_t a0 = mod_cr(L);
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-            const uint32_t o = 16 * (lane + 64 * i);
-            if (L + o < csize) {
-                const uint32_t a = cr_fold(a0 + o);
-                *(U32x4*)(cr + a) = cur[i];
-                if (a < kCrPad) *(U32x4*)(cr + kCrBytes + a) = cur[i];
-            }
-        }
-        wave_lds_fence();
-        if (lane == 0) lds_store_release(&misc[M_CHI], nL < csize ? nL : csize);
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) cur[i] = nxt[i];
-        L = nL;
-    }
-}
-
-// ------------------------------------------------------------------------------ FEEDER
-// A plain mover: the record table -> the 2048-row LDS ring, 256 rows a trip (the next 256 on their way from memory
-// meanwhile), and the pre-parse's region index (first record of every 1 KB region of output) -> its LDS ring, 64
-// regions a trip.  No per-record work: whatever the copy needs to know about a region it reads from those two rings.
-// It also tells the loader which stream bytes the copy has left behind.  Nothing here blocks on the copy: whatever
-// does not fit now is tried again on the next trip.
-__device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t rend, char* smem) {
+// ------------------------------------------------------------------------------ MOVER
+// One wave moves everything the copy reads into LDS, as far ahead as the rings allow, and does nothing else:
+//   * the compressed block -> the 32 KB ring the literals are read from,
+//   * the record table -> the 2048-row record ring,
+//   * the pre-parse's region index (first record of every 1 KB region of output) -> its 512-entry ring, 64 a trip.
+// Stream and records travel by LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no registers in between), up to
+// kDmaDepth KB in flight; the wave keeps the order of what it issued in a bit queue and publishes what has landed.
+// The stream is fetched in the ALIGNED 16-byte granules of its memory (position P sits at ring address P + mis, mis =
+// the block's misalignment): the first and the last granule reach up to 15 bytes beyond the block, inside the same
+// granule (and page); those bytes are never used.  No per-record work: whatever the copy needs to know about a region it
+// reads from the rings.  Nothing here blocks on the copy: what does not fit now is tried on the next trip.
+__device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t rend, char* smem) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     uint32_t* idx = (uint32_t*)(smem + kOffIdx);
-    SeqRec* recs = (SeqRec*)(smem + kOffRecs);
+    const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
+    char* cr = smem + kOffCr;
     const uint32_t lane = lane_here();
     wave_priority_high();                              // fifteen waves wait for what this one produces
     const uint32_t nrows = nseq + 1;                   // (the table ends with a sentinel row: where the block's output ends)
-    uint32_t head = 0, ihead = kFirstRegion, tail = 0, clo_sent = 0;
-    // the next batch of rows, in registers / on its way from memory: [head, head + 256)
-    SeqRec pa[kFeedRows / 64];
-#pragma unroll
-    for (uint32_t k = 0; k < kFeedRows / 64; k++) {
-        pa[k].outpos = pa[k].litpos = pa[k].ll = pa[k].off = 0;
-        if (64 * k + lane < nrows) pa[k] = rectab[64 * k + lane];
-    }
+    const uint32_t mis = stream_misalign(src);
+    lz4amd_gsrc src0 = src - mis;                      // 16-byte aligned
+    const uint32_t ngran = (mis + csize + 15) >> 4, nchunks = (ngran + 63) >> 6;      // granules, 1 KB chunks of the stream
+    uint32_t si = 0, sc = 0;                           // stream chunks issued / landed
+    uint32_t hi = 0, hc = 0;                           // table rows issued / landed (multiples of 64)
+    uint32_t ihead = kFirstRegion, tail = 0, need = 0;
+    uint64_t fifo = 0; uint32_t q = 0;                 // what is in flight, oldest at bit 0: 0 = a stream chunk, 1 = 64 table rows
     uint32_t pidx = 0, icarry = 0;
     if (ihead + lane < rend) pidx = ridx[lane];
     for (;;) {
@@ -266,34 +233,58 @@ __device__ __forceinline__ void feeder_role(uint32_t csize, const SeqRec* rectab
         wave_lds_fence();
         // ---- what the copy still needs: the first record and the first literal byte of the first open region g (both only
         //      ever move forward, so stale values are merely careful: less room)
-        uint32_t need = clo_sent;
         if (g >= rend) need = csize;
         else if (g < ihead) {
             tail = __builtin_amdgcn_readfirstlane(idx[g & kIdxMask]);
-            if (tail < head) {
+            if (tail < hc) {
                 const SeqRec r = recs[tail & kRecMask];
                 uint32_t d = (g << kRegionShift) - r.outpos; if (d > r.ll) d = r.ll;
                 need = __builtin_amdgcn_readfirstlane(r.litpos + d);
             }
         }
-        if (need != clo_sent) { clo_sent = need; if (lane == 0) lds_store_release(&misc[M_CLO], need); }   // what the loader may overwrite
-        // ---- records: rows [head, head + 256)
-        if (head < nrows) {
-            const uint32_t n = nrows - head < kFeedRows ? nrows - head : kFeedRows;
-            if (head + n - tail <= kRecCap) {
-#pragma unroll
-                for (uint32_t k = 0; k < kFeedRows / 64; k++) if (64 * k + lane < n) recs[(head + 64 * k + lane) & kRecMask] = pa[k];
-                head += n;
-#pragma unroll
-                for (uint32_t k = 0; k < kFeedRows / 64; k++) if (head + 64 * k + lane < nrows) pa[k] = rectab[head + 64 * k + lane];
-                progress = true;
+        // ---- issue: stream chunk si may be written once nobody needs the bytes 32 K below its last one; rows [hi, hi + 64)
+        //      once the ring has let go of the rows 2048 below them
+        bool issued = false;
+        while (q < kDmaDepth) {
+            bool did = false;
+            if (si < nchunks && ((si + 1) << 10) <= need + mis + kCrBytes) {
+                uint32_t gr = 64 * si + lane; if (gr >= ngran) gr = ngran - 1;
+                lds_dma16((const void*)(src0 + 16 * (uint64_t)gr), cr + ((si << 10) & (kCrBytes - 1)));
+                q++; si++; did = true;                                               // (its fifo bit is 0)
             }
+            if (q < kDmaDepth && hi < nrows && hi + 64 - tail <= kRecCap) {
+                lds_dma16(rectab + (hi + lane < nrows ? hi + lane : nrows - 1), (char*)recs + ((hi & kRecMask) << 4));      // (rows behind the table's last: the last again, nobody reads them)
+                fifo |= 1ull << q; q++; hi += 64; did = true;
+            }
+            if (!did) break;
+            issued = true;
+        }
+        // ---- retire: busy = all but the youngest half of the queue, idle = everything
+        uint32_t keep = q;
+        if (!issued) { vmem_wait<0>(); keep = 0; }
+        else if (q > kDmaDepth / 2) { vmem_wait<kDmaDepth / 2>(); keep = kDmaDepth / 2; }
+        if (keep < q) {
+            const uint32_t r = q - keep;
+            const uint32_t nrec = (uint32_t)__popcll(fifo & ((1ull << r) - 1ull));
+            const uint32_t s1 = sc + (r - nrec);
+            // the ring's pad mirrors its first 32 bytes: reads never wrap
+            if (((sc + (kCrBytes >> 10) - 1) & ~((kCrBytes >> 10) - 1)) < s1) {            // (a chunk that starts a lap has landed)
+                if (lane < kCrPad / 16) *(U32x4*)(cr + kCrBytes + 16 * lane) = *(const U32x4*)(cr + 16 * lane);
+            }
+            sc = s1; hc += 64 * nrec;
+            fifo >>= r; q = keep;
+            wave_lds_fence();
+            if (lane == 0) {
+                const uint32_t got = sc << 10;
+                lds_store_release(&misc[M_CHI], got <= mis ? 0u : (got - mis < csize ? got - mis : csize));
+            }
+            progress = true;
         }
         if (progress) {
             wave_lds_fence();
-            if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)head | ((uint64_t)ihead << 32));
+            if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(hc < nrows ? hc : nrows) | ((uint64_t)ihead << 32));
         }
-        if (head == nrows && ihead == rend && c.chi >= csize && need == csize) break;     // (the loader may still be behind: keep telling it what the copy has consumed)
+        if (hc >= nrows && ihead == rend && sc == nchunks) break;
         if (!progress) { spin_pause_long(); spin_pause_long(); }      // (the rings hold tens of thousands of cycles of work: a look every ~1000 is plenty, and every look takes issue slots from the copy waves of this SIMD)
     }
 }
@@ -304,6 +295,7 @@ struct RegionCtx {
     uint32_t R, x0, x1, slot;       // region, its output range, its ring slot
     uint32_t g;                     // regions below g are final
     uint32_t chi;                   // compressed bytes resident
+    uint32_t mis;                   // the compressed block's misalignment in memory (stream position P sits at ring address P + mis)
     uint32_t ringB;                 // output position of ring address 0 two laps below the region
     uint32_t j0, nrec;              // records that overlap the region
     uint64_t mydone;                // chunks of this region that are final
@@ -346,7 +338,7 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     key = kKeyAlways;
     // -- a literal piece: stream bytes [A, A + n)
     const uint32_t A = rec.litpos + (d - rec.outpos);
-    const uint32_t a = mod_cr(A - lo);                                       // (the ring is direct mapped; below position 0 only masked-off bytes)
+    const uint32_t a = mod_cr(A + C.mis - lo);                               // (the ring is direct mapped on memory address: position + the block's misalignment; below position 0 only masked-off bytes)
     const bool lit_ok = A + n <= C.chi;
     // -- a match piece: output bytes [s, s + n)
     uint32_t dist = rec.off;
@@ -608,7 +600,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     }
 }
 
-__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, uint32_t nseq, uint32_t total, uint32_t rend, char* smem, uint64_t* prof) {
+__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t nseq, uint32_t total, uint32_t rend, char* smem, uint64_t* prof) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const DoneEnt* ents = (const DoneEnt*)(smem + kOffBits);
     const uint32_t lane = lane_here();
@@ -622,7 +614,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gdst dst, uint32_t 
         R = __builtin_amdgcn_readfirstlane(R);
         if (R >= rend) break;
         const uint32_t slot = R % kSlots;
-        RegionCtx C; C.smem = smem; C.R = R; C.slot = slot;
+        RegionCtx C; C.smem = smem; C.R = R; C.slot = slot; C.mis = stream_misalign(src);
         C.x0 = R << kRegionShift;
         C.x1 = C.x0 + kRegion < kBias + total ? C.x0 + kRegion : kBias + total;
         // ---- wait until the region's records are in the ring and its ring slot is free: region R takes the slot of
@@ -698,9 +690,8 @@ __device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz
     __syncthreads();
 
     const uint32_t rend = (kBias + total + kRegion - 1) >> kRegionShift;          // regions [kFirstRegion, rend)
-    if (w == kFeedWave) feeder_role(csize, rectab, ridx, nseq, rend, smem);
-    else if (w == kLoadWave) loader_role(src, csize, smem);
-    else copy_role(w, dst, nseq, total, rend, smem, prof);
+    if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem);
+    else copy_role(w, src, dst, nseq, total, rend, smem, prof);
 
 }
 

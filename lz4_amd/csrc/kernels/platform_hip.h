@@ -91,6 +91,16 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 // (Everything derived from the thread index is loop invariant for the whole kernel; hoisted there, dozens of such
 // values stay live through every phase of every block and push the phases' own values out to scratch memory.)
 __device__ __forceinline__ uint32_t opaque_u32(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS, no register in between: lane l's 16 bytes land at
+// lds_dst + 16 * l (lds_dst: the same in every lane).  Asynchronous and unknown to the compiler's wait bookkeeping: the
+// bytes are there after vmem_wait<N>() with N = the number of LATER memory instructions of this wave that may still be
+// in flight (they complete in issue order; instructions the count misses only make the wait longer).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(a) : "memory");
+}
+template <int N> __device__ __forceinline__ void vmem_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8); }
 __device__ __forceinline__ void chain_wait_pause() { __builtin_amdgcn_s_sleep(32); }      // waiting for another workgroup

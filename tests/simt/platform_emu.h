@@ -23,6 +23,8 @@ static inline void wave_lds_order() { (void)__ballot(1); }
 static inline void lds_store_relaxed(uint32_t* w, uint32_t v) { *(volatile uint32_t*)w = v; }
 static inline uint32_t lanes_below(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << (simt::cur()->tid & 63u)) - 1)); }
 static inline uint32_t opaque_u32(uint32_t x) { return x; }
+static inline void lds_dma16(const void* gsrc, void* lds_dst) { memcpy((char*)lds_dst + 16 * (threadIdx.x & 63u), gsrc, 16); }
+template <int N> static inline void vmem_wait() {}
 static inline void spin_pause() { simt::yield_to_sched(); }
 static inline long long chain_load_acquire(const long long* w) { return __atomic_load_n(w, __ATOMIC_ACQUIRE); }
 static inline void chain_store_release(long long* w, long long v) { __atomic_store_n(w, v, __ATOMIC_RELEASE); }

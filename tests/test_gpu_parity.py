@@ -28,11 +28,11 @@ def _dev(b, pad=0, fill=0xEE):
     return t
 
 
-def gpu_decompress(ctx, comps, caps, guard=64):
+def gpu_decompress(ctx, comps, caps, guard=64, salign=0):
     import lz4_amd
-    srcs = [_dev(c, pad=16) for c in comps]
+    srcs = [_dev(b"\xA5" * salign + c, pad=16) for c in comps]      # the block at byte `salign` of an aligned allocation
     dsts = [torch.full((max(c, 0) + guard,), 0xEE, dtype=torch.uint8, device="cuda") for c in caps]
-    table = lz4_amd.BlockTable([s.data_ptr() for s in srcs], [len(c) for c in comps],
+    table = lz4_amd.BlockTable([s.data_ptr() + salign for s in srcs], [len(c) for c in comps],
                                [d.data_ptr() for d in dsts], caps)
     plan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, table)
     plan.launch(torch.cuda.current_stream().cuda_stream)
@@ -78,6 +78,15 @@ def test_decompress_reference_bytes(ctx, ocodec, corpus):
     comps = [ocodec.compress(d)[1] for d in corpus]                # byte-identical to the reference
     for d, (r, o) in zip(corpus, gpu_decompress(ctx, comps, [len(d) for d in corpus])):
         assert r == len(d) and o == d
+
+
+def test_decompress_sources_anywhere_on_the_16_byte_grid(ctx, ocodec, corpus):
+    """The stream is fetched in the aligned 16-byte granules of its memory: every misalignment of the block decodes alike."""
+    datas = [d for d in corpus if len(d) <= 300000]
+    comps = [ocodec.compress(d)[1] for d in datas]
+    for sal in (1, 7, 15):
+        for d, (r, o) in zip(datas, gpu_decompress(ctx, comps, [len(d) for d in datas], salign=sal)):
+            assert r == len(d) and o == d, (sal, len(d))
 
 
 def test_decompress_golden_reference_blocks(ctx, golden):

@@ -10,14 +10,18 @@ import pytest
 CANARY = 0xEE
 
 
-def emu_decompress(emu, blocks, caps, grid=0, align=0):
+def emu_decompress(emu, blocks, caps, grid=0, align=0, salign=0):
     n = len(blocks)
-    srcs = [ctypes.create_string_buffer(b, len(b)) if b else ctypes.create_string_buffer(1) for b in blocks]
+    # the compressed block at byte `salign` of the 16-byte grid (the decoder fetches the stream in aligned 16-byte granules)
+    srcs = [ctypes.create_string_buffer(b"\xA5" * (16 + salign) + b + b"\xA5" * 32, len(b) + 48 + salign) for b in blocks]
+    sptr = lambda buf: ((ctypes.addressof(buf) + 15) & ~15) + salign
     dsts = [ctypes.create_string_buffer(max(c, 0) + 96) for c in caps]
     for d in dsts:
         ctypes.memset(d, CANARY, len(d))
     ptr = lambda buf: ((ctypes.addressof(buf) + 15) & ~15) + align
-    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs])
+    for s, b in zip(srcs, blocks):
+        ctypes.memmove(sptr(s), b, len(b))
+    sp = (ctypes.c_void_p * n)(*[sptr(s) for s in srcs])
     dp = (ctypes.c_void_p * n)(*[ptr(d) for d in dsts])
     ss = (ctypes.c_int32 * n)(*[len(b) for b in blocks])
     dc = (ctypes.c_int32 * n)(*caps)
@@ -104,6 +108,13 @@ def test_decompress_capacities_and_alignment(emu, ocodec, datagen):
     for al in (1, 3, 8):
         (r, o), = emu_decompress(emu, [c], [n], align=al)
         assert r == n and o == d
+    for sal in (1, 5, 15):                      # the compressed block anywhere on the 16-byte grid
+        (r, o), = emu_decompress(emu, [c], [n], salign=sal)
+        assert r == n and o == d
+    small = ocodec.compress(d[:700])[1]
+    for sal in (0, 7, 15):
+        (r, o), = emu_decompress(emu, [small], [700], salign=sal)
+        assert r == 700 and o == d[:700]
 
 
 def _periodic_corpus():
