@@ -53,7 +53,6 @@ namespace lz4amd {
 using DecBatch = ::lz4amd_dec_params;     // argument block (lz4amd_params.h)
 
 using SeqRec = pre::SeqRec;               // { outpos, litpos, ll, off }, output positions biased by kBias
-struct alignas(16) DoneEnt { uint64_t mask; uint32_t tag, pad; };
 
 enum : uint32_t {
     kDecThreads = 1024,
@@ -86,8 +85,9 @@ enum : uint32_t {
     kOffMisc = 0,                                            // u32[64] control words
     kOffMaskTab = kOffMisc + 64 * 4,                         // U32x4[17]: byte masks, entry n selects bytes [0, n) of a chunk
     kOffFin = kOffMaskTab + 17 * 16 + 16,                    // u32[16] regions completed per copy wave
-    kOffBits = kOffFin + 16 * 4,                             // DoneEnt[kSlots]
-    kOffIdx = kOffBits + kSlots * 16,                        // u32[kIdxRing]
+    kOffBits = kOffFin + 16 * 4,                             // u8[kSlots * 64] per chunk of the output ring: the lap tag of the region whose bytes are final there
+    kOffRegDone = kOffBits + kSlots * 64,                    // u32[kSlots] region + 1 that is complete in the slot
+    kOffIdx = kOffRegDone + kSlots * 4,                      // u32[kIdxRing]
     kOffPend = kOffIdx + kIdxRing * 4,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
     kOffRecs = (kOffPend + kCopyWaves * (kMaxTrips + 2) * 8 + 15) & ~15u,   // SeqRec[kRecCap]
     kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
@@ -298,26 +298,22 @@ struct RegionCtx {
     uint32_t mis;                   // the compressed block's misalignment in memory (stream position P sits at ring address P + mis)
     uint32_t ringB;                 // output position of ring address 0 two laps below the region
     uint32_t j0, nrec;              // records that overlap the region
-    uint64_t mydone;                // chunks of this region that are final
+    uint32_t tagLo, tagHi;          // lap tags of the ring's two laps the region can read: the one below its own, its own
 };
 
-__device__ __forceinline__ bool chunk_is_final(const RegionCtx& C, uint32_t c) {
-    const uint32_t r = c >> 6;
-    if (r < C.g) return true;
-    if (r == C.R) return (C.mydone >> (c & 63)) & 1ull;
-    int32_t s = (int32_t)C.slot - (int32_t)(C.R - r); if (s < 0) s += kSlots;
-    const DoneEnt* e = (const DoneEnt*)(C.smem + kOffBits) + s;
-    uint32_t tag; uint64_t mask;
-    lds_load_tag_mask(&e->tag, &e->mask, tag, mask);         // the tag first: tag == want means the mask is this region's
-    const uint32_t want = r + kSlots;
-    return tag > want || (tag == want && ((mask >> (c & 63)) & 1ull));
-}
-// output bytes [sa, sb] final?  (sb - sa < 16)
+// Finality of output bytes is kept per 16-byte chunk of the output ring as ONE BYTE: the lap tag of the region whose
+// bytes are final there (a region's lap = region / kSlots; tag = lap + 1 mod 256, 0 = nothing yet).  A slot is recycled
+// only once nobody can read its old region (kMaxLead), so "the byte holds the tag of the lap I mean" is the whole test -
+// no region numbers, no 64-bit masks, no first-open-region compare.
+__device__ __forceinline__ uint32_t lap_tag(uint32_t lap) { return (lap + 1u) & 0xFFu; }
+// output bytes [sa, sb] final?  (sb - sa < 16; both within the 64 KB below the region's end)
 __device__ __forceinline__ bool range_is_final(const RegionCtx& C, uint32_t sa, uint32_t sb) {
-    if ((sb >> kRegionShift) < C.g) return true;
-    bool ok = chunk_is_final(C, sa >> 4);
-    if ((sb >> 4) != (sa >> 4)) ok = ok && chunk_is_final(C, sb >> 4);
-    return ok;
+    const uint8_t* done = (const uint8_t*)(C.smem + kOffBits);
+    const uint32_t oa = sa - C.ringB, ob = sb - C.ringB;                 // [0, 2 * ring): the lap below the region's, then its own
+    const bool ha = oa >= kRingBytes, hb = ob >= kRingBytes;
+    uint32_t fa, fb;
+    lds_load_flags2(done + ((ha ? oa - kRingBytes : oa) >> 4), done + ((hb ? ob - kRingBytes : ob) >> 4), fa, fb);
+    return fa == (ha ? C.tagHi : C.tagLo) && fb == (hb ? C.tagHi : C.tagLo);
 }
 __device__ __forceinline__ U32x4 ring_read16(const RegionCtx& C, uint32_t pos) {
     return lds_read16_at((const uint8_t*)(C.smem + kOffRing), ring_fold(pos - C.ringB));
@@ -436,13 +432,11 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     char* smem = C.smem;
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
-    DoneEnt* ents = (DoneEnt*)(smem + kOffBits);
+    uint8_t* done = (uint8_t*)(smem + kOffBits) + C.slot * 64;        // my chunks' bytes (they hold the tag of the lap below: not final)
     unsigned long long* pend = (unsigned long long*)(smem + kOffPend) + w * (kMaxTrips + 2);     // [0] scratch, [1..] trips
     const uint32_t lane = lane_here();
     const uint32_t slot_off = kOffRing + (C.slot << kRegionShift);
-    // the slot is mine now: no chunk of region R is done (mask first, then the tag)
-    if (lane == 0) { lds_store_release64(&ents[C.slot].mask, 0ull); lds_store_release(&ents[C.slot].tag, C.R + kSlots); }
-    C.mydone = 0;
+    {   const uint32_t lap = (C.R - C.slot) / kSlots; C.tagHi = lap_tag(lap); C.tagLo = lap_tag(lap - 1); }
     C.ringB = (C.R - C.slot - kSlots) << kRegionShift;
     // ---- round A: which record covers the first byte of each chunk?  (scratch: the slot itself)
     uint32_t* fs = (uint32_t*)(smem + slot_off);
@@ -507,9 +501,12 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
             for (;;) {
                 // chunks without a pending piece are final: tell the other waves
                 const uint64_t pendchunks = pendA | pendBc;
-                C.mydone = ~pendchunks;
                 const uint64_t pub = ~pendchunks & actm;
-                if (pub != published) { published = pub; if (lane == 0) lds_store_release64(&ents[C.slot].mask, pub); }
+                if (pub != published) {
+                    wave_lds_fence();                  // (their bytes first)
+                    if (((pub & ~published) >> lane) & 1ull) lds_store_flag(done + lane, C.tagHi);
+                    published = pub;
+                }
                 if (!pendchunks) break;
                 n_iter++;
                 {
@@ -589,7 +586,9 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
     if (actA) v = *(const U32x4*)(smem + slot_off + kChunk * lane);
     wave_lds_fence();                                   // (the slot is not read again: whoever recycles it may)
-    if (lane == 0) lds_store_release64(&ents[C.slot].mask, ~0ull);
+    lds_store_flag(done + lane, C.tagHi);
+    wave_lds_fence();
+    if (lane == 0) lds_store_release((uint32_t*)(smem + kOffRegDone) + C.slot, C.R + 1);
     if (actA) {
         const uint32_t c1 = c0 + kChunk < C.x1 ? c0 + kChunk : C.x1;
         if (c1 - c0 == kChunk) st_global16(dst + (c0 - kBias), v);
@@ -602,7 +601,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
 
 __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t nseq, uint32_t total, uint32_t rend, char* smem, uint64_t* prof) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
-    const DoneEnt* ents = (const DoneEnt*)(smem + kOffBits);
+    const uint32_t* regdone = (const uint32_t*)(smem + kOffRegDone);
     const uint32_t lane = lane_here();
     uint32_t k = 0;
     uint64_t t_rec = 0, t_lead = 0, t_work = 0, t_retry = 0;
@@ -654,9 +653,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
         for (;;) {
             const uint32_t g = uload(&misc[M_OPEN]);
             const uint32_t gs = g % kSlots;
-            uint32_t tag; uint64_t mask;
-            lds_load_tag_mask(&ents[gs].tag, &ents[gs].mask, tag, mask);
-            const bool complete = tag == g + kSlots && mask == ~0ull;
+            const bool complete = lds_load_acquire(&regdone[gs]) == g + 1;
             if (!__builtin_amdgcn_readfirstlane(complete ? 1u : 0u)) break;
             if (lane == 0) atomicCAS(&misc[M_OPEN], g, g + 1);
         }
@@ -675,7 +672,9 @@ __device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz
     if (tid == 0) { misc[M_ABORT] = 0; misc[M_SPARE] = 0; misc[M_CHI] = 0; misc[M_IHEAD] = kFirstRegion; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
     if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
     if (tid < 17) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid, k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
-    if (tid < kSlots) { DoneEnt e; e.mask = 0; e.tag = 0; e.pad = 0; ((DoneEnt*)(smem + kOffBits))[tid] = e; }
+    // chunk flags: the history before dst (positions below kBias = regions 0..63, lap 0) is final, nothing else is
+    for (uint32_t i = tid; i < kSlots * 16; i += kDecThreads) ((uint32_t*)(smem + kOffBits))[i] = i < kFirstRegion * 16 ? 0x01010101u * lap_tag(0) : 0u;
+    if (tid < kSlots) ((uint32_t*)(smem + kOffRegDone))[tid] = 0;
     if (prefix) {
         uint8_t* ring = (uint8_t*)(smem + kOffRing);
         const uint32_t lo = kBias - prefix;

@@ -51,6 +51,13 @@ __device__ __forceinline__ void lds_load_tag_mask(const uint32_t* tagp, const ui
     mask = *(const volatile __attribute__((address_space(3))) uint64_t*)maskp;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// two flag bytes another wave may be writing: read now (not hoisted, not cached), both in one trip to the LDS
+__device__ __forceinline__ void lds_load_flags2(const uint8_t* p0, const uint8_t* p1, uint32_t& v0, uint32_t& v1) {
+    v0 = *(const volatile __attribute__((address_space(3))) uint8_t*)p0;
+    v1 = *(const volatile __attribute__((address_space(3))) uint8_t*)p1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_store_flag(uint8_t* p, uint32_t v) { *(volatile __attribute__((address_space(3))) uint8_t*)p = (uint8_t)v; }
 // two consecutive 16-byte LDS reads issued back to back (one wait for both)
 __device__ __forceinline__ void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b) {
     const volatile __attribute__((address_space(3))) lz4amd_u32x4* q = (const volatile __attribute__((address_space(3))) lz4amd_u32x4*)p;
