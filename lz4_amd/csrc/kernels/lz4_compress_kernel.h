@@ -1031,6 +1031,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             { const uint64_t* m64 = (const uint64_t*)(smem + kCOffMisc); mx = m64[12]; mn = m64[13]; sm = m64[14] * kCmpWaves; }
 #endif
             prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = (uint64_t)misc[6] << 4; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
+#ifdef LZ4AMD_PROF_WAVES
+            for (uint32_t i = 0; i < 8; i++) prof[i] = (uint64_t)misc[16 + 2 * i] | ((uint64_t)misc[17 + 2 * i] << 32);      // developer build: match + emit time of each wave (>> 4)
+#endif
 #ifdef LZ4AMD_PROF_MATCH
             // developer build: wave 0's match time by phase (probe, runs, list, measure, select, records)
             prof[2] = mtp[0]; prof[3] = mtp[1]; prof[5] = mtp[2]; prof[6] = mtp[3]; prof[7] = mtp[4]; prof[0] = mtp[5];

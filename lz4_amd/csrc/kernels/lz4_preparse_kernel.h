@@ -35,6 +35,7 @@ enum : uint32_t {
     kSpanMax = 1u << 20,                        // stream bytes per span
     kSegMin = 64,                              // a thread's segment is at least this long (short blocks use fewer threads; 256 -> 64: 64 KiB blocks decode 12 % faster)
     kBridgeTrips = 192,                         // lockstep trips of the bridge walk (96: more spans cut short, 4 MiB blocks 25 % slower; 384: no change)
+    kBridgeFirst = 96,                          // ... of its first stage (32: the true chain is still walking more often than not; 64 / 128: as 96 within noise)
     kExtMax = 64,                               // longer length fields take the slow path
     kBias = 65536,                              // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kNone = 0xFFFFFFFFu,
@@ -315,9 +316,17 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         // ---- P2: walk on until a marked position (a token of a later thread's walk)
         const uint32_t x = s.p;
         uint32_t okind = !inuse ? OUT_IDLE : (s.dead ? OUT_STOP : OUT_NONE), opos = s.dead ? s.tok : s.p, nb = 0;
-        for (uint32_t trip = 0;; trip++) {
+        // (in stages: all that matters is that the threads ON THE TRUE CHAIN have merged, and they do so within a few tokens; the
+        //  slowest of a thousand walkers - one that started inside literals and decodes noise - nearly always needs all the trips
+        //  there are, and every wave would wait for it.  So: a short walk, P3; only if the true chain ends in a thread that is
+        //  still walking, the walk goes on.)
+        uint32_t trip = 0, stage_limit = kBridgeFirst;
+        bool active; uint32_t term, tend, myT; bool stop;
+        for (;;) {
+        for (;; trip++) {
             const bool run = okind == OUT_NONE;
             if (!__any(run)) break;
+            if (trip >= stage_limit) break;
             const bool at_tok = s.mode == 0;
             const bool c_exit = at_tok && s.p >= sp1;
             uint32_t bit = 0;
@@ -356,15 +365,19 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
             jump[tid] = (uint16_t)j2;
             __syncthreads();
         }
-        const bool active = mark[tid] != 0;
+        active = mark[tid] != 0;
         if (active && okind == OUT_MERGE) tinv[(opos - sp0) / S] = opos;
         if (active && okind != OUT_MERGE) misc[M_TERM] = tid;
         __syncthreads();
-        const uint32_t term = misc[M_TERM];
-        const uint32_t tend = oposv[term];
-        const bool stop = kindv[term] == OUT_STOP;
-        const uint32_t myT = tinv[tid];
+        term = misc[M_TERM];
+        tend = oposv[term];
+        stop = kindv[term] == OUT_STOP;
+        myT = tinv[tid];
         LZ4AMD_PSTAMP(2);
+        if (kindv[term] != OUT_NONE || stage_limit > kBridgeTrips) break;       // (the second stage runs to the end: c_trips)
+        stage_limit = kBridgeTrips + 1;
+        __syncthreads();
+        }
         // ---- P4: the bitmap of the true tokens in [e, tend)
         for (uint32_t w = 0; w < wps; w++) {
             const uint32_t base = seg_lo + 32 * w;

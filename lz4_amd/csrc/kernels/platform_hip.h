@@ -113,6 +113,8 @@ __device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8);
 __device__ __forceinline__ void chain_wait_pause() { __builtin_amdgcn_s_sleep(32); }      // waiting for another workgroup
 // issue priority of this wave among the waves of its SIMD (0..3)
 __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
+// (0..3, wave-uniform; the instruction takes an immediate)
+__device__ __forceinline__ void wave_priority(uint32_t p) { if (p == 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
 
 // {hi,lo} >> (8 * (sh & 3)), low 32 bits (v_alignbyte_b32)
 __device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {

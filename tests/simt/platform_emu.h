@@ -25,6 +25,7 @@ static inline uint32_t lanes_below(unsigned long long m) { return (uint32_t)__bu
 static inline uint32_t opaque_u32(uint32_t x) { return x; }
 static inline void lds_dma16(const void* gsrc, void* lds_dst) { memcpy((char*)lds_dst + 16 * (threadIdx.x & 63u), gsrc, 16); }
 template <int N> static inline void vmem_wait() {}
+static inline void wave_priority(uint32_t) {}
 static inline void spin_pause() { simt::yield_to_sched(); }
 static inline long long chain_load_acquire(const long long* w) { return __atomic_load_n(w, __ATOMIC_ACQUIRE); }
 static inline void chain_store_release(long long* w, long long v) { __atomic_store_n(w, v, __ATOMIC_RELEASE); }
