@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lz4_amd", "csrc")
 LIB = os.path.join(ROOT, "lz4_amd", "liblz4_amd.so")
-HOST_C = ["lz4amd_batch.c", "lz4_api.c", "lz4_stream_api.c", "lz4hc_api.c", "lz4frame_api.c", "lz4frame_stream_api.c", "lz4_compat_api.c"]
+HOST_C = ["lz4amd_batch.c", "lz4_api.c", "lz4_stream_api.c", "lz4hc_api.c", "lz4frame_api.c", "lz4frame_stream_api.c", "lz4_compat_api.c", "lz4file_api.c"]
 
 
 def _run(cmd, cwd=None):

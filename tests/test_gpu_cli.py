@@ -50,3 +50,20 @@ def test_cli_bench_mode_and_pipes(datagen, tmp_path):
     assert c.returncode == 0
     d = subprocess.run([THEIRS, "-dc"], input=c.stdout, capture_output=True, timeout=120)
     assert d.returncode == 0 and d.stdout == src.read_bytes()
+
+
+def test_file_helper_example_round_trip(datagen, tmp_path):
+    """SURVEY 8(f) item 4, lib/lz4file.h: the reference's examples/fileCompress.c (unmodified; LZ4F_writeOpen / LZ4F_write /
+    LZ4F_writeClose, LZ4F_readOpen / LZ4F_read / LZ4F_readClose) compiled against include/lz4file.h and linked against the
+    library: compresses a file, decodes it again, verifies; the reference CLI decodes the .lz4 it wrote as well."""
+    exe = os.path.join(REF, "fileCompress_amd")
+    if not (os.path.exists(exe) and os.path.exists(THEIRS)):
+        pytest.skip("oracle/_ref/fileCompress_amd not built (needs /root/reference at build time)")
+    src = tmp_path / "in.bin"
+    src.write_bytes(datagen(3000000, 60, 23))
+    r = _run(exe, str(src))
+    assert r.returncode == 0 and b"verify : OK" in r.stdout, (r.stdout[-300:], r.stderr[-300:])
+    assert open(str(src) + ".lz4.dec", "rb").read() == src.read_bytes()
+    out = str(tmp_path / "ref.out")
+    assert _run(THEIRS, "-d", "-f", str(src) + ".lz4", out).returncode == 0
+    assert open(out, "rb").read() == src.read_bytes()
