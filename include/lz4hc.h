@@ -11,8 +11,11 @@
  * The streaming HC context (lz4hc.h:98-180) tracks where the previous data is and ships its last 64 KB with
  * every block as history (lz4hc_api.c).
  *
- * Not provided (SURVEY.md section 8f "next"): LZ4_compress_HC_destSize, LZ4_attach_HC_dictionary, and the
- * optimal parser of levels 10-12 (those levels run the level-9 search; lz4amd_last_notice() says so after such a call).
+ * Levels 10-12 (lz4hc.c:92-106, LZ4HC_compress_optimal 1823-2130) run an optimal parse on the device: the level-9 search
+ * result of every position, then the cheapest sequence boundaries by price (kernels/lz4_hc_kernel.h: hc_parse_strip_opt).
+ * One setting for the three levels (256 candidates per position, 64-byte sufficient length: between the reference's
+ * levels 10 and 11); lz4amd_last_notice() says so after a call with level 11 or 12.  LZ4MID (level 2) is served by the
+ * hash-chain search with 4 candidates.
  */
 #ifndef LZ4_AMD_LZ4HC_H
 #define LZ4_AMD_LZ4HC_H

@@ -101,7 +101,7 @@ static_assert(kHOffParse + kHcWaves * 2 * kHcChunk * 4 <= kHcLdsBytes, "parse st
 static_assert(kHcLdsBytes <= 160 * 1024, "one CU's LDS");
 static_assert(kHcBands * kHcBandStep >= 65535 + kHcTile + kHcAhead, "bands must cover the LZ4 window");
 static_assert(kHOffMine % 16 == 0 && kHOffRes0 % 16 == 0 && kHOffRes1 % 16 == 0 && kHOffChain % 16 == 0, "16-byte LDS accesses");
-enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5, HM_NLIST = 6 };
+enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5, HM_NLIST = 6, HM_FIRST0 = 16 /* [16]: first record of each strip's record area */ };
 
 // scratch layout of one workgroup, for blocks of at most n bytes
 __host__ __device__ inline uint64_t hc_chain_bytes(uint32_t n) { return ((uint64_t)2 * (n + 64) + 255) & ~255ull; }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void hc_group_links(uint32_t h, bool valid, uint32_t*
 }
 
 __device__ __forceinline__ void hc_build_chain(lz4amd_gsrc src, uint32_t n, uint16_t* chain_g, char* smem) {
-    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t tid = opaque_u32(threadIdx.x), lane = lane_here(), w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
     uint32_t* head = (uint32_t*)(smem + kHOffHead);
     uint32_t* wtab = (uint32_t*)(smem + kHOffWtab) + w * 256;
@@ -256,7 +256,7 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
 
 __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
                                                uint32_t band, uint32_t attempts, char* smem) {
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = opaque_u32(threadIdx.x);
     uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
     uint16_t* cring = (uint16_t*)(smem + kHOffChain);
     uint8_t* mine = (uint8_t*)(smem + kHOffMine);
@@ -329,7 +329,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
         //    and predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
         //    nothing else on the path), then VERIFIES the candidates found (independent reads).
         {
-            const uint32_t lane = lane_id();
+            const uint32_t lane = lane_here();
             bool pool_dry = false;                                       // the tile's pool of runs is empty
             uint32_t run_left = 0;                                       // positions of my run still to start
             uint32_t inh_len = 0, inh_off = 0;                           // what the previous position of my run leaves to the next
@@ -476,7 +476,7 @@ __device__ __forceinline__ uint64_t hc_ld8(lz4amd_gsrc src, uint32_t n, uint32_t
 
 __device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, const uint32_t* best_g, MatchRec* recs,
                                                uint32_t* strip, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce) {
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_here();
     uint32_t nseq = 0, enc = 0, ll0 = 0, anchor = cs;
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         const uint32_t last_q = n - kMfLimit;
@@ -551,9 +551,148 @@ __device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, cons
     }
 }
 
+// ------------------------------------------------------------------------------ phase 3, levels 10-12: optimal parse (one strip)
+// What LZ4HC_compress_optimal does for the reference's levels 10-12 (lz4hc.c:1823-2130): instead of taking matches
+// greedily with a two-position lookahead, choose the sequence boundaries that minimise the encoded size, given every
+// position's longest match (any shorter length at the same offset may be used too).  price[c] = fewest bytes that encode
+// the strip up to cell c; from cell p one can go to p + 1 by a literal (1 byte, 1 more when the literal run reaches a
+// length-field boundary: 15, 270, ... lz4hc.c:1730-1740 LZ4HC_literalsPrice) or to p + ml by a match (token + offset +
+// length bytes: 3, 4 from ml = 19 on; lz4hc.c:1743-1759 LZ4HC_sequencePrice).  A match longer than the window is taken at
+// once, as the reference does with its sufficient length (lz4hc.c:1893-1901).
+//
+// Not the reference's loop: the prices of the next 64 cells live in ONE VGPR, cell p + 1 + l in lane l.  A step is a
+// lane shift (DPP), one candidate per lane (lane l: the match of length l + 1 from p; lane 0: the literal) and a min -
+// no memory access on the path from one position to the next.  The winning move of every cell (literal run length so
+// far, or match length) goes to a 2-byte-per-position array (the search's second state array, free by now); a backward
+// walk over it, staged through LDS in chunks, yields the sequences, which are recorded from the end of the strip's
+// record area towards its start.
+enum : uint32_t { kOptWin = 64, kOptLit = 0x8000u, kOptInf = 0xFFFFFF00u };
+
+__device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, const uint32_t* best_g, uint16_t* choice_g, MatchRec* recs, uint32_t rec_cap,
+                                                   uint32_t* strip, uint32_t* first_rec, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce) {
+    const uint32_t lane = lane_here();
+    uint32_t nseq = 0, enc = 0, ll0 = 0, tail = ce - cs;
+    if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
+        const uint32_t last_q = n - kMfLimit;
+        uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
+        // ---- forward: prices
+        uint32_t win = kOptInf;                                          // lane l: price << 8 | move of cell p + 1 + l (move: 0 literal, else match length)
+        uint32_t P = 0, ll_cur = 0, ll_bump = 15;                        // cell p: its price, the literal run that ends there; the run length at which the next length byte opens (15, 270, ...)
+        uint32_t chv = 0, chbase = cs; uint64_t chm = 0;                 // moves of cells [chbase, chbase + 64), lane = cell - chbase (cs is a multiple of 64); chm: the lanes that hold one
+        // (only those are stored: the cells around a strip's ends belong to the neighbouring strips' waves)
+        uint32_t bv = 0, bbase = 0xFFFFFFFFu;                            // search results of positions [bbase, bbase + 64)
+        uint32_t p = cs;
+        while (p < ce) {
+            if ((p & ~63u) != bbase) { bbase = p & ~63u; bv = best_g[bbase + lane]; }        // (the array is padded)
+            const uint32_t s = wave_readlane(bv, p & 63u);
+            uint32_t L = s & 0xFFu; const uint32_t of = s >> 8;
+            if (p > last_q || L < kMinMatch || p + kMinMatch > mlimit) L = 0;
+            uint32_t np, nP, move;                                       // the next cell, its price, the move that reaches it
+            if (L > kOptWin) {
+                // -- longer than the window: taken at once (measured to its end if the search capped it)
+                uint32_t ml = L;
+                if (ml >= kHcLenCap && p + ml < mlimit) {
+                    for (;;) {
+                        const uint32_t a = p + ml + 8 * lane;
+                        uint32_t same = 0;
+                        if (a < mlimit) { same = equal_bytes8(hc_ld8(src, n, a), hc_ld8(src, n, a - of)); if (same > mlimit - a) same = mlimit - a; }
+                        const unsigned long long brk = __ballot(same < 8);
+                        if (brk) { const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1; ml += 8 * fl + wave_readlane(same, fl); break; }
+                        ml += 512;
+                    }
+                }
+                if (p + ml > mlimit) ml = mlimit - p;
+                if (ml > 0x7FFFu) ml = 0x7FFFu;                          // (the move is kept in 15 bits; the rest is found again from where this one ends)
+                np = p + ml; nP = P + 3 + (ml >= 19 ? 1 + (ml - 19) / 255 : 0); move = ml;
+                win = kOptInf;
+            } else {
+                uint32_t Lc = L; if (Lc && p + Lc > mlimit) Lc = mlimit - p;
+                win = wave_next_u32(win);
+                if (lane == 63) win = kOptInf;
+                const uint32_t ml = lane + 1;
+                uint32_t cand = kOptInf;
+                if (lane == 0) cand = (P + 1 + (ll_cur + 1 == ll_bump ? 1u : 0u)) << 8;
+                else if (ml >= kMinMatch && ml <= Lc) cand = ((P + 3 + (ml >= 19 ? 1u : 0u)) << 8) | ml;
+                win = cand < win ? cand : win;
+                const uint32_t head = wave_readlane(win, 0);
+                np = p + 1; nP = head >> 8; move = head & 0xFFu;
+            }
+            ll_cur = move ? 0u : ll_cur + 1;
+            if (move) ll_bump = 15; else if (ll_cur == ll_bump) ll_bump += 255;
+            P = nP;
+            // -- note the move of cell np (a literal cell notes its run length, at most 0x7FFF: longer runs chain)
+            if ((np & ~63u) != chbase) { if ((chm >> lane) & 1ull) choice_g[chbase + lane] = (uint16_t)chv; chbase = np & ~63u; chv = 0; chm = 0; }
+            { const uint32_t val = move ? move : (kOptLit | (ll_cur < 0x7FFFu ? ll_cur : 0x7FFFu)); if (lane == (np & 63u)) chv = val; chm |= 1ull << (np & 63u); }
+            p = np;
+        }
+        if ((chm >> lane) & 1ull) choice_g[chbase + lane] = (uint16_t)chv;
+        // (a literal run of more than 0x7FFF noted 0x7FFF in every cell behind that: the walk below takes it in steps)
+        __threadfence_block();
+        wave_lds_fence();
+        // ---- backward: the sequences, from the strip's end (chunks of kHcChunk cells staged in LDS: moves and search results)
+        uint16_t* cstage = (uint16_t*)stage;                             // moves of cells [sb, sb + kHcChunk]
+        uint32_t* bstage = stage + kHcChunk;                             // search results of positions [sb, sb + kHcChunk)
+        uint32_t sb = 0xFFFFFFFFu;
+        auto stage_at = [&](uint32_t cell) {                             // make cell's chunk resident (cell > cs)
+            const uint32_t want = cs + (((cell - 1 - cs) / kHcChunk) * kHcChunk);      // chunks hold cells (sb, sb + kHcChunk]
+            if (want != sb) {
+                sb = want;
+                wave_lds_fence();
+#pragma unroll
+                for (uint32_t k = 0; k < kHcChunk / 64; k++) {
+                    cstage[1 + lane + 64 * k] = choice_g[sb + 1 + lane + 64 * k];
+                    bstage[lane + 64 * k] = best_g[sb + lane + 64 * k];
+                }
+                wave_lds_fence();
+            }
+        };
+        uint32_t pos = ce;
+        // trailing literals of the strip
+        tail = 0;
+        for (;;) {
+            if (pos <= cs) break;
+            stage_at(pos);
+            const uint32_t c = cstage[pos - sb];
+            if (!(c & kOptLit)) break;
+            const uint32_t r = c & 0x7FFFu;
+            tail += r; pos -= r;
+        }
+        while (pos > cs) {
+            stage_at(pos);
+            const uint32_t ml = cstage[pos - sb];                        // a match ends here
+            const uint32_t start = pos - ml;
+            // its offset: the search result of its first position (start >= sb? else the chunk below)
+            uint32_t of;
+            if (start >= sb) of = bstage[start - sb] >> 8; else of = best_g[start] >> 8;
+            // the literals before it
+            uint32_t ll = 0, q = start;
+            for (;;) {
+                if (q <= cs) break;
+                stage_at(q);
+                const uint32_t c = cstage[q - sb];
+                if (!(c & kOptLit)) break;
+                const uint32_t r = c & 0x7FFFu;
+                ll += r; q -= r;
+            }
+            if (lane == 0) { MatchRec r; r.ll = ll; r.mo = of | ((ml - kMinMatch) << 16); recs[rec_cap - 1 - nseq] = r; }
+            enc += enc_size(ll, ml - kMinMatch);
+            ll0 = ll;
+            nseq++;
+            pos = q;
+        }
+    }
+    if (lane == 0) {
+        strip[S_N * kCmpWaves + w] = nseq;
+        strip[S_ENC * kCmpWaves + w] = enc;
+        strip[S_LL0 * kCmpWaves + w] = ll0;
+        strip[S_TAIL * kCmpWaves + w] = tail;
+        first_rec[w] = rec_cap - nseq;                                   // where the strip's records start in its record area
+    }
+}
+
 // ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char* smem) {
-    const uint32_t tid = threadIdx.x, w = wave_id();
+    const uint32_t tid = opaque_u32(threadIdx.x), w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
     uint32_t* strip = (uint32_t*)(smem + kHOffStrip);
     const lz4amd_gsrc src0 = LZ4AMD_TO_GSRC(P.src[b]);
@@ -598,22 +737,24 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         strip_len = (((own + nstrips - 1) / nstrips) + 63) & ~63u;
         nstrips = (own + strip_len - 1) / strip_len;
         const uint32_t rec_cap = strip_len / 4 + 4;
+        const bool optimal = P.level >= 10;                              // lz4hc.c:92-106: levels 10-12 are the optimal parser's
         if (w < nstrips) {
             const uint32_t cs = first + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > n) ce = n;
-            hc_parse_strip(src, n, st0_g, recs_g + (uint64_t)w * rec_cap, strip, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce);
+            if (optimal) hc_parse_strip_opt(src, n, st0_g, st1_g, recs_g + (uint64_t)w * rec_cap, rec_cap, strip, misc + HM_FIRST0, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce);
+            else { hc_parse_strip(src, n, st0_g, recs_g + (uint64_t)w * rec_cap, strip, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce); if (lane_here() == 0) misc[HM_FIRST0 + w] = 0; }
         }
         __syncthreads();
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[4] += t - tq; tq = t; }
         // -- offsets (wave 0; limitedOutput: a block that does not fit fails as a whole, lz4hc.c:297-300)
         if (w == 0) {
             const StripTotals t = strip_offsets(strip, nstrips, 0, 0, 0, cap);
-            if (lane_id() == 0) { misc[HM_OUT] = t.out; misc[HM_CARRY] = t.carry; misc[HM_FAIL] = t.fail; }
+            if (lane_here() == 0) { misc[HM_OUT] = t.out; misc[HM_CARRY] = t.carry; misc[HM_FAIL] = t.fail; }
         }
         __syncthreads();
         // -- emit
         if (w < nstrips && !misc[HM_FAIL] && strip[S_N * kCmpWaves + w])
-            emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap, strip, w, src, dst, first + w * strip_len, 0xFFFFFFFFu);
+            emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap + misc[HM_FIRST0 + w], strip, w, src, dst, first + w * strip_len, 0xFFFFFFFFu);
         __syncthreads();
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[5] += t - tq; tq = t; }
     } else {

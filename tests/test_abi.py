@@ -105,7 +105,7 @@ def test_bounds_match_the_reference(libpath, reflib):
 
 
 def test_ignored_arguments_leave_a_notice():
-    """acceleration > 1 and HC levels > 9 are accepted and not acted on; the ABI says so (lz4amd_last_notice), also
+    """acceleration > 1 and HC levels > 10 are accepted and not (fully) acted on; the ABI says so (lz4amd_last_notice), also
     without a device: the notice is recorded before the block is touched."""
     import ctypes
     import lz4_amd
@@ -119,6 +119,8 @@ def test_ignored_arguments_leave_a_notice():
     L.LZ4_compress_fast(b"abc", dst, -1, 64, 1)
     assert L.lz4amd_last_notice() == b""
     L.LZ4_compress_HC(b"abc", dst, -1, 64, 12)
-    assert b"level-9" in L.lz4amd_last_notice()
+    assert b"level 10" in L.lz4amd_last_notice()                       # levels 10-12 share one optimal parse
+    L.LZ4_compress_HC(b"abc", dst, -1, 64, 10)
+    assert L.lz4amd_last_notice() == b""
     L.LZ4_compress_HC(b"abc", dst, -1, 64, 9)
     assert L.lz4amd_last_notice() == b""

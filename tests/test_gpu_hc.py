@@ -69,7 +69,7 @@ def test_hc_levels(ctx, golden, datagen):
     data = datagen(4 << 20, 60, 0)
     blocks = [data[o:o + 262144] for o in range(0, len(data), 262144)]
     sizes = {lvl: sum(r for r, _ in gpu_compress_hc(ctx, blocks, level=lvl)) for lvl in (3, 6, 9, 12, 0)}
-    assert sizes[3] >= sizes[6] >= sizes[9] == sizes[12] == sizes[0]
+    assert sizes[3] >= sizes[6] >= sizes[9] == sizes[0] >= sizes[12]          # (levels 10-12: the optimal parse over the level-9 search)
     for lvl in (3, 6, 9):
         g = golden["ratio"]["p60_4m_256k_blocks_hc%d" % lvl]
         assert abs(sizes[lvl] - g["csize"]) / g["csize"] < 0.03, lvl
@@ -136,7 +136,7 @@ def test_hc_boundary_sizes(ctx, ocodec, datagen):
     base = datagen(700000, 70, 6)
     datas = [base[rnd.randrange(0, 9000):][:n] for n in sizes]
     datas += [bytes(n) for n in (13, 64, 8193, 70001, 1 << 20)] + [b"ab" * 40000, b"abcdefg" * 100000]
-    for lvl in (9, 3):
+    for lvl in (9, 3, 12):
         for d, (r, c) in zip(datas, gpu_compress_hc(ctx, datas, level=lvl)):
             assert 0 < r <= ocodec.bound(len(d))
             ro, o = ocodec.decompress(c, len(d))
@@ -191,3 +191,36 @@ def test_hc_random_mix_roundtrip(ctx, datagen):
         from test_gpu_parity import gpu_decompress
         for d, (r, o) in zip(blocks, gpu_decompress(ctx, comps, [len(d) for d in blocks])):
             assert r == len(d) and o == d
+
+
+def test_hc_optimal_parse_levels_10_to_12(ctx, ocodec, corpus, datagen):
+    """SURVEY 8(f) item 3, lz4hc.c:92-106 / LZ4HC_compress_optimal 1823-2130: levels 10-12 choose the sequence boundaries by
+    price (kernels/lz4_hc_kernel.h hc_parse_strip_opt).  Every block decodes bit-exactly; the output is not larger than
+    level 9's (strip seams aside) and within 3 % of the reference's own level 12 when oracle/_ref travelled."""
+    outs = gpu_compress_hc(ctx, corpus, level=12)
+    nine = gpu_compress_hc(ctx, corpus, level=9)
+    for d, (r, c), (r9, _) in zip(corpus, outs, nine):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+        assert r <= r9 + 16, (len(d), r, r9)
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "liblz4_ref.so")
+    ref = ctypes.CDLL(so) if os.path.exists(so) else None
+    for pct in (20, 60, 90):
+        data = datagen(4 << 20, pct, 9)
+        blocks = [data[o:o + 262144] for o in range(0, len(data), 262144)]
+        o12 = gpu_compress_hc(ctx, blocks, level=12)
+        o10 = gpu_compress_hc(ctx, blocks, level=10)
+        o9 = gpu_compress_hc(ctx, blocks, level=9)
+        assert [r for r, _ in o10] == [r for r, _ in o12]                  # one setting for the three levels
+        s12, s9 = sum(r for r, _ in o12), sum(r for r, _ in o9)
+        assert s12 <= s9, (pct, s12, s9)
+        for b, (r, c) in zip(blocks, o12):
+            ro, o = ocodec.decompress(c, len(b))
+            assert ro == len(b) and o == b
+        if ref is not None:
+            rs = 0
+            for b in blocks:
+                dst = ctypes.create_string_buffer(len(b) + len(b) // 255 + 16)
+                rs += ref.LZ4_compress_HC(b, dst, len(b), len(dst), 12)
+            assert abs(s12 - rs) / rs < 0.03, (pct, s12, rs)

@@ -456,11 +456,41 @@ def test_hc_levels_trade_ratio_for_depth(emu, golden, datagen):
     data = datagen(1 << 20, 60, 0)
     blocks = [data[o:o + 262144] for o in range(0, len(data), 262144)]
     sizes = {lvl: sum(r for r, _ in emu_compress_hc(emu, blocks[:2], level=lvl)) for lvl in (3, 6, 9, 12, 0)}
-    assert sizes[3] >= sizes[6] >= sizes[9] == sizes[12] == sizes[0]
+    assert sizes[3] >= sizes[6] >= sizes[9] == sizes[0] >= sizes[12]      # (levels 10-12: the optimal parse over the level-9 search)
     for lvl in (3, 6):
         g = golden["ratio"]["p60_4m_256k_blocks_hc%d" % lvl]
         ref = g["csize"] / (g["src"] / g["block"]) * 2
         assert abs(sizes[lvl] - ref) / ref < 0.03
+
+
+def test_hc_optimal_parse_levels_10_to_12(emu, ocodec, reflib, corpus, datagen):
+    """Levels 10-12 (lz4hc.c:92-106, LZ4HC_compress_optimal 1823-2130): the sequence boundaries are chosen by price instead
+    of greedily.  Every block still decodes with the pinned decoder; the output is never larger than level 9's (beyond the
+    strips' seams), and stays within 3 % of the reference's own level 12."""
+    outs = emu_compress_hc(emu, corpus, level=12)
+    nine = emu_compress_hc(emu, corpus, level=9)
+    for d, (r, c), (r9, _) in zip(corpus, outs, nine):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+        assert r <= r9 + 16, (len(d), r, r9)
+    for pct in (20, 60, 90):
+        data = datagen(1 << 19, pct, 7)
+        blocks = [data[o:o + 262144] for o in range(0, len(data), 262144)]
+        ours = sum(r for r, _ in emu_compress_hc(emu, blocks, level=12))
+        ours9 = sum(r for r, _ in emu_compress_hc(emu, blocks, level=9))
+        ref = 0
+        for b in blocks:
+            dst = ctypes.create_string_buffer(len(b) + len(b) // 255 + 16)
+            ref += reflib.LZ4_compress_HC(b, dst, len(b), len(dst), 12)
+        assert ours <= ours9 and abs(ours - ref) / ref < 0.03, (pct, ours, ours9, ref)
+    # a block whose best parse needs literal runs past the length-field boundaries and matches longer than the price window
+    rnd = random.Random(5)
+    junk = bytes(rnd.randrange(256) for _ in range(40000))
+    d = junk[:300] + b"q" * 5000 + junk[300:20000] + junk[100:9000] + junk[20000:]
+    (r, c), = emu_compress_hc(emu, [d], level=11)
+    ro, o = ocodec.decompress(c, len(d))
+    assert ro == len(d) and o == d
 
 
 def test_hc_matches_beyond_32k_are_found(emu, ocodec):
@@ -502,6 +532,11 @@ def test_hc_sizes_around_tile_band_and_strip_boundaries(emu, ocodec, datagen):
         assert ro == len(d) and o == d, len(d)
     # low search depth takes the same paths with different state sizes
     for d, (r, c) in zip(datas[:20], emu_compress_hc(emu, datas[:20], level=3)):
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+    # the optimal parse of levels 10-12: its price window, its move array and its backward walk cross the same borders
+    for d, (r, c) in zip(datas, emu_compress_hc(emu, datas, level=10)):
+        assert 0 < r <= ocodec.bound(len(d))
         ro, o = ocodec.decompress(c, len(d))
         assert ro == len(d) and o == d, len(d)
 
