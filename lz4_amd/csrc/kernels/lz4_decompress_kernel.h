@@ -259,6 +259,7 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
             if (!did) break;
             issued = true;
         }
+        if (issued) progress = true;                         // (what was just issued is looked after on the next trip, without a pause)
         // ---- retire: busy = all but the youngest half of the queue, idle = everything
         uint32_t keep = q;
         if (!issued) { vmem_wait<0>(); keep = 0; }
