@@ -83,6 +83,7 @@ enum : uint32_t {
 static_assert(kCmpLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert(kCOffRing % 16 == 0 && kCOffStage % 16 == 0 && kCOffCarry % 16 == 0 && kSrcRing % 16 == 0, "LDS alignment");
 enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4,     // CM_READY: tiles whose output offsets are fixed
+                  CM_EMITQ = 5,        // next strip of the settled tile to write out (handed to whichever wave is free)
                   CM_TILE = 8 };       // u32[2][4] per tile in flight: { first output position, end, written directly (not staged),
                                        //   first pending byte of its carry chunk }
 enum : uint32_t { T_OUT0 = 0, T_OUT1 = 1, T_DIRECT = 2, T_CFROM = 3 };
@@ -847,7 +848,8 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
 #endif
 }
 // every wave: its strip of the settled tile (parity pp), into the staging buffer or straight to HBM
-__device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo) {
+// (w: the strip; sw: the wave that does it - any wave may, the strip's place in the output was fixed when the tile was settled)
+__device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, uint32_t sw, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo) {
     const uint32_t* misc = (const uint32_t*)(smem + kCOffMisc);
     const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
     if (misc[CM_FAIL] || !strip_p[S_N * kCmpWaves + w]) return;
@@ -856,7 +858,7 @@ __device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_
     const uint32_t* T = misc + CM_TILE + 4 * pp;
     if (T[T_DIRECT]) emit_strip_plain(recs_w, strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w]);
     else emit_strip_lds(ring, recs_w, strip_p, w, (uint8_t*)(smem + kCOffStage), ((T[T_OUT0] + a0) & ~15u) - a0, strip_p[S_P * kCmpWaves + w],
-                        (uint32_t*)(smem + kCOffCandS) + w * kCandPerPass);    // (scratch: the wave's candidate list, idle now; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
+                        (uint32_t*)(smem + kCOffCandS) + sw * kCandPerPass);    // (scratch: the executing wave's candidate list, idle now; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
 }
 
 // ------------------------------------------------------------------------------ one block
@@ -895,7 +897,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
-        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0;
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0;
 #ifdef LZ4AMD_PROF_TILE
         for (uint32_t i = 24; i < 30; i++) misc[i] = 0;
 #endif
@@ -957,9 +959,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: write out tile k-1 (into the staging buffer)
-        if (w < prev_nstrips) {
+        //    The strips are handed out from a counter to whichever wave is free: the waves do not finish their matching together
+        //    (the wave that settled the tile starts late, and the arbiter serves a SIMD's low wave slots first), and the barrier
+        //    below waits for the last one.
+        if (prev_nstrips) {
             while (uload_cm(&misc[CM_READY]) < tiles_parsed) spin_pause();
-            emit_tile_strip(smem, par ^ 1, w, src, dst, a0, ring_lo);
+            for (;;) {
+                uint32_t sx = 0;
+                if (lane_id() == 0) sx = atomicAdd(&misc[CM_EMITQ], 1u);
+                sx = __builtin_amdgcn_readfirstlane(sx);
+                if (sx >= prev_nstrips) break;
+                emit_tile_strip(smem, par ^ 1, sx, w, src, dst, a0, ring_lo);
+            }
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         __syncthreads();
@@ -967,6 +978,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         // -- B: tile k-1's bytes leave; everybody inserts tile k into the table (positions that may start a match):
         //    8 consecutive positions per thread, hashed out of four aligned dwords
         const bool do_flush = prev_nstrips && !misc[CM_FAIL];
+        if (tid == 0) misc[CM_EMITQ] = 0;                           // (nobody looks at it between the two barriers)
         FlushCtx fc;
         if (do_flush) fc = flush_begin(smem, par ^ 1, a0);
         if (n >= kMfLimit + 1) {
@@ -1012,7 +1024,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (w == kSettleWave) settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
         __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
-        if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, src, dst, a0, ring_lo);
+        if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, w, src, dst, a0, ring_lo);
         __syncthreads();
         if (!misc[CM_FAIL]) { const FlushCtx fc = flush_begin(smem, par ^ 1, a0); flush_end(smem, fc, dst, a0); }
     }
