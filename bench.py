@@ -201,11 +201,16 @@ def stream_copy_gbps(ctx, lz4_amd, torch, nbytes, stream):
 
 def roofline_obj(kernel, ms, alg_bytes, copy_gbps, traffic):
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBPS, 5),
-            "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
-            "frac_of_measured_copy": round(ach / copy_gbps, 5) if copy_gbps else None,
-            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": round(ms, 4)}
+    r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBPS, 5),
+         "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
+         "frac_of_measured_copy": round(ach / copy_gbps, 5) if copy_gbps else None,
+         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": round(ms, 4)}
+    # what holds the kernel below that roofline today: VALU issue (committed SQ counters of the same kernel sources)
+    v = measured_traffic().get(kernel, {}).get("valu")
+    if v:
+        r["limited_by"] = {"what": "VALU issue (one wave64 instruction per 4 cycles per SIMD)", **v}
+    return r
 
 
 def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, copy_gbps, level=9, bs=256 << 10, with_cpu=True):

@@ -50,6 +50,26 @@ def main():
         a, b = counters(hf).get("lz4amd_k_compress_hc"), counters(hw).get("lz4amd_k_compress_hc")
         if a and b:
             doc["compress_hc"] = {"FETCH_SIZE_KiB": a, "WRITE_SIZE_KiB": b, "hbm_bytes_per_launch": int((a * fcorr + b * wcorr) * 1024)}
+    # VALU issue: SQ_INSTS_VALU wave-instructions per dispatch and the kernel's average duration in the same pass.  A SIMD's
+    # VALU pipe takes one wave64 instruction per 4 cycles (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles in every pass),
+    # so instructions x 4 / (CUs x 4 SIMDs) are the pipe-cycles each SIMD spends; against duration x 2.4 GHz (the engine's
+    # top clock: the fraction is a lower bound) that is how full the pipes are.
+    sq = os.path.join(g, files["pmc_sq1"])
+    if os.path.exists(sq):
+        dur, valu = {}, {}
+        for line in open(sq):
+            m = re.match(r"\s+(lz4amd_k_\w+)\(.*?\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", line)
+            if m:
+                dur[m.group(1)] = float(m.group(4))
+            m = re.match(r"\s+(lz4amd_k_\w+)\(.*?\s+SQ_INSTS_VALU\s+([0-9.]+)\s+\(n=", line)
+            if m:
+                valu[m.group(1)] = float(m.group(2))
+        for key, kern in (("compress", "lz4amd_k_compress"), ("decompress", "lz4amd_k_decompress")):
+            if key in doc and kern in dur and kern in valu:
+                pipe = valu[kern] * 4.0 / (256 * 4)
+                doc[key]["valu"] = {"SQ_INSTS_VALU": valu[kern], "kernel_us_in_that_pass": dur[kern],
+                                    "pipe_cycles_per_simd": int(pipe), "frac_of_kernel_cycles_at_2.4GHz": round(pipe / (dur[kern] * 2400.0), 3),
+                                    "source": f"profiles/{name}_rocprof_pmc_sq1.txt"}
     json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     json.dump(doc, open(os.path.join(ROOT, "profiles", f"{name}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(doc, indent=1))
