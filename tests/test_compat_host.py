@@ -110,3 +110,44 @@ def test_xxh_exports(ours, reflib):
         ours.LZ4_XXH64_update(st, b[i:i + 37], len(b[i:i + 37]))
     assert ours.LZ4_XXH64_digest(st) == reflib.LZ4_XXH64(b, 5000, 7)
     ours.LZ4_XXH64_freeState(st)
+
+
+def test_lz4file_argument_and_io_errors(ours, tmp_path):
+    """include/lz4file.h (lib/lz4file.c:73-138, 217-279): NULL arguments -> parameter_null, a file shorter than an empty frame
+    -> io_read, a file that does not start with a frame -> the header's error; no state is left behind (*out == NULL).  These
+    paths end before any block is coded: no device needed."""
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = vp
+    libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    libc.fclose.argtypes = [vp]
+    for f in (ours.LZ4F_readOpen, ours.LZ4F_writeOpen, ours.LZ4F_readClose, ours.LZ4F_writeClose, ours.LZ4F_read, ours.LZ4F_write):
+        f.restype = ctypes.c_size_t
+    ours.LZ4F_readOpen.argtypes = [ctypes.POINTER(vp), vp]
+    ours.LZ4F_writeOpen.argtypes = [ctypes.POINTER(vp), vp, vp]
+    ours.LZ4F_readClose.argtypes = [vp]
+    ours.LZ4F_writeClose.argtypes = [vp]
+    ours.LZ4F_read.argtypes = [vp, vp, ctypes.c_size_t]
+    ours.LZ4F_write.argtypes = [vp, vp, ctypes.c_size_t]
+    ours.LZ4F_getErrorName.restype = ctypes.c_char_p
+    ours.LZ4F_getErrorName.argtypes = [ctypes.c_size_t]
+    ours.LZ4F_isError.argtypes = [ctypes.c_size_t]
+    name = lambda code: ours.LZ4F_getErrorName(code)
+    h = vp()
+    assert name(ours.LZ4F_readOpen(ctypes.byref(h), None)) == b"ERROR_parameter_null"
+    assert name(ours.LZ4F_readOpen(None, None)) == b"ERROR_parameter_null"
+    assert name(ours.LZ4F_writeOpen(ctypes.byref(h), None, None)) == b"ERROR_parameter_null"
+    assert name(ours.LZ4F_readClose(None)) == b"ERROR_parameter_null" and name(ours.LZ4F_writeClose(None)) == b"ERROR_parameter_null"
+    assert name(ours.LZ4F_read(None, None, 0)) == b"ERROR_parameter_null" and name(ours.LZ4F_write(None, None, 0)) == b"ERROR_parameter_null"
+    short = tmp_path / "short.lz4"
+    short.write_bytes(b"\x04\x22\x4d\x18\x60")
+    fp = libc.fopen(str(short).encode(), b"rb")
+    h = vp(1)
+    assert name(ours.LZ4F_readOpen(ctypes.byref(h), fp)) == b"ERROR_io_read" and not h.value
+    libc.fclose(fp)
+    junk = tmp_path / "junk.lz4"
+    junk.write_bytes(b"not an lz4 frame at all, twenty+ bytes")
+    fp = libc.fopen(str(junk).encode(), b"rb")
+    h = vp(1)
+    rc = ours.LZ4F_readOpen(ctypes.byref(h), fp)
+    assert ours.LZ4F_isError(rc) and not h.value
+    libc.fclose(fp)
