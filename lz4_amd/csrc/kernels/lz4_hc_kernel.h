@@ -569,28 +569,61 @@ __device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, cons
 enum : uint32_t { kOptWin = 64, kOptLit = 0x8000u, kOptInf = 0xFFFFFF00u };
 
 __device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, const uint32_t* best_g, uint16_t* choice_g, MatchRec* recs, uint32_t rec_cap,
-                                                   uint32_t* strip, uint32_t* first_rec, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce) {
+                                                   uint32_t* strip, uint32_t* first_rec, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce, uint64_t* prof = nullptr) {
     const uint32_t lane = lane_here();
+    const uint64_t tf0 = prof ? clock_ticks() : 0;
     uint32_t nseq = 0, enc = 0, ll0 = 0, tail = ce - cs;
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         const uint32_t last_q = n - kMfLimit;
         uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
         // ---- forward: prices
         uint32_t win = kOptInf;                                          // lane l: price << 8 | move of cell p + 1 + l (move: 0 literal, else match length)
-        uint32_t P = 0, ll_cur = 0, ll_bump = 15;                        // cell p: its price, the literal run that ends there; the run length at which the next length byte opens (15, 270, ...)
-        uint32_t chv = 0, chbase = cs; uint64_t chm = 0;                 // moves of cells [chbase, chbase + 64), lane = cell - chbase (cs is a multiple of 64); chm: the lanes that hold one
-        // (only those are stored: the cells around a strip's ends belong to the neighbouring strips' waves)
-        uint32_t bv = 0, bbase = 0xFFFFFFFFu;                            // search results of positions [bbase, bbase + 64)
+        uint32_t Psh = 0, ll_cur = 0, ll_bump = 15;                      // cell p: its price << 8, the literal run that ends there; the run length at which the next length byte opens (15, 270, ...)
+        // what a lane stands for: lane 0 the literal, lane l >= 3 the match of length l + 1 (lanes 1, 2: nothing)
+        const uint32_t mlv = lane == 0 ? 0u : (lane < 3 ? 0xFFFFu : lane + 1);
+        const uint32_t kv = lane == 0 ? (1u << 8) : (((lane + 1 >= 19 ? 4u : 3u) << 8) | (lane + 1));      // (price << 8 | move) a lane's step adds
+        const uint32_t b0 = lane == 0 ? 256u : 0u;                       // ... plus this when the literal opens a new length byte
         uint32_t p = cs;
         while (p < ce) {
-            if ((p & ~63u) != bbase) { bbase = p & ~63u; bv = best_g[bbase + lane]; }        // (the array is padded)
-            const uint32_t s = wave_readlane(bv, p & 63u);
-            uint32_t L = s & 0xFFu; const uint32_t of = s >> 8;
-            if (p > last_q || L < kMinMatch || p + kMinMatch > mlimit) L = 0;
-            uint32_t np, nP, move;                                       // the next cell, its price, the move that reaches it
-            if (L > kOptWin) {
-                // -- longer than the window: taken at once (measured to its end if the search capped it)
-                uint32_t ml = L;
+            // -- a group of 64 positions: their search results, cut to what may be used, one per lane; the moves of the group's cells
+            const uint32_t gbase = p & ~63u, gend = gbase + 64 < ce ? gbase + 64 : ce;
+            const uint32_t bv = best_g[gbase + lane];                   // (the array is padded)
+            uint32_t Lv = bv & 0xFFu;
+            {   const uint32_t pos = gbase + lane;
+                if (pos > last_q || Lv < kMinMatch || pos + kMinMatch > mlimit) Lv = 0;
+                else if (Lv <= kOptWin && pos + Lv > mlimit) Lv = mlimit - pos; }
+            uint32_t chv = 0;                                            // moves of cells [gbase, gbase + 64), lane = cell - gbase
+            const uint32_t lo_cell = p + 1;                              // the first cell this pass notes
+            bool jumped = false;
+            while (p < gend) {
+                const uint32_t Lc = wave_readlane(Lv, p & 63u);
+                if (Lc > kOptWin) { jumped = true; break; }
+                win = wave_next_u32(win);
+                if (lane == 63) win = kOptInf;
+                const uint32_t bump = ll_cur + 1 == ll_bump ? 1u : 0u;
+                uint32_t cand = Psh + kv + (bump ? b0 : 0u);
+                cand = mlv <= Lc ? cand : kOptInf;
+                win = cand < win ? cand : win;
+                const uint32_t head = wave_readlane(win, 0);
+                const uint32_t move = head & 0xFFu;
+                Psh = head & ~0xFFu;
+                ll_cur = move ? 0u : ll_cur + 1;
+                if (move) ll_bump = 15; else if (ll_cur == ll_bump) ll_bump += 255;
+                p++;
+                // the move of cell p (a literal cell notes its run length, at most 0x7FFF: longer runs chain); cell gbase + 64 is lane 0 of the next group
+                const uint32_t val = move ? move : (kOptLit | (ll_cur < 0x7FFFu ? ll_cur : 0x7FFFu));
+                if ((p & 63u) == 0) { if (lane == 0) choice_g[p] = (uint16_t)val; }
+                else if (lane == (p & 63u)) chv = val;
+            }
+            {   // the group's cells noted in this pass: [lo_cell, p] without the cell that went to the next group
+                const uint32_t cell = gbase + lane;
+                if (cell >= lo_cell && cell <= p && cell < gbase + 64) choice_g[cell] = (uint16_t)chv;
+            }
+            if (jumped) {
+                // -- a match longer than the window: taken at once (measured to its end if the search capped it)
+                const uint32_t s1 = wave_readlane(bv, p & 63u);
+                const uint32_t of = s1 >> 8;
+                uint32_t ml = s1 & 0xFFu;
                 if (ml >= kHcLenCap && p + ml < mlimit) {
                     for (;;) {
                         const uint32_t a = p + ml + 8 * lane;
@@ -603,29 +636,13 @@ __device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, 
                 }
                 if (p + ml > mlimit) ml = mlimit - p;
                 if (ml > 0x7FFFu) ml = 0x7FFFu;                          // (the move is kept in 15 bits; the rest is found again from where this one ends)
-                np = p + ml; nP = P + 3 + (ml >= 19 ? 1 + (ml - 19) / 255 : 0); move = ml;
-                win = kOptInf;
-            } else {
-                uint32_t Lc = L; if (Lc && p + Lc > mlimit) Lc = mlimit - p;
-                win = wave_next_u32(win);
-                if (lane == 63) win = kOptInf;
-                const uint32_t ml = lane + 1;
-                uint32_t cand = kOptInf;
-                if (lane == 0) cand = (P + 1 + (ll_cur + 1 == ll_bump ? 1u : 0u)) << 8;
-                else if (ml >= kMinMatch && ml <= Lc) cand = ((P + 3 + (ml >= 19 ? 1u : 0u)) << 8) | ml;
-                win = cand < win ? cand : win;
-                const uint32_t head = wave_readlane(win, 0);
-                np = p + 1; nP = head >> 8; move = head & 0xFFu;
+                Psh += (3 + (ml >= 19 ? 1 + (ml - 19) / 255 : 0)) << 8;
+                win = kOptInf; ll_cur = 0; ll_bump = 15;
+                p += ml;
+                if (lane == 0) choice_g[p] = (uint16_t)ml;
             }
-            ll_cur = move ? 0u : ll_cur + 1;
-            if (move) ll_bump = 15; else if (ll_cur == ll_bump) ll_bump += 255;
-            P = nP;
-            // -- note the move of cell np (a literal cell notes its run length, at most 0x7FFF: longer runs chain)
-            if ((np & ~63u) != chbase) { if ((chm >> lane) & 1ull) choice_g[chbase + lane] = (uint16_t)chv; chbase = np & ~63u; chv = 0; chm = 0; }
-            { const uint32_t val = move ? move : (kOptLit | (ll_cur < 0x7FFFu ? ll_cur : 0x7FFFu)); if (lane == (np & 63u)) chv = val; chm |= 1ull << (np & 63u); }
-            p = np;
         }
-        if ((chm >> lane) & 1ull) choice_g[chbase + lane] = (uint16_t)chv;
+        if (prof && w == 0 && lane == 0) prof[3] += clock_ticks() - tf0;      // (developer profile: the forward pass of wave 0's strip)
         // (a literal run of more than 0x7FFF noted 0x7FFF in every cell behind that: the walk below takes it in steps)
         __threadfence_block();
         wave_lds_fence();
@@ -741,7 +758,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         if (w < nstrips) {
             const uint32_t cs = first + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > n) ce = n;
-            if (optimal) hc_parse_strip_opt(src, n, st0_g, st1_g, recs_g + (uint64_t)w * rec_cap, rec_cap, strip, misc + HM_FIRST0, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce);
+            if (optimal) hc_parse_strip_opt(src, n, st0_g, st1_g, recs_g + (uint64_t)w * rec_cap, rec_cap, strip, misc + HM_FIRST0, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce, prof);
             else { hc_parse_strip(src, n, st0_g, recs_g + (uint64_t)w * rec_cap, strip, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce); if (lane_here() == 0) misc[HM_FIRST0 + w] = 0; }
         }
         __syncthreads();

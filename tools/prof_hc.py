@@ -20,7 +20,7 @@ print("HC level %d, %d x %d B P%d: kernel ms %.2f  GB/s in %.2f  ratio %.3f" % (
 L = lz4_amd.lib()
 w = (ctypes.c_ulonglong * (256 * 8))()
 n = L.lz4amd_plan_profile(plan._h, w, len(w))
-names = ["chain build", "search band 0", "search band 1", "-", "parse", "offsets + emit"]
+names = ["chain build", "search band 0", "search band 1", "optimal parse: forward pass of wave 0 (levels 10-12)", "parse", "offsets + emit"]
 blocks_per_wg = nb / (n // 8) * (runs + 1)
 for k, name in enumerate(names):
     d = [w[i * 8 + k] for i in range(n // 8)]
