@@ -674,28 +674,31 @@ __device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, 
             const uint32_t r = c & 0x7FFFu;
             tail += r; pos -= r;
         }
+        // (the walk is one dependent chain of LDS reads: the move of the cell a match ends at is carried over from the step that
+        //  found the cell, and a match's offset and the move of its first cell are read together)
+        uint32_t ml = 0;
+        if (pos > cs) { stage_at(pos); ml = cstage[pos - sb]; }         // a match ends at pos
         while (pos > cs) {
-            stage_at(pos);
-            const uint32_t ml = cstage[pos - sb];                        // a match ends here
             const uint32_t start = pos - ml;
-            // its offset: the search result of its first position (start >= sb? else the chunk below)
-            uint32_t of;
-            if (start >= sb) of = bstage[start - sb] >> 8; else of = best_g[start] >> 8;
-            // the literals before it
+            uint32_t of, c1 = 0;
+            if (start > sb) { of = bstage[start - sb] >> 8; c1 = cstage[start - sb]; }       // both in the staged chunk (the common case)
+            else {
+                of = best_g[start] >> 8;
+                if (start > cs) { stage_at(start); c1 = cstage[start - sb]; }
+            }
+            // the literals before it: cell `start` says how many (0x7FFF: the run goes on below), then the cell a match ends at
             uint32_t ll = 0, q = start;
-            for (;;) {
-                if (q <= cs) break;
-                stage_at(q);
-                const uint32_t c = cstage[q - sb];
-                if (!(c & kOptLit)) break;
-                const uint32_t r = c & 0x7FFFu;
+            while (q > cs && (c1 & kOptLit)) {
+                const uint32_t r = c1 & 0x7FFFu;
                 ll += r; q -= r;
+                c1 = 0;
+                if (q > cs) { stage_at(q); c1 = cstage[q - sb]; }
             }
             if (lane == 0) { MatchRec r; r.ll = ll; r.mo = of | ((ml - kMinMatch) << 16); recs[rec_cap - 1 - nseq] = r; }
             enc += enc_size(ll, ml - kMinMatch);
             ll0 = ll;
             nseq++;
-            pos = q;
+            pos = q; ml = c1;                                            // (c1: the move of cell q, a match's end, or nothing at the origin)
         }
     }
     if (lane == 0) {
