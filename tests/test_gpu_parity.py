@@ -183,6 +183,21 @@ def test_decompress_long_overlapping_matches(ctx, ocodec):
         assert r == len(d) and o == d
 
 
+def test_decompress_sequences_far_longer_and_far_shorter_than_a_region(ctx, ocodec):
+    """The pre-parse's region index and the mover's rings (see tests/test_kernels_emulated.py::_region_index_corpus), from
+    reference-format streams: the oracle's, and the library's own HC output of the same data (other sequence shapes)."""
+    from test_kernels_emulated import _region_index_corpus
+    from test_gpu_hc import gpu_compress_hc
+    cases = _region_index_corpus()
+    comps = [ocodec.compress(d)[1] for d in cases]
+    for sal in (0, 5):
+        for d, (r, o) in zip(cases, gpu_decompress(ctx, comps, [len(d) for d in cases], salign=sal)):
+            assert r == len(d) and o == d, (sal, len(d))
+    hcs = [c for _, c in gpu_compress_hc(ctx, cases, level=12)]
+    for d, (r, o) in zip(cases, gpu_decompress(ctx, hcs, [len(d) for d in cases])):
+        assert r == len(d) and o == d, len(d)
+
+
 def test_compress_ratio_window_grid(ctx, reflib, datagen):
     """The fast compressor's size against the reference's on datagen P20 / P50 / P90 at 64 KiB, 256 KiB and 4 MiB
     blocks (BASELINE north_star: within 3 % of the reference's ratio), and every block decodes.  No cell is larger

@@ -117,6 +117,29 @@ def test_decompress_capacities_and_alignment(emu, ocodec, datagen):
         assert r == 700 and o == d[:700]
 
 
+def _region_index_corpus():
+    """Blocks whose sequences are much longer than a 1 KB output region, or far shorter, in every mix: the decoder's region
+    index (one note per region start, written by the pre-parse; holes behind long sequences filled when the index is moved
+    to LDS) and its record / stream rings see sequences that cover hundreds of regions, regions with more than a hundred
+    records, and region starts that fall exactly on sequence borders."""
+    rnd = random.Random(17)
+    noise = bytes(rnd.randrange(256) for _ in range(300000))
+    cases = [
+        noise[:200000],                                                    # one literal run over ~195 regions
+        noise[:7] + b"z" * 700000 + noise[7:40],                           # one match over ~680 regions
+        noise[:1024] + noise[:1024] * 300,                                 # matches that start and end exactly on region borders
+        b"".join(noise[i * 50:i * 50 + 9] + b"ab" * 3 for i in range(4000)),   # ~60 records per region, all short
+        noise[:3000] + b"".join(noise[100:100 + 5 + (i % 7)] for i in range(30000)),    # short matches into old history
+        noise[:70000] + noise[:70000] + noise[5:69000] * 3,               # 64 KB matches at distance 65535-ish, chained
+    ]
+    big = bytearray()
+    for i in range(60):                                                    # long literal runs and long matches alternating, odd lengths
+        big += noise[i * 4001:i * 4001 + 1500 + 37 * i]
+        big += bytes(big[-(900 + i):]) * (1 + i % 3)
+    cases.append(bytes(big))
+    return cases
+
+
 def _periodic_corpus():
     """Long matches that overlap themselves (offset < length): periods that do and do not divide the output ring,
     runs far longer than the 64 KB window, plus a mix of random stretches, runs and ordinary matches."""
@@ -415,6 +438,14 @@ def emu_compress_hc(emu, datas, level=9, caps=None, grid=0):
         assert raw[:off] == bytes([CANARY]) * off, f"block {i}: wrote before dst"
         outs.append((res[i], raw[off:off + max(res[i], 0)]))
     return outs
+
+
+def test_decompress_sequences_far_longer_and_far_shorter_than_a_region(emu, ocodec):
+    cases = _region_index_corpus()
+    comps = [ocodec.compress(d)[1] for d in cases]
+    for sal in (0, 9):
+        for d, (r, o) in zip(cases, emu_decompress(emu, comps, [len(d) for d in cases], salign=sal)):
+            assert r == len(d) and o == d, (sal, len(d))
 
 
 def test_hc_roundtrip_through_oracle_decoder(emu, ocodec, corpus):
