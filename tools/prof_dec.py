@@ -21,7 +21,7 @@ for _ in range(5):
 U, C = nb * bs, sum(csizes)
 print("decoder %s: %d x %d B P%d%s  kernel ms %.3f  GB/s out %.1f  (U+C)/t %.1f GB/s = %.3f of 8 TB/s" % (
     "v4", nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
-assert torch.equal(out, data), "decode mismatch"
+assert os.environ.get("NOCHECK") or torch.equal(out, data), "decode mismatch"
 if not os.environ.get("NOPROF"):
     L = lz4_amd.lib()
     w = (ctypes.c_ulonglong * (256 * 8))()
