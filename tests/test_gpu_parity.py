@@ -198,6 +198,29 @@ def test_decompress_sequences_far_longer_and_far_shorter_than_a_region(ctx, ocod
         assert r == len(d) and o == d, len(d)
 
 
+def test_decompress_random_legal_sequence_lists(ctx, ocodec):
+    """Legal blocks built from random sequence lists rather than by a compressor (tests/test_kernels_emulated.py::_random_legal_block):
+    length fields around every extension boundary, zero-literal sequences, offsets from 1 to 65535, self-overlapping matches;
+    checked against the pinned decoder first, then decoded on the GPU, at every source misalignment class and one byte short."""
+    import random as _r
+    from test_kernels_emulated import _random_legal_block
+    rnd = _r.Random(77)
+    blocks, wants = [], []
+    for target in [0, 1, 100, 1024, 65536, 200000, 1 << 20, 3 << 20] + [rnd.randrange(10, 400000) for _ in range(24)]:
+        c, d = _random_legal_block(rnd, target)
+        if len(d) <= 300000:
+            ro, o = ocodec.decompress(c, len(d))
+            assert ro == len(d) and o == d
+        blocks.append(c); wants.append(d)
+    big_ref = ocodec.decompress(blocks[7], len(wants[7]))
+    assert big_ref[0] == len(wants[7]) and big_ref[1] == wants[7]
+    for sal in (0, 11):
+        for d, (r, o) in zip(wants, gpu_decompress(ctx, blocks, [len(d) for d in wants], salign=sal)):
+            assert r == len(d) and o == d, (sal, len(d))
+    short = gpu_decompress(ctx, blocks[2:12], [len(d) - 1 for d in wants[2:12]])
+    assert all(r < 0 for r, _ in short)
+
+
 def test_compress_ratio_window_grid(ctx, reflib, datagen):
     """The fast compressor's size against the reference's on datagen P20 / P50 / P90 at 64 KiB, 256 KiB and 4 MiB
     blocks (BASELINE north_star: within 3 % of the reference's ratio), and every block decodes.  No cell is larger

@@ -625,3 +625,65 @@ def test_gather_rows_of_any_size_and_alignment(emu):
         assert res[i] == len(d), i
         assert raw[off:off + len(d)] == d, i
         assert raw[:off] == bytes([CANARY]) * off and raw[off + len(d):] == bytes([CANARY]) * (len(raw) - off - len(d)), i
+
+
+def _random_legal_block(rnd, target, prefix=b""):
+    """A legal LZ4 block built from a random list of sequences (not by a compressor): literal and match lengths around every
+    length-field boundary (14/15/16, 269/270/271 ..., ml 18/19/20, 273/274 ...), zero-literal sequences, offsets from 1 to the
+    whole history, matches that overlap themselves.  Returns (block bytes, decoded bytes)."""
+    out = bytearray(prefix)
+    comp = bytearray()
+    p0 = len(prefix)
+
+    def put_len(v):
+        while v >= 255:
+            comp.append(255); v -= 255
+        comp.append(v)
+
+    edge_ll = [0, 0, 0, 1, 2, 14, 15, 16, 17, 269, 270, 271, 524, 525, 526]
+    edge_ml = [4, 4, 5, 7, 8, 18, 19, 20, 21, 272, 273, 274, 275, 528, 529, 1040, 5000]
+    while len(out) - p0 < target:
+        ll = rnd.choice(edge_ll) if rnd.random() < 0.6 else rnd.randrange(0, 40)
+        ml = rnd.choice(edge_ml) if rnd.random() < 0.5 else rnd.randrange(4, 60)
+        lits = bytes(rnd.randrange(256) for _ in range(ll))
+        have = len(out) + ll
+        if have == 0:
+            continue
+        r = rnd.random()
+        off = 1 if r < 0.1 else rnd.randrange(1, min(have, 20) + 1) if r < 0.4 else rnd.randrange(1, min(have, 65535) + 1)
+        tok = (min(ll, 15) << 4) | min(ml - 4, 15)
+        comp.append(tok)
+        if ll >= 15:
+            put_len(ll - 15)
+        comp += lits
+        out += lits
+        comp += bytes((off & 255, off >> 8))
+        if ml - 4 >= 15:
+            put_len(ml - 4 - 15)
+        for _ in range(ml):
+            out.append(out[-off])
+    ll = rnd.choice((12, 13, 15, 16, 27, 270, 300))                          # the last sequence: literals only (>= 12: the end rules)
+    lits = bytes(rnd.randrange(256) for _ in range(ll))
+    comp.append(min(ll, 15) << 4)
+    if ll >= 15:
+        put_len(ll - 15)
+    comp += lits
+    out += lits
+    return bytes(comp), bytes(out[p0:])
+
+
+def test_decompress_random_legal_sequence_lists(emu, ocodec):
+    rnd = random.Random(2024)
+    blocks, wants = [], []
+    for target in [0, 1, 30, 300, 1000, 1023, 1024, 1025, 5000, 20000, 70000, 150000] + [rnd.randrange(10, 60000) for _ in range(10)]:
+        c, d = _random_legal_block(rnd, target)
+        ro, o = ocodec.decompress(c, len(d))                         # the generator against the pinned decoder first
+        assert ro == len(d) and o == d
+        blocks.append(c); wants.append(d)
+    for sal in (0, 3):
+        for d, (r, o) in zip(wants, emu_decompress(emu, blocks, [len(d) for d in wants], salign=sal)):
+            assert r == len(d) and o == d, (sal, len(d))
+    # capacity one byte short: rejected like the reference does
+    for c, d in list(zip(blocks, wants))[3:8]:
+        (r, _), = emu_decompress(emu, [c], [len(d) - 1])
+        assert r < 0 and ocodec.decompress(c, len(d) - 1)[0] < 0
