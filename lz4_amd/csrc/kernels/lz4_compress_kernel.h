@@ -239,7 +239,7 @@ __device__ __forceinline__ Pair32 ring_ld8_32(const uint8_t* ring, uint32_t o) {
 #define MPROF_PASS
 #endif
 // one probe round: the four positions of a lane's kLaneBytes source bytes from p + lane * kLaneBytes on
-struct Round { uint32_t dd[4]; uint32_t sb, eb; };      // distance of the candidate that holds at slot j (0: none); run starts / ends
+struct Round { uint32_t dd[4]; uint32_t sb, eb; uint32_t hh[2]; };      // distance of the candidate that holds at slot j (0: none); run starts / ends; the four table indices probed (two per word)
 template <uint32_t SH>
 __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi) {
     constexpr bool small = SH == 0;
@@ -255,7 +255,9 @@ __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t
             f0 = j == 0 ? R0 : j == 1 ? align_bytes(R1, R0, 2) : j == 2 ? R1 : align_bytes(R2, R1, 2);
             f4 = j == 0 ? R1 : j == 1 ? R1 >> 16 : j == 2 ? R2 : R2 >> 16;
         } else f0 = j == 0 ? R0 : align_bytes(R1, R0, j);
-        const uint32_t c = tab[hash_pos32(f0, f4, small)];
+        const uint32_t hj = hash_pos32(f0, f4, small);
+        if (j & 1) R.hh[j >> 1] |= hj << 16; else R.hh[j >> 1] = hj;
+        const uint32_t c = tab[hj];
         const uint32_t d = q - c;
         const bool ok = q <= q_hi && d - 1u < kMaxDistance;             // c < q, q - c <= 65535 (d - 1 wraps for c >= q)
         const uint32_t co = ok ? ring_back(o0 + (j << SH), d) : 0u;
@@ -298,7 +300,7 @@ __device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t
 
 template <uint32_t SH>
 __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
-                                            uint32_t* candS, uint16_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend MPROF_ARGS) {
+                                            uint32_t* candS, uint16_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend, uint32_t (&probe_h)[2] MPROF_ARGS) {
     const uint32_t lane = lane_id();
 #ifdef LZ4AMD_PROF_MATCH
     uint64_t mtq = clock_ticks();
@@ -323,6 +325,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                 //      probed again for the next 64 (the table is frozen: same answers), which keeps one round's registers live.
                 {
                     const Round A = probe_round<SH>(ring, tab, ring_fwd(cs_off, rel0), cs + rel0, q_hi);
+                    if (lo == 0) { probe_h[0] = A.hh[0]; probe_h[1] = A.hh[1]; }      // (the insert of this tile uses them again)
                     const uint32_t cntA = (uint32_t)__popc(A.sb) | ((uint32_t)__popc(A.eb) << 16);
                     const uint32_t inclA = wave_incl_sum(cntA), exA = inclA - cntA;
                     total = wave_readlane(inclA, 63);
@@ -951,11 +954,14 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
         }
         // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
+        uint32_t probe_h[2] = {0, 0}; bool probe_h_valid = false;
         if (w < nstrips) {
             const uint32_t cs = strip_lo(g0, t0, w, strip_len);
             uint32_t ce = g0 + (w + 1) * strip_len; if (ce > t1) ce = t1;
-            if (small) match_strip<0>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
-            else match_strip<1>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1 MPROF_PASS);
+            if (small) match_strip<0>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
+            else match_strip<1>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
+            // the lane probed positions cs + 8 * lane + {0, 2, 4, 6}: with 512-byte strips those are this thread's insert positions
+            probe_h_valid = !small && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: write out tile k-1 (into the staging buffer)
@@ -992,9 +998,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
                 uint32_t h[8];
 #pragma unroll
-                for (uint32_t i = 0; i < 8; i++) {
+                for (uint32_t i = 1; i < 8; i += 2) {
                     const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
                     h[i] = hash_pos32(lo, hi, small);
+                }
+                if (probe_h_valid) {                                    // the even ones were computed when the strip was probed (wave-uniform)
+                    h[0] = probe_h[0] & 0xFFFFu; h[2] = probe_h[0] >> 16; h[4] = probe_h[1] & 0xFFFFu; h[6] = probe_h[1] >> 16;
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; i += 2) {
+                        const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
+                        h[i] = hash_pos32(lo, hi, small);
+                    }
                 }
                 if (q0 + 7 < t1 && q0 + 7 <= last_q) {                  // every thread but the ones at a block's very end: no per-position test
 #pragma unroll
