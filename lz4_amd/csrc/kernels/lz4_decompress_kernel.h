@@ -429,7 +429,7 @@ __device__ __forceinline__ BItem b_item(const RegionCtx& C, uint32_t t) {
 }
 
 // Compose region C.R in its ring slot and store it.
-__device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint32_t w, uint64_t& t_retry, uint32_t& n_iter) {
+__device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint32_t w, bool timed, uint64_t& t_retry, uint32_t& n_iter) {
     char* smem = C.smem;
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
@@ -496,7 +496,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
         }
         // ---- pieces whose sources were still in flight: try again until they are all in
         if (pendA || pendBc) {
-            const uint64_t tr0 = clock_ticks();
+            const uint64_t tr0 = timed ? clock_ticks() : 0;
             uint64_t published = 0;
             const uint64_t actm = __ballot(actA);
             for (;;) {
@@ -578,7 +578,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                     if (left) { earlier_clear = false; pendBc |= chunks_of(left, it.chunk); }
                 }
             }
-            t_retry += clock_ticks() - tr0;
+            if (timed) t_retry += clock_ticks() - tr0;
         }
     }
     // ---- the region is complete: its bytes into registers, tell the other waves (they read the ring, not HBM: a region
@@ -645,7 +645,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
             ts = t; n_lead = n_cov = 0; }
         uint64_t tr = 0; uint32_t ni = 0;
         DTRACE("region R=%u x0=%u x1=%u j0=%u nrec=%u g=%u\n", R, C.x0, C.x1, C.j0, C.nrec, C.g);
-        copy_region(C, dst, w, tr, ni);
+        copy_region(C, dst, w, prof != nullptr, tr, ni);
         n_iters += ni; n_retried += ni ? 1u : 0u;
         DTRACE("region R=%u done\n", R);
         if (uload(&misc[M_ABORT])) goto out;
