@@ -48,7 +48,7 @@ const char* lz4amd_last_error(void);
  * either: the call records a notice (thread local, like the error text; "" when the last such call had nothing to say).
  * Today: LZ4_compress_fast* with acceleration > 1 (lz4.c:1389: the GPU parse has no speed / ratio knob) and
  * LZ4_compress_HC* with compressionLevel > 10 (lz4hc.c:92-106: levels 10-12 all run ONE optimal parse - 256 candidates per
- * position like level 9, 64-byte sufficient length like level 10) and LZ4_favorDecompressionSpeed. */
+ * position like level 9, 64-byte sufficient length like level 10). */
 const char* lz4amd_last_notice(void);
 int         lz4amd_device_cus(const lz4amd_ctx* ctx);
 
@@ -106,6 +106,11 @@ int  lz4amd_plan_profile(lz4amd_plan* plan, unsigned long long* words, int max_w
 /* one-shot conveniences: plan + launch + results (synchronous) */
 int  lz4amd_compress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                            void* const* d_dst, const int* dst_caps, int* results, int n, void* stream);
+/* The `level` of the LZ4AMD_OP_COMPRESS_HC entry points: the reference's compressionLevel, optionally with this flag on top: the
+ * optimal parse of levels 10-12 then prefers what decodes fast (no offsets below 8, lengths 19..36 cut to 18), like
+ * LZ4_favorDecompressionSpeed (lz4hc.h:364; lz4hc.c:926-929, 1816-1818).  Ignored below level 10, as in the reference. */
+#define LZ4AMD_HC_FAVOR_DEC_SPEED 0x100
+
 /* LZ4_compress_HC (lz4hc.h:66) per block; level as in the reference (3..9 = hash chain with 4..256
  * attempts; values outside are mapped to the nearest of those, 0 and below to the default 9) */
 int  lz4amd_compress_hc_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,

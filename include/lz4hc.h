@@ -65,7 +65,7 @@ int             LZ4_saveDictHC(LZ4_streamHC_t* streamHCPtr, char* safeBuffer, in
 /* ---- the long tail (lz4_amd/csrc/lz4_compat_api.c) */
 int  LZ4_compress_HC_extStateHC_fastReset(void* state, const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel);   /* lz4hc.h:397 */
 void LZ4_attach_HC_dictionary(LZ4_streamHC_t* working_stream, const LZ4_streamHC_t* dictionary_stream);      /* lz4hc.h:403 */
-void LZ4_favorDecompressionSpeed(LZ4_streamHC_t* LZ4_streamHCPtr, int favor);    /* lz4hc.h:364: accepted, not acted on (lz4amd_last_notice) */
+void LZ4_favorDecompressionSpeed(LZ4_streamHC_t* LZ4_streamHCPtr, int favor);    /* lz4hc.h:364: acts on levels 10-12 (no offsets < 8, lengths 19..36 cut to 18) */
 /* lz4hc.h:89, 170: as much of src as fits targetDstSize (prefixes compressed on the device, bisection) */
 int  LZ4_compress_HC_destSize(void* stateHC, const char* src, char* dst, int* srcSizePtr, int targetDstSize, int compressionLevel);
 int  LZ4_compress_HC_continue_destSize(LZ4_streamHC_t* LZ4_streamHCPtr, const char* src, char* dst, int* srcSizePtr, int targetDstSize);

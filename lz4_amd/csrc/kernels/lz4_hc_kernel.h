@@ -255,7 +255,7 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
 }
 
 __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
-                                               uint32_t band, uint32_t attempts, char* smem) {
+                                               uint32_t band, uint32_t attempts, bool favor, char* smem) {
     const uint32_t tid = opaque_u32(threadIdx.x);
     uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
     uint16_t* cring = (uint16_t*)(smem + kHOffChain);
@@ -421,7 +421,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                 // once per trip for every lane's nearest passing candidate, again only for lanes that have another
                 uint32_t hits = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt) ? 1u << k : 0u;
+                for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                 while (__ballot(hits != 0)) {
                     if (hits) {
                         const uint32_t k = (uint32_t)__ffs((int)hits) - 1;
@@ -569,7 +569,7 @@ __device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, cons
 enum : uint32_t { kOptWin = 64, kOptLit = 0x8000u, kOptInf = 0xFFFFFF00u };
 
 __device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, const uint32_t* best_g, uint16_t* choice_g, MatchRec* recs, uint32_t rec_cap,
-                                                   uint32_t* strip, uint32_t* first_rec, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce, uint64_t* prof = nullptr) {
+                                                   uint32_t* strip, uint32_t* first_rec, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce, bool favor, uint64_t* prof = nullptr) {
     const uint32_t lane = lane_here();
     const uint64_t tf0 = prof ? clock_ticks() : 0;
     uint32_t nseq = 0, enc = 0, ll0 = 0, tail = ce - cs;
@@ -590,6 +590,7 @@ __device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, 
             const uint32_t bv = best_g[gbase + lane];                   // (the array is padded)
             uint32_t Lv = bv & 0xFFu;
             {   const uint32_t pos = gbase + lane;
+                if (favor && Lv > 18 && Lv <= 36) Lv = 18;               // lz4hc.c:1816-1818: no length byte for a few bytes more
                 if (pos > last_q || Lv < kMinMatch || pos + kMinMatch > mlimit) Lv = 0;
                 else if (Lv <= kOptWin && pos + Lv > mlimit) Lv = mlimit - pos; }
             uint32_t chv = 0;                                            // moves of cells [gbase, gbase + 64), lane = cell - gbase
@@ -745,10 +746,14 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     if ((uint32_t)n_i >= kMfLimit + 1) {
         hc_build_chain(src, n, chain_g, smem);
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[0] += t - tq; tq = t; }
-        const uint32_t attempts = hc_attempts(P.level);
+        // (P.level: the reference's compressionLevel in the low byte; LZ4AMD_HC_FAVOR_DEC_SPEED = 0x100 on top of it asks the optimal
+        //  parse of levels 10-12 for the reference's decompression-speed preference, lz4hc.c:926-929, 1816-1818)
+        const int level = P.level & 0xFF;
+        const bool favor = (P.level & 0x100) != 0 && level >= 10;
+        const uint32_t attempts = hc_attempts(level);
 
         for (uint32_t band = 0; band < kHcBands; band++) {
-            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, smem);
+            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, favor, smem);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         }
         // -- parse: one wave per strip of the block proper
@@ -757,11 +762,11 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         strip_len = (((own + nstrips - 1) / nstrips) + 63) & ~63u;
         nstrips = (own + strip_len - 1) / strip_len;
         const uint32_t rec_cap = strip_len / 4 + 4;
-        const bool optimal = P.level >= 10;                              // lz4hc.c:92-106: levels 10-12 are the optimal parser's
+        const bool optimal = level >= 10;                                // lz4hc.c:92-106: levels 10-12 are the optimal parser's
         if (w < nstrips) {
             const uint32_t cs = first + w * strip_len;
             uint32_t ce = cs + strip_len; if (ce > n) ce = n;
-            if (optimal) hc_parse_strip_opt(src, n, st0_g, st1_g, recs_g + (uint64_t)w * rec_cap, rec_cap, strip, misc + HM_FIRST0, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce, prof);
+            if (optimal) hc_parse_strip_opt(src, n, st0_g, st1_g, recs_g + (uint64_t)w * rec_cap, rec_cap, strip, misc + HM_FIRST0, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce, favor, prof);
             else { hc_parse_strip(src, n, st0_g, recs_g + (uint64_t)w * rec_cap, strip, (uint32_t*)(smem + kHOffParse) + w * 2 * kHcChunk, w, cs, ce); if (lane_here() == 0) misc[HM_FIRST0 + w] = 0; }
         }
         __syncthreads();

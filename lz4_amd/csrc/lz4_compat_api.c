@@ -51,9 +51,8 @@ void LZ4_attach_HC_dictionary(LZ4_streamHC_t* workingStream, const LZ4_streamHC_
 }
 int LZ4_loadDictSlow(LZ4_stream_t* s, const char* dictionary, int dictSize) { return LZ4_loadDict(s, dictionary, dictSize); }   /* lz4.c:1621: the table is built on the device either way */
 void LZ4_favorDecompressionSpeed(LZ4_streamHC_t* s, int favor)
-{   /* lz4hc.c:1608: a parsing preference of the optimal parser (levels 10-12): accepted, not acted on (the device parse prices by size only) */
-    (void)s;
-    lz4amd_set_notice(favor ? "LZ4_favorDecompressionSpeed: accepted and not acted on (the optimal parse of levels 10-12 prices sequences by size only)" : "");
+{   /* lz4hc.c:1621: a preference of the optimal parser (levels 10-12); it travels to the kernel with the level (LZ4AMD_HC_FAVOR_DEC_SPEED) */
+    if (s) s->internal_donotuse.favorDecSpeed = (signed char)(favor != 0);
 }
 int LZ4_decompress_safe_withPrefix64k(const char* src, char* dst, int compressedSize, int maxOutputSize)
 {   /* lz4.c:2479: 64 KB of history sit right before dst */

@@ -160,7 +160,8 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     }
     if (p.compressionLevel >= 2) {
         /* lz4frame.c:943-958 LZ4F_selectCompression: levels >= LZ4HC_CLEVEL_MIN take the HC compressor */
-        if (lz4amd_plan_create_compress_hc_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL, p.compressionLevel)) goto done;
+        if (lz4amd_plan_create_compress_hc_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL,
+                                                  p.compressionLevel | (p.favorDecSpeed ? LZ4AMD_HC_FAVOR_DEC_SPEED : 0))) goto done;      /* lz4frame.c:713 */
     } else
     if (lz4amd_plan_create_compress_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL)) goto done;
     if (lz4amd_plan_launch(cplan, NULL)) goto done;

@@ -81,7 +81,8 @@ int LZ4_compress_HC_continue(LZ4_streamHC_t* s, const char* src, char* dst, int 
         if (srcEnd >= hist + hsz) { hist = NULL; hsz = 0; }
         else { hsz = (unsigned)((hist + hsz) - srcEnd); hist = srcEnd; if (hsz < 4) { hist = NULL; hsz = 0; } }
     }
-    r = lz4amd_compress_with_history(hist, (int)hsz, src, dst, srcSize, maxDstSize, s->internal_donotuse.compressionLevel);
+    r = lz4amd_compress_with_history(hist, (int)hsz, src, dst, srcSize, maxDstSize,
+                                     s->internal_donotuse.compressionLevel | (s->internal_donotuse.favorDecSpeed ? LZ4AMD_HC_FAVOR_DEC_SPEED : 0));
     if (hist && hist + hsz == src) {                                 /* contiguous: the window slides over both */
         unsigned long long total = (unsigned long long)hsz + (unsigned)srcSize;
         if (total > WINDOW) { hist += total - WINDOW; total = WINDOW; }

@@ -224,3 +224,37 @@ def test_hc_optimal_parse_levels_10_to_12(ctx, ocodec, corpus, datagen):
                 dst = ctypes.create_string_buffer(len(b) + len(b) // 255 + 16)
                 rs += ref.LZ4_compress_HC(b, dst, len(b), len(dst), 12)
             assert abs(s12 - rs) / rs < 0.03, (pct, s12, rs)
+
+
+def test_hc_favor_decompression_speed_through_the_stream_api(ctx, ocodec, datagen):
+    """LZ4_favorDecompressionSpeed (lz4hc.h:364) + LZ4_compress_HC_continue at level 12: the preference reaches the kernel with the
+    level (LZ4AMD_HC_FAVOR_DEC_SPEED): no offsets below 8 in the output (lz4hc.c:926-929), decodes bit-exactly, a little larger
+    than without; at level 9 the call changes nothing (the hash-chain levels ignore it, as in the reference)."""
+    import lz4_amd
+    from test_kernels_emulated import _sequences
+    L = lz4_amd.lib()
+    L.LZ4_createStreamHC.restype = ctypes.c_void_p
+    L.LZ4_freeStreamHC.argtypes = [ctypes.c_void_p]
+    L.LZ4_resetStreamHC_fast.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.LZ4_favorDecompressionSpeed.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.LZ4_compress_HC_continue.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    d = b"abcdefg" * 20000 + datagen(200000, 70, 8)
+    dst = ctypes.create_string_buffer(L.LZ4_compressBound(len(d)))
+    sizes = {}
+    for level in (12, 9):
+        for favor in (0, 1):
+            s = L.LZ4_createStreamHC()
+            L.LZ4_resetStreamHC_fast(s, level)
+            L.LZ4_favorDecompressionSpeed(s, favor)
+            r = L.LZ4_compress_HC_continue(s, d, dst, len(d), len(dst))
+            L.LZ4_freeStreamHC(s)
+            assert r > 0
+            c = dst.raw[:r]
+            ro, o = ocodec.decompress(c, len(d))
+            assert ro == len(d) and o == d
+            sizes[(level, favor)] = r
+            if level == 12 and favor:
+                assert all(off >= 8 for _, off, ml in _sequences(c) if ml)
+            if level == 12 and not favor:
+                assert any(off < 8 for _, off, ml in _sequences(c) if ml)
+    assert sizes[(12, 1)] >= sizes[(12, 0)] and sizes[(9, 1)] == sizes[(9, 0)]

@@ -524,6 +524,49 @@ def test_hc_optimal_parse_levels_10_to_12(emu, ocodec, reflib, corpus, datagen):
     assert ro == len(d) and o == d
 
 
+def _sequences(block):
+    """(literal length, offset, match length) of every sequence of a legal block (offset 0 for the last one)."""
+    i, out = 0, []
+    while i < len(block):
+        t = block[i]; i += 1
+        ll = t >> 4
+        if ll == 15:
+            while True:
+                b = block[i]; i += 1; ll += b
+                if b != 255:
+                    break
+        i += ll
+        if i >= len(block):
+            out.append((ll, 0, 0))
+            break
+        off = block[i] | (block[i + 1] << 8); i += 2
+        ml = t & 15
+        if ml == 15:
+            while True:
+                b = block[i]; i += 1; ml += b
+                if b != 255:
+                    break
+        out.append((ll, off, ml + 4))
+    return out
+
+
+def test_hc_favor_decompression_speed(emu, ocodec, datagen):
+    """LZ4_favorDecompressionSpeed (lz4hc.h:364) on the optimal parse of levels 10-12: level | LZ4AMD_HC_FAVOR_DEC_SPEED (0x100).
+    As in the reference (lz4hc.c:926-929, 1816-1818): no match with an offset below 8, lengths 19..36 found by the search are
+    cut to 18; the block still decodes, is a little larger, and the flag does nothing below level 10."""
+    datas = [datagen(262144, 60, 3), datagen(200000, 90, 4), b"abcdefg" * 30000 + datagen(50000, 50, 5), b"ab" * 50000]
+    plain = emu_compress_hc(emu, datas, level=12)
+    fav = emu_compress_hc(emu, datas, level=12 | 0x100)
+    for d, (r, c), (rp, cp) in zip(datas, fav, plain):
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        assert all(off >= 8 for _, off, ml in _sequences(c) if ml), len(d)
+        assert r >= rp
+    assert any(off < 8 for _, cp in plain for _, off, ml in _sequences(cp) if ml)     # (the plain parse does use such offsets)
+    nine = emu_compress_hc(emu, datas[:2], level=9)
+    assert [r for r, _ in emu_compress_hc(emu, datas[:2], level=9 | 0x100)] == [r for r, _ in nine]
+
+
 def test_hc_matches_beyond_32k_are_found(emu, ocodec):
     """The window is searched in two bands of 32 K positions: a repeat 40 000 / 60 000 bytes back must be
     found by the second band (offsets > 32 768 in the stream)."""
