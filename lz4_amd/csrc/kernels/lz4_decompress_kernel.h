@@ -534,11 +534,6 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                 }
                 if (!pendchunks) break;
                 n_iter++;
-                {
-                    const Ctl c = ctl_snapshot(smem);          // abort, stream bytes resident, first open region: one look
-                    if (c.abort_) return;
-                    C.chi = c.chi; C.g = c.open;
-                }
                 wave_lds_fence();                      // (pend[] of the last pass)
                 {
                     // the cheap way first: plain matches that only waited for their source chunks (one poll, one ring read)
@@ -566,6 +561,12 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                         if (!(doneA | doneB)) spin_pause();
                         continue;
                     }
+                }
+                {   // the full attempt: literal pieces wait for stream bytes - how many are resident now?  (plain matches, the cheap way
+                    // above, need none of the control words)
+                    const Ctl c = ctl_snapshot(smem);
+                    if (c.abort_) return;
+                    C.chi = c.chi; C.g = c.open;
                 }
                 pendBc = 0;
                 if (pendA) {
