@@ -184,6 +184,25 @@ def cpu_baseline_hc(block_bytes, pct, seed, level):
             "ref_comp_bytes": full["comp_bytes"], "ref_src_bytes": full["src_bytes"], "sample_blocks": full["blocks"]}
 
 
+def reference_blocks(host, bs, n):
+    """The first n blocks of `host` compressed by the reference's LZ4_compress_default (oracle/_ref, test infrastructure used
+    here as a data source only) -> (uint8 array [n, stride], sizes); None when the reference is not built."""
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "_ref", "liblz4_ref.so")
+    if not os.path.exists(so):
+        return None
+    R = ctypes.CDLL(so)
+    R.LZ4_compress_default.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    stride = (bs + bs // 255 + 16 + 255) & ~255
+    comp = np.zeros((n, stride), dtype=np.uint8)
+    sizes = []
+    for i in range(n):
+        r = R.LZ4_compress_default(host.ctypes.data + i * bs, comp.ctypes.data + i * stride, bs, stride)
+        assert r > 0
+        sizes.append(int(r))
+    return comp, sizes
+
+
 def stream_copy_gbps(ctx, lz4_amd, torch, nbytes, stream):
     """This box's own read+write stream rate: a plain 16-bytes-per-lane copy kernel of the library (2 * bytes / time)."""
     L = lz4_amd.lib()
@@ -449,6 +468,8 @@ def main():
     ap.add_argument("--no-hc", action="store_true", help="skip the LZ4_compress_HC (configs[3]) side measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the 2048-block shape and the configs[2] frame object")
     ap.add_argument("--no-data-path", action="store_true", help="N>1: skip the RCCL scatter / gather measurement")
+    ap.add_argument("--no-hints", action="store_true",
+                    help="do not pass the compressor's entry-point tables to the decoder (include/lz4amd.h): every block is decoded the way a foreign block is")
     args = ap.parse_args()
 
     import torch
@@ -498,6 +519,12 @@ def main():
     ctab = lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb,
                               [comp.data_ptr() + i * stride for i in range(nb)], [stride] * nb)
     cplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, ctab)
+    # the optional out-of-band column of the block table: the compressor writes an entry-point table next to every block
+    # (16 B per KB of source), the decoder of the same job parses from it.  Part of the step on both sides.
+    hstride = lz4_amd.hint_bytes(bs)
+    hints = None if args.no_hints else torch.zeros((nb, hstride), dtype=torch.uint8, device=dev)
+    if hints is not None:
+        cplan.attach_hints(hints.data_ptr(), hstride)
     cplan.launch(stream)
     csizes = cplan.results(stream)
     assert all(c > 0 for c in csizes), "compression failed"
@@ -505,6 +532,8 @@ def main():
     dtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nb)], csizes,
                               [out.data_ptr() + i * bs for i in range(nb)], [bs] * nb)
     dplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+    if hints is not None:
+        dplan.attach_hints(hints.data_ptr(), hstride)
     dplan.launch(stream)
     dres = dplan.results(stream)
     assert dres == [bs] * nb, "decompression failed"
@@ -545,6 +574,39 @@ def main():
     c_total /= args.steps
     d_total /= args.steps
     assert torch.equal(out, data), "round trip is not bit exact after the timed loop"
+    table_stats = dplan.hint_stats() if hints is not None else None
+    # ---- not part of the step: the same blocks decoded WITHOUT their tables (what a block of foreign origin costs: the
+    #      decoder first discovers the token chain), and blocks the reference compressor made (oracle/_ref, on the host)
+    foreign = {}
+    if rank == 0:
+        fplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+        out.zero_()
+        fplan.launch(stream)
+        assert fplan.results(stream) == [bs] * nb and torch.equal(out, data), "round trip without tables is not bit exact"
+        fms = sum(fplan.launch_timed(stream)[0][0] for _ in range(args.steps)) / args.steps
+        foreign["own_blocks_without_table"] = {"decompress_GBps": round(U / (fms * 1e-3) / 1e9, 2), "avg_ms": round(fms, 4),
+                                               "frac_of_hbm_peak": round((U + C) / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        try:
+            rb = reference_blocks(host, bs, min(nb, 64))
+            if rb is not None:
+                rcomp, rsz = rb
+                nr = len(rsz)
+                rdev = torch.from_numpy(rcomp).to(dev)
+                rstride = rcomp.shape[1]
+                reps = nb // nr                                  # the sample, repeated to the full table (same work per block)
+                rtab = lz4_amd.BlockTable([rdev.data_ptr() + (i % nr) * rstride for i in range(nr * reps)], [rsz[i % nr] for i in range(nr * reps)],
+                                          [out.data_ptr() + i * bs for i in range(nr * reps)], [bs] * (nr * reps))
+                rplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, rtab)
+                out.zero_()
+                rplan.launch(stream)
+                ok = rplan.results(stream) == [bs] * (nr * reps) and torch.equal(out[:nr * bs], data[:nr * bs])
+                rms = sum(rplan.launch_timed(stream)[0][0] for _ in range(args.steps)) / args.steps
+                Ur, Cr = nr * reps * bs, sum(rsz) * reps
+                foreign["reference_compressed_blocks"] = {"decompress_GBps": round(Ur / (rms * 1e-3) / 1e9, 2), "avg_ms": round(rms, 4), "bit_exact": bool(ok),
+                                                          "frac_of_hbm_peak": round((Ur + Cr) / (rms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                          "sample": "%d blocks compressed by the reference's LZ4_compress_default on the host, %d times over" % (nr, reps)}
+        except Exception as e:
+            foreign["reference_compressed_blocks"] = {"error": str(e)}
 
     # ---- not part of the step: the batched XXH32 kernel (frame block checksums) over the same blocks
     xplan = lz4_amd.Plan(ctx, lz4_amd.OP_XXH32, lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb, [0] * nb, [0] * nb))
@@ -581,6 +643,13 @@ def main():
             "roofline": roofline_obj(dom["kernel"], dom["avg_ms"], dom["algorithmic_bytes"], copy_gbps, traffic.get(dom["kernel"])),
             "roofline_decompress": roofline_obj("decompress", k_ms["decompress"], alg["decompress"], copy_gbps, traffic.get("decompress")),
             "kernels": kernels,
+            "entry_point_tables": ({"used": True, "bytes_per_block": hstride, "bytes_per_launch": hstride * nb,
+                                    "blocks_decoded_from_their_table": table_stats[0], "tables_rejected": table_stats[1],
+                                    "launches_counted": 1 + args.warmup + 2 * args.steps,
+                                    "note": "optional out-of-band column of the block table (include/lz4amd.h): written by lz4amd_k_compress, checked row by row by the decoder; "
+                                            "`decompress_GBps` above is WITH the tables, `decode_of_foreign_blocks` is without"}
+                                   if hints is not None else {"used": False}),
+            "decode_of_foreign_blocks": foreign,
             "kernel_sources_sha": kernel_sources_sha(),
             "extras": {"xxh32_batch_GBps": round(U / (x_ms * 1e-3) / 1e9, 1), "xxh32_batch_ms": round(x_ms, 3),
                        "note": "XXH32 (seed 0) of every 4 MiB block, one wave per block; not in `value`"},

@@ -89,6 +89,27 @@ int  lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, i
 int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                            const void* const* d_src, const int* src_sizes,
                                            void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix);
+/* Entry-point tables ("hints") - an optional, out-of-band column of the block table.
+ * A compress plan (LZ4AMD_OP_COMPRESS) that has them attached writes, next to every block, a small table that names one
+ * sequence of the block's token chain per 1 KB of source: {position of its token in the block, position of its literals
+ * in the source, sequences before it} (16 bytes per KB + 32; layout: csrc/lz4amd_params.h).  The block itself is an ordinary
+ * LZ4 block, byte for byte what it is without the table.  A decompress plan (LZ4AMD_OP_DECOMPRESS, lz4amd_plan_create /
+ * _prefix) that has the tables attached parses every block from all its entries at once instead of first discovering the
+ * serial token chain (what LZ4_decompress_generic's loop does implicitly, lz4.c:2123-2445) - about a third of the decoder's
+ * time on blocks of a few MB.  The tables are never trusted: every entry is checked against the stream, with the same
+ * rules as without them, before anything that depends on it becomes visible; a table that does not fit its block (wrong
+ * block, stale, corrupt) only costs time - the block is then decoded without it, with the same result and error codes.
+ * Block i's table lives at d_hints + i * stride (device memory, 16-byte aligned, stride a multiple of 16 and at least
+ * lz4amd_hint_bytes(largest source / decoded size)); it must stay valid while the plan is launched.
+ * LZ4_decompress_safe, the frame API and every plan without tables are unaffected. */
+size_t lz4amd_hint_bytes(int src_size);
+int  lz4amd_plan_attach_hints(lz4amd_plan* plan, void* d_hints, size_t stride);
+/* a decompress plan's count, since the tables were attached, of blocks decoded from their table and of tables that were
+ * rejected (those blocks were decoded without); synchronises the device */
+int  lz4amd_plan_hint_stats(lz4amd_plan* plan, unsigned* used, unsigned* rejected);
+/* LZ4_compress_fast's `acceleration` (lz4.h:236, lz4.c:1382-1400) for the blocks of a LZ4AMD_OP_COMPRESS plan: 1 = default,
+ * larger = faster and less compression, clamped to 65537 like the reference (lz4.c:1386-1387). */
+int  lz4amd_plan_set_acceleration(lz4amd_plan* plan, int acceleration);
 void lz4amd_plan_destroy(lz4amd_plan* plan);
 /* enqueue the whole table on `stream` (asynchronous) */
 int  lz4amd_plan_launch(lz4amd_plan* plan, void* stream);

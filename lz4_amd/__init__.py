@@ -5,8 +5,8 @@ only the Python-side binding used by tests and bench.py: ctypes over that C ABI,
 tensors as device memory.  There is no CPU codec here; importing works without a GPU, calling
 anything that needs the device raises.
 """
-from .api import (Context, Plan, OP_COMPRESS, OP_DECOMPRESS, OP_COMPRESS_HC, OP_XXH32, OP_GATHER, compress_bound, lib, lib_path,
+from .api import (Context, Plan, OP_COMPRESS, OP_DECOMPRESS, OP_COMPRESS_HC, OP_XXH32, OP_GATHER, compress_bound, hint_bytes, lib, lib_path,
                   BlockTable, compress_blocks, decompress_blocks, Lz4AmdError)
 
-__all__ = ["Context", "Plan", "OP_COMPRESS", "OP_DECOMPRESS", "OP_COMPRESS_HC", "OP_XXH32", "OP_GATHER", "compress_bound", "lib", "lib_path",
+__all__ = ["Context", "Plan", "OP_COMPRESS", "OP_DECOMPRESS", "OP_COMPRESS_HC", "OP_XXH32", "OP_GATHER", "compress_bound", "hint_bytes", "lib", "lib_path",
            "BlockTable", "compress_blocks", "decompress_blocks", "Lz4AmdError"]

@@ -53,12 +53,22 @@ def lib():
     L.LZ4_versionString.restype = ctypes.c_char_p
     L.lz4amd_plan_create_decompress_chained.argtypes = [vp, ctypes.POINTER(vp), i, ctypes.POINTER(vp), ip, vp, ip, ctypes.c_char_p, i]
     L.lz4amd_plan_create_prefix.argtypes = [vp, ctypes.POINTER(vp), i, ctypes.POINTER(vp), ip, ctypes.POINTER(vp), ip, ip]
+    L.lz4amd_hint_bytes.argtypes = [i]
+    L.lz4amd_hint_bytes.restype = ctypes.c_size_t
+    L.lz4amd_plan_attach_hints.argtypes = [vp, vp, ctypes.c_size_t]
+    L.lz4amd_plan_hint_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+    L.lz4amd_plan_set_acceleration.argtypes = [vp, i]
     _LIB = L
     return L
 
 
 def compress_bound(n):
     return lib().lz4amd_compress_bound(int(n))
+
+
+def hint_bytes(n):
+    """Bytes of the entry-point table of a block of n source bytes (include/lz4amd.h)."""
+    return int(lib().lz4amd_hint_bytes(int(n)))
 
 
 def _check(rc, what):
@@ -127,6 +137,19 @@ class Plan:
                                                            flags, int(initial_prefix)), "lz4amd_plan_create_decompress_chained")
         return self
 
+    def attach_hints(self, d_hints, stride):
+        """Entry-point tables: block i's at d_hints + i * stride (written by a compress plan, read by a decompress plan)."""
+        _check(lib().lz4amd_plan_attach_hints(self._h, ctypes.c_void_p(int(d_hints) if d_hints else None), int(stride)), "lz4amd_plan_attach_hints")
+
+    def hint_stats(self):
+        """(blocks decoded from their table, tables rejected) since the tables were attached."""
+        u, r = ctypes.c_uint(), ctypes.c_uint()
+        _check(lib().lz4amd_plan_hint_stats(self._h, ctypes.byref(u), ctypes.byref(r)), "lz4amd_plan_hint_stats")
+        return u.value, r.value
+
+    def set_acceleration(self, acceleration):
+        _check(lib().lz4amd_plan_set_acceleration(self._h, int(acceleration)), "lz4amd_plan_set_acceleration")
+
     def launch(self, stream=0):
         _check(lib().lz4amd_plan_launch(self._h, ctypes.c_void_p(stream)), "lz4amd_plan_launch")
 
@@ -162,9 +185,10 @@ def _stream_handle(stream):
     return getattr(stream, "cuda_stream", stream)
 
 
-def compress_blocks(ctx, data, block_size, stream=None, hc_level=None):
+def compress_blocks(ctx, data, block_size, stream=None, hc_level=None, hints=None, acceleration=1):
     """Compress a CUDA uint8 tensor as independent blocks of `block_size` bytes (LZ4_compress_default
-    per block, or LZ4_compress_HC at `hc_level` when given).
+    per block, or LZ4_compress_HC at `hc_level` when given).  hints: a CUDA uint8 tensor [n, hint_bytes(block_size)]
+    that receives the blocks' entry-point tables.
     Returns (comp tensor [n, stride], sizes list, plan)."""
     import torch
     assert data.is_cuda and data.dtype == torch.uint8 and data.dim() == 1
@@ -177,13 +201,17 @@ def compress_blocks(ctx, data, block_size, stream=None, hc_level=None):
     table = BlockTable([base + i * block_size for i in range(n)], sizes,
                        [cbase + i * stride for i in range(n)], [stride] * n)
     plan = Plan(ctx, OP_COMPRESS, table) if hc_level is None else Plan(ctx, OP_COMPRESS_HC, table, level=hc_level)
+    if hints is not None:
+        plan.attach_hints(hints.data_ptr(), hints.stride(0))
+    if acceleration != 1:
+        plan.set_acceleration(acceleration)
     s = _stream_handle(stream)
     plan.launch(s)
     return comp, plan.results(s), plan
 
 
-def decompress_blocks(ctx, comp, csizes, block_size, total, stream=None):
-    """Inverse of compress_blocks.  Returns (out tensor [total], results list, plan)."""
+def decompress_blocks(ctx, comp, csizes, block_size, total, stream=None, hints=None):
+    """Inverse of compress_blocks (hints: the tables compress_blocks filled).  Returns (out tensor [total], results list, plan)."""
     import torch
     n = len(csizes)
     out = torch.empty(max(total, 1), dtype=torch.uint8, device=comp.device)
@@ -192,6 +220,8 @@ def decompress_blocks(ctx, comp, csizes, block_size, total, stream=None):
     table = BlockTable([comp.data_ptr() + i * stride for i in range(n)], csizes,
                        [out.data_ptr() + i * block_size for i in range(n)], caps)
     plan = Plan(ctx, OP_DECOMPRESS, table)
+    if hints is not None:
+        plan.attach_hints(hints.data_ptr(), hints.stride(0))
     s = _stream_handle(stream)
     plan.launch(s)
     return out[:total], plan.results(s), plan

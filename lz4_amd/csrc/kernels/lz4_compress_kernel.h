@@ -84,6 +84,8 @@ static_assert(kCmpLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert(kCOffRing % 16 == 0 && kCOffStage % 16 == 0 && kCOffCarry % 16 == 0 && kSrcRing % 16 == 0, "LDS alignment");
 enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4,     // CM_READY: tiles whose output offsets are fixed
                   CM_EMITQ = 5,        // next strip of the settled tile to write out (handed to whichever wave is free)
+                  CM_SEQS = 6,         // entry-point table: sequences of the tiles settled so far
+                  CM_HPEND = 7,        // ... first region whose entry is not written yet (no sequence at or behind it so far)
                   CM_TILE = 8 };       // u32[2][4] per tile in flight: { first output position, end, written directly (not staged),
                                        //   first pending byte of its carry chunk }
 enum : uint32_t { T_OUT0 = 0, T_OUT1 = 1, T_DIRECT = 2, T_CFROM = 3 };
@@ -864,6 +866,49 @@ __device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_
                         (uint32_t*)(smem + kCOffCandS) + sw * kCandPerPass);    // (scratch: the executing wave's candidate list, idle now; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
 }
 
+// ------------------------------------------------------------------------------ entry-point table (optional output)
+// For every 1 KB region of the source, the first sequence that the strips from the region's first byte on emitted:
+// {where its token sits in the block, where its literals start in the source, how many sequences precede it}
+// (lz4amd_params.h: lz4amd_hint_entry).  A decoder that is handed the table parses the block from all those entries at
+// once instead of discovering the token chain (lz4_decompress_kernel.h: PARSER); the block itself is an ordinary LZ4 block.
+// One wave per tile, whichever is free first once the tile is settled: lane = strip.
+__device__ __forceinline__ void st_hint(lz4amd_gdst hints, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord) {
+    U32x4 v; v[0] = tok; v[1] = out; v[2] = ord; v[3] = 0;
+    st_global16(hints + 16 * (uint64_t)(r + 1), v);                 // (row 0 is the header)
+}
+__device__ __forceinline__ void hint_tile(char* smem, uint32_t pp, uint32_t nstrips, uint32_t t0, uint32_t strip_len, uint32_t t1,
+                                          uint32_t pre, lz4amd_gdst hints) {
+    uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
+    const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
+    const uint32_t lane = lane_id();
+    const bool mine = lane < nstrips;
+    const uint32_t nk = mine ? strip_p[S_N * kCmpWaves + lane] : 0u;
+    const unsigned long long m = __ballot(nk != 0);                 // strips with sequences
+    const uint32_t incl = wave_incl_sum(nk), seq0 = misc[CM_SEQS], pend = misc[CM_HPEND];
+    const uint32_t nseq_tile = wave_readlane(incl, 63);
+    wave_lds_fence();
+    if (lane == 0) misc[CM_SEQS] = seq0 + nseq_tile;
+    if (!m) return;                                                 // (the regions of this tile stay pending)
+    const uint32_t ord = seq0 + incl - nk;
+    const uint32_t tok = mine ? strip_p[S_OUT * kCmpWaves + lane] : 0u;
+    const uint32_t start = mine ? strip_p[S_P * kCmpWaves + lane] - strip_p[S_CARRY * kCmpWaves + lane] - pre : 0u;     // first literal of the strip's first sequence
+    // regions before this tile that had no sequence behind them so far: the tile's first one
+    const uint32_t F = (uint32_t)__ffsll((long long)m) - 1;
+    const uint32_t ra = (t0 - pre) >> LZ4AMD_HINT_REGION_SHIFT, nr = (t1 - t0 + 1023) >> LZ4AMD_HINT_REGION_SHIFT;     // the tile's regions (tiles start on the 1 KB grid of the block)
+    {
+        const uint32_t ft = wave_readlane(tok, F), fs = wave_readlane(start, F), fo = wave_readlane(ord, F);
+        for (uint32_t r = pend + lane; r < ra; r += 64) st_hint(hints, r, ft, fs, fo);
+    }
+    // regions of this tile, lane = region (at most 8): the first strip with sequences from the region's first strip on
+    const uint32_t s = (lane << LZ4AMD_HINT_REGION_SHIFT) >> (31 - __clz((int)strip_len));
+    const unsigned long long rest = (lane < nr && s < 64) ? m >> s : 0ull;
+    const uint32_t nv = rest ? s + (uint32_t)__ffsll((long long)rest) - 1 : 0u;
+    const uint32_t et = (uint32_t)__shfl((int)tok, (int)nv), es = (uint32_t)__shfl((int)start, (int)nv), eo = (uint32_t)__shfl((int)ord, (int)nv);
+    if (rest) st_hint(hints, ra + lane, et, es, eo);
+    const uint32_t done = (uint32_t)__popcll(__ballot(rest != 0));    // (a region without a strip behind it: so are all later ones)
+    if (lane == 0) misc[CM_HPEND] = ra + done;
+}
+
 // ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t b, char* smem) {
     const uint32_t tid = threadIdx.x, w = wave_id();
@@ -889,18 +934,19 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const int32_t n_i = P.src_size[b];
     const int32_t cap_i = P.dst_cap[b];
     if (n_i < 0 || (uint32_t)n_i > kMaxInput || cap_i <= 0 || P.dst[b] == nullptr || (P.src[b] == nullptr && n_i != 0)) {
-        if (tid == 0) P.result[b] = 0;                               // lz4.c:1360
+        if (tid == 0) { P.result[b] = 0; if (P.hints) *(uint32_t*)(P.hints + (uint64_t)b * P.hint_stride) = 0; }      // lz4.c:1360
         return;
     }
-    if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }      // lz4.c:1361-1371
+    if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; if (P.hints) *(uint32_t*)(P.hints + (uint64_t)b * P.hint_stride) = 0; } return; }      // lz4.c:1361-1371 (no table for an empty block)
     const uint32_t n = (uint32_t)n_i + pre, cap = (uint32_t)cap_i;
     const bool small = (uint32_t)n_i < kSmallBlockLimit;       // (the block's own size: a small block is probed at every position whatever history precedes it)
     const uint32_t a0 = (uint32_t)((uintptr_t)P.dst[b] & 15u);        // dst's place on HBM's 16-byte grid
+    const lz4amd_gdst hints = P.hints ? LZ4AMD_TO_GDST(P.hints + (uint64_t)b * P.hint_stride) : (lz4amd_gdst)nullptr;      // optional entry-point table
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
-        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0;
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_SEQS] = 0; misc[CM_HPEND] = 0;
 #ifdef LZ4AMD_PROF_TILE
         for (uint32_t i = 24; i < 30; i++) misc[i] = 0;
 #endif
@@ -974,7 +1020,11 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 uint32_t sx = 0;
                 if (lane_id() == 0) sx = atomicAdd(&misc[CM_EMITQ], 1u);
                 sx = __builtin_amdgcn_readfirstlane(sx);
-                if (sx >= prev_nstrips) break;
+                if (sx >= prev_nstrips) {
+                    // (the first wave to find the queue empty writes the settled tile's rows of the entry-point table)
+                    if (hints && sx == prev_nstrips) hint_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, pre, hints);
+                    break;
+                }
                 emit_tile_strip(smem, par ^ 1, sx, w, src, dst, a0, ring_lo);
             }
         }
@@ -1036,7 +1086,10 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     __syncthreads();
     // -- the last tile's sequences (settled by wave 0 first)
     if (prev_nstrips) {
-        if (w == kSettleWave) settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
+        if (w == kSettleWave) {
+            settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
+            if (hints) hint_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, pre, hints);
+        }
         __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
         if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, w, src, dst, a0, ring_lo);
@@ -1046,7 +1099,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     __syncthreads();
     if (prof) {
         // developer aid: match + emit time of every wave (spread between the strips of a tile)
-        if (w == 0 && lane_id() == 0) misc[6] = (uint32_t)(tp[4] >> 4);
+        if (w == 0 && lane_id() == 0) misc[CM_EMITQ] = (uint32_t)(tp[4] >> 4);
 #ifndef LZ4AMD_PROF_TILE
         if (lane_id() == 0) misc[16 + w] = (uint32_t)((tp[1] + tp[4]) >> 4);
 #endif
@@ -1057,7 +1110,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #ifdef LZ4AMD_PROF_TILE
             { const uint64_t* m64 = (const uint64_t*)(smem + kCOffMisc); mx = m64[12]; mn = m64[13]; sm = m64[14] * kCmpWaves; }
 #endif
-            prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = (uint64_t)misc[6] << 4; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
+            prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = (uint64_t)misc[CM_EMITQ] << 4; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
 #ifdef LZ4AMD_PROF_WAVES
             for (uint32_t i = 0; i < 8; i++) prof[i] = (uint64_t)misc[16 + 2 * i] | ((uint64_t)misc[17 + 2 * i] << 32);      // developer build: match + emit time of each wave (>> 4)
 #endif
@@ -1070,7 +1123,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     // -- the pending bytes of the last chunk, then the final literal run (lz4.c:1302-1329)
     const uint32_t out = misc[CM_OUT], run = misc[CM_CARRY];
     const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;
-    if (misc[CM_FAIL] || total > cap) { if (tid == 0) P.result[b] = 0; return; }
+    if (misc[CM_FAIL] || total > cap) { if (tid == 0) { P.result[b] = 0; if (hints) *(uint32_t*)hints = 0; } return; }
+    if (hints && w == kCmpWaves - 1) {
+        // the table's last rows: regions without a sequence at or behind them name the block's last sequence (its final
+        // literals), the row behind the last region is the block's end; the header makes the table valid
+        const uint32_t seqs = misc[CM_SEQS], nreg = ((uint32_t)n_i + 1023) >> LZ4AMD_HINT_REGION_SHIFT;
+        for (uint32_t r = misc[CM_HPEND] + lane_id(); r < nreg; r += 64) st_hint(hints, r, out, n - run - pre, seqs);
+        if (lane_id() == 0) {
+            st_hint(hints, nreg, (uint32_t)total, (uint32_t)n_i, seqs + 1);
+            U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = (uint32_t)n_i; h[2] = (uint32_t)total; h[3] = seqs + 1;
+            st_global16(hints, h);
+        }
+    }
     {
         const uint32_t r = (out + a0) & 15u, cfrom = misc[CM_TILE + 4 * par + T_CFROM];
         const uint8_t* Cn = (const uint8_t*)(smem + kCOffCarry) + 16 * par;

@@ -58,7 +58,8 @@ enum : uint32_t {
     kDecThreads = 1024,
     kDecWaves = kDecThreads / 64,
     kMoveWave = kDecWaves - 1,                  // compressed stream, sequence records, region index -> LDS
-    kCopyWaves = kDecWaves - 1,                 // waves 0 .. kCopyWaves-1
+    kCopyWaves = kDecWaves - 1,                 // waves 0 .. kCopyWaves-1 (one fewer when the block comes with an entry-point table:
+    kParseWave = kDecWaves - 2,                 //   this wave then parses the stream from the table's entries, PARSER below)
     kChunk = 16,                                // output bytes composed at a time
     kRegionShift = 10,
     kRegion = 1u << kRegionShift,               // 64 chunks
@@ -72,6 +73,9 @@ enum : uint32_t {
     kRecMask = kRecCap - 1,
     kIdxRing = 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
+    kEntRing = 256,                             // rows of the block's entry-point table (16 B each), ring
+    kEntMask = kEntRing - 1,
+    kLaneSeqMax = 1024,                         // sequences between two entries of a table (one is 1 KB of source: at most 257)
     kDmaDepth = 16,                             // LDS-DMA instructions (1 KB each) the mover keeps in flight
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
     kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
@@ -89,7 +93,8 @@ enum : uint32_t {
     kOffRegDone = kOffBits + kSlots * 64,                    // u32[kSlots] region + 1 that is complete in the slot
     kOffIdx = kOffRegDone + kSlots * 4,                      // u32[kIdxRing]
     kOffPend = kOffIdx + kIdxRing * 4,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
-    kOffRecs = (kOffPend + kCopyWaves * (kMaxTrips + 2) * 8 + 15) & ~15u,   // SeqRec[kRecCap]
+    kOffEnt = (kOffPend + kCopyWaves * (kMaxTrips + 2) * 8 + 15) & ~15u,    // lz4amd_hint_entry[kEntRing]
+    kOffRecs = kOffEnt + kEntRing * 16,                      // SeqRec[kRecCap]
     kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
     kOffRing = kOffCr + kCrBytes + kCrPad,                   // output ring + pad
     kStreamLdsBytes = kOffRing + kRingBytes + kRingPad,
@@ -98,7 +103,10 @@ enum : uint32_t {
 static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0, "LDS alignment");
 
-enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_SPARE, M_CHI, M_CLO, M_HEAD, M_IHEAD, M_NEXT, M_OPEN };      // (M_HEAD, M_IHEAD: one aligned 64-bit word, published together: table rows resident, region index entries resident)      // (word 1 is the pre-parse's error word)
+enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_SPARE, M_CHI, M_CLO, M_HEAD, M_IHEAD, M_NEXT, M_OPEN,
+                  M_EHEAD,       // rows of the entry-point table resident (mover -> parser)
+                  M_PR0,         // first row the parser still needs (parser -> mover)
+                  M_PBAD };      // the table does not fit the stream: the block is decoded again without it      // (M_HEAD, M_IHEAD: one aligned 64-bit word, published together: table rows resident, region index entries resident)      // (word 1 is the pre-parse's error word)
 
 // scratch of one workgroup: the sequence-record table of the block it is decoding, the pre-parse's token list, the region index
 __host__ __device__ inline uint64_t dec_scratch_bytes(uint32_t max_csize, uint32_t max_out) { return pre::scratch_bytes(max_csize, max_out); }
@@ -206,7 +214,10 @@ __device__ __forceinline__ uint32_t first_open_region(const char* smem) {
 // the block's misalignment): the first and the last granule reach up to 15 bytes beyond the block, inside the same
 // granule (and page); those bytes are never used.  No per-record work: whatever the copy needs to know about a region it
 // reads from the rings.  Nothing here blocks on the copy: what does not fit now is tried on the next trip.
-__device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t rend, char* smem) {
+// With an entry-point table (hint != null) records and region index are made by the PARSER wave, in LDS: the mover then
+// moves the table's rows (a 256-row ring, 64 rows per DMA instruction) instead of records and index.
+__device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t rend, char* smem,
+                                           lz4amd_gsrc hint, uint32_t nent) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     uint32_t* idx = (uint32_t*)(smem + kOffIdx);
     const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
@@ -223,11 +234,16 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
     uint32_t ihead = kFirstRegion, tail = 0, need = 0;
     uint64_t fifo = 0; uint32_t q = 0;                 // what is in flight, oldest at bit 0: 0 = a stream chunk, 1 = 64 table rows
     uint32_t pidx = 0, icarry = 0;
-    if (ihead + lane < rend) pidx = ridx[lane];
+    const bool hinted = hint != nullptr;
+    char* ent = smem + kOffEnt;
+    uint32_t ei = 0, ec = 0;                           // table rows issued / landed (multiples of 64)
+    if (!hinted && ihead + lane < rend) pidx = ridx[lane];
     for (;;) {
         const Ctl c = ctl_snapshot(smem);
         if (c.abort_) break;
         bool progress = false;
+        const uint32_t pr0 = hinted ? uload(&misc[M_PR0]) : 0u;
+        if (hinted) { ihead = c.ihead; hc = c.head; }  // (published by the parser)
         // ---- the first open region: this wave is the only one that moves the word, over every complete region in front of it
         //      (at most kMaxLead + 1 regions are in flight; their complete marks in one read, lane = region)
         uint32_t g = c.open;
@@ -239,7 +255,7 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
             if (adv) { g += adv; if (lane == 0) lds_store_release(&misc[M_OPEN], g); progress = true; }
         }
         // ---- the region index: regions [ihead, ihead + 64), once the ring has let go of the regions 512 below them
-        if (ihead < rend) {
+        if (!hinted && ihead < rend) {
             const uint32_t n = rend - ihead < 64 ? rend - ihead : 64;
             if (ihead + n <= g + kIdxRing) {
                 // (a sequence that covers several region starts noted only the first: holes take the entry before them)
@@ -274,9 +290,13 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
                 lds_dma16((const void*)(src0 + 16 * (uint64_t)gr), cr + ((si << 10) & (kCrBytes - 1)));
                 q++; si++; did = true;                                               // (its fifo bit is 0)
             }
-            if (q < kDmaDepth && hi < nrows && hi + 64 - tail <= kRecCap) {
+            if (!hinted && q < kDmaDepth && hi < nrows && hi + 64 - tail <= kRecCap) {
                 lds_dma16(rectab + (hi + lane < nrows ? hi + lane : nrows - 1), (char*)recs + ((hi & kRecMask) << 4));      // (rows behind the table's last: the last again, nobody reads them)
                 fifo |= 1ull << q; q++; hi += 64; did = true;
+            }
+            if (hinted && q < kDmaDepth && ei < nent && ei + 64 <= pr0 + kEntRing) {
+                lds_dma16((const void*)(hint + 16 * (uint64_t)(ei + lane < nent ? ei + lane : nent - 1)), ent + ((ei & kEntMask) << 4));
+                fifo |= 1ull << q; q++; ei += 64; did = true;
             }
             if (!did) break;
             issued = true;
@@ -294,7 +314,7 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
             if (((sc + (kCrBytes >> 10) - 1) & ~((kCrBytes >> 10) - 1)) < s1) {            // (a chunk that starts a lap has landed)
                 if (lane < kCrPad / 16) *(U32x4*)(cr + kCrBytes + 16 * lane) = *(const U32x4*)(cr + 16 * lane);
             }
-            sc = s1; hc += 64 * nrec;
+            sc = s1; if (hinted) ec += 64 * nrec; else hc += 64 * nrec;
             fifo >>= r; q = keep;
             wave_lds_fence();
             if (lane == 0) {
@@ -305,10 +325,211 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
         }
         if (progress) {
             wave_lds_fence();
-            if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(hc < nrows ? hc : nrows) | ((uint64_t)ihead << 32));
+            if (hinted) { if (lane == 0) lds_store_release(&misc[M_EHEAD], ec < nent ? ec : nent); }
+            else if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(hc < nrows ? hc : nrows) | ((uint64_t)ihead << 32));
         }
-        if (hc >= nrows && ihead == rend && sc == nchunks && g >= rend) break;          // everything moved, every region complete
-        if (!progress) { spin_pause_long(); if (sc < nchunks || hc < nrows) spin_pause_long(); }      // (the rings hold tens of thousands of cycles of work: a look every ~1000 is plenty, and every look takes issue slots from the copy waves of this SIMD)
+        if (hinted ? (ec >= nent && sc == nchunks && g >= rend) : (hc >= nrows && ihead == rend && sc == nchunks && g >= rend)) break;          // everything moved, every region complete
+        if (!progress) { spin_pause_long(); if (sc < nchunks || (!hinted && hc < nrows)) spin_pause_long(); }      // (the rings hold tens of thousands of cycles of work: a look every ~1000 is plenty, and every look takes issue slots from the copy waves of this SIMD)
+    }
+}
+
+// ------------------------------------------------------------------------------ PARSER (blocks that come with an entry-point table)
+// An entry-point table (lz4amd_params.h: lz4amd_hint_entry; written by lz4amd_k_compress next to the block it made, or by
+// anybody else) names one sequence of the token chain per 1 KB of output.  With it the serial chain is cut in pieces that
+// are parsed side by side: LANE k of this wave walks the sequences from row r0 + k up to row r0 + k + 1 out of the
+// compressed ring in LDS - token, literal length, offset, match length, the same rules as the pre-parse's P5
+// (read_variable_length lz4.c:1979-2014; lz4.c:2279, 2312-2318, 2356, 2423) - and writes their records and the region
+// index straight into the rings the copy waves read.  Stage A, its scratch in HBM and its two passes over the stream
+// are not needed at all.
+// The table is NEVER trusted: row 0 must be the block's first byte, every lane must arrive exactly at the next row (token
+// position, output position and sequence count), the last row must be the block's end - by induction every record then
+// lies on the true chain - and nothing a batch of lanes wrote is published before all of them have arrived.  A table
+// that does not fit the stream costs time only: M_PBAD, and the block is decoded again the ordinary way.
+// Bytes that are not in the ring (a row far ahead of what the mover has loaded; length fields of many bytes) are read
+// from memory instead.
+struct HintEnt { uint32_t tok, out, ord, zero; };
+
+// one stream byte at position x (x < csize): out of the compressed ring when it is resident, else from memory
+__device__ __forceinline__ uint32_t pbyte(const char* cr, lz4amd_gsrc src, uint32_t x, uint32_t mis, uint32_t chi) {
+    if (x < chi) return (uint32_t)*(const uint8_t*)(cr + mod_cr(x + mis));
+    return (uint32_t)src[x];
+}
+// A length field's extension bytes (lz4.c:1979-2014): acc += bytes from pos on, up to and including the first one that is
+// not 255.  A byte at position x may be read iff x + tailroom <= csize (16 for literal lengths, 5 for match lengths: what
+// the reference's ilimit / iend - 4 tests say); else the block is malformed.  The first bytes lane by lane (nearly all
+// fields end there), the rest of a long field 64 bytes at a time by the whole wave, from memory.
+__device__ __forceinline__ void ext_field(bool need, uint32_t& pos, uint32_t& acc, bool& bad, uint32_t tailroom,
+                                          const char* cr, lz4amd_gsrc src, uint32_t csize, uint32_t mis, uint32_t chi) {
+    const uint32_t lane = lane_here();
+    bool more = need;
+    for (uint32_t trip = 0; trip < 4 && __any(more); trip++) {
+        const bool legal = pos + tailroom <= csize;
+        uint32_t x = 0;
+        if (more && legal) x = pbyte(cr, src, pos, mis, chi);
+        bad = bad || (more && !legal);
+        acc += more && legal ? x : 0u; pos += more && legal ? 1u : 0u;
+        more = more && legal && x == 255;
+    }
+    unsigned long long pm = __ballot(more);
+    while (pm) {
+        const uint32_t l = (uint32_t)__ffsll((long long)pm) - 1; pm &= pm - 1;
+        uint32_t P0 = wave_readlane(pos, l), add = 0; bool fbad = false;
+        for (;;) {
+            const uint32_t ps = P0 + lane;
+            const bool legal = ps + tailroom <= csize;
+            const uint32_t x = legal ? (uint32_t)src[ps] : 0u;
+            const unsigned long long stopm = __ballot(!legal || x != 255);
+            if (!stopm) { add += 255 * 64; P0 += 64; if (add > 0x7F000000u) { fbad = true; break; } continue; }
+            const uint32_t kk = (uint32_t)__ffsll((long long)stopm) - 1;
+            if (!wave_readlane(legal ? 1u : 0u, kk)) fbad = true;
+            else { add += 255 * kk + wave_readlane(x, kk); P0 += kk + 1; }
+            break;
+        }
+        if (lane == l) { acc += add; pos = P0; bad = bad || fbad; }
+    }
+}
+
+__device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix, uint32_t total, uint32_t nseq,
+                                            uint32_t nreg, uint32_t rend, char* smem) {
+    uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    uint32_t* idx = (uint32_t*)(smem + kOffIdx);
+    SeqRec* recs = (SeqRec*)(smem + kOffRecs);
+    const HintEnt* ent = (const HintEnt*)(smem + kOffEnt);
+    const char* cr = smem + kOffCr;
+    const uint32_t lane = lane_here();
+    const uint32_t mis = stream_misalign(src);
+    const uint32_t capB = cap + kBias, low = kBias - prefix;
+    uint32_t r0 = 0;                                   // first row not parsed yet
+    uint32_t Ra = kFirstRegion;                        // regions below Ra have their index entry
+    uint32_t head = 0, icarry = 0, tail = 0, stall = 0;
+    bool fail = false;
+    while (r0 < nreg) {
+        const Ctl c = ctl_snapshot(smem);
+        if (c.abort_) return;
+        const uint32_t ehead = uload(&misc[M_EHEAD]);
+        const uint32_t g = c.open, chi = c.chi;
+        // ---- how many lanes?  Rows [r0, r0 + nl] must be resident; the lanes' records must fit the record ring behind the first
+        //      record an open region still needs, their regions the index ring; and the lanes' stream bytes should be resident.
+        uint32_t nlmax = nreg - r0 < 64 ? nreg - r0 : 64;
+        if (ehead < r0 + 2) { spin_pause(); continue; }
+        if (ehead - r0 - 1 < nlmax) nlmax = ehead - r0 - 1;
+        HintEnt A, B; A.tok = A.out = A.ord = A.zero = 0; B = A;
+        if (lane < nlmax) { A = ent[(r0 + lane) & kEntMask]; B = ent[(r0 + lane + 1) & kEntMask]; }
+        // the rows themselves: never decreasing, inside the block, no more sequences between two of them than 1 KB of output can start
+        bool rowbad = lane < nlmax && (A.tok > B.tok || A.out > B.out || A.ord > B.ord || B.tok > csize || B.out > total || B.ord - A.ord > kLaneSeqMax
+                                       || (A.tok == B.tok) != (A.ord == B.ord) || (A.tok == B.tok && A.out != B.out));
+        if (r0 == 0 && lane == 0 && (A.tok | A.out | A.ord)) rowbad = true;
+        if (r0 + lane + 1 == nreg && lane < nlmax && (B.tok != csize || B.out != total || B.ord != nseq)) rowbad = true;
+        if (__any(rowbad)) { fail = true; break; }
+        if (g < c.ihead) tail = __builtin_amdgcn_readfirstlane(idx[g & kIdxMask]);      // first record an open region needs (only ever grows)
+        const uint32_t Rb = (B.out + kBias + kRegion - 1) >> kRegionShift;              // regions below Rb have their first byte before my lane's end
+        const bool okrec = B.ord + 1 - tail <= kRecCap;
+        const bool okidx = Rb + 1 <= g + kIdxRing;
+        const unsigned long long mh = __ballot(lane < nlmax && okrec && okidx), mr = __ballot(lane < nlmax && okrec && okidx && B.tok <= chi);
+        const uint32_t nl_hard = ~mh ? (uint32_t)__ffsll((long long)~mh) - 1 : 64u, nl_res = ~mr ? (uint32_t)__ffsll((long long)~mr) - 1 : 64u;      // leading lanes that may go
+        if (!nl_res && nl_hard && chi < csize && stall < 16) { stall++; spin_pause(); continue; }      // (the mover is about to bring the bytes)
+        stall = 0;
+        uint32_t nl = nl_res ? nl_res : (nl_hard ? 1u : 0u);
+        DTRACE("parser r0=%u nlmax=%u ehead=%u g=%u chi=%u nl_hard=%u nl_res=%u tail=%u Ra=%u\n", r0, nlmax, ehead, g, chi, nl_hard, nl_res, tail, Ra);
+        bool smode = false;                             // a lane whose regions do not fit the index ring at once: alone, filling the index as it goes
+        if (!nl) {
+            const uint32_t Rb0 = wave_readlane(Rb, 0);
+            if (wave_readlane(okrec ? 1u : 0u, 0) && Rb0 - Ra > kIdxRing / 2) { smode = true; nl = 1; }
+            else { spin_pause(); continue; }
+        }
+        const uint32_t RbN = wave_readlane(Rb, nl - 1);
+        if (!smode) { for (uint32_t R = Ra + lane; R < RbN; R += 64) idx[R & kIdxMask] = 0; }      // (notes below; regions without one are holes)
+        wave_lds_fence();
+        // ---- walk
+        uint32_t p = A.tok, o = A.out + kBias, i = A.ord;
+        const uint32_t end = B.tok, oend = B.out + kBias, iend = B.ord;
+        bool act = lane < nl && p < end, bad = false;
+        while (__any(act)) {
+            // token, literal length
+            uint32_t b = 0;
+            if (act) b = pbyte(cr, src, p, mis, chi);
+            uint32_t ll = b >> 4, q = p + 1;
+            ext_field(act && ll == 15, q, ll, bad, 16, cr, src, csize, mis, chi);
+            bad = bad || (act && ll > csize);
+            act = act && !bad;
+            const uint32_t rem = csize - q, room = capB - o;
+            const bool last = rem < ll + 8 || room < ll + kMfLimit;                 // lz4.c:2279
+            const bool lastok = last && rem == ll && room >= ll;                    // lz4.c:2312-2318
+            bad = bad || (act && last && !lastok);
+            // offset, match length
+            const bool mt = act && !last;
+            const uint32_t m = q + ll;                                              // (mt: m + 8 <= csize)
+            uint32_t off = 0;
+            if (mt) off = pbyte(cr, src, m, mis, chi) | (pbyte(cr, src, m + 1, mis, chi) << 8);
+            uint32_t ml = b & 15, nx = m + 2;
+            ext_field(mt && ml == 15, nx, ml, bad, 5, cr, src, csize, mis, chi);
+            ml += kMinMatch;
+            const uint32_t ms = o + ll;
+            bad = bad || (mt && (off == 0 || off > ms - low || capB - ms < ml + kLastLiterals));      // lz4.c:2356, 2423
+            bad = bad || (act && i >= iend);                                         // (more sequences than the rows say)
+            act = act && !bad;
+            const uint32_t oe = act ? (last ? ms : ms + ml) : o;
+            if (act) {
+                SeqRec r; r.outpos = o; r.litpos = q; r.ll = ll; r.off = last ? 0u : off;
+                recs[i & kRecMask] = r;
+                const uint32_t gq = (o + kRegion - 1) >> kRegionShift;
+                if (!smode && (gq << kRegionShift) < oe) idx[gq & kIdxMask] = i + 1;           // the first region whose first byte the sequence holds
+            }
+            if (smode) {
+                // the index entries of this one sequence, as far as the ring has room, publishing as it goes (the copy must be
+                // able to move on for room to appear)
+                const uint32_t so = wave_readlane(o, 0), se = wave_readlane(oe, 0), si = wave_readlane(i, 0);
+                if (wave_readlane(act ? 1u : 0u, 0)) {
+                    wave_lds_fence();
+                    if (lane == 0) { SeqRec z; z.outpos = se; z.litpos = csize; z.ll = 0; z.off = 0; recs[(si + 1) & kRecMask] = z; }
+                    head = si + 2;
+                    uint32_t ga = (so + kRegion - 1) >> kRegionShift;
+                    const uint32_t gb = (se + kRegion - 1) >> kRegionShift;
+                    for (;;) {
+                        wave_lds_fence();
+                        if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)head | ((uint64_t)ga << 32));
+                        if (ga >= gb) break;
+                        const Ctl c2 = ctl_snapshot(smem);
+                        if (c2.abort_) return;
+                        const uint32_t n = gb - ga < 64 ? gb - ga : 64;
+                        if (ga + n + 1 <= c2.open + kIdxRing) { if (lane < n) idx[(ga + lane) & kIdxMask] = si; ga += n; }
+                        else spin_pause();
+                    }
+                    icarry = si + 1;
+                }
+            }
+            i += act ? 1u : 0u; o = oe; p = act ? (last ? csize : nx) : p;
+            act = act && p < end;
+        }
+        // ---- every lane must have arrived exactly at the next row
+        const bool arrived = lane >= nl || (!bad && p == end && o == oend && i == iend);
+        if (__any(!arrived)) { fail = true; break; }
+        const uint32_t iendN = wave_readlane(iend, nl - 1), oendN = wave_readlane(oend, nl - 1);
+        const bool final = r0 + nl == nreg;
+        wave_lds_fence();
+        if (!smode) {
+            // holes (regions whose first byte lies in a sequence that noted an earlier region) take the entry before them
+            for (uint32_t R = Ra; R < RbN; R += 64) {
+                const uint32_t v = R + lane < RbN ? idx[(R + lane) & kIdxMask] : 0u;
+                const uint32_t filled = wave_incl_max_u32(v > icarry ? v : icarry);
+                icarry = wave_readlane(filled, 63);
+                if (R + lane < RbN) idx[(R + lane) & kIdxMask] = filled - 1;
+            }
+        }
+        if (lane == 0) { SeqRec z; z.outpos = oendN; z.litpos = csize; z.ll = 0; z.off = 0; recs[iendN & kRecMask] = z; }      // where the last record ends (the next batch writes the whole row)
+        head = iendN + 1;
+        Ra = RbN;
+        if (final) { if (lane == 0) idx[rend & kIdxMask] = nseq - 1; Ra = rend + 1; }          // (the last region asks for the entry behind it like every other)
+        r0 += nl;
+        wave_lds_fence();
+        if (lane == 0) {
+            lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)head | ((uint64_t)Ra << 32));
+            lds_store_release(&misc[M_PR0], r0);
+        }
+    }
+    if (fail) {
+        wave_lds_fence();
+        if (lane == 0) { lds_store_release(&misc[M_PBAD], 1u); lds_store_release(&misc[M_ABORT], 1u); }
     }
 }
 
@@ -558,7 +779,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                     const bool hard = __any((((pendA >> lane) & 1ull) && keyA == kKeyAlways) || (((left0 >> lane) & 1ull) && keyB0 == kKeyAlways));
                     if (!hard && !later) {
                         pendBc = left0 ? chunks_of(left0, packB0 >> 9) : 0;
-                        if (!(doneA | doneB)) spin_pause();
+                        if (!(doneA | doneB)) { spin_pause(); if (uload(&misc[M_ABORT])) return; }
                         continue;
                     }
                 }
@@ -625,7 +846,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
     }
 }
 
-__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t nseq, uint32_t total, uint32_t rend, char* smem, uint64_t* prof) {
+__device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t nseq, uint32_t total, uint32_t rend, char* smem, uint64_t* prof, bool hinted) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const uint32_t lane = lane_here();
     uint32_t k = 0;
@@ -645,7 +866,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
         // ---- wait until the region's records are in the ring and its ring slot is free: region R takes the slot of
         //      region R-80, which regions up to R-16 may still read
         uint64_t ts = prof ? clock_ticks() : 0;
-        const uint32_t iwant = R + 2 < rend ? R + 2 : rend;        // index entries of R and R + 1
+        const uint32_t iwant = (hinted || R + 2 < rend) ? R + 2 : rend;        // index entries of R and R + 1 (the parser writes one behind the last region)
         for (;;) {
             uint32_t i0, i1;
             const Ctl c = ctl_snapshot_region(smem, R, i0, i1);
@@ -654,7 +875,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
             bool covered = c.ihead >= iwant;
             if (covered) {
                 C.j0 = i0;
-                const uint32_t jl = R + 1 < rend ? i1 : nseq - 1;
+                const uint32_t jl = (hinted || R + 1 < rend) ? i1 : nseq - 1;
                 uint32_t nrec = jl - C.j0 + 1;
                 if (nrec > 32 * kMaxTrips) nrec = 32 * kMaxTrips;             // (more than 258 records never overlap a region)
                 C.nrec = nrec;
@@ -682,12 +903,16 @@ out:
 }
 
 // ------------------------------------------------------------------------------ stage B of one block
-__device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, uint32_t prefix,
-                                             const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t total, char* smem, uint64_t* prof) {
+// hint: the block's entry-point table (null: records and region index come from stage A's scratch).  Returns false when
+// the table turned out not to fit the stream (the block must then be decoded again without it).
+__device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, uint32_t cap, uint32_t prefix,
+                                             const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t total, char* smem, uint64_t* prof,
+                                             lz4amd_gsrc hint) {
     const uint32_t tid = threadIdx.x, w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
-    if (tid == 0) { misc[M_ABORT] = 0; misc[M_SPARE] = 0; misc[M_CHI] = 0; misc[M_IHEAD] = kFirstRegion; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion; }
+    if (tid == 0) { misc[M_ABORT] = 0; misc[M_SPARE] = 0; misc[M_CHI] = 0; misc[M_IHEAD] = kFirstRegion; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion;
+                    misc[M_EHEAD] = 0; misc[M_PR0] = 0; misc[M_PBAD] = 0; }
     if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
     if (tid < 17) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid, k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
     // chunk flags: the history before dst (positions below kBias = regions 0..63, lap 0) is final, nothing else is
@@ -707,9 +932,13 @@ __device__ __forceinline__ void stream_block(lz4amd_gsrc src, uint32_t csize, lz
     __syncthreads();
 
     const uint32_t rend = (kBias + total + kRegion - 1) >> kRegionShift;          // regions [kFirstRegion, rend)
-    if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem);
-    else copy_role(w, src, dst, nseq, total, rend, smem, prof);
-
+    const bool hinted = hint != nullptr;
+    const uint32_t nreg = (total + kRegion - 1) >> kRegionShift;                  // rows of the table: nreg + 1, behind its 16-byte header
+    if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem, hinted ? hint + 16 : hint, nreg + 1);
+    else if (hinted && w == kParseWave) parser_role(src, csize, cap, prefix, total, nseq, nreg, rend, smem);
+    else copy_role(w, src, dst, nseq, total, rend, smem, prof, hinted);
+    __syncthreads();
+    return misc[M_PBAD] == 0;
 }
 
 // ------------------------------------------------------------------------------ one DEPENDENT block
@@ -724,7 +953,9 @@ __device__ __forceinline__ void chain_publish(const DecBatch& P, uint32_t b, lon
 }
 // ------------------------------------------------------------------------------ one block
 // (independent and dependent blocks share ONE copy of stage A and stage B: the kernel is instruction-cache bound enough)
-__device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, char* smem) {
+// use_hints: try the block's entry-point table, if the plan has one.  Returns false when the table did not fit the stream:
+// the caller decodes the block again without it.
+__device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, char* smem, bool use_hints) {
     const uint32_t tid = threadIdx.x;
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
 
@@ -738,12 +969,12 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     // -- degenerate inputs (lz4.c:2036, 2062-2069); in a chain they are failures like any other
     bool ok = true;
     if (!chained) {
-        if (src == nullptr || cap_i < 0) { if (tid == 0) P.result[b] = -1; return; }
+        if (src == nullptr || cap_i < 0) { if (tid == 0) P.result[b] = -1; return true; }
         if (cap_i == 0) {
             if (tid == 0) P.result[b] = (csize_i == 1 && src[0] == 0) ? 0 : -1;
-            return;
+            return true;
         }
-        if (csize_i <= 0) { if (tid == 0) P.result[b] = -1; return; }
+        if (csize_i <= 0) { if (tid == 0) P.result[b] = -1; return true; }
     } else ok = src != nullptr && (csize_i > 0 || (stored && csize_i == 0)) && cap_i > 0 && !(stored && csize_i > cap_i);    // (a stored block may be empty: tests/frametest.c:1237 inserts such blocks)
     const uint32_t csize = (uint32_t)csize_i, cap = (uint32_t)cap_i;
     // a dependent block is pre-parsed against the largest history there can be; what is really there is checked below
@@ -754,11 +985,22 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
     uint64_t tstart = 0;
     if (prof && tid == 0) tstart = clock_ticks();
 
-    // ---- stage A: the record table (a malformed block ends here, nothing written)
+    // ---- a block that comes with an entry-point table needs no stage A: the table's header says how much output and how
+    //      many sequences to expect; whether the table tells the truth is found out while it is used (PARSER)
     uint32_t nseq = 0, total = stored ? csize : 0u;
     uint32_t* ridx = nullptr;
-    if (ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx)) {
-        if (!chained) { if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]); return; }
+    lz4amd_gsrc hint = nullptr;
+    if (use_hints && !chained && P.hints) {
+        const lz4amd_gsrc hp = LZ4AMD_TO_GSRC(P.hints + (uint64_t)b * P.hint_stride);
+        const U32x4 h = ld_global16(hp);                     // { magic, output bytes, compressed bytes, sequences }
+        const uint64_t rows = (((uint64_t)h[1] + kRegion - 1) >> kRegionShift) + 2;
+        if (h[0] == LZ4AMD_HINT_MAGIC && h[2] == csize && h[1] != 0 && h[1] <= cap && h[3] != 0 && h[3] <= csize && rows * 16 <= P.hint_stride) {
+            hint = hp; total = h[1]; nseq = h[3];
+        }
+    }
+    // ---- stage A: the record table (a malformed block ends here, nothing written)
+    if (!hint && ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx)) {
+        if (!chained) { if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]); return true; }
         ok = false;
     }
     if (prof && tid == 0) prof[1] = clock_ticks() - tstart;
@@ -782,13 +1024,17 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
         if (start < 0 || !ok || (!stored && minref < kBias - prefix)) {
             if (tid == 0) P.result[b] = -1;
             chain_publish(P, b, -2);                            // the chain ends here
-            return;
+            return true;
         }
         dst = LZ4AMD_TO_GDST(P.dst[0]) + start;
         if (stored) for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
     }
 
-    if (!stored) stream_block(src, csize, dst, prefix, rectab, ridx, nseq, total, smem, prof);
+    if (!stored && !stream_block(src, csize, dst, cap, prefix, rectab, ridx, nseq, total, smem, prof, hint)) {
+        if (tid == 0 && P.hint_stats) atomicAdd(&P.hint_stats[1], 1u);
+        return false;
+    }
+    if (hint && tid == 0 && P.hint_stats) atomicAdd(&P.hint_stats[0], 1u);
 
     __syncthreads();
     if (tid == 0) {
@@ -796,6 +1042,7 @@ __device__ __forceinline__ void decode_one_block(const DecBatch& P, uint32_t b, 
         if (prof) prof[0] = clock_ticks() - tstart;
     }
     if (chained) chain_publish(P, b, start + (long long)total);
+    return true;
 }
 
 // Workgroups pull blocks from a device-wide ticket counter (load balance for ragged batches).
@@ -808,7 +1055,8 @@ __device__ __forceinline__ void decompress_batch_body(const DecBatch& P) {
         __syncthreads();
         const uint32_t b = misc[M_BLOCK];
         if (b >= P.n_blocks) break;
-        decode_one_block(P, b, smem);
+        bool use_hints = true;
+        while (!decode_one_block(P, b, smem, use_hints)) { use_hints = false; __syncthreads(); }
     }
 }
 

@@ -118,7 +118,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
-        q->prefix = NULL;
+        q->prefix = NULL; q->hints = NULL; q->hint_stride = 0; q->hint_stats = NULL;
         q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c, max_cap) + 255) & ~(uint64_t)255;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase timestamps */
@@ -138,7 +138,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
         q->ticket = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
-        q->prefix = NULL;
+        q->prefix = NULL; q->hints = NULL; q->hint_stride = 0; q->acceleration = 1;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase cycle counts */
             q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
@@ -243,6 +243,52 @@ int lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, in
     if (stored) p->dec.stored = (const uint8_t*)(p->bufs[k + 1] = dev_array(stored, (size_t)n, &err));
     if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
     if (err) { lz4amd_plan_destroy(p); *out = NULL; return err; }
+    return LZ4AMD_OK;
+}
+
+size_t lz4amd_hint_bytes(int src_size)
+{   /* header + one row per started KB + the end row (lz4amd_params.h) */
+    if (src_size < 0) return 0;
+    return 16u * (((size_t)src_size + 1023u) / 1024u + 2u);
+}
+
+int lz4amd_plan_attach_hints(lz4amd_plan* p, void* d_hints, size_t stride)
+{
+    if (!p || ((size_t)d_hints & 15u) || (stride & 15u) || (d_hints && stride < 32)) return LZ4AMD_E_ARG;
+    if (p->op == LZ4AMD_OP_COMPRESS) { p->comp.hints = (uint8_t*)d_hints; p->comp.hint_stride = stride; }
+    else if (p->op == LZ4AMD_OP_DECOMPRESS && !p->dec.chain) {
+        if (d_hints && !p->dec.hint_stats) {
+            int k, err = 0;
+            for (k = 0; k < LZ4AMD_PLAN_MAX_BUFS && p->bufs[k]; k++) {}
+            if (k >= LZ4AMD_PLAN_MAX_BUFS) return LZ4AMD_E_MEMORY;
+            (void)lz4amd_hip_use_device(p->ctx->device);
+            p->bufs[k] = lz4amd_hip_malloc(64);
+            if (!p->bufs[k]) return LZ4AMD_E_MEMORY;
+            if (lz4amd_hip_memset(p->bufs[k], 0, 64, NULL) || lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
+            if (err) { lz4amd_set_error(lz4amd_hip_errstr()); return err; }
+            p->dec.hint_stats = (uint32_t*)p->bufs[k];
+        }
+        p->dec.hints = (const uint8_t*)d_hints; p->dec.hint_stride = stride;
+    }
+    else return LZ4AMD_E_ARG;
+    return LZ4AMD_OK;
+}
+
+int lz4amd_plan_hint_stats(lz4amd_plan* p, unsigned* used, unsigned* rejected)
+{   /* since the tables were attached: blocks decoded from their table / tables that did not fit (those blocks were decoded without) */
+    unsigned v[2] = {0, 0};
+    if (!p || p->op != LZ4AMD_OP_DECOMPRESS || !p->dec.hint_stats) return LZ4AMD_E_ARG;
+    (void)lz4amd_hip_use_device(p->ctx->device);
+    if (lz4amd_hip_d2h(v, p->dec.hint_stats, sizeof v, NULL) || lz4amd_hip_sync(NULL)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
+    if (used) *used = v[0];
+    if (rejected) *rejected = v[1];
+    return LZ4AMD_OK;
+}
+
+int lz4amd_plan_set_acceleration(lz4amd_plan* p, int acceleration)
+{
+    if (!p || p->op != LZ4AMD_OP_COMPRESS) return LZ4AMD_E_ARG;
+    p->comp.acceleration = acceleration < 1 ? 1 : (acceleration > 65537 ? 65537 : acceleration);     /* lz4.c:1386-1387 */
     return LZ4AMD_OK;
 }
 

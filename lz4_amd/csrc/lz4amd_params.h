@@ -22,7 +22,21 @@ typedef struct lz4amd_dec_params {
      * stored[i] != 0 marks a block that is copied as is (lz4frame.c:1758-1830). */
     long long* chain;               /* [n + 1] or NULL */
     const uint8_t* stored;          /* [n] or NULL */
+    /* entry-point tables ("hints", include/lz4amd.h): block i's table starts at hints + i * hint_stride; NULL = none.
+     * Read only, never trusted: every entry is checked against the stream before a byte that depends on it is final. */
+    const uint8_t* hints;
+    uint64_t hint_stride;
+    uint32_t* hint_stats;           /* optional: [0] += blocks decoded from their table, [1] += tables that did not fit their block */
 } lz4amd_dec_params;
+
+/* One block's entry-point table: a 16-byte header followed by regions + 1 entries of 16 bytes, regions = ceil(out_size / 1024).
+ * Entry r names a sequence of the block's token chain: where its token sits in the compressed block, where its literals
+ * start in the output, how many sequences precede it.  Entry 0 is the first sequence, entry `regions` the block's end
+ * {csize, out_size, nseq}; entries never decrease.  The compressor picks, for region r, the first sequence that the source
+ * strips from byte 1024 r on emitted. */
+#define LZ4AMD_HINT_MAGIC 0x48345A4Cu           /* "LZ4H" */
+#define LZ4AMD_HINT_REGION_SHIFT 10
+typedef struct lz4amd_hint_entry { uint32_t tok, out, ord, zero; } lz4amd_hint_entry;      /* header: { magic, out_size, csize, nseq } */
 
 typedef struct lz4amd_comp_params {
     const uint8_t* const* src;      /* [n_blocks] */
@@ -34,6 +48,9 @@ typedef struct lz4amd_comp_params {
     uint32_t n_blocks;
     uint32_t* ticket;               /* work-queue counter, zero before launch */
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase cycle counts */
+    uint8_t* hints;                 /* optional: block i's entry-point table is written at hints + i * hint_stride (layout below lz4amd_dec_params) */
+    uint64_t hint_stride;
+    int32_t acceleration;           /* LZ4_compress_fast's speed / ratio knob (lz4.c:1382-1400); values < 1 mean 1 */
 } lz4amd_comp_params;
 
 typedef struct lz4amd_hc_params {

@@ -30,7 +30,7 @@ extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int3
     uint64_t stride = (dec_scratch_bytes(max_c, max_cap) + 15) & ~15ull;
     std::vector<uint8_t> scratch((size_t)(stride * grid + 64));
     uint32_t ticket = 0;
-    DecBatch P;
+    DecBatch P = {};
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
     P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix; P.chain = nullptr; P.stored = nullptr;
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.prof = nullptr;
@@ -53,7 +53,7 @@ extern "C" int emu_decompress_chained(const uint8_t* const* src, const int32_t* 
     std::vector<long long> chain(n + 1, -1); chain[0] = 0;
     std::vector<int32_t> pre(n ? n : 1, 0); pre[0] = initial_prefix;
     uint32_t ticket = 0;
-    DecBatch P;
+    DecBatch P = {};
     P.src = src; P.src_size = src_size; P.dst = dsts.data(); P.dst_cap = dst_cap; P.result = result;
     P.n_blocks = n; P.ticket = &ticket; P.prefix = pre.data(); P.chain = chain.data(); P.stored = stored;
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.prof = nullptr;
@@ -75,7 +75,7 @@ extern "C" int emu_compress_batch_prefix(const uint8_t* const* src, const int32_
     using namespace lz4amd;
     if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
     uint32_t ticket = 0;
-    CompBatch P;
+    CompBatch P = {};
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
     P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr; P.prefix = prefix;
     if (n) simt::launch(grid, kCmpThreads, kCmpLdsBytes, [&] { compress_batch_body(P); });
@@ -115,10 +115,40 @@ extern "C" int emu_compress_hc_batch_prefix(const uint8_t* const* src, const int
     max_src += 65536;
     const uint64_t stride = (hc_scratch_bytes(max_src) + 255) & ~255ull;
     std::vector<uint8_t> scratch((size_t)(stride * grid + 512));
-    HcBatch P;
+    HcBatch P = {};
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
     P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr; P.level = level; P.max_src = max_src; P.prefix = prefix;
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 255) & ~(uintptr_t)255); P.scratch_stride = stride;
     if (n) simt::launch(grid, kHcThreads, kHcLdsBytes, [&] { hc_batch_body(P); });
+    return 0;
+}
+
+// ---- entry-point tables: the compressor writes one per block (hints + i * stride), the decoder parses from it
+extern "C" int emu_compress_batch_hints(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
+                                        int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix, uint8_t* hints, uint64_t stride, int32_t accel) {
+    using namespace lz4amd;
+    if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
+    uint32_t ticket = 0;
+    CompBatch P = {};
+    P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
+    P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr; P.prefix = prefix; P.hints = hints; P.hint_stride = stride; P.acceleration = accel;
+    if (n) simt::launch(grid, kCmpThreads, kCmpLdsBytes, [&] { compress_batch_body(P); });
+    return 0;
+}
+extern "C" int emu_decompress_batch_hints(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
+                                          int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix, const uint8_t* hints, uint64_t stride, uint32_t* stats) {
+    using namespace lz4amd;
+    uint32_t max_c = 0, max_cap = 0;
+    for (uint32_t i = 0; i < n; i++) if (src_size[i] > 0 && (uint32_t)src_size[i] > max_c) max_c = src_size[i];
+    for (uint32_t i = 0; i < n; i++) if (dst_cap[i] > 0 && (uint32_t)dst_cap[i] > max_cap) max_cap = dst_cap[i];
+    if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
+    uint64_t sstride = (dec_scratch_bytes(max_c, max_cap) + 15) & ~15ull;
+    std::vector<uint8_t> scratch((size_t)(sstride * grid + 64));
+    uint32_t ticket = 0;
+    DecBatch P = {};
+    P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
+    P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix; P.hints = hints; P.hint_stride = stride; P.hint_stats = stats;
+    P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = sstride;
+    if (n) simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
     return 0;
 }

@@ -1,0 +1,289 @@
+"""Entry-point tables ("hints", include/lz4amd.h) on the CPU SIMT interpreter: the tables lz4amd_k_compress writes are
+checked row by row against the block's real token chain, the decoder's PARSER path is driven with them and with tables
+made here for blocks of ANY origin (reference-compressed, HC, hand-built sequence lists), and with tables that lie.
+Test infrastructure: the -m gpu twin of this file is tests/test_gpu_hints.py."""
+import ctypes
+import os
+import random
+import struct
+
+import pytest
+
+import test_kernels_emulated as tk
+
+MAGIC = 0x48345A4C
+CANARY = 0xEE
+
+
+def hint_bytes(n):
+    return 16 * ((n + 1023) // 1024 + 2)
+
+
+def token_chain(comp):
+    """[(token position, output position of the sequence's first literal)] of a legal block, and its decoded size."""
+    p = o = 0
+    out = []
+    while True:
+        out.append((p, o))
+        b = comp[p]; ll = b >> 4; q = p + 1
+        if ll == 15:
+            while True:
+                x = comp[q]; q += 1; ll += x
+                if x != 255:
+                    break
+        if q + ll >= len(comp):
+            assert q + ll == len(comp)
+            return out, o + ll
+        m = q + ll; ml = b & 15; nx = m + 2
+        if ml == 15:
+            while True:
+                x = comp[nx]; nx += 1; ml += x
+                if x != 255:
+                    break
+        o += ll + ml + 4; p = nx
+
+
+def make_table(comp, every=1):
+    """A valid table for any legal block: row r = the first sequence that starts at or behind byte 1024 r of the output (the
+    last sequence when there is none); `every` > 1 thins the rows out (row r then names what row r - r % every would)."""
+    ch, n = token_chain(comp)
+    nreg = (n + 1023) // 1024
+    rows, j = [], 0
+    for r in range(nreg):
+        want = (r - r % every) * 1024
+        while j + 1 < len(ch) and ch[j][1] < want:
+            j += 1
+        k = j
+        if ch[k][1] < want:
+            k = len(ch) - 1
+        rows.append((ch[k][0], ch[k][1], k))
+    rows.append((len(comp), n, len(ch)))
+    if nreg:
+        rows[0] = (0, 0, 0)
+        for r in range(1, nreg):            # never decreasing
+            if rows[r] < rows[r - 1]:
+                rows[r] = rows[r - 1]
+    t = struct.pack("<4I", MAGIC, n, len(comp), len(ch))
+    for tok, out, ordn in rows:
+        t += struct.pack("<4I", tok, out, ordn, 0)
+    return t
+
+
+def check_table(comp, table, n):
+    magic, osz, csz, nseq = struct.unpack_from("<4I", table, 0)
+    assert (magic, osz, csz) == (MAGIC, n, len(comp))
+    ch, total = token_chain(comp)
+    assert total == n and nseq == len(ch)
+    where = {t: (o, i) for i, (t, o) in enumerate(ch)}
+    nreg = (n + 1023) // 1024
+    prev = (0, 0, 0)
+    for r in range(nreg + 1):
+        tok, out, ordn, z = struct.unpack_from("<4I", table, 16 * (r + 1))
+        assert z == 0
+        if r == nreg:
+            assert (tok, out, ordn) == (len(comp), n, nseq)
+        else:
+            assert where.get(tok) == (out, ordn), (r, tok, out, ordn)
+            # the row is near its region: its sequence starts inside the strips of region r or is the first one behind them
+            assert out < (r + 1) * 1024 or ordn == 0 or ch[ordn - 1][1] < r * 1024 + 1024
+        assert (tok, out, ordn) >= prev
+        prev = (tok, out, ordn)
+    assert struct.unpack_from("<3I", table, 16) == (0, 0, 0)
+
+
+def emu_compress_tables(emu, datas, accel=1):
+    n = len(datas)
+    caps = [len(d) + len(d) // 255 + 16 for d in datas]
+    srcs = [ctypes.create_string_buffer(d, len(d)) if d else ctypes.create_string_buffer(1) for d in datas]
+    dsts = [ctypes.create_string_buffer(c + 64) for c in caps]
+    stride = max(hint_bytes(len(d)) for d in datas)
+    hraw = ctypes.create_string_buffer(stride * n + 16)
+    hbase = (ctypes.addressof(hraw) + 15) & ~15
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs])
+    dp = (ctypes.c_void_p * n)(*[ctypes.addressof(d) for d in dsts])
+    ss = (ctypes.c_int32 * n)(*[len(d) for d in datas]); dc = (ctypes.c_int32 * n)(*caps); res = (ctypes.c_int32 * n)()
+    emu.emu_compress_batch_hints(sp, ss, dp, dc, res, n, 0, None, ctypes.c_void_p(hbase), ctypes.c_uint64(stride), accel)
+    off = hbase - ctypes.addressof(hraw)
+    return [dsts[i].raw[:res[i]] for i in range(n)], [hraw.raw[off + i * stride: off + (i + 1) * stride] for i in range(n)]
+
+
+def emu_decompress_tables(emu, blocks, caps, tables, salign=0, align=0, prefixes=None):
+    """-> ([(result, bytes)], blocks decoded from their table, tables rejected); canaries around every output."""
+    n = len(blocks)
+    srcs = [ctypes.create_string_buffer(len(b) + 64 + salign) for b in blocks]
+    sptr = lambda buf: ((ctypes.addressof(buf) + 15) & ~15) + salign
+    for s, b in zip(srcs, blocks):
+        ctypes.memset(s, 0xA5, len(s)); ctypes.memmove(sptr(s), b, len(b))
+    pres = prefixes or [b""] * n
+    dsts = [ctypes.create_string_buffer(len(p) + max(c, 0) + 96) for p, c in zip(pres, caps)]
+    ptr = lambda i: ((ctypes.addressof(dsts[i]) + 15) & ~15) + align + len(pres[i])
+    for i, d in enumerate(dsts):
+        ctypes.memset(d, CANARY, len(d))
+        ctypes.memmove(ptr(i) - len(pres[i]), pres[i], len(pres[i]))
+    stride = max(16 * ((len(t) + 15) // 16) for t in tables)
+    hraw = ctypes.create_string_buffer(stride * n + 16)
+    hbase = (ctypes.addressof(hraw) + 15) & ~15
+    for i, t in enumerate(tables):
+        ctypes.memmove(hbase + i * stride, t, len(t))
+    sp = (ctypes.c_void_p * n)(*[sptr(s) for s in srcs]); dp = (ctypes.c_void_p * n)(*[ptr(i) for i in range(n)])
+    ss = (ctypes.c_int32 * n)(*[len(b) for b in blocks]); dc = (ctypes.c_int32 * n)(*caps); res = (ctypes.c_int32 * n)()
+    pre = (ctypes.c_int32 * n)(*[len(p) for p in pres]) if prefixes else None
+    stats = (ctypes.c_uint32 * 2)()
+    emu.emu_decompress_batch_hints(sp, ss, dp, dc, res, n, 0, pre, ctypes.c_void_p(hbase), ctypes.c_uint64(stride), stats)
+    outs = []
+    for i in range(n):
+        off = ptr(i) - ctypes.addressof(dsts[i])
+        raw = dsts[i].raw
+        cap = max(caps[i], 0)
+        assert raw[off + cap:off + cap + 32] == bytes([CANARY]) * 32, f"block {i}: wrote past dst[cap]"
+        assert raw[off - len(pres[i]):off] == pres[i] and raw[:off - len(pres[i])] == bytes([CANARY]) * (off - len(pres[i]))
+        outs.append((res[i], raw[off:off + max(res[i], 0)]))
+    return outs, stats[0], stats[1]
+
+
+def foreign_cases(ocodec, reflib, datagen):
+    """(decoded bytes, block) of every decoder corpus of test_kernels_emulated: reference-fast, reference-HC and hand-built blocks"""
+    cases = []
+    specs = [(65536, 50, 0), (100, 50, 1), (13, 50, 0), (12, 50, 0), (200000, 60, 2), (1 << 20, 60, 3), (300000, 90, 4), (50000, 0, 5),
+             (1, 50, 0), (65547, 50, 1), (131073, 60, 1), (300000, 20, 6)]
+    datas = [datagen(*s) for s in specs]
+    datas += tk._region_index_corpus() + tk._periodic_corpus()[::2] + tk._field_length_corpus()[:2]
+    datas += [b"\x00" * 300000, b"abcd" * 70000, os.urandom(70000), b"x" * 64, b"x" * 65, bytes(2 << 20)]
+    for d in datas:
+        cases.append((d, ocodec.compress(d)[1]))
+    for d in [random.Random(11).randbytes(1 << 20), b"0123456789abcdef" * (1 << 16), datas[4], tk._field_length_corpus()[0]]:
+        cap = len(d) + len(d) // 255 + 16
+        cb = ctypes.create_string_buffer(cap)
+        n = reflib.LZ4_compress_HC(d, cb, len(d), cap, 9)
+        cases.append((d, cb.raw[:n]))
+    rnd = random.Random(2024)
+    for target in [1, 30, 300, 1000, 1023, 1024, 1025, 5000, 20000, 70000, 150000] + [rnd.randrange(10, 60000) for _ in range(8)]:
+        c, d = tk._random_legal_block(rnd, target)
+        cases.append((d, c))
+    return cases
+
+
+@pytest.fixture(scope="module")
+def foreign(ocodec, reflib, datagen):
+    return foreign_cases(ocodec, reflib, datagen)
+
+
+def test_tables_made_for_foreign_blocks_decode_every_corpus(emu, foreign):
+    blocks = [c for _, c in foreign]
+    wants = [d for d, _ in foreign]
+    for every, sal in ((1, 0), (1, 5), (3, 0), (40, 0)):
+        tables = [make_table(c, every) for c in blocks]
+        outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], tables, salign=sal)
+        for d, (r, o) in zip(wants, outs):
+            assert r == len(d) and o == d, (every, sal, len(d))
+        # (rows 40 KB apart: a lane of the parser may then own more sequences than it accepts - such a table is rejected, not wrong)
+        assert used + rejected == len(blocks) and (rejected == 0 or every == 40) and used >= 50, (every, used, rejected)
+
+
+def test_compressor_tables_name_real_sequences_and_are_used(emu, ocodec, datagen):
+    specs = [(200000, 60, 2), (65536, 50, 0), (1 << 20, 60, 3), (300000, 90, 4), (50000, 0, 5), (100, 50, 1), (13, 50, 0), (5000, 20, 1),
+             (131073, 60, 1), (4 << 20, 60, 0), (700000, 20, 3), (1024, 60, 1), (1025, 60, 1), (2048, 90, 2), (65535, 60, 1)]
+    datas = [datagen(*s) for s in specs] + [b"\x00" * 300000, b"abcd" * 70000, os.urandom(70000), b"a" * 40000 + os.urandom(3000) + b"a" * 40000,
+                                            os.urandom(1 << 20) + b"q" * 100000 + os.urandom(50000)] + tk._region_index_corpus()[2:5]
+    comps, tables = emu_compress_tables(emu, datas)
+    plain = tk.emu_compress(emu, datas, align=0)
+    for d, c, t, (pr, pc) in zip(datas, comps, tables, plain):
+        assert c == pc                                            # the block is byte for byte what it is without the table
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        check_table(c, t, len(d))
+    for sal in (0, 9):
+        outs, used, rejected = emu_decompress_tables(emu, comps, [len(d) for d in datas], tables, salign=sal)
+        for d, (r, o) in zip(datas, outs):
+            assert r == len(d) and o == d
+        assert used == len(datas) and rejected == 0
+    # more room than the block needs is fine; less is the same failure as without a table
+    outs, used, _ = emu_decompress_tables(emu, comps[:3], [len(d) + 100 for d in datas[:3]], tables[:3])
+    assert [r for r, _ in outs] == [len(d) for d in datas[:3]] and used == 3
+    outs, used, _ = emu_decompress_tables(emu, comps[:3], [len(d) - 1 for d in datas[:3]], tables[:3])
+    assert all(r < 0 for r, _ in outs) and used == 0
+    # a failed or empty compression leaves no valid table
+    comps2, tables2 = emu_compress_tables(emu, [b"", datas[0]])
+    assert struct.unpack_from("<I", tables2[0], 0)[0] != MAGIC and struct.unpack_from("<I", tables2[1], 0)[0] == MAGIC
+
+
+def test_tables_that_lie_only_cost_time(emu, ocodec, datagen):
+    rnd = random.Random(77)
+    d = datagen(300000, 60, 5)
+    c = ocodec.compress(d)[1]
+    good = make_table(c)
+    other = make_table(ocodec.compress(datagen(300000, 60, 6))[1])
+    nrows = len(good) // 16
+    blocks, tables = [], []
+    for t in range(60):
+        bad = bytearray(good)
+        kind = t % 6
+        if kind == 0:                                              # random words anywhere behind the header
+            for _ in range(rnd.randint(1, 4)):
+                struct.pack_into("<I", bad, 16 + 4 * rnd.randrange(4 * (nrows - 1)), rnd.randrange(1 << 22))
+        elif kind == 1:                                            # a row moved a little: still inside the block, not on the chain
+            r = rnd.randrange(1, nrows - 1)
+            tok, out, ordn, z = struct.unpack_from("<4I", bad, 16 * r)
+            struct.pack_into("<4I", bad, 16 * r, tok + rnd.choice((1, 2, 3)), out + rnd.choice((0, 1)), ordn, z)
+        elif kind == 2:                                            # a true token with the wrong output position / count
+            r = rnd.randrange(1, nrows - 1)
+            tok, out, ordn, z = struct.unpack_from("<4I", bad, 16 * r)
+            struct.pack_into("<4I", bad, 16 * r, tok, out + (1 if t % 2 else 0), ordn + (0 if t % 2 else 1), z)
+        elif kind == 3:                                            # header says something else
+            struct.pack_into("<I", bad, 4 * rnd.randrange(1, 4), rnd.randrange(1 << 20))
+        elif kind == 4:                                            # another block's table
+            bad = bytearray(other[:len(good)].ljust(len(good), b"\0"))
+        else:                                                      # noise
+            bad = bytearray(rnd.randbytes(len(good)))
+            if t % 2:
+                struct.pack_into("<4I", bad, 0, *struct.unpack_from("<4I", good, 0))
+        blocks.append(c); tables.append(bytes(bad))
+    outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d)] * len(blocks), tables)
+    for r, o in outs:
+        assert r == len(d) and o == d
+    assert used + rejected >= 40 and rejected >= 30               # (tables with a broken header are not even tried)
+
+
+def test_hostile_streams_with_true_looking_tables_match_the_oracle(emu, ocodec, datagen, golden):
+    rnd = random.Random(5)
+    muts, caps, tables = [], [], []
+    for size, count in ((150000, 200), (3000, 200)):
+        base = ocodec.compress(datagen(size, 60, 9))[1]
+        table = make_table(base)
+        for t in range(count):
+            cc = bytearray(base)
+            for _ in range(rnd.randint(1, 3)):
+                cc[rnd.randrange(len(cc))] = rnd.randrange(256)
+            muts.append(bytes(cc)); caps.append(size); tables.append(table)
+    outs, used, rejected = emu_decompress_tables(emu, muts, caps, tables)
+    accepted = 0
+    for cc, cap, (r, o) in zip(muts, caps, outs):
+        ro, oo = ocodec.decompress(cc, cap)
+        assert (r < 0) == (ro < 0)
+        if r >= 0:
+            accepted += 1
+            assert r == ro and o == oo
+    assert 0 < accepted < len(muts) and used > 0 and rejected > 0
+
+
+def test_tables_with_history_before_the_block(emu, oracle, datagen):
+    d = datagen(400000, 60, 3)
+    hist, body = d[:70000], d[70000:]
+    # the compressor with history: blocks that reach into the 64 KB before them
+    n = 1
+    src = ctypes.create_string_buffer(d, len(d))
+    cap = len(body) + len(body) // 255 + 16
+    dst = ctypes.create_string_buffer(cap + 64)
+    stride = hint_bytes(len(body))
+    hraw = ctypes.create_string_buffer(stride + 16); hbase = (ctypes.addressof(hraw) + 15) & ~15
+    sp = (ctypes.c_void_p * 1)(ctypes.addressof(src) + len(hist)); dp = (ctypes.c_void_p * 1)(ctypes.addressof(dst))
+    ss = (ctypes.c_int32 * 1)(len(body)); dc = (ctypes.c_int32 * 1)(cap); res = (ctypes.c_int32 * 1)(); pre = (ctypes.c_int32 * 1)(65536)
+    emu.emu_compress_batch_hints(sp, ss, dp, dc, res, 1, 1, pre, ctypes.c_void_p(hbase), ctypes.c_uint64(stride), 1)
+    comp = dst.raw[:res[0]]
+    table = hraw.raw[hbase - ctypes.addressof(hraw):][:stride]
+    check_table(comp, table, len(body))
+    outs, used, rejected = emu_decompress_tables(emu, [comp], [len(body)], [table], prefixes=[hist[-65536:]])
+    assert outs[0] == (len(body), body) and used == 1 and rejected == 0
+    # the same block without its history: offsets reach before the output, with or without the table
+    outs, used, rejected = emu_decompress_tables(emu, [comp], [len(body)], [table])
+    assert outs[0][0] < 0

@@ -1,5 +1,5 @@
 """Developer aid: role breakdown of the streaming decompress kernel (LZ4AMD_PROF stamps). GPU only.
-usage: prof_dec.py [n_blocks] [block_bytes] [P] [hc_level]"""
+usage: prof_dec.py [n_blocks] [block_bytes] [P] [hc_level]      (NOHINTS=1: decode without the compressor's entry-point tables)"""
 import ctypes, os, sys, statistics
 if not os.environ.get("NOPROF"): os.environ["LZ4AMD_PROF"] = "1"        # NOPROF=1: kernel time only, without the stamps
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,15 +12,17 @@ pct = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 hc = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = lz4_amd.Context(0)
 data = torch.from_numpy(gen_data(nb * bs, pct, 0)).cuda()
-comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs, hc_level=(hc or None))
-out, res, plan = lz4_amd.decompress_blocks(ctx, comp, csizes, bs, nb * bs)
+use_hints = not hc and not os.environ.get("NOHINTS")
+hints = torch.zeros((nb, lz4_amd.hint_bytes(bs)), dtype=torch.uint8, device="cuda") if use_hints else None
+comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs, hc_level=(hc or None), hints=hints)
+out, res, plan = lz4_amd.decompress_blocks(ctx, comp, csizes, bs, nb * bs, hints=hints)
 best = 1e9
 for _ in range(5):
     km, tot = plan.launch_timed(torch.cuda.current_stream().cuda_stream)
     best = min(best, km[0])
 U, C = nb * bs, sum(csizes)
 print("decoder %s: %d x %d B P%d%s  kernel ms %.3f  GB/s out %.1f  (U+C)/t %.1f GB/s = %.3f of 8 TB/s" % (
-    "v4", nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
+    "v5 " + ("with tables %s" % (plan.hint_stats(),) if use_hints else "no tables"), nb, bs, pct, " hc%d" % hc if hc else "", best, U / best / 1e6, (U + C) / best / 1e6, (U + C) / best / 1e6 / 8000))
 assert os.environ.get("NOCHECK") or torch.equal(out, data), "decode mismatch"
 if not os.environ.get("NOPROF"):
     L = lz4_amd.lib()
