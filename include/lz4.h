@@ -11,8 +11,9 @@
  * Streaming (lz4.h:314-560): LZ4_stream_t / LZ4_streamDecode_t contexts that track up to 64 KB of
  * history between calls, each block still a round trip through HBM (lz4_stream_api.c).
  *
- * Not provided (SURVEY.md section 8f "next"): LZ4_compress_destSize, LZ4_decompress_safe_partial,
- * LZ4_attach_dictionary and the deprecated LZ4_decompress_fast family.
+ * The long tail of the reference header is here too (csrc/lz4_compat_api.c): LZ4_compress_destSize (device compressions of
+ * prefixes), LZ4_attach_dictionary, and - host code by their contract, they do not know where their input or output
+ * ends - LZ4_decompress_safe_partial and the deprecated LZ4_decompress_fast family.
  */
 #ifndef LZ4_AMD_LZ4_H
 #define LZ4_AMD_LZ4_H

@@ -139,6 +139,8 @@ size_t LZ4F_compressFrame_usingCDict(LZ4F_cctx* cctx, void* dst, size_t dstCapac
                                      const LZ4F_CDict* cdict, const LZ4F_preferences_t* preferencesPtr);
 size_t LZ4F_compressBegin_usingCDict(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_CDict* cdict, const LZ4F_preferences_t* prefsPtr);
 size_t LZ4F_compressBegin_usingDict(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* dictBuffer, size_t dictSize, const LZ4F_preferences_t* prefsPtr);
+/* reference lz4frame.c:824-836 (not in its header; lz4io.c declares it itself): the dictionary is the history of the frame's first block only */
+size_t LZ4F_compressBegin_usingDictOnce(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* dictBuffer, size_t dictSize, const LZ4F_preferences_t* prefsPtr);
 size_t LZ4F_decompress_usingDict(LZ4F_dctx* dctxPtr, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
                                  const void* dict, size_t dictSize, const LZ4F_decompressOptions_t* decompressOptionsPtr);
 /* custom memory (lz4frame.h:712-747) */

@@ -867,7 +867,7 @@ __device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_
 }
 
 // ------------------------------------------------------------------------------ entry-point table (optional output)
-// For every 1 KB region of the source, the first sequence that the strips from the region's first byte on emitted:
+// For every 512 bytes (a ROW) of the source, the first sequence that the strips from the row's first byte on emitted:
 // {where its token sits in the block, where its literals start in the source, how many sequences precede it}
 // (lz4amd_params.h: lz4amd_hint_entry).  A decoder that is handed the table parses the block from all those entries at
 // once instead of discovering the token chain (lz4_decompress_kernel.h: PARSER); the block itself is an ordinary LZ4 block.
@@ -894,13 +894,13 @@ __device__ __forceinline__ void hint_tile(char* smem, uint32_t pp, uint32_t nstr
     const uint32_t start = mine ? strip_p[S_P * kCmpWaves + lane] - strip_p[S_CARRY * kCmpWaves + lane] - pre : 0u;     // first literal of the strip's first sequence
     // regions before this tile that had no sequence behind them so far: the tile's first one
     const uint32_t F = (uint32_t)__ffsll((long long)m) - 1;
-    const uint32_t ra = (t0 - pre) >> LZ4AMD_HINT_REGION_SHIFT, nr = (t1 - t0 + 1023) >> LZ4AMD_HINT_REGION_SHIFT;     // the tile's regions (tiles start on the 1 KB grid of the block)
+    const uint32_t ra = (t0 - pre) >> LZ4AMD_HINT_ROW_SHIFT, nr = (t1 - t0 + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT;     // the tile's rows (tiles start on the 1 KB grid of the block, strips on its 256-byte grid)
     {
         const uint32_t ft = wave_readlane(tok, F), fs = wave_readlane(start, F), fo = wave_readlane(ord, F);
         for (uint32_t r = pend + lane; r < ra; r += 64) st_hint(hints, r, ft, fs, fo);
     }
-    // regions of this tile, lane = region (at most 8): the first strip with sequences from the region's first strip on
-    const uint32_t s = (lane << LZ4AMD_HINT_REGION_SHIFT) >> (31 - __clz((int)strip_len));
+    // rows of this tile, lane = row (at most 16): the first strip with sequences from the row's first strip on
+    const uint32_t s = (lane << LZ4AMD_HINT_ROW_SHIFT) >> (31 - __clz((int)strip_len));
     const unsigned long long rest = (lane < nr && s < 64) ? m >> s : 0ull;
     const uint32_t nv = rest ? s + (uint32_t)__ffsll((long long)rest) - 1 : 0u;
     const uint32_t et = (uint32_t)__shfl((int)tok, (int)nv), es = (uint32_t)__shfl((int)start, (int)nv), eo = (uint32_t)__shfl((int)ord, (int)nv);
@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     if (hints && w == kCmpWaves - 1) {
         // the table's last rows: regions without a sequence at or behind them name the block's last sequence (its final
         // literals), the row behind the last region is the block's end; the header makes the table valid
-        const uint32_t seqs = misc[CM_SEQS], nreg = ((uint32_t)n_i + 1023) >> LZ4AMD_HINT_REGION_SHIFT;
+        const uint32_t seqs = misc[CM_SEQS], nreg = ((uint32_t)n_i + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT;
         for (uint32_t r = misc[CM_HPEND] + lane_id(); r < nreg; r += 64) st_hint(hints, r, out, n - run - pre, seqs);
         if (lane_id() == 0) {
             st_hint(hints, nreg, (uint32_t)total, (uint32_t)n_i, seqs + 1);

@@ -59,7 +59,7 @@ enum : uint32_t {
     kDecWaves = kDecThreads / 64,
     kMoveWave = kDecWaves - 1,                  // compressed stream, sequence records, region index -> LDS
     kCopyWaves = kDecWaves - 1,                 // waves 0 .. kCopyWaves-1 (one fewer when the block comes with an entry-point table:
-    kParseWave = kDecWaves - 2,                 //   this wave then parses the stream from the table's entries, PARSER below)
+                                                //   kParsers waves below the mover then parse the stream from the table's entries, PARSER below)
     kChunk = 16,                                // output bytes composed at a time
     kRegionShift = 10,
     kRegion = 1u << kRegionShift,               // 64 chunks
@@ -75,7 +75,7 @@ enum : uint32_t {
     kIdxMask = kIdxRing - 1,
     kEntRing = 256,                             // rows of the block's entry-point table (16 B each), ring
     kEntMask = kEntRing - 1,
-    kLaneSeqMax = 1024,                         // sequences between two entries of a table (one is 1 KB of source: at most 257)
+    kLaneSeqMax = 1024,                         // sequences between two rows of a table (a row is 512 bytes of source: at most 129)
     kDmaDepth = 16,                             // LDS-DMA instructions (1 KB each) the mover keeps in flight
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
     kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
@@ -236,11 +236,12 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
     uint32_t pidx = 0, icarry = 0;
     const bool hinted = hint != nullptr;
     char* ent = smem + kOffEnt;
+    const uint32_t crBytes = kCrBytes;
     uint32_t ei = 0, ec = 0;                           // table rows issued / landed (multiples of 64)
     if (!hinted && ihead + lane < rend) pidx = ridx[lane];
     for (;;) {
         const Ctl c = ctl_snapshot(smem);
-        if (c.abort_) break;
+        if (c.abort_) { vmem_wait<0>(); break; }
         bool progress = false;
         const uint32_t pr0 = hinted ? uload(&misc[M_PR0]) : 0u;
         if (hinted) { ihead = c.ihead; hc = c.head; }  // (published by the parser)
@@ -279,15 +280,15 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
                 uint32_t d = (g << kRegionShift) - r.outpos; if (d > r.ll) d = r.ll;
                 need = __builtin_amdgcn_readfirstlane(r.litpos + d);
             }
-        }
+        } else if (hinted && c.clo > need) need = c.clo;         // every region that has records is complete: what is needed next is the token the parser stands at
         // ---- issue: stream chunk si may be written once nobody needs the bytes 32 K below its last one; rows [hi, hi + 64)
         //      once the ring has let go of the rows 2048 below them
         bool issued = false;
         while (q < kDmaDepth) {
             bool did = false;
-            if (si < nchunks && ((si + 1) << 10) <= need + mis + kCrBytes) {
+            if (si < nchunks && ((si + 1) << 10) <= need + mis + crBytes) {
                 uint32_t gr = 64 * si + lane; if (gr >= ngran) gr = ngran - 1;
-                lds_dma16((const void*)(src0 + 16 * (uint64_t)gr), cr + ((si << 10) & (kCrBytes - 1)));
+                lds_dma16((const void*)(src0 + 16 * (uint64_t)gr), cr + ((si << 10) & (crBytes - 1)));
                 q++; si++; did = true;                                               // (its fifo bit is 0)
             }
             if (!hinted && q < kDmaDepth && hi < nrows && hi + 64 - tail <= kRecCap) {
@@ -311,8 +312,8 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
             const uint32_t nrec = (uint32_t)__popcll(fifo & ((1ull << r) - 1ull));
             const uint32_t s1 = sc + (r - nrec);
             // the ring's pad mirrors its first 32 bytes: reads never wrap
-            if (((sc + (kCrBytes >> 10) - 1) & ~((kCrBytes >> 10) - 1)) < s1) {            // (a chunk that starts a lap has landed)
-                if (lane < kCrPad / 16) *(U32x4*)(cr + kCrBytes + 16 * lane) = *(const U32x4*)(cr + 16 * lane);
+            if (((sc + (crBytes >> 10) - 1) & ~((crBytes >> 10) - 1)) < s1) {            // (a chunk that starts a lap has landed)
+                if (lane < kCrPad / 16) *(U32x4*)(cr + crBytes + 16 * lane) = *(const U32x4*)(cr + 16 * lane);
             }
             sc = s1; if (hinted) ec += 64 * nrec; else hc += 64 * nrec;
             fifo >>= r; q = keep;
@@ -328,14 +329,17 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
             if (hinted) { if (lane == 0) lds_store_release(&misc[M_EHEAD], ec < nent ? ec : nent); }
             else if (lane == 0) lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(hc < nrows ? hc : nrows) | ((uint64_t)ihead << 32));
         }
-        if (hinted ? (ec >= nent && sc == nchunks && g >= rend) : (hc >= nrows && ihead == rend && sc == nchunks && g >= rend)) break;          // everything moved, every region complete
-        if (!progress) { spin_pause_long(); if (sc < nchunks || (!hinted && hc < nrows)) spin_pause_long(); }      // (the rings hold tens of thousands of cycles of work: a look every ~1000 is plenty, and every look takes issue slots from the copy waves of this SIMD)
+        if (hinted ? (ec >= nent && sc == nchunks && g >= rend) : (hc >= nrows && ihead == rend && sc == nchunks && g >= rend)) {          // everything moved, every region complete
+            vmem_wait<0>();                                  // (nothing of this block may land in LDS later)
+            break;
+        }
+        if (!progress) { if (hinted) spin_pause(); else { spin_pause_long(); if (sc < nchunks || hc < nrows) spin_pause_long(); } }      // (the rings hold tens of thousands of cycles of work: a look every ~1000 is plenty, and every look takes issue slots from the copy waves of this SIMD)
     }
 }
 
 // ------------------------------------------------------------------------------ PARSER (blocks that come with an entry-point table)
 // An entry-point table (lz4amd_params.h: lz4amd_hint_entry; written by lz4amd_k_compress next to the block it made, or by
-// anybody else) names one sequence of the token chain per 1 KB of output.  With it the serial chain is cut in pieces that
+// anybody else) names one sequence of the token chain per 512 bytes of output.  With it the serial chain is cut in pieces that
 // are parsed side by side: LANE k of this wave walks the sequences from row r0 + k up to row r0 + k + 1 out of the
 // compressed ring in LDS - token, literal length, offset, match length, the same rules as the pre-parse's P5
 // (read_variable_length lz4.c:1979-2014; lz4.c:2279, 2312-2318, 2356, 2423) - and writes their records and the region
@@ -349,6 +353,13 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
 // from memory instead.
 struct HintEnt { uint32_t tok, out, ord, zero; };
 
+// four stream bytes from position x on, out of the compressed ring (two aligned dwords and a byte alignment; the ring's pad
+// covers the dword behind its end)
+__device__ __forceinline__ uint32_t cr_fetch4(const char* cr, uint32_t x, uint32_t mis) {
+    const uint32_t a = mod_cr(x + mis);
+    const uint32_t* d = (const uint32_t*)(cr + (a & ~3u));
+    return align_bytes(d[1], d[0], a & 3u);
+}
 // one stream byte at position x (x < csize): out of the compressed ring when it is resident, else from memory
 __device__ __forceinline__ uint32_t pbyte(const char* cr, lz4amd_gsrc src, uint32_t x, uint32_t mis, uint32_t chi) {
     if (x < chi) return (uint32_t)*(const uint8_t*)(cr + mod_cr(x + mis));
@@ -389,99 +400,192 @@ __device__ __forceinline__ void ext_field(bool need, uint32_t& pos, uint32_t& ac
     }
 }
 
+// One step of a lane's walk: the sequence whose token is at W.p, by the decoder's rules.  The FAST form covers what nearly
+// every sequence is - length fields of at most two extension bytes (lengths below 525), not in the block's last 24 bytes,
+// every byte in the ring: the token and the three bytes behind it in one look, the offset and the two bytes behind it in
+// another (two aligned dwords + a byte alignment each).  Whatever it does not cover takes the CAREFUL form: the same
+// rules, any field length, bytes from memory when they are not resident, the block's last sequence.
+struct Walk { uint32_t p, o, i, end, oend, iend, W; bool act, res, bad; };      // res: every byte of the lane's row is in the ring; W: the four stream bytes at p (asked for as soon as p is known: the walk is a chain of dependent LDS round trips)
+struct StepOut { SeqRec r; uint32_t oe; bool ok; };
+struct PCtx { const char* cr; lz4amd_gsrc src; uint32_t csize, mis, chi, capB, low; };
+__device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t& n_careful) {
+    StepOut S; S.r.outpos = w.o; S.r.litpos = 0; S.r.ll = 0; S.r.off = 0; S.oe = w.o; S.ok = false;
+    uint32_t pn = w.p;
+    bool careful = w.act && !w.res;
+    {
+        const uint32_t W = w.W;
+        const uint32_t b = W & 0xFFu, e1 = (W >> 8) & 0xFFu, e2 = (W >> 16) & 0xFFu;
+        const bool lx = (b >> 4) == 15, lx2 = lx && e1 == 255;
+        const uint32_t ll = (b >> 4) + (lx ? e1 : 0u) + (lx2 ? e2 : 0u);
+        const uint32_t q = w.p + 1 + (lx ? 1u : 0u) + (lx2 ? 1u : 0u), m = q + ll;
+        // (m + 24 <= csize: not the last sequence, lz4.c:2279, and every length byte looked at may be read, lz4.c:1986-2006)
+        careful = careful || (w.act && ((lx2 && e2 == 255) || m + 24 > X.csize || X.capB - w.o < ll + kMfLimit));
+        const uint32_t V = cr_fetch4(X.cr, m, X.mis);
+        const uint32_t off = V & 0xFFFFu, f1 = (V >> 16) & 0xFFu, f2 = V >> 24;
+        const bool mx = (b & 15u) == 15, mx2 = mx && f1 == 255;
+        const uint32_t ml = (b & 15u) + (mx ? f1 : 0u) + (mx2 ? f2 : 0u) + kMinMatch;
+        careful = careful || (w.act && mx2 && f2 == 255);
+        const bool fast = w.act && !careful;
+        const uint32_t ms = w.o + ll;
+        const bool fbad = off - 1u >= ms - X.low || X.capB - ms < ml + kLastLiterals || w.i >= w.iend;      // lz4.c:2356 (offset 0 wraps), 2423; more sequences than the rows say
+        w.bad = w.bad || (fast && fbad);
+        S.ok = fast && !fbad;
+        S.r.litpos = q; S.r.ll = ll; S.r.off = off;
+        S.oe = S.ok ? ms + ml : S.oe;
+        pn = S.ok ? m + 2 + (mx ? 1u : 0u) + (mx2 ? 1u : 0u) : pn;
+        w.W = cr_fetch4(X.cr, pn, X.mis);                  // the next token, on its way while this sequence's record is written
+    }
+    if (__any(careful)) {
+        n_careful++;
+        const bool on = careful;
+        uint32_t b = 0;
+        if (on) b = pbyte(X.cr, X.src, w.p, X.mis, X.chi);
+        uint32_t ll = b >> 4, q = w.p + 1;
+        bool cbad = false;
+        ext_field(on && ll == 15, q, ll, cbad, 16, X.cr, X.src, X.csize, X.mis, X.chi);
+        cbad = cbad || (on && ll > X.csize);
+        bool go = on && !cbad;
+        const uint32_t rem = X.csize - q, room = X.capB - w.o;
+        const bool last = rem < ll + 8 || room < ll + kMfLimit;                 // lz4.c:2279
+        cbad = cbad || (go && last && !(rem == ll && room >= ll));               // lz4.c:2312-2318
+        const bool mt = go && !cbad && !last;
+        const uint32_t m = q + ll;                                              // (mt: m + 8 <= csize)
+        uint32_t off = 0;
+        if (mt) off = pbyte(X.cr, X.src, m, X.mis, X.chi) | (pbyte(X.cr, X.src, m + 1, X.mis, X.chi) << 8);
+        uint32_t ml = b & 15, nx = m + 2;
+        ext_field(mt && ml == 15, nx, ml, cbad, 5, X.cr, X.src, X.csize, X.mis, X.chi);
+        ml += kMinMatch;
+        const uint32_t ms = w.o + ll;
+        cbad = cbad || (mt && (off == 0 || off > ms - X.low || X.capB - ms < ml + kLastLiterals));      // lz4.c:2356, 2423
+        cbad = cbad || (on && w.i >= w.iend);
+        go = on && !cbad;
+        w.bad = w.bad || (on && cbad);
+        if (go) { S.r.litpos = q; S.r.ll = ll; S.r.off = last ? 0u : off; S.oe = last ? ms : ms + ml; pn = last ? X.csize : nx; S.ok = true; }
+        if (on) w.W = cr_fetch4(X.cr, pn, X.mis);
+    }
+    w.p = pn;
+    return S;
+}
+
+// kParsers waves parse side by side.  A wave CLAIMS the next batch of rows under a lock (as many rows as are resident and
+// fit the rings, one per lane), walks it, and PUBLISHES it when every earlier batch is published (a ticket per claim):
+// publication in order is what makes the induction work - a batch's first row is true because the batch before arrived
+// at it.  A wave's walk is a chain of dependent steps of ~1000 cycles that leaves its SIMD nearly idle: three of them
+// cost the copy waves little and triple what the parser delivers (one wave alone set the decoder's pace).
+#ifndef LZ4AMD_PARSERS
+#define LZ4AMD_PARSERS 3
+#endif
+enum : uint32_t { kParsers = LZ4AMD_PARSERS, kFirstParseWave = kDecWaves - 1 - kParsers };
+enum : uint32_t { P_LOCK = 16, P_NEXT, P_RZ, P_TICKET, P_TURN, P_ICARRY };      // shared words of the parser waves (misc[])
+__device__ __forceinline__ void parser_unlock(uint32_t* misc) { wave_lds_fence(); if (lane_here() == 0) lds_store_release(&misc[P_LOCK], 0u); }
 __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix, uint32_t total, uint32_t nseq,
-                                            uint32_t nreg, uint32_t rend, char* smem) {
+                                            uint32_t nreg, uint32_t rend, char* smem, uint64_t* prof) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     uint32_t* idx = (uint32_t*)(smem + kOffIdx);
     SeqRec* recs = (SeqRec*)(smem + kOffRecs);
     const HintEnt* ent = (const HintEnt*)(smem + kOffEnt);
-    const char* cr = smem + kOffCr;
     const uint32_t lane = lane_here();
-    const uint32_t mis = stream_misalign(src);
-    const uint32_t capB = cap + kBias, low = kBias - prefix;
-    uint32_t r0 = 0;                                   // first row not parsed yet
-    uint32_t Ra = kFirstRegion;                        // regions below Ra have their index entry
-    uint32_t head = 0, icarry = 0, tail = 0, stall = 0;
+    PCtx X; X.cr = smem + kOffCr; X.src = src; X.csize = csize; X.mis = stream_misalign(src); X.chi = 0; X.capB = cap + kBias; X.low = kBias - prefix;
+    wave_priority_high();                              // the copy waves wait for what these waves produce
+    uint32_t tail = 0, stall = 0;
     bool fail = false;
-    while (r0 < nreg) {
+    uint32_t n_batch = 0, n_lanes = 0, n_steps = 0, n_careful = 0; uint64_t t_wait = 0, t_walk = 0, tq = prof ? clock_ticks() : 0;      // developer profile
+#ifdef LZ4AMD_PROF_PARSER
+    uint64_t t_lock = 0, t_sel = 0, t_turn = 0, t_pub = 0, tp = clock_ticks(); uint32_t n_nowork = 0;
+#define PSTAMP(acc) do { const uint64_t t_ = clock_ticks(); acc += t_ - tp; tp = t_; } while (0)
+#else
+#define PSTAMP(acc) do {} while (0)
+#endif
+    for (;;) {
+        // ---- claim the next batch of rows (one wave at a time)
+        PSTAMP(t_pub);
+        for (;;) {
+            uint32_t got = 0;
+            if (lane == 0) got = atomicCAS(&misc[P_LOCK], 0u, 1u) == 0u ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane(got)) break;
+            if (uload(&misc[M_ABORT])) return;
+            spin_pause();
+        }
+        wave_lds_fence();
+        PSTAMP(t_lock);
         const Ctl c = ctl_snapshot(smem);
-        if (c.abort_) return;
+        const uint32_t r0 = uload(&misc[P_NEXT]);
+        if (c.abort_ || r0 >= nreg) { parser_unlock(misc); break; }
+        const uint32_t Ra = uload(&misc[P_RZ]);            // regions below Ra belong to the batches claimed before
         const uint32_t ehead = uload(&misc[M_EHEAD]);
-        const uint32_t g = c.open, chi = c.chi;
-        // ---- how many lanes?  Rows [r0, r0 + nl] must be resident; the lanes' records must fit the record ring behind the first
-        //      record an open region still needs, their regions the index ring; and the lanes' stream bytes should be resident.
+        const uint32_t g = c.open;
+        X.chi = c.chi;
+        // how many lanes?  Rows [r0, r0 + nl] must be resident; the lanes' records must fit the record ring behind the first
+        // record an open region still needs, their regions the index ring; and the lanes' stream bytes should be resident.
         uint32_t nlmax = nreg - r0 < 64 ? nreg - r0 : 64;
-        if (ehead < r0 + 2) { spin_pause(); continue; }
-        if (ehead - r0 - 1 < nlmax) nlmax = ehead - r0 - 1;
+        const uint32_t er = ehead > r0 + 1 ? ehead - r0 - 1 : 0;
+        if (er < nlmax) nlmax = er;
         HintEnt A, B; A.tok = A.out = A.ord = A.zero = 0; B = A;
         if (lane < nlmax) { A = ent[(r0 + lane) & kEntMask]; B = ent[(r0 + lane + 1) & kEntMask]; }
-        // the rows themselves: never decreasing, inside the block, no more sequences between two of them than 1 KB of output can start
+        // the rows themselves: never decreasing, inside the block, no more sequences between two of them than 512 bytes of output can start
         bool rowbad = lane < nlmax && (A.tok > B.tok || A.out > B.out || A.ord > B.ord || B.tok > csize || B.out > total || B.ord - A.ord > kLaneSeqMax
                                        || (A.tok == B.tok) != (A.ord == B.ord) || (A.tok == B.tok && A.out != B.out));
-        if (r0 == 0 && lane == 0 && (A.tok | A.out | A.ord)) rowbad = true;
+        if (r0 == 0 && lane == 0 && nlmax && (A.tok | A.out | A.ord)) rowbad = true;
         if (r0 + lane + 1 == nreg && lane < nlmax && (B.tok != csize || B.out != total || B.ord != nseq)) rowbad = true;
-        if (__any(rowbad)) { fail = true; break; }
+        if (__any(rowbad)) { fail = true; parser_unlock(misc); break; }
         if (g < c.ihead) tail = __builtin_amdgcn_readfirstlane(idx[g & kIdxMask]);      // first record an open region needs (only ever grows)
         const uint32_t Rb = (B.out + kBias + kRegion - 1) >> kRegionShift;              // regions below Rb have their first byte before my lane's end
         const bool okrec = B.ord + 1 - tail <= kRecCap;
         const bool okidx = Rb + 1 <= g + kIdxRing;
-        const unsigned long long mh = __ballot(lane < nlmax && okrec && okidx), mr = __ballot(lane < nlmax && okrec && okidx && B.tok <= chi);
+        const unsigned long long mh = __ballot(lane < nlmax && okrec && okidx), mr = __ballot(lane < nlmax && okrec && okidx && B.tok <= X.chi);
         const uint32_t nl_hard = ~mh ? (uint32_t)__ffsll((long long)~mh) - 1 : 64u, nl_res = ~mr ? (uint32_t)__ffsll((long long)~mr) - 1 : 64u;      // leading lanes that may go
-        if (!nl_res && nl_hard && chi < csize && stall < 16) { stall++; spin_pause(); continue; }      // (the mover is about to bring the bytes)
-        stall = 0;
-        uint32_t nl = nl_res ? nl_res : (nl_hard ? 1u : 0u);
-        DTRACE("parser r0=%u nlmax=%u ehead=%u g=%u chi=%u nl_hard=%u nl_res=%u tail=%u Ra=%u\n", r0, nlmax, ehead, g, chi, nl_hard, nl_res, tail, Ra);
+        const bool drained = uload(&misc[P_TURN]) == uload(&misc[P_TICKET]);            // every claimed batch is published
+        uint32_t nl = nl_res;
         bool smode = false;                             // a lane whose regions do not fit the index ring at once: alone, filling the index as it goes
-        if (!nl) {
-            const uint32_t Rb0 = wave_readlane(Rb, 0);
-            if (wave_readlane(okrec ? 1u : 0u, 0) && Rb0 - Ra > kIdxRing / 2) { smode = true; nl = 1; }
-            else { spin_pause(); continue; }
+        if (!nl && nl_hard && drained) {
+            // nothing in flight and the next row's bytes are not resident: the mover is about to bring them - or the row is
+            // longer than the ring, then its lane reads from memory
+            if (X.chi < csize && stall < 16) { stall++; parser_unlock(misc); spin_pause(); continue; }
+            nl = 1;
         }
+        if (!nl && !nl_hard && drained && nlmax && wave_readlane(okrec ? 1u : 0u, 0) && wave_readlane(Rb, 0) - Ra > kIdxRing / 2) { smode = true; nl = 1; }
+        if (!nl) {
+#ifdef LZ4AMD_PROF_PARSER
+            n_nowork++;
+#endif
+            parser_unlock(misc); spin_pause_long(); PSTAMP(t_sel); continue; }
+        stall = 0;
         const uint32_t RbN = wave_readlane(Rb, nl - 1);
+        const uint32_t ticket = uload(&misc[P_TICKET]);
+        const bool allres = nl_res != 0;
+        wave_lds_fence();
+        if (lane == 0) {
+            misc[P_NEXT] = r0 + nl; misc[P_RZ] = RbN > Ra ? RbN : Ra; misc[P_TICKET] = ticket + 1;
+            lds_store_release(&misc[M_PR0], r0 + nl);       // (the rows of claimed batches are in their waves' registers)
+        }
+        if (!smode) parser_unlock(misc);                    // (a row that fills the index as it goes keeps the lock: nobody may run ahead of it)
+        PSTAMP(t_sel);
+        if (prof) { const uint64_t t = clock_ticks(); t_wait += t - tq; tq = t; n_batch++; n_lanes += nl; }
         if (!smode) { for (uint32_t R = Ra + lane; R < RbN; R += 64) idx[R & kIdxMask] = 0; }      // (notes below; regions without one are holes)
         wave_lds_fence();
         // ---- walk
-        uint32_t p = A.tok, o = A.out + kBias, i = A.ord;
-        const uint32_t end = B.tok, oend = B.out + kBias, iend = B.ord;
-        bool act = lane < nl && p < end, bad = false;
-        while (__any(act)) {
-            // token, literal length
-            uint32_t b = 0;
-            if (act) b = pbyte(cr, src, p, mis, chi);
-            uint32_t ll = b >> 4, q = p + 1;
-            ext_field(act && ll == 15, q, ll, bad, 16, cr, src, csize, mis, chi);
-            bad = bad || (act && ll > csize);
-            act = act && !bad;
-            const uint32_t rem = csize - q, room = capB - o;
-            const bool last = rem < ll + 8 || room < ll + kMfLimit;                 // lz4.c:2279
-            const bool lastok = last && rem == ll && room >= ll;                    // lz4.c:2312-2318
-            bad = bad || (act && last && !lastok);
-            // offset, match length
-            const bool mt = act && !last;
-            const uint32_t m = q + ll;                                              // (mt: m + 8 <= csize)
-            uint32_t off = 0;
-            if (mt) off = pbyte(cr, src, m, mis, chi) | (pbyte(cr, src, m + 1, mis, chi) << 8);
-            uint32_t ml = b & 15, nx = m + 2;
-            ext_field(mt && ml == 15, nx, ml, bad, 5, cr, src, csize, mis, chi);
-            ml += kMinMatch;
-            const uint32_t ms = o + ll;
-            bad = bad || (mt && (off == 0 || off > ms - low || capB - ms < ml + kLastLiterals));      // lz4.c:2356, 2423
-            bad = bad || (act && i >= iend);                                         // (more sequences than the rows say)
-            act = act && !bad;
-            const uint32_t oe = act ? (last ? ms : ms + ml) : o;
-            if (act) {
-                SeqRec r; r.outpos = o; r.litpos = q; r.ll = ll; r.off = last ? 0u : off;
-                recs[i & kRecMask] = r;
-                const uint32_t gq = (o + kRegion - 1) >> kRegionShift;
-                if (!smode && (gq << kRegionShift) < oe) idx[gq & kIdxMask] = i + 1;           // the first region whose first byte the sequence holds
+        Walk w; w.p = A.tok; w.o = A.out + kBias; w.i = A.ord; w.end = B.tok; w.oend = B.out + kBias; w.iend = B.ord;
+        w.act = lane < nl && w.p < w.end; w.res = allres; w.bad = false;
+        w.W = cr_fetch4(X.cr, w.p, X.mis);
+        uint32_t head = 0, sRa = Ra, scarry = 0;
+        while (__any(w.act)) {
+            n_steps++;
+            const uint32_t o0 = w.o, i0 = w.i;
+            const StepOut S = parser_step(X, w, n_careful);
+            if (S.ok) {
+                recs[w.i & kRecMask] = S.r;
+                const uint32_t gq = (w.o + kRegion - 1) >> kRegionShift;
+                if (!smode && (gq << kRegionShift) < S.oe) idx[gq & kIdxMask] = w.i + 1;           // the first region whose first byte the sequence holds
             }
+            w.i += S.ok ? 1u : 0u; w.o = S.oe;
+            w.act = w.act && S.ok && w.p < w.end;
             if (smode) {
                 // the index entries of this one sequence, as far as the ring has room, publishing as it goes (the copy must be
-                // able to move on for room to appear)
-                const uint32_t so = wave_readlane(o, 0), se = wave_readlane(oe, 0), si = wave_readlane(i, 0);
-                if (wave_readlane(act ? 1u : 0u, 0)) {
+                // able to move on for room to appear).  Every earlier batch is published: the row is true, and so are its records.
+                const uint32_t so = wave_readlane(o0, 0), se = wave_readlane(S.oe, 0), si = wave_readlane(i0, 0);
+                if (wave_readlane(S.ok ? 1u : 0u, 0)) {
                     wave_lds_fence();
-                    if (lane == 0) { SeqRec z; z.outpos = se; z.litpos = csize; z.ll = 0; z.off = 0; recs[(si + 1) & kRecMask] = z; }
+                    if (lane == 0) recs[(si + 1) & kRecMask].outpos = se;
                     head = si + 2;
                     uint32_t ga = (so + kRegion - 1) >> kRegionShift;
                     const uint32_t gb = (se + kRegion - 1) >> kRegionShift;
@@ -495,38 +599,58 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
                         if (ga + n + 1 <= c2.open + kIdxRing) { if (lane < n) idx[(ga + lane) & kIdxMask] = si; ga += n; }
                         else spin_pause();
                     }
-                    icarry = si + 1;
+                    scarry = si + 1;
+                    if (gb > sRa) sRa = gb;
                 }
             }
-            i += act ? 1u : 0u; o = oe; p = act ? (last ? csize : nx) : p;
-            act = act && p < end;
         }
+        if (prof) { const uint64_t t = clock_ticks(); t_walk += t - tq; tq = t; }
         // ---- every lane must have arrived exactly at the next row
-        const bool arrived = lane >= nl || (!bad && p == end && o == oend && i == iend);
-        if (__any(!arrived)) { fail = true; break; }
-        const uint32_t iendN = wave_readlane(iend, nl - 1), oendN = wave_readlane(oend, nl - 1);
-        const bool final = r0 + nl == nreg;
+        const bool arrived = lane >= nl || (!w.bad && w.p == w.end && w.o == w.oend && w.i == w.iend);
+        const bool all_arrived = !__any(!arrived);
+        const uint32_t iendN = wave_readlane(w.iend, nl - 1), oendN = wave_readlane(w.oend, nl - 1), tokN = wave_readlane(w.end, nl - 1);
+        // ---- publish, once every earlier batch is published
+        if (!smode) {
+            for (;;) {
+                if (uload(&misc[P_TURN]) == ticket) break;
+                if (uload(&misc[M_ABORT])) return;
+                spin_pause();
+            }
+        }
+        if (!all_arrived) { fail = true; if (smode) parser_unlock(misc); break; }
         wave_lds_fence();
+#ifdef LZ4AMD_PROF_PARSER
+        { const uint64_t t_ = clock_ticks(); t_turn += t_ - tp; tp = t_; t_turn -= 0; }
+#endif
+        uint32_t pubRa = RbN > Ra ? RbN : Ra;
         if (!smode) {
             // holes (regions whose first byte lies in a sequence that noted an earlier region) take the entry before them
+            uint32_t icarry = uload(&misc[P_ICARRY]);
             for (uint32_t R = Ra; R < RbN; R += 64) {
                 const uint32_t v = R + lane < RbN ? idx[(R + lane) & kIdxMask] : 0u;
                 const uint32_t filled = wave_incl_max_u32(v > icarry ? v : icarry);
                 icarry = wave_readlane(filled, 63);
                 if (R + lane < RbN) idx[(R + lane) & kIdxMask] = filled - 1;
             }
-        }
-        if (lane == 0) { SeqRec z; z.outpos = oendN; z.litpos = csize; z.ll = 0; z.off = 0; recs[iendN & kRecMask] = z; }      // where the last record ends (the next batch writes the whole row)
-        head = iendN + 1;
-        Ra = RbN;
-        if (final) { if (lane == 0) idx[rend & kIdxMask] = nseq - 1; Ra = rend + 1; }          // (the last region asks for the entry behind it like every other)
-        r0 += nl;
+            if (lane == 0) misc[P_ICARRY] = icarry;
+        } else { if (lane == 0) misc[P_ICARRY] = scarry; if (sRa > pubRa) pubRa = sRa; }
+        if (lane == 0) recs[iendN & kRecMask].outpos = oendN;           // where the batch's last record ends (only this field: the next batch may have written its first record there already - with this value)
+        const bool final = r0 + nl == nreg;
+        if (final) { if (lane == 0) idx[rend & kIdxMask] = nseq - 1; pubRa = rend + 1; }          // (the last region asks for the entry behind it like every other)
         wave_lds_fence();
         if (lane == 0) {
-            lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)head | ((uint64_t)Ra << 32));
-            lds_store_release(&misc[M_PR0], r0);
+            lds_store_release64((uint64_t*)&misc[M_HEAD], (uint64_t)(iendN + 1) | ((uint64_t)pubRa << 32));
+            lds_store_release(&misc[M_CLO], tokN);                       // (AFTER the records: the mover reads this word first, the heads second - a new
+            lds_store_release(&misc[P_TURN], ticket + 1);                //  position never meets old heads, which would let go of literals still to be copied)
         }
+        if (smode) { if (lane == 0) misc[P_RZ] = pubRa; parser_unlock(misc); }
     }
+#ifdef LZ4AMD_PROF_PARSER
+    // developer build: where the first parser wave's time goes (the walk's time is counted with the wait for its turn: subtract t_walk)
+    if (prof && lane == 0 && wave_id() == kFirstParseWave) { prof[5] = (t_lock >> 4) | ((t_sel >> 4) << 32); prof[6] = (t_turn >> 4) | ((t_pub >> 4) << 32); prof[7] = n_nowork; }
+#endif
+#undef PSTAMP
+    if (prof && lane == 0 && wave_id() == kFirstParseWave) { prof[2] = n_batch | ((uint64_t)n_lanes << 32); prof[3] = n_steps | ((uint64_t)n_careful << 32); prof[4] = (t_wait >> 4) | ((t_walk >> 4) << 32); }
     if (fail) {
         wave_lds_fence();
         if (lane == 0) { lds_store_release(&misc[M_PBAD], 1u); lds_store_release(&misc[M_ABORT], 1u); }
@@ -882,8 +1006,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
                 covered = c.head >= jl + 2;                                    // (row jl + 1 says where record jl ends)
             }
             if (covered && C.g + kMaxLead >= R) break;
-            if (covered) n_lead++; else n_cov++;               // (developer profile: what the wait was for)
-            spin_pause();
+            if (covered) { n_lead++; spin_pause(); } else { n_cov++; spin_pause_long(); }      // (a wave that waits for records leaves the issue slots to the waves that make them)
         }
         if (prof) {   // (the clock reads and this bookkeeping only under the developer profile: they were ~5 % of a region's time)
             const uint64_t t = clock_ticks(), dt = t - ts;
@@ -898,8 +1021,10 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
         // (the first-open-region word is moved by the mover wave: it reads the complete marks of the regions in flight in one trip)
         if (prof) { const uint64_t t = clock_ticks(); t_work += t - ts - tr; t_retry += tr; }
     }
-out:
+out: ;
+#ifndef LZ4AMD_PROF_PARSER
     if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[5] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); }
+#endif
 }
 
 // ------------------------------------------------------------------------------ stage B of one block
@@ -912,7 +1037,8 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
     if (tid == 0) { misc[M_ABORT] = 0; misc[M_SPARE] = 0; misc[M_CHI] = 0; misc[M_IHEAD] = kFirstRegion; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion;
-                    misc[M_EHEAD] = 0; misc[M_PR0] = 0; misc[M_PBAD] = 0; }
+                    misc[M_EHEAD] = 0; misc[M_PR0] = 0; misc[M_PBAD] = 0;
+                    misc[P_LOCK] = 0; misc[P_NEXT] = 0; misc[P_RZ] = kFirstRegion; misc[P_TICKET] = 0; misc[P_TURN] = 0; misc[P_ICARRY] = 0; }
     if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
     if (tid < 17) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid, k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
     // chunk flags: the history before dst (positions below kBias = regions 0..63, lap 0) is final, nothing else is
@@ -933,9 +1059,9 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
 
     const uint32_t rend = (kBias + total + kRegion - 1) >> kRegionShift;          // regions [kFirstRegion, rend)
     const bool hinted = hint != nullptr;
-    const uint32_t nreg = (total + kRegion - 1) >> kRegionShift;                  // rows of the table: nreg + 1, behind its 16-byte header
+    const uint32_t nreg = (total + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT;      // rows of the table: nreg + 1, behind its 16-byte header
     if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem, hinted ? hint + 16 : hint, nreg + 1);
-    else if (hinted && w == kParseWave) parser_role(src, csize, cap, prefix, total, nseq, nreg, rend, smem);
+    else if (hinted && w >= kFirstParseWave) parser_role(src, csize, cap, prefix, total, nseq, nreg, rend, smem, prof);
     else copy_role(w, src, dst, nseq, total, rend, smem, prof, hinted);
     __syncthreads();
     return misc[M_PBAD] == 0;
@@ -993,7 +1119,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     if (use_hints && !chained && P.hints) {
         const lz4amd_gsrc hp = LZ4AMD_TO_GSRC(P.hints + (uint64_t)b * P.hint_stride);
         const U32x4 h = ld_global16(hp);                     // { magic, output bytes, compressed bytes, sequences }
-        const uint64_t rows = (((uint64_t)h[1] + kRegion - 1) >> kRegionShift) + 2;
+        const uint64_t rows = (((uint64_t)h[1] + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT) + 2;
         if (h[0] == LZ4AMD_HINT_MAGIC && h[2] == csize && h[1] != 0 && h[1] <= cap && h[3] != 0 && h[3] <= csize && rows * 16 <= P.hint_stride) {
             hint = hp; total = h[1]; nseq = h[3];
         }

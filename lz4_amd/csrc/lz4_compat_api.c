@@ -245,7 +245,10 @@ int LZ4_decompress_fast_continue(LZ4_streamDecode_t* sd, const char* src, char* 
     } else {
         sd->internal_donotuse.extDictSize = sd->internal_donotuse.prefixSize;
         sd->internal_donotuse.externalDict = sd->internal_donotuse.prefixEnd - sd->internal_donotuse.extDictSize;
-        r = LZ4_decompress_fast_usingDict(src, dst, originalSize, (const char*)sd->internal_donotuse.externalDict, (int)(sd->internal_donotuse.extDictSize > 65536 ? 65536 : sd->internal_donotuse.extDictSize));
+        {   /* the LAST 64 KB of what was decoded before (lz4.c:2817-2825: the dictionary ends where the previous prefix ended) */
+            const size_t es = sd->internal_donotuse.extDictSize, use = es > 65536 ? 65536 : es;
+            r = LZ4_decompress_fast_usingDict(src, dst, originalSize, (const char*)sd->internal_donotuse.externalDict + (es - use), (int)use);
+        }
         if (r <= 0) return r;
         sd->internal_donotuse.prefixSize = (size_t)originalSize;
         sd->internal_donotuse.prefixEnd = (const unsigned char*)dst + originalSize;

@@ -62,6 +62,17 @@ int   lz4amd_dev_upload(void* d, const void* h, size_t n)
 int   lz4amd_dev_download(void* h, const void* d, size_t n)
 { if (lz4amd_hip_d2h(h, d, n, NULL) || lz4amd_hip_sync(NULL)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; } return 0; }
 
+/* LZ4_compress_HC's compressionLevel as the kernel takes it: the reference's clamp (lz4hc.c:1414-1415: below 1 the default 9,
+ * above 12 level 12), LZ4AMD_HC_FAVOR_DEC_SPEED kept on top.  (The kernel looks at the low byte only: -1 must not become 255.) */
+static int hc_level_norm(int level)
+{
+    int flag = 0;
+    if (level >= LZ4AMD_HC_FAVOR_DEC_SPEED && level < 2 * LZ4AMD_HC_FAVOR_DEC_SPEED) { flag = LZ4AMD_HC_FAVOR_DEC_SPEED; level -= LZ4AMD_HC_FAVOR_DEC_SPEED; }
+    if (level < 1) level = 9;
+    if (level > 12) level = 12;
+    return level | flag;
+}
+
 /* --------------------------------------------------------------------- plan */
 static void* dev_array(const void* host, size_t bytes, int* err)
 {
@@ -156,7 +167,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
-        q->level = level; q->max_src = max_n + 65536;           /* room for a block's history (lz4amd_plan_create_compress_hc_prefix) */
+        q->level = hc_level_norm(level); q->max_src = max_n + 65536;           /* room for a block's history (lz4amd_plan_create_compress_hc_prefix) */
         q->prefix = NULL;
         q->scratch_stride = (lz4amd_hip_hc_scratch_bytes(q->max_src) + 255) & ~(uint64_t)255;
         q->prof = NULL;
@@ -247,9 +258,9 @@ int lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, in
 }
 
 size_t lz4amd_hint_bytes(int src_size)
-{   /* header + one row per started KB + the end row (lz4amd_params.h) */
+{   /* header + one row per started 512 bytes + the end row (lz4amd_params.h) */
     if (src_size < 0) return 0;
-    return 16u * (((size_t)src_size + 1023u) / 1024u + 2u);
+    return 16u * (((size_t)src_size + LZ4AMD_HINT_ROW_BYTES - 1u) / LZ4AMD_HINT_ROW_BYTES + 2u);
 }
 
 int lz4amd_plan_attach_hints(lz4amd_plan* p, void* d_hints, size_t stride)
@@ -398,7 +409,7 @@ int lz4amd_plan_set_row0(lz4amd_plan* p, int src_size, int dst_cap, int level, v
     const int32_t* dsz; const int32_t* dcap;
     if (!p || p->n != 1) return LZ4AMD_E_ARG;
     if (p->op == LZ4AMD_OP_DECOMPRESS) { dsz = p->dec.src_size; dcap = p->dec.dst_cap; }
-    else if (p->op == LZ4AMD_OP_COMPRESS_HC) { dsz = p->hc.src_size; dcap = p->hc.dst_cap; p->hc.level = level; }
+    else if (p->op == LZ4AMD_OP_COMPRESS_HC) { dsz = p->hc.src_size; dcap = p->hc.dst_cap; p->hc.level = hc_level_norm(level); }
     else if (p->op == LZ4AMD_OP_COMPRESS) { dsz = p->comp.src_size; dcap = p->comp.dst_cap; }
     else return LZ4AMD_E_ARG;
     p->row0[0] = src_size; p->row0[1] = dst_cap;          /* (the copies are asynchronous: the source must outlive the call) */
@@ -409,7 +420,7 @@ int lz4amd_plan_set_row0(lz4amd_plan* p, int src_size, int dst_cap, int level, v
     return LZ4AMD_OK;
 }
 
-void lz4amd_plan_set_level(lz4amd_plan* p, int level) { if (p && p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.level = level; p->level = level; } }
+void lz4amd_plan_set_level(lz4amd_plan* p, int level) { if (p && p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.level = hc_level_norm(level); p->level = level; } }
 
 int lz4amd_plan_bind_host_row(lz4amd_plan* p, int* row)
 {

@@ -29,13 +29,14 @@ typedef struct lz4amd_dec_params {
     uint32_t* hint_stats;           /* optional: [0] += blocks decoded from their table, [1] += tables that did not fit their block */
 } lz4amd_dec_params;
 
-/* One block's entry-point table: a 16-byte header followed by regions + 1 entries of 16 bytes, regions = ceil(out_size / 1024).
+/* One block's entry-point table: a 16-byte header followed by rows + 1 entries of 16 bytes, rows = ceil(out_size / 512).
  * Entry r names a sequence of the block's token chain: where its token sits in the compressed block, where its literals
  * start in the output, how many sequences precede it.  Entry 0 is the first sequence, entry `regions` the block's end
  * {csize, out_size, nseq}; entries never decrease.  The compressor picks, for region r, the first sequence that the source
  * strips from byte 1024 r on emitted. */
 #define LZ4AMD_HINT_MAGIC 0x48345A4Cu           /* "LZ4H" */
-#define LZ4AMD_HINT_REGION_SHIFT 10
+#define LZ4AMD_HINT_ROW_SHIFT 9
+#define LZ4AMD_HINT_ROW_BYTES (1u << LZ4AMD_HINT_ROW_SHIFT)
 typedef struct lz4amd_hint_entry { uint32_t tok, out, ord, zero; } lz4amd_hint_entry;      /* header: { magic, out_size, csize, nseq } */
 
 typedef struct lz4amd_comp_params {

@@ -62,7 +62,7 @@ LZ4F_errorCode_t LZ4F_readOpen(LZ4_readFile_t** out, FILE* fp) {
     memcpy(r->in, head + used, got - used);
     r->at = 0; r->have = got - used;
     *out = r;
-    return rc;
+    return LZ4F_OK_NoError;                      /* (lz4file.c:96-140: the result of LZ4F_createDecompressionContext, not getFrameInfo's size hint) */
 }
 
 size_t LZ4F_read(LZ4_readFile_t* r, void* buf, size_t size) {

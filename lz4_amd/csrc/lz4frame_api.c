@@ -244,6 +244,7 @@ struct LZ4F_dctx_s {
     LZ4F_CustomMem cmem; int has_cmem;            /* LZ4F_createDecompressionContext_advanced: who allocated the context */
     int skipc, skipc_call;                        /* skipChecksums: once asked for it holds for the rest of the frame (lz4frame.c:1634) */
     const uint8_t* dict; size_t dict_len;         /* LZ4F_decompress_usingDict: what the frame's first bytes (every block of an independent-block frame) may reference */
+    int dict_keep;                                /* ... installed by the call that is running: the reset between two frames inside that call leaves it */
     /* the content checksum of a batch runs on a helper thread while its bytes are delivered and the next input is taken */
     int hashing; pthread_t hthread; size_t hash_n;
 };
@@ -265,6 +266,7 @@ void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
     d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
     d->out_size = d->out_pos = 0;
     d->total_out = d->skip_left = 0; d->hist_len = 0;
+    if (!d->dict_keep) { d->dict = NULL; d->dict_len = 0; }      /* lz4frame.c:1331-1332: a dictionary counts for one frame */
 }
 LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* d)
 {
@@ -331,16 +333,20 @@ static size_t header_want(const uint8_t* p, size_t n)
     if (n < 7) return 7;                         /* the smallest header; the smallest frame is 11 bytes, so this never reads past one */
     return 7 + ((p[4] & 8) ? 8 : 0) + ((p[4] & 1) ? 4 : 0);
 }
+static void seed_history(LZ4F_dctx* d)
+{   /* lz4frame.c:1904-1912: a linked frame's first block sees the dictionary as the output before it */
+    d->hist_len = 0;
+    if (d->dict_len && d->info.frameType == LZ4F_frame && d->info.blockMode == LZ4F_blockLinked) {
+        if (d->hist || (d->hist = (uint8_t*)malloc(65536))) { memcpy(d->hist, d->dict, d->dict_len); d->hist_len = d->dict_len; }
+    }
+}
 static void enter_frame(LZ4F_dctx* d, size_t block_max)
 {
     d->block_max = block_max;
     d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
     d->total_out = 0; d->hist_len = 0;
     d->skipc = d->skipc_call;                    /* a new frame: only what the current call asks for */
-    if (d->dict_len && d->info.frameType == LZ4F_frame && d->info.blockMode == LZ4F_blockLinked) {
-        /* lz4frame.c:1904-1912: a linked frame's first block sees the dictionary as the output before it */
-        if (d->hist || (d->hist = (uint8_t*)malloc(65536))) { memcpy(d->hist, d->dict, d->dict_len); d->hist_len = d->dict_len; }
-    }
+    seed_history(d);
     xxh32_reset(&d->xxh);
     if (d->info.frameType == LZ4F_skippableFrame) { d->skip_left = d->info.contentSize; d->stage = d->skip_left ? ST_SKIP : ST_DONE; }
     else d->stage = ST_BLOCKS;
@@ -675,12 +681,22 @@ size_t LZ4F_headerSize(const void* src, size_t srcSize)
 size_t LZ4F_decompress_usingDict(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
                                  const void* dict, size_t dictSize, const LZ4F_decompressOptions_t* decompressOptionsPtr)
 {   /* lz4frame.c:2070-2083: the dictionary counts when a frame starts; it must stay in place while the frame is decoded */
+    size_t r;
+    /* the header was consumed (LZ4F_getFrameInfo, to read the dictID) and nothing of the first block yet: the reference
+     * still takes the dictionary there (dStage <= dstage_init) */
+    int fresh;
     if (dctx == NULL) return ERR(parameter_null);
-    if (dctx->stage == ST_HEADER || dctx->stage == ST_DONE) {
+    if (dctx->stage == ST_DONE && dctx->out_pos >= dctx->out_size) LZ4F_resetDecompressionContext(dctx);      /* the frame before is complete and delivered */
+    fresh = dctx->stage == ST_BLOCKS && dctx->total_out == 0 && dctx->in_size == 0 && dctx->nready == 0 && dctx->out_size == 0 && !dctx->end_seen;
+    if (dctx->stage == ST_HEADER || dctx->stage == ST_DONE || fresh) {
         if (dict && dictSize) {
             if (dictSize > 65536) { dict = (const uint8_t*)dict + (dictSize - 65536); dictSize = 65536; }
             dctx->dict = (const uint8_t*)dict; dctx->dict_len = dictSize;
         } else { dctx->dict = NULL; dctx->dict_len = 0; }
+        if (fresh) seed_history(dctx);
+        if (dctx->stage == ST_DONE) dctx->dict_keep = 1;          /* (bytes of the frame before are still to be delivered: the reset comes inside this call) */
     }
-    return LZ4F_decompress(dctx, dstBuffer, dstSizePtr, srcBuffer, srcSizePtr, decompressOptionsPtr);
+    r = LZ4F_decompress(dctx, dstBuffer, dstSizePtr, srcBuffer, srcSizePtr, decompressOptionsPtr);
+    dctx->dict_keep = 0;
+    return r;
 }

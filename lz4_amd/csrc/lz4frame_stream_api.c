@@ -42,6 +42,7 @@ struct LZ4F_cctx_s {
     xxh32_state xxh;
     LZ4F_CustomMem cmem;        /* lz4frame.h:712-727: the context and its buffer come from the caller's allocator when one is given */
     uint8_t* dict; size_t dict_len;     /* compressBegin_usingDict / usingCDict: the last 64 KB of the dictionary (a copy) */
+    int dict_once;                      /* a raw dictionary buffer (usingDict / usingDictOnce) is the history of the frame's FIRST block only; a CDict that of every independent block (lz4frame.c:690-826) */
     int fill_raw;               /* the gathered bytes came through LZ4F_uncompressedUpdate: they leave as a stored block */
 };
 struct LZ4F_CDict_s { LZ4F_CustomMem cmem; uint8_t* content; size_t size; };
@@ -135,9 +136,16 @@ size_t LZ4F_compressBegin(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, con
 {
     return begin_internal(c, dstBuffer, dstCapacity, NULL, 0, prefsPtr);
 }
+size_t LZ4F_compressBegin_usingDictOnce(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const void* dictBuffer, size_t dictSize, const LZ4F_preferences_t* prefsPtr)
+{   /* lz4frame.c:824-836: the dictionary is the history of the frame's first block (the lz4 CLI's multi-threaded linked-block
+     * compression starts every job with the 64 KB before it this way, lz4io.c:1118-1128) */
+    const size_t r = begin_internal(c, dstBuffer, dstCapacity, dictBuffer, dictSize, prefsPtr);
+    if (c && !LZ4F_isError(r)) c->dict_once = 1;
+    return r;
+}
 size_t LZ4F_compressBegin_usingDict(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const void* dictBuffer, size_t dictSize, const LZ4F_preferences_t* prefsPtr)
-{   /* lz4frame.c:838-845 */
-    return begin_internal(c, dstBuffer, dstCapacity, dictBuffer, dictSize, prefsPtr);
+{   /* lz4frame.c:838-849: the same thing ("this will only use the dictionary once") */
+    return LZ4F_compressBegin_usingDictOnce(c, dstBuffer, dstCapacity, dictBuffer, dictSize, prefsPtr);
 }
 size_t LZ4F_compressBegin_usingCDict(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const LZ4F_CDict* cdict, const LZ4F_preferences_t* prefsPtr)
 {   /* lz4frame.c:862-868 */
@@ -156,7 +164,7 @@ static size_t begin_internal(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, 
     c->win = (uint8_t*)cm_alloc(&c->cmem, WINDOW + c->block_size, 0);
     if (!c->win) return ERR(allocation_failed);
     c->hist = c->fill = 0; c->total_in = 0; c->fill_raw = 0;
-    cm_free(&c->cmem, c->dict); c->dict = NULL; c->dict_len = 0;
+    cm_free(&c->cmem, c->dict); c->dict = NULL; c->dict_len = 0; c->dict_once = 0;
     if (dict && dictSize) {
         if (dictSize > WINDOW) { dict = (const uint8_t*)dict + (dictSize - WINDOW); dictSize = WINDOW; }
         c->dict = (uint8_t*)cm_alloc(&c->cmem, dictSize, 0);
@@ -190,7 +198,7 @@ static size_t put_block(LZ4F_cctx* c, uint8_t* op)
     int cs = 0;
     /* lz4frame.c:943-958: levels >= LZ4HC_CLEVEL_MIN take the HC compressor; linked blocks see the 64 KB before them, the
      * blocks of an independent-block frame that was begun with a dictionary see the dictionary (lz4frame.c:917-943) */
-    if (!linked && c->dict_len) { memcpy(c->win + WINDOW - c->dict_len, c->dict, c->dict_len); c->hist = c->dict_len; }
+    if (!linked && c->dict_len && !c->dict_once) { memcpy(c->win + WINDOW - c->dict_len, c->dict, c->dict_len); c->hist = c->dict_len; }
     if (!c->fill_raw)
         cs = lz4amd_compress_with_history(c->hist ? (const char*)blk - c->hist : NULL, (int)c->hist,
                                           (const char*)blk, (char*)op + BH, (int)n, (int)n - 1,

@@ -151,3 +151,48 @@ def test_lz4file_argument_and_io_errors(ours, tmp_path):
     rc = ours.LZ4F_readOpen(ctypes.byref(h), fp)
     assert ours.LZ4F_isError(rc) and not h.value
     libc.fclose(fp)
+
+
+def test_fast_continue_with_a_long_prefix_and_a_buffer_switch(ours, reflib, datagen):
+    """LZ4_decompress_fast_continue (lz4.c:2798-2830): a first block of more than 64 KB, then a block decoded into ANOTHER buffer
+    that copies from the tail of the first - the dictionary is the LAST 64 KB of the previous output, not its first."""
+    vp_ = ctypes.c_void_p
+    data = datagen(140000, 70, 12)
+    a, b = data[:100000], data[100000:]
+    reflib.LZ4_createStream.restype = vp_
+    reflib.LZ4_compress_fast_continue.argtypes = [vp_, ctypes.c_char_p, ctypes.c_char_p, ci, ci, ci]
+    reflib.LZ4_freeStream.argtypes = [vp_]
+    s = reflib.LZ4_createStream()
+    srcbuf = ctypes.create_string_buffer(data, len(data))                 # both blocks contiguous: the second sees the first as its prefix
+    cap = reflib.LZ4_compressBound(len(a))
+    ca, cb = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(cap)
+    base = ctypes.addressof(srcbuf)
+    na = reflib.LZ4_compress_fast_continue(s, ctypes.cast(base, ctypes.c_char_p), ca, len(a), cap, 1)
+    nb = reflib.LZ4_compress_fast_continue(s, ctypes.cast(base + len(a), ctypes.c_char_p), cb, len(b), cap, 1)
+    reflib.LZ4_freeStream(s)
+    assert na > 0 and nb > 0
+    for lib in (reflib, ours):
+        lib.LZ4_createStreamDecode.restype = vp_
+        lib.LZ4_decompress_fast_continue.argtypes = [vp_, ctypes.c_char_p, ctypes.c_char_p, ci]
+        lib.LZ4_freeStreamDecode.argtypes = [vp_]
+        sd = lib.LZ4_createStreamDecode()
+        o1, o2 = ctypes.create_string_buffer(len(a) + 16), ctypes.create_string_buffer(len(b) + 16)      # two separate buffers
+        assert lib.LZ4_decompress_fast_continue(sd, ca.raw[:na], o1, len(a)) == na
+        assert lib.LZ4_decompress_fast_continue(sd, cb.raw[:nb], o2, len(b)) == nb
+        assert o1.raw[:len(a)] == a and o2.raw[:len(b)] == b, lib
+        lib.LZ4_freeStreamDecode(sd)
+
+
+def test_lz4file_read_open_returns_ok(ours, tmp_path):
+    """LZ4F_readOpen (lib/lz4file.c:73-140) returns LZ4F_OK_NoError on success, not LZ4F_getFrameInfo's size hint: callers may
+    compare with 0.  Only the header is touched here: no device needed."""
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = vp; libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]; libc.fclose.argtypes = [vp]
+    ours.LZ4F_readOpen.restype = ctypes.c_size_t; ours.LZ4F_readOpen.argtypes = [ctypes.POINTER(vp), vp]
+    ours.LZ4F_readClose.restype = ctypes.c_size_t; ours.LZ4F_readClose.argtypes = [vp]
+    src = os.path.join(ROOT, "tests", "golden", "f_p60_600k_B4_BD_cs.lz4")
+    fp = libc.fopen(src.encode(), b"rb")
+    h = vp()
+    assert ours.LZ4F_readOpen(ctypes.byref(h), fp) == 0 and h.value
+    assert ours.LZ4F_readClose(h) == 0
+    libc.fclose(fp)

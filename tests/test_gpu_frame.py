@@ -321,3 +321,71 @@ def test_reference_cli_accepts_our_frames(L, datagen, tmp_path):
         assert t.returncode == 0, (name, t.stderr)
         d = subprocess.run([exe, "-dc", str(f)], capture_output=True)
         assert d.returncode == 0 and d.stdout == data, name
+
+
+def _dict_frame(L, dictionary, body, **kw):
+    st, vp = ctypes.c_size_t, ctypes.c_void_p
+    L.LZ4F_createCDict.restype = vp
+    L.LZ4F_createCDict.argtypes = [ctypes.c_char_p, st]
+    L.LZ4F_freeCDict.argtypes = [vp]
+    L.LZ4F_createCompressionContext.restype = st
+    L.LZ4F_createCompressionContext.argtypes = [ctypes.POINTER(vp), ctypes.c_uint]
+    L.LZ4F_freeCompressionContext.argtypes = [vp]
+    L.LZ4F_compressFrame_usingCDict.restype = st
+    L.LZ4F_compressFrame_usingCDict.argtypes = [vp, ctypes.c_char_p, st, ctypes.c_char_p, st, vp, ctypes.POINTER(Prefs)]
+    p = Prefs()
+    for k, v in kw.items():
+        setattr(p.frameInfo, k, v)
+    cd = L.LZ4F_createCDict(dictionary, len(dictionary))
+    c = vp()
+    assert cd and L.LZ4F_createCompressionContext(ctypes.byref(c), 100) == 0
+    cap = L.LZ4F_compressFrameBound(len(body), ctypes.byref(p))
+    dst = ctypes.create_string_buffer(cap)
+    n = L.LZ4F_compressFrame_usingCDict(c, dst, cap, body, len(body), cd, ctypes.byref(p))
+    assert not L.LZ4F_isError(n), L.LZ4F_getErrorName(n)
+    L.LZ4F_freeCompressionContext(c); L.LZ4F_freeCDict(cd)
+    return dst.raw[:n]
+
+
+@pytest.mark.parametrize("mode", [0, 1])          # linked, independent blocks
+def test_a_dictionary_counts_for_one_frame_and_after_get_frame_info(L, datagen, mode):
+    """lz4frame.c:1327-1335, 2070-2083: LZ4F_decompress_usingDict's dictionary is taken while the frame has not started - also
+    after LZ4F_getFrameInfo consumed the header (the way to read the dictID first) - and is forgotten when the frame ends: a
+    later frame decoded with plain LZ4F_decompress on the same context must not see it."""
+    st, vp = ctypes.c_size_t, ctypes.c_void_p
+    L.LZ4F_decompress_usingDict.restype = st
+    L.LZ4F_decompress_usingDict.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(st), ctypes.c_char_p, ctypes.POINTER(st), ctypes.c_char_p, st, vp]
+    dictionary = datagen(40000, 60, 21)
+    body = dictionary[5000:30000] + datagen(30000, 60, 22) + dictionary[100:9000]
+    frame = _dict_frame(L, dictionary, body, blockSizeID=4, blockMode=mode)
+    plain = compress_frame(L, body, blockSizeID=4, blockMode=mode)
+    assert len(frame) < len(plain) - 5000                      # the dictionary was used
+
+    def run(d, fr, use_dict, skip=0):
+        out, pos = bytearray(), skip
+        for _ in range(1000):
+            dst = ctypes.create_string_buffer(200000)
+            dsz, ssz = st(len(dst)), st(len(fr) - pos)
+            if use_dict:
+                r = L.LZ4F_decompress_usingDict(d, dst, ctypes.byref(dsz), fr[pos:], ctypes.byref(ssz), dictionary, len(dictionary), None)
+            else:
+                r = L.LZ4F_decompress(d, dst, ctypes.byref(dsz), fr[pos:], ctypes.byref(ssz), None)
+            if L.LZ4F_isError(r):
+                return None
+            out += dst.raw[:dsz.value]; pos += ssz.value
+            if r == 0:
+                return bytes(out)
+        return None
+
+    d = vp()
+    assert L.LZ4F_createDecompressionContext(ctypes.byref(d), 100) == 0
+    # the header first (LZ4F_getFrameInfo consumes it), then the dictionary
+    info, used = FrameInfo(), st(len(frame))
+    assert not L.LZ4F_isError(L.LZ4F_getFrameInfo(d, ctypes.byref(info), frame, ctypes.byref(used)))
+    assert run(d, frame, True, skip=used.value) == body
+    # the same frame again on the same context, without the dictionary: its matches reach before the output
+    assert run(d, frame, False) is None
+    # ... and the context is usable afterwards
+    assert run(d, frame, True) == body
+    assert run(d, plain, False) == body
+    L.LZ4F_freeDecompressionContext(d)

@@ -15,8 +15,11 @@ MAGIC = 0x48345A4C
 CANARY = 0xEE
 
 
+ROW = 512
+
+
 def hint_bytes(n):
-    return 16 * ((n + 1023) // 1024 + 2)
+    return 16 * ((n + ROW - 1) // ROW + 2)
 
 
 def token_chain(comp):
@@ -44,13 +47,13 @@ def token_chain(comp):
 
 
 def make_table(comp, every=1):
-    """A valid table for any legal block: row r = the first sequence that starts at or behind byte 1024 r of the output (the
+    """A valid table for any legal block: row r = the first sequence that starts at or behind byte 512 r of the output (the
     last sequence when there is none); `every` > 1 thins the rows out (row r then names what row r - r % every would)."""
     ch, n = token_chain(comp)
-    nreg = (n + 1023) // 1024
+    nreg = (n + ROW - 1) // ROW
     rows, j = [], 0
     for r in range(nreg):
-        want = (r - r % every) * 1024
+        want = (r - r % every) * ROW
         while j + 1 < len(ch) and ch[j][1] < want:
             j += 1
         k = j
@@ -75,7 +78,7 @@ def check_table(comp, table, n):
     ch, total = token_chain(comp)
     assert total == n and nseq == len(ch)
     where = {t: (o, i) for i, (t, o) in enumerate(ch)}
-    nreg = (n + 1023) // 1024
+    nreg = (n + ROW - 1) // ROW
     prev = (0, 0, 0)
     for r in range(nreg + 1):
         tok, out, ordn, z = struct.unpack_from("<4I", table, 16 * (r + 1))
@@ -85,7 +88,7 @@ def check_table(comp, table, n):
         else:
             assert where.get(tok) == (out, ordn), (r, tok, out, ordn)
             # the row is near its region: its sequence starts inside the strips of region r or is the first one behind them
-            assert out < (r + 1) * 1024 or ordn == 0 or ch[ordn - 1][1] < r * 1024 + 1024
+            assert out < (r + 1) * ROW or ordn == 0 or ch[ordn - 1][1] < r * ROW + ROW
         assert (tok, out, ordn) >= prev
         prev = (tok, out, ordn)
     assert struct.unpack_from("<3I", table, 16) == (0, 0, 0)
@@ -176,7 +179,7 @@ def test_tables_made_for_foreign_blocks_decode_every_corpus(emu, foreign):
         outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], tables, salign=sal)
         for d, (r, o) in zip(wants, outs):
             assert r == len(d) and o == d, (every, sal, len(d))
-        # (rows 40 KB apart: a lane of the parser may then own more sequences than it accepts - such a table is rejected, not wrong)
+        # (rows 20 KB apart: a lane of the parser may then own more sequences than it accepts - such a table is rejected, not wrong)
         assert used + rejected == len(blocks) and (rejected == 0 or every == 40) and used >= 50, (every, used, rejected)
 
 

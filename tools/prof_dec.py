@@ -34,6 +34,10 @@ if not os.environ.get("NOPROF"):
     print("  block total        %10d" % med(lambda i: w[i * 8]))
     print("  pre-parse %d  (P1 %d  P2 %d  P3 %d  P4 %d  list %d  P5 %d)" % (med(lambda i: w[i * 8 + 1]), med(lambda i: w[i * 8 + 2] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 2] >> 32),
           med(lambda i: w[i * 8 + 3] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 3] >> 32), med(lambda i: w[i * 8 + 4] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 4] >> 32)))
+    if use_hints:
+        print("  parser: batches %d  lanes per batch %.1f  steps %d (careful %d)  cycles waiting %d  walking %d" % (
+            med(lambda i: w[i * 8 + 2] & 0xFFFFFFFF), med(lambda i: (w[i * 8 + 2] >> 32) / max(1, w[i * 8 + 2] & 0xFFFFFFFF)), med(lambda i: w[i * 8 + 3] & 0xFFFFFFFF),
+            med(lambda i: w[i * 8 + 3] >> 32), med(lambda i: (w[i * 8 + 4] & 0xFFFFFFFF) << 4), med(lambda i: (w[i * 8 + 4] >> 32) << 4)))
     print("  copy wave 0: regions %d, with retry %d, retry iterations %d" % (med(lambda i: w[i * 8 + 5] >> 48), med(lambda i: (w[i * 8 + 5] >> 32) & 0xFFFF), med(lambda i: w[i * 8 + 5] & 0xFFFFFFFF)))
     print("  copy wave 0: wait records %d  wait lead %d  work %d  retry (sources in flight) %d" % (
         med(lambda i: w[i * 8 + 6] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 6] >> 32), med(lambda i: w[i * 8 + 7] & 0xFFFFFFFF), med(lambda i: w[i * 8 + 7] >> 32)))
