@@ -66,7 +66,7 @@ int LZ4_decompress_safe_usingDict(const char* src, char* dst, int compressedSize
                                   const char* dictStart, int dictSize);
 
 int LZ4_compressBound(int inputSize);                                              /* lz4.h:226 */
-int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:236; acceleration > 1 is accepted and ignored: lz4amd_last_notice() (lz4amd.h) reports it */
+int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:236; acceleration 1: every second position of a block of 64 KB or more is probed, 2 and above: every fourth */
 int LZ4_sizeofState(void);                                                         /* lz4.h:245 */
 int LZ4_compress_fast_extState(void* state, const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);   /* lz4.h:246 */
 

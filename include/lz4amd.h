@@ -46,7 +46,7 @@ void        lz4amd_ctx_destroy(lz4amd_ctx* ctx);
 const char* lz4amd_last_error(void);
 /* Arguments the reference acts on and this library accepts without acting on them are not errors, but they are not silent
  * either: the call records a notice (thread local, like the error text; "" when the last such call had nothing to say).
- * Today: LZ4_compress_fast* with acceleration > 1 (lz4.c:1389: the GPU parse has no speed / ratio knob) and
+ * Today: LZ4_compress_fast* with acceleration > 2 (lz4.c:1389: the GPU parse knows two settings, 1 and 2) and
  * LZ4_compress_HC* with compressionLevel > 10 (lz4hc.c:92-106: levels 10-12 all run ONE optimal parse - 256 candidates per
  * position like level 9, 64-byte sufficient length like level 10). */
 const char* lz4amd_last_notice(void);
@@ -107,8 +107,9 @@ int  lz4amd_plan_attach_hints(lz4amd_plan* plan, void* d_hints, size_t stride);
 /* a decompress plan's count, since the tables were attached, of blocks decoded from their table and of tables that were
  * rejected (those blocks were decoded without); synchronises the device */
 int  lz4amd_plan_hint_stats(lz4amd_plan* plan, unsigned* used, unsigned* rejected);
-/* LZ4_compress_fast's `acceleration` (lz4.h:236, lz4.c:1382-1400) for the blocks of a LZ4AMD_OP_COMPRESS plan: 1 = default,
- * larger = faster and less compression, clamped to 65537 like the reference (lz4.c:1386-1387). */
+/* LZ4_compress_fast's `acceleration` (lz4.h:236, lz4.c:1382-1400) for the blocks of a LZ4AMD_OP_COMPRESS plan: 1 = default
+ * (every second position of a block of 64 KB or more is probed), 2 and above = every fourth position: faster, larger
+ * output; clamped to 65537 like the reference (lz4.c:1386-1387). */
 int  lz4amd_plan_set_acceleration(lz4amd_plan* plan, int acceleration);
 void lz4amd_plan_destroy(lz4amd_plan* plan);
 /* enqueue the whole table on `stream` (asynchronous) */

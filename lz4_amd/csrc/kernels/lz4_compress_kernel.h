@@ -39,6 +39,9 @@
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
 
+#ifndef LZ4AMD_STRIDE4_FROM
+#define LZ4AMD_STRIDE4_FROM 2
+#endif
 namespace lz4amd {
 
 using CompBatch = ::lz4amd_comp_params;   // argument block (lz4amd_params.h)
@@ -246,14 +249,18 @@ template <uint32_t SH>
 __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi) {
     constexpr bool small = SH == 0;
     Round R;
-    uint32_t R0, R1, R2 = 0;
-    if (SH) { const uint64_t v = *(const uint64_t*)(ring + o0); R0 = (uint32_t)v; R1 = (uint32_t)(v >> 32); R2 = *(const uint32_t*)(ring + o0 + 8); }
+    uint32_t R0, R1, R2 = 0, R3 = 0, R4 = 0;
+    if (SH == 2) { const U32x4 v = *(const U32x4*)(ring + o0); R0 = v[0]; R1 = v[1]; R2 = v[2]; R3 = v[3]; R4 = *(const uint32_t*)(ring + o0 + 16); }      // (o0 is a multiple of 16)
+    else if (SH == 1) { const uint64_t v = *(const uint64_t*)(ring + o0); R0 = (uint32_t)v; R1 = (uint32_t)(v >> 32); R2 = *(const uint32_t*)(ring + o0 + 8); }
     else { R0 = *(const uint32_t*)(ring + o0); R1 = *(const uint32_t*)(ring + o0 + 4); }
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t q = q0 + (j << SH);
         uint32_t f0, f4 = 0;
-        if (SH) {
+        if (SH == 2) {                                  // every fourth position: whole dwords
+            f0 = j == 0 ? R0 : j == 1 ? R1 : j == 2 ? R2 : R3;
+            f4 = j == 0 ? R1 : j == 1 ? R2 : j == 2 ? R3 : R4;
+        } else if (SH == 1) {
             f0 = j == 0 ? R0 : j == 1 ? align_bytes(R1, R0, 2) : j == 2 ? R1 : align_bytes(R2, R1, 2);
             f4 = j == 0 ? R1 : j == 1 ? R1 >> 16 : j == 2 ? R2 : R2 >> 16;
         } else f0 = j == 0 ? R0 : align_bytes(R1, R0, j);
@@ -940,6 +947,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; if (P.hints) *(uint32_t*)(P.hints + (uint64_t)b * P.hint_stride) = 0; } return; }      // lz4.c:1361-1371 (no table for an empty block)
     const uint32_t n = (uint32_t)n_i + pre, cap = (uint32_t)cap_i;
     const bool small = (uint32_t)n_i < kSmallBlockLimit;       // (the block's own size: a small block is probed at every position whatever history precedes it)
+    const bool stride4 = !small && P.acceleration >= LZ4AMD_STRIDE4_FROM;      // LZ4_compress_fast's speed / ratio knob: every fourth position is probed instead of every second
     const uint32_t a0 = (uint32_t)((uintptr_t)P.dst[b] & 15u);        // dst's place on HBM's 16-byte grid
     const lz4amd_gdst hints = P.hints ? LZ4AMD_TO_GDST(P.hints + (uint64_t)b * P.hint_stride) : (lz4amd_gdst)nullptr;      // optional entry-point table
 
@@ -1005,9 +1013,10 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             const uint32_t cs = strip_lo(g0, t0, w, strip_len);
             uint32_t ce = g0 + (w + 1) * strip_len; if (ce > t1) ce = t1;
             if (small) match_strip<0>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
+            else if (stride4) match_strip<2>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
             else match_strip<1>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
             // the lane probed positions cs + 8 * lane + {0, 2, 4, 6}: with 512-byte strips those are this thread's insert positions
-            probe_h_valid = !small && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
+            probe_h_valid = !small && !stride4 && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: write out tile k-1 (into the staging buffer)

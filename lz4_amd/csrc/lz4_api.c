@@ -158,16 +158,18 @@ int lz4amd_run_one(lz4amd_op op, const char* src, char* dst, int srcSize, int ds
     return run_one_hist(op, NULL, 0, src, dst, srcSize, dstCapacity, level, fail);
 }
 
-/* lz4.c:1453 LZ4_compress_fast: `acceleration` trades ratio for speed in the reference's serial
- * probe loop (lz4.c:1044-1053); the wave-parallel matcher probes every position at no extra cost,
- * so the value is accepted and ignored (any value yields a valid block). */
+/* lz4.c:1453 LZ4_compress_fast: `acceleration` trades ratio for speed.  In the reference's serial probe loop it is the
+ * initial step between probed positions (lz4.c:1044-1053, clamped lz4.c:1386-1387).  Here every probe of a tile runs at
+ * once, so the knob has two settings: 1 probes every second position of a block of 64 KB or more (every position of a
+ * smaller one), 2 and above every fourth.  Sizes never shrink as the value grows; at 1 and at 2 they are within 3 % of
+ * the reference's at the same value (tests/test_gpu_parity.py). */
 int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration)
 {
-    lz4amd_set_notice(acceleration > 1 ? "LZ4_compress_fast: acceleration > 1 is accepted and ignored (the block is parsed as with acceleration 1)" : "");
+    lz4amd_set_notice(acceleration > 2 ? "LZ4_compress_fast: acceleration > 2 is parsed as acceleration 2 (every fourth position is probed)" : "");
     if (srcSize < 0 || (unsigned)srcSize > (unsigned)LZ4_MAX_INPUT_SIZE) return 0;   /* lz4.c:1360 */
     if (dst == NULL || dstCapacity <= 0) return 0;
     if (src == NULL && srcSize != 0) return 0;
-    return lz4amd_run_one(LZ4AMD_OP_COMPRESS, src, dst, srcSize, dstCapacity, 0, 0);
+    return lz4amd_run_one(LZ4AMD_OP_COMPRESS, src, dst, srcSize, dstCapacity, acceleration, 0);
 }
 
 int LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity)
@@ -207,8 +209,8 @@ int LZ4_decompress_safe_usingDict(const char* src, char* dst, int compressedSize
  * LZ4_compress_fast_continue): history and block are staged back to back in device memory and the block
  * is compressed with the history as its prefix (include/lz4amd.h lz4amd_plan_create_compress_prefix). */
 int lz4amd_compress_with_history(const char* hist, int histSize, const char* src, char* dst, int srcSize, int dstCapacity, int hc_level)
-{   /* hc_level 0: LZ4_compress_default semantics; > 0: LZ4_compress_HC at that level */
+{   /* hc_level 0: LZ4_compress_default semantics; > 0: LZ4_compress_HC at that level; < 0: LZ4_compress_fast with acceleration -hc_level */
     if (srcSize < 0 || (unsigned)srcSize > (unsigned)LZ4_MAX_INPUT_SIZE || dst == NULL || dstCapacity <= 0) return 0;
     if (src == NULL && srcSize != 0) return 0;
-    return run_one_hist(hc_level > 0 ? LZ4AMD_OP_COMPRESS_HC : LZ4AMD_OP_COMPRESS, hist, histSize, src, dst, srcSize, dstCapacity, hc_level, 0);
+    return run_one_hist(hc_level > 0 ? LZ4AMD_OP_COMPRESS_HC : LZ4AMD_OP_COMPRESS, hist, histSize, src, dst, srcSize, dstCapacity, hc_level > 0 ? hc_level : -hc_level, 0);
 }

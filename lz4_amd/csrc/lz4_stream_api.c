@@ -49,7 +49,6 @@ int LZ4_compress_fast_continue(LZ4_stream_t* s, const char* src, char* dst, int 
     const char* hist;
     unsigned hsz;
     int r;
-    (void)acceleration;
     if (s == NULL) return 0;
     hist = s->internal_donotuse.dictionary; hsz = s->internal_donotuse.dictSize;
     /* a source that overlaps the dictionary invalidates the overlapped part (lz4.c:1737-1747) */
@@ -58,7 +57,7 @@ int LZ4_compress_fast_continue(LZ4_stream_t* s, const char* src, char* dst, int 
         if (srcEnd >= hist + hsz) { hist = NULL; hsz = 0; }
         else { hsz = (unsigned)((hist + hsz) - srcEnd); hist = srcEnd; if (hsz < 4) { hist = NULL; hsz = 0; } }
     }
-    r = lz4amd_compress_with_history(hist, (int)hsz, src, dst, srcSize, dstCapacity, 0);
+    r = lz4amd_compress_with_history(hist, (int)hsz, src, dst, srcSize, dstCapacity, acceleration > 1 ? -(acceleration > 65537 ? 65537 : acceleration) : 0);
     /* what the next call may reference: the block, plus what precedes it if it is contiguous (prefix
      * mode, lz4.c:1750-1757); otherwise only the block (lz4.c:1776-1779) */
     if (hist && hist + hsz == src) {

@@ -420,7 +420,11 @@ int lz4amd_plan_set_row0(lz4amd_plan* p, int src_size, int dst_cap, int level, v
     return LZ4AMD_OK;
 }
 
-void lz4amd_plan_set_level(lz4amd_plan* p, int level) { if (p && p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.level = hc_level_norm(level); p->level = level; } }
+void lz4amd_plan_set_level(lz4amd_plan* p, int level)
+{   /* LZ4_compress_HC: the compression level; LZ4_compress_fast: the acceleration */
+    if (p && p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.level = hc_level_norm(level); p->level = level; }
+    else if (p && p->op == LZ4AMD_OP_COMPRESS) (void)lz4amd_plan_set_acceleration(p, level);
+}
 
 int lz4amd_plan_bind_host_row(lz4amd_plan* p, int* row)
 {

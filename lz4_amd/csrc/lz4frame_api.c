@@ -164,6 +164,7 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
                                                   p.compressionLevel | (p.favorDecSpeed ? LZ4AMD_HC_FAVOR_DEC_SPEED : 0))) goto done;      /* lz4frame.c:713 */
     } else
     if (lz4amd_plan_create_compress_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL)) goto done;
+    if (p.compressionLevel < 0) (void)lz4amd_plan_set_acceleration(cplan, -p.compressionLevel + 1);      /* lz4frame.c:924-927: negative levels are accelerations */
     if (lz4amd_plan_launch(cplan, NULL)) goto done;
     if (lz4amd_plan_results(cplan, csz, NULL)) goto done;
     for (i = 0; i < nb; i++) if (csz[i] <= 0 || csz[i] >= sizes[i]) csz[i] = 0;   /* stored raw */

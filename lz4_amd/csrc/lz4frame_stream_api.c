@@ -203,7 +203,8 @@ static size_t put_block(LZ4F_cctx* c, uint8_t* op)
         cs = lz4amd_compress_with_history(c->hist ? (const char*)blk - c->hist : NULL, (int)c->hist,
                                           (const char*)blk, (char*)op + BH, (int)n, (int)n - 1,
                                           c->prefs.compressionLevel >= LZ4HC_CLEVEL_MIN
-                                              ? (c->prefs.compressionLevel | (c->prefs.favorDecSpeed ? LZ4AMD_HC_FAVOR_DEC_SPEED : 0)) : 0);      /* lz4frame.c:713: favorDecSpeed */
+                                              ? (c->prefs.compressionLevel | (c->prefs.favorDecSpeed ? LZ4AMD_HC_FAVOR_DEC_SPEED : 0))
+                                              : (c->prefs.compressionLevel < 0 ? c->prefs.compressionLevel - 1 : 0));      /* lz4frame.c:713: favorDecSpeed; 924-927: a negative level is the acceleration -level + 1 */
     c->fill_raw = 0;
     if (cs <= 0 || (size_t)cs >= n) {                            /* lz4frame.c:896-899: stored raw */
         wr32(op, (uint32_t)n | 0x80000000u); memcpy(op + BH, blk, n); cs = (int)n;

@@ -485,3 +485,44 @@ def test_many_small_blocks(ctx, datagen, ocodec):
     assert res[-1] == 65536 - 12345
     ro, o = ocodec.decompress(comp[3, :csizes[3]].cpu().numpy().tobytes(), 65536)
     assert o == host[3 * 65536:4 * 65536]
+
+
+def test_acceleration_trades_size_for_speed(ctx, ocodec, reflib, datagen):
+    """LZ4_compress_fast's acceleration (lz4.c:1382-1400): through the batch plan (lz4amd_plan_set_acceleration) and through the
+    classic name.  Every setting decodes, sizes never shrink as the value grows, acceleration 1 is LZ4_compress_default,
+    acceleration 2 is near the reference's at 2, blocks under 64 KB are probed at every position whatever it says."""
+    import lz4_amd
+    L = lz4_amd.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    datas = [datagen(4 << 20, 60, 3), datagen(4 << 20, 20, 4), datagen(4 << 20, 90, 5), datagen(300000, 50, 6), datagen(60000, 60, 7)]
+    sizes = {}
+    for accel in (1, 2, 9):
+        caps = [lz4_amd.compress_bound(len(d)) for d in datas]
+        srcs = [_dev(d, pad=16) for d in datas]
+        dsts = [torch.full((c + 64,), 0xEE, dtype=torch.uint8, device="cuda") for c in caps]
+        plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, lz4_amd.BlockTable([x.data_ptr() for x in srcs], [len(d) for d in datas], [x.data_ptr() for x in dsts], caps))
+        plan.set_acceleration(accel)
+        plan.launch(s)
+        res = plan.results(s)
+        for d, r, t in zip(datas, res, dsts):
+            c = t[:r].cpu().numpy().tobytes()
+            ro, o = ocodec.decompress(c, len(d))
+            assert ro == len(d) and o == d
+        sizes[accel] = res
+    assert all(a <= b for a, b in zip(sizes[1], sizes[2])) and sizes[2] == sizes[9] and sizes[1][4] == sizes[2][4]
+    assert all(a < b for a, b in zip(sizes[1][:3], sizes[2][:3]))
+    reflib.LZ4_compress_fast.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    for accel, hi in ((1, 1.03), (2, 1.05)):
+        for d, ours in zip(datas[:3], sizes[accel][:3]):               # the BASELINE block size
+            cap = len(d) + len(d) // 255 + 16
+            cb = ctypes.create_string_buffer(cap)
+            ref = reflib.LZ4_compress_fast(d, cb, len(d), cap, accel)
+            assert 0.90 * ref <= ours <= hi * ref, (accel, ours, ref)
+    # the classic name, host pointers
+    d = datas[3]
+    cap = lz4_amd.compress_bound(len(d))
+    out1, out2 = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(cap)
+    n1 = L.LZ4_compress_fast(d, out1, len(d), cap, 1)
+    n2 = L.LZ4_compress_fast(d, out2, len(d), cap, 4)
+    assert n1 == sizes[1][3] and n2 == sizes[2][3] and n1 < n2
+    assert ocodec.decompress(out2.raw[:n2], len(d)) == (len(d), d)

@@ -730,3 +730,43 @@ def test_decompress_random_legal_sequence_lists(emu, ocodec):
     for c, d in list(zip(blocks, wants))[3:8]:
         (r, _), = emu_decompress(emu, [c], [len(d) - 1])
         assert r < 0 and ocodec.decompress(c, len(d) - 1)[0] < 0
+
+
+def emu_compress_accel(emu, datas, accel):
+    n = len(datas)
+    caps = [len(d) + len(d) // 255 + 16 for d in datas]
+    srcs = [ctypes.create_string_buffer(d, len(d)) for d in datas]
+    dsts = [ctypes.create_string_buffer(c + 64) for c in caps]
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs]); dp = (ctypes.c_void_p * n)(*[ctypes.addressof(d) for d in dsts])
+    ss = (ctypes.c_int32 * n)(*[len(d) for d in datas]); dc = (ctypes.c_int32 * n)(*caps); res = (ctypes.c_int32 * n)()
+    emu.emu_compress_batch_hints(sp, ss, dp, dc, res, n, 0, None, None, ctypes.c_uint64(0), accel)
+    return [dsts[i].raw[:res[i]] for i in range(n)]
+
+
+def test_compress_acceleration_trades_size_for_speed(emu, ocodec, reflib, datagen):
+    """LZ4_compress_fast's acceleration (lz4.c:1382-1400, 1044-1053): 1 probes every second position of a big block, 2 and above
+    every fourth.  Every setting decodes; sizes never shrink as the value grows; at 1 the sizes are within 3 % above the reference's
+    (they may be smaller), at 2 within 5 % of the reference's at acceleration 2; blocks under 64 KB are probed at every position whatever it says."""
+    datas = [datagen(1 << 20, 60, 3), datagen(1 << 20, 20, 4), datagen(1 << 20, 90, 5), datagen(300000, 50, 6), datagen(60000, 60, 7)]
+    sizes = {}
+    for accel in (1, 2, 9):
+        comps = emu_compress_accel(emu, datas, accel)
+        for d, c in zip(datas, comps):
+            ro, o = ocodec.decompress(c, len(d))
+            assert ro == len(d) and o == d
+        sizes[accel] = [len(c) for c in comps]
+    assert all(a <= b for a, b in zip(sizes[1], sizes[2])) and sizes[2] == sizes[9]
+    assert sizes[1][4] == sizes[2][4]                                   # the 60 000-byte block
+    assert any(a < b for a, b in zip(sizes[1][:4], sizes[2][:4]))
+    reflib.LZ4_compress_fast.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    for accel in (1, 2):
+        refs = []
+        for d in datas[:4]:
+            cap = len(d) + len(d) // 255 + 16
+            cb = ctypes.create_string_buffer(cap)
+            refs.append(reflib.LZ4_compress_fast(d, cb, len(d), cap, accel))
+        # (one highly compressible MiB on its own may land 4 % above the reference - its first tiles are parsed against a
+        #  nearly empty table; the BASELINE shapes are asserted block by block in tests/test_gpu_parity.py)
+        hi = 1.03 if accel == 1 else 1.05            # (acceleration 2 is "every fourth position", not the reference's growing step: near it, not it)
+        assert all(0.88 * r <= o <= (hi + 0.03) * r for o, r in zip(sizes[accel][:4], refs)), (accel, sizes[accel], refs)
+        assert 0.90 * sum(refs) <= sum(sizes[accel][:4]) <= hi * sum(refs), (accel, sizes[accel], refs)
