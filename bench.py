@@ -61,10 +61,42 @@ def aggregate(dist, local_seconds, local_bytes, device=None):
     return float(t.item()), float(b.item())
 
 
+def gen_data_seeds(nbytes, pct, seeds):
+    """nbytes of datagen output as len(seeds) equal streams behind one another (stream k: `datagen -s<seeds[k]>`), generated on as
+    many threads (the generator is one serial PRNG chain per stream: ~0.5 GB/s per core; ctypes releases the GIL)."""
+    import numpy as np
+    k = len(seeds)
+    part = nbytes // k
+    assert part * k == nbytes
+    buf = np.empty(nbytes, dtype=np.uint8)
+    L = _datagen_lib()
+    errs = []
+
+    def work(i):
+        if L.lz4amd_datagen(buf.ctypes.data + i * part, part, pct / 100.0, 0.0, seeds[i]) != 0:
+            errs.append(i)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
+    return buf
+
+
+def _datagen_lib():
+    so = os.path.join(ROOT, "tools", "libdatagen.so")
+    if not os.path.exists(so):
+        subprocess.run(["gcc", "-O3", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "datagen.c")], check=True)
+    L = ctypes.CDLL(so)
+    L.lz4amd_datagen.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_uint32]
+    return L
+
+
 def gen_data(nbytes, pct, seed):
     so = os.path.join(ROOT, "tools", "libdatagen.so")
     if not os.path.exists(so):
-        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "datagen.c")], check=True)
+        subprocess.run(["gcc", "-O3", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "datagen.c")], check=True)
     L = ctypes.CDLL(so)
     L.lz4amd_datagen.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_uint32]
     import numpy as np
@@ -315,6 +347,45 @@ def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps):
             "roofline_decompress": roofline_obj("decompress", dms, U + C, copy_gbps, None)}
 
 
+def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(20, 90), nblk=64, nref=16):
+    """The step's two kernels on other compressibilities (the ratio window is two-sided, and the rates depend on the
+    data): nblk blocks of `datagen -P<pct> -s1`, compressed and decoded like the step's; ratio_vs_reference = reference bytes / our
+    bytes on the first nref blocks (> 1: ours is smaller)."""
+    out = {}
+    for pct in pcts:
+        host = gen_data(nblk * bs, pct, 1)
+        data = torch.from_numpy(host).cuda()
+        stride = (lz4_amd.compress_bound(bs) + 255) & ~255
+        comp = torch.empty((nblk, stride), dtype=torch.uint8, device=data.device)
+        dec = torch.empty(nblk * bs, dtype=torch.uint8, device=data.device)
+        ctab = lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nblk)], [bs] * nblk, [comp.data_ptr() + i * stride for i in range(nblk)], [stride] * nblk)
+        cplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, ctab)
+        hints = torch.zeros((nblk, lz4_amd.hint_bytes(bs)), dtype=torch.uint8, device=data.device) if use_hints else None
+        if hints is not None:
+            cplan.attach_hints(hints.data_ptr(), hints.stride(0))
+        cplan.launch(stream)
+        cs = cplan.results(stream)
+        dtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nblk)], cs, [dec.data_ptr() + i * bs for i in range(nblk)], [bs] * nblk)
+        dplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+        if hints is not None:
+            dplan.attach_hints(hints.data_ptr(), hints.stride(0))
+        dplan.launch(stream)
+        ok = all(c > 0 for c in cs) and dplan.results(stream) == [bs] * nblk and bool(torch.equal(dec, data))
+        cms = min(cplan.launch_timed(stream)[0][0] for _ in range(3))
+        dms = min(dplan.launch_timed(stream)[0][0] for _ in range(3))
+        U, C = nblk * bs, sum(cs)
+        o = {"blocks": nblk, "ratio": round(U / C, 4), "bit_exact": ok,
+             "compress_GBps": round(U / (cms * 1e-3) / 1e9, 1), "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 1),
+             "compress_frac_of_hbm_peak": round((U + C) / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "decompress_frac_of_hbm_peak": round((U + C) / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        rb = reference_blocks(host, bs, min(nref, nblk))
+        if rb is not None:
+            o["ratio_vs_reference"] = round(sum(rb[1]) / sum(cs[:len(rb[1])]), 4)
+        out["P%d" % pct] = o
+    out["note"] = ("%d blocks per row (a quarter of the step's table: the last of a CU's blocks weighs more); the step's own compressibility is in the top-level fields" % nblk)
+    return out
+
+
 def bench_frame(lz4_amd, host):
     """configs[2]: the GiB as one frame (LZ4F_max4MB, blockLinked, content checksum) through the host-pointer API."""
     class FrameInfo(ctypes.Structure):
@@ -373,10 +444,58 @@ def bench_frame(lz4_amd, host):
         return {"header_hex": bytes(dst[:7]).hex(), "frame_bytes": int(fsz), "ratio": round(n / fsz, 4),
                 "compress_GBps": round(n / tc / 1e9, 3), "decompress_GBps": round(n / td / 1e9, 3), "bit_exact": ok}
 
+    def ref_frame(bsid, mode, csum, sample):
+        """the reference's own LZ4F_compressFrame / LZ4F_decompress (oracle/_ref, one host thread) on the first `sample` bytes"""
+        so = os.path.join(ROOT, "oracle", "_ref", "liblz4_ref.so")
+        if not os.path.exists(so):
+            return None
+        R = ctypes.CDLL(so)
+        R.LZ4F_compressFrameBound.restype = st; R.LZ4F_compressFrameBound.argtypes = [st, ctypes.POINTER(Prefs)]
+        R.LZ4F_compressFrame.restype = st; R.LZ4F_compressFrame.argtypes = [vp, st, vp, st, ctypes.POINTER(Prefs)]
+        R.LZ4F_isError.argtypes = [st]
+        R.LZ4F_createDecompressionContext.restype = st; R.LZ4F_createDecompressionContext.argtypes = [ctypes.POINTER(vp), ctypes.c_uint]
+        R.LZ4F_freeDecompressionContext.argtypes = [vp]
+        R.LZ4F_decompress.restype = st; R.LZ4F_decompress.argtypes = [vp, vp, ctypes.POINTER(st), vp, ctypes.POINTER(st), vp]
+        p = Prefs()
+        p.frameInfo.blockSizeID = bsid; p.frameInfo.blockMode = mode; p.frameInfo.contentChecksumFlag = csum
+        cap = R.LZ4F_compressFrameBound(sample, ctypes.byref(p))
+        dst = np.empty(cap, dtype=np.uint8); out = np.empty(sample, dtype=np.uint8)
+        dst[:] = 0; out[:] = 0                                        # touch the pages outside the timed region
+        t0 = time.perf_counter()
+        fsz = R.LZ4F_compressFrame(dst.ctypes.data, cap, host.ctypes.data, sample, ctypes.byref(p))
+        tc = time.perf_counter() - t0
+        if R.LZ4F_isError(fsz):
+            return {"error": "reference LZ4F_compressFrame failed"}
+        d = vp()
+        R.LZ4F_createDecompressionContext(ctypes.byref(d), 100)
+        t0 = time.perf_counter()
+        ipos = opos = 0
+        while ipos < fsz:
+            ss = st(fsz - ipos); ds = st(sample - opos)
+            rr = R.LZ4F_decompress(d, out.ctypes.data + opos, ctypes.byref(ds), dst.ctypes.data + ipos, ctypes.byref(ss), None)
+            if R.LZ4F_isError(rr):
+                break
+            ipos += ss.value; opos += ds.value
+            if rr == 0:
+                break
+        td = time.perf_counter() - t0
+        R.LZ4F_freeDecompressionContext(d)
+        return {"kind": "reference", "cores": 1, "unit": "GB/s", "compress_GBps": round(sample / tc / 1e9, 3), "decompress_GBps": round(sample / td / 1e9, 3),
+                "frame_bytes": int(fsz), "bit_exact": bool(opos == sample and (out == host[:sample]).all()),
+                "sample": "the first %d MiB of the same data through the reference's LZ4F_compressFrame / LZ4F_decompress (lib/lz4frame.c), same preferences, one host thread, one call each" % (sample >> 20)}
+
     r = {"workload": "configs[2]: %.2f GiB as one frame, LZ4F_max4MB, blockLinked, content checksum; host buffers (upload, kernels, download, XXH32 on the host)" % (n / 2**30)}
     r.update(one_frame(7, 0, 1))
+    try:
+        r["cpu_baseline"] = ref_frame(7, 0, 1, min(n, 512 << 20))
+    except Exception as e:
+        r["cpu_baseline"] = {"error": str(e)}
     d64 = one_frame(4, 1, 0)
     d64["workload"] = "the same GiB as one frame of independent 64 KiB blocks (the frame format's default block size), no checksums"
+    try:
+        d64["cpu_baseline"] = ref_frame(4, 1, 0, min(n, 512 << 20))
+    except Exception as e:
+        d64["cpu_baseline"] = {"error": str(e)}
     r["independent_64K"] = d64
     r["note"] = ("PCIe inclusive and single-threaded on the host side: a parity path, not the HBM-resident rate; second of two calls. "
                  "Linked blocks decode chained inside one launch per 64 MiB batch (only their copy stages run one after the other); independent blocks decode 1024 per launch")
@@ -504,12 +623,13 @@ def main():
     bs, nb = args.block_bytes, plan_s["n_blocks"]
     U = nb * bs
 
-    # the synthetic shard: at most 1 GiB is generated (datagen runs at ~0.2 GB/s on one host core), larger shards repeat it
-    gen_u = U if U <= (1 << 30) or (1 << 30) % bs else (1 << 30)
-    host = gen_data(gen_u, args.pct, plan_s["seed"])
+    # the synthetic shard: one datagen stream per GiB (seeds 1000 * rank + k), generated on one thread each - every block of
+    # the shard is distinct data (a single 8 GiB stream is one serial PRNG chain: 15 s per rank)
+    n_streams = U >> 30 if (U >= (2 << 30) and U % (1 << 30) == 0) else 1
+    seeds = [plan_s["seed"]] if n_streams == 1 else [1000 * plan_s["seed"] + k for k in range(n_streams)]
+    host = gen_data(U, args.pct, seeds[0]) if n_streams == 1 else gen_data_seeds(U, args.pct, seeds)
+    gen_u = U
     data = torch.from_numpy(host).to(dev)
-    if gen_u < U:
-        data = data.repeat((U + gen_u - 1) // gen_u)[:U].contiguous()
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- block tables (built once, like the reference bench's blockParam_t table)
@@ -602,6 +722,7 @@ def main():
                 ok = rplan.results(stream) == [bs] * (nr * reps) and torch.equal(out[:nr * bs], data[:nr * bs])
                 rms = sum(rplan.launch_timed(stream)[0][0] for _ in range(args.steps)) / args.steps
                 Ur, Cr = nr * reps * bs, sum(rsz) * reps
+                foreign["_ref_ratio"] = round(sum(rsz) / sum(csizes[:nr]), 4)      # reference bytes / our bytes on the same blocks
                 foreign["reference_compressed_blocks"] = {"decompress_GBps": round(Ur / (rms * 1e-3) / 1e9, 2), "avg_ms": round(rms, 4), "bit_exact": bool(ok),
                                                           "frac_of_hbm_peak": round((Ur + Cr) / (rms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                                           "sample": "%d blocks compressed by the reference's LZ4_compress_default on the host, %d times over" % (nr, reps)}
@@ -635,7 +756,7 @@ def main():
             "dtype": "u8", "data": "synthetic (datagen -P%d restated in tools/datagen.c, md5-pinned to the reference tool)" % args.pct,
             "config": {"workload": "%s: %d independent %d-byte blocks per GPU (%.2f GiB%s), datagen -P%d -s<rank>, block compress + decompress, device resident"
                                    % ("configs[1]" if world == 1 else "configs[4] (%d GPUs)" % world, nb, bs, U / 2**30,
-                                      ": the rank's 1 GiB of datagen output %d times over" % (U // gen_u) if gen_u < U else "", args.pct),
+                                      ": %d datagen streams of 1 GiB, seeds 1000 * rank + k" % n_streams if n_streams > 1 else "", args.pct),
                        "blocks_per_gpu": nb, "block_bytes": bs, "parallelism": "blocks sharded over %d GPU(s), no collective inside the codec" % world},
             "compress_GBps": round(U / (c_total * 1e-3) / 1e9, 2),
             "decompress_GBps": round(U / (d_total * 1e-3) / 1e9, 2),
@@ -734,6 +855,17 @@ def main():
                                         with_cpu=not args.no_cpu_baseline)
             except Exception as e:                           # the side measurement never kills the bench line
                 result["hc"] = {"error": str(e)}
+        if world == 1 and not args.no_extras and bs == 4 << 20:
+            try:
+                byc = bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, hints is not None)
+                own = {"blocks": nb, "ratio": result["ratio"], "compress_GBps": result["compress_GBps"], "decompress_GBps": result["decompress_GBps"]}
+                if "_ref_ratio" in foreign:
+                    own["ratio_vs_reference"] = foreign["_ref_ratio"]
+                byc["P%d" % args.pct] = own
+                result["by_compressibility"] = byc
+            except Exception as e:
+                result["by_compressibility"] = {"error": str(e)}
+        foreign.pop("_ref_ratio", None)
         if world == 1 and not args.no_extras and nb == 256 and bs == 4 << 20:
             try:
                 result["shape_2048"] = bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps)

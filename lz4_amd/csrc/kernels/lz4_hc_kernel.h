@@ -111,10 +111,12 @@ __host__ __device__ inline uint64_t hc_recs_bytes(uint32_t n) { return (uint64_t
 __host__ __device__ inline uint64_t hc_scratch_bytes(uint32_t n) { return hc_chain_bytes(n) + hc_st0_bytes(n) + hc_st1_bytes(n) + hc_recs_bytes(n); }
 
 __device__ __forceinline__ uint32_t hc_attempts(int level) {
-    // k_clTable lz4hc.c:92-106 (levels below 3 and the optimal-parser levels 10-12 are served by the
-    // hash-chain search too, with the nearest depth: 4 and 256)
+    // k_clTable lz4hc.c:92-106: levels 3..9 = 4..256 candidates per position; level 10 = 96 (lz4hc.c:103); levels 11 and 12 ask
+    // for 512 and 16384 there (lz4hc.c:104-105) and get 256 here: the walk's state between bands counts them in 8 bits.
+    // Levels below 3 (the reference's LZ4MID, lz4hc.c:93-94) are served by the chain search with 4 candidates.
     if (level < 1) level = 9;            // LZ4HC_CLEVEL_DEFAULT (lz4hc.c:110-113)
     if (level < 3) level = 3;
+    if (level == 10) return 96u;
     if (level > 9) level = 9;
     return 4u << (level - 3);
 }

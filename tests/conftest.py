@@ -61,7 +61,7 @@ def reflib():
 @pytest.fixture(scope="session")
 def datagen():
     so = _ensure(os.path.join(ROOT, "tools", "libdatagen.so"),
-                 ["gcc", "-O2", "-shared", "-fPIC", "-o", "tools/libdatagen.so", "tools/datagen.c"])
+                 ["gcc", "-O3", "-shared", "-fPIC", "-o", "tools/libdatagen.so", "tools/datagen.c"])
     L = ctypes.CDLL(so)
     L.lz4amd_datagen.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_uint32]
 

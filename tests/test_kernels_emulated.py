@@ -510,6 +510,8 @@ def test_hc_optimal_parse_levels_10_to_12(emu, ocodec, reflib, corpus, datagen):
         blocks = [data[o:o + 262144] for o in range(0, len(data), 262144)]
         ours = sum(r for r, _ in emu_compress_hc(emu, blocks, level=12))
         ours9 = sum(r for r, _ in emu_compress_hc(emu, blocks, level=9))
+        ours10 = sum(r for r, _ in emu_compress_hc(emu, blocks, level=10))       # 96 candidates per position (lz4hc.c:103), 11-12: 256
+        assert ours <= ours10 <= ours9 * 1.002, (pct, ours, ours10, ours9)
         ref = 0
         for b in blocks:
             dst = ctypes.create_string_buffer(len(b) + len(b) // 255 + 16)

@@ -1,4 +1,4 @@
-"""Developer aid: randomized round-trip stress on the GPU (not a test: run by hand through gpurun).
+"""Randomized round-trip stress on the GPU (tests/test_gpu_parity.py::test_randomized_round_trip_stress runs it for 25 s).
 usage: stress_gpu.py [seconds] [seed]"""
 import ctypes, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ pool = {pct: gen_data(24 << 20, pct, 7) for pct in (0, 20, 50, 60, 90)}
 pool[100] = np.zeros(24 << 20, dtype=np.uint8)
 pool[101] = np.frombuffer(bytes(range(256)) * (24 << 12), dtype=np.uint8)         # period 256
 t_end = time.time() + budget
-rounds = blocks = bytes_ = 0
+rounds = blocks = bytes_ = tabled = 0
 while time.time() < t_end:
     nb = rng.choice((1, 2, 7, 64, 300))
     sizes = [rng.choice((1, 5, 13, 64, 100, 4095, 65536, 65537, 262144, 1 << 20, 4 << 20)) if rng.random() < 0.5 else rng.randint(1, 300000) for _ in range(nb)]
@@ -38,13 +38,27 @@ while time.time() < t_end:
     comp = torch.empty(int(sum(bound)) + 64, dtype=torch.uint8, device="cuda")
     tab = lz4_amd.BlockTable([data.data_ptr() + int(o) for o in offs], sizes, [comp.data_ptr() + int(o) for o in coff], bound)
     plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS if hc is None else lz4_amd.OP_COMPRESS_HC, tab, level=hc or 0)
+    hints = None
+    if hc is None and rng.random() < 0.5:                           # entry-point tables (include/lz4amd.h): written here, used by the decoder below
+        hstride = lz4_amd.hint_bytes(max(sizes))
+        hints = torch.zeros((nb, hstride), dtype=torch.uint8, device="cuda")
+        plan.attach_hints(hints.data_ptr(), hstride)
+        if rng.random() < 0.3:
+            plan.set_acceleration(2)
     st = torch.cuda.current_stream().cuda_stream
     plan.launch(st); cs = plan.results(st); plan.close()
     assert all(c > 0 for c in cs), ("compress failed", sizes, cs)
     out = torch.full((len(host) + 64,), 0xEE, dtype=torch.uint8, device="cuda")
     dt = lz4_amd.BlockTable([comp.data_ptr() + int(o) for o in coff], cs, [out.data_ptr() + int(o) for o in offs], sizes)
     dp = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dt)
-    dp.launch(st); res = dp.results(st); dp.close()
+    if hints is not None:
+        dp.attach_hints(hints.data_ptr(), hints.stride(0))
+    dp.launch(st); res = dp.results(st)
+    if hints is not None:
+        used, rejected = dp.hint_stats()
+        assert rejected == 0 and used == sum(1 for s in sizes if s > 0), ("tables", used, rejected, nb)
+        tabled += used
+    dp.close()
     assert res == sizes, ("decode sizes", [(i, r, s) for i, (r, s) in enumerate(zip(res, sizes)) if r != s][:5])
     assert torch.equal(out[:len(host)], data), "decode mismatch"
     assert bool((out[len(host):] == 0xEE).all())
@@ -55,4 +69,4 @@ while time.time() < t_end:
             r = ref.LZ4_decompress_safe(ch[int(coff[i]):int(coff[i]) + cs[i]].tobytes(), dst, cs[i], sizes[i])
             assert r == sizes[i] and dst.raw == chunks[i].tobytes(), ("reference decode", i)
     rounds += 1; blocks += nb; bytes_ += len(host)
-print("stress ok: %d rounds, %d blocks, %.1f GiB" % (rounds, blocks, bytes_ / 2**30))
+print("stress ok: %d rounds, %d blocks (%d decoded from entry-point tables), %.1f GiB" % (rounds, blocks, tabled, bytes_ / 2**30))
