@@ -347,7 +347,7 @@ def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps):
             "roofline_decompress": roofline_obj("decompress", dms, U + C, copy_gbps, None)}
 
 
-def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(20, 90), nblk=64, nref=16):
+def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(20, 90), nblk=256, nref=16):
     """The step's two kernels on other compressibilities (the ratio window is two-sided, and the rates depend on the
     data): nblk blocks of `datagen -P<pct> -s1`, compressed and decoded like the step's; ratio_vs_reference = reference bytes / our
     bytes on the first nref blocks (> 1: ours is smaller)."""
@@ -382,7 +382,7 @@ def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(2
         if rb is not None:
             o["ratio_vs_reference"] = round(sum(rb[1]) / sum(cs[:len(rb[1])]), 4)
         out["P%d" % pct] = o
-    out["note"] = ("%d blocks per row (a quarter of the step's table: the last of a CU's blocks weighs more); the step's own compressibility is in the top-level fields" % nblk)
+    out["note"] = "%d blocks per row, like the step's table; the step's own compressibility is in the top-level fields" % nblk
     return out
 
 

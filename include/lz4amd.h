@@ -90,9 +90,9 @@ int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, i
                                            const void* const* d_src, const int* src_sizes,
                                            void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix);
 /* Entry-point tables ("hints") - an optional, out-of-band column of the block table.
- * A compress plan (LZ4AMD_OP_COMPRESS) that has them attached writes, next to every block, a small table that names one
- * sequence of the block's token chain per 512 bytes of source: {position of its token in the block, position of its literals
- * in the source, sequences before it} (32 bytes per KB + 32; layout: csrc/lz4amd_params.h).  The block itself is an ordinary
+ * A compress plan (LZ4AMD_OP_COMPRESS) that has them attached writes, next to every block, a small table that names every
+ * eighth sequence of the block's token chain: {position of its token in the block, position of its literals in the source,
+ * sequences before it} (16 bytes per 8 sequences + 48, ~2.5 % of a `datagen -P60` block; layout: csrc/lz4amd_params.h).  The block itself is an ordinary
  * LZ4 block, byte for byte what it is without the table.  A decompress plan (LZ4AMD_OP_DECOMPRESS, lz4amd_plan_create /
  * _prefix) that has the tables attached parses every block from all its entries at once instead of first discovering the
  * serial token chain (what LZ4_decompress_generic's loop does implicitly, lz4.c:2123-2445) - about a third of the decoder's
@@ -100,7 +100,8 @@ int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, i
  * rules as without them, before anything that depends on it becomes visible; a table that does not fit its block (wrong
  * block, stale, corrupt) only costs time - the block is then decoded without it, with the same result and error codes.
  * Block i's table lives at d_hints + i * stride (device memory, 16-byte aligned, stride a multiple of 16 and at least
- * lz4amd_hint_bytes(largest source / decoded size)); it must stay valid while the plan is launched.
+ * lz4amd_hint_bytes(largest source / decoded size): room for a row per 128 bytes - a block that averages fewer than 16
+ * bytes per sequence gets no table and is decoded without); it must stay valid while the plan is launched.
  * LZ4_decompress_safe, the frame API and every plan without tables are unaffected. */
 size_t lz4amd_hint_bytes(int src_size);
 int  lz4amd_plan_attach_hints(lz4amd_plan* plan, void* d_hints, size_t stride);

@@ -66,12 +66,12 @@ enum : uint32_t {
     kStageBytes = 12288,               // a tile's encoded bytes are composed here (LDS) and leave with 16-byte stores
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
     kSmallBlockLimit = 65536 + 11,     // lz4.c:710 LZ4_64Klimit
-    kStripFields = 9,
+    kStripFields = 10,
 };
 // LDS carve-up (bytes)
 enum : uint32_t {
-    kCOffMisc = 0,                                        // u32[32]
-    kCOffStrip = kCOffMisc + 32 * 4,                      // u32[2][kStripFields][16] per-strip summaries (two tiles in flight)
+    kCOffMisc = 0,                                        // u32[64]
+    kCOffStrip = kCOffMisc + 64 * 4,                      // u32[2][kStripFields][16] per-strip summaries (two tiles in flight)
     kCOffTab = kCOffStrip + 2 * kStripFields * kCmpWaves * 4,   // u32[1 << kHashBits]
     kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kStrips][kRecsPerStrip]
     kCOffEnds = kCOffRecs + 2 * kStrips * kRecsPerStrip * 8,        // u16[2][kStrips][kRecsPerStrip] where a record's match ends (from the strip's start)
@@ -87,15 +87,19 @@ static_assert(kCmpLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert(kCOffRing % 16 == 0 && kCOffStage % 16 == 0 && kCOffCarry % 16 == 0 && kSrcRing % 16 == 0, "LDS alignment");
 enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4,     // CM_READY: tiles whose output offsets are fixed
                   CM_EMITQ = 5,        // next strip of the settled tile to write out (handed to whichever wave is free)
-                  CM_SEQS = 6,         // entry-point table: sequences of the tiles settled so far
-                  CM_HPEND = 7,        // ... first region whose entry is not written yet (no sequence at or behind it so far)
+                  CM_SEQS = 6,         // sequences of the tiles settled so far
+                  CM_HOVER = 7,        // entry-point table: a row did not fit the table's room (the table is then left invalid)
+                  CM_ROWS = 32,        // ... rows of the tiles settled so far
+                  CM_PREVSEQ = 33,     // ... sequences of the tile settled last (sets the next tile's row distance)
+                  CM_HTILE = 40,       // u32[2][4] per tile in flight: { first ordinal, first row, log2 of the row distance, - }
                   CM_TILE = 8 };       // u32[2][4] per tile in flight: { first output position, end, written directly (not staged),
                                        //   first pending byte of its carry chunk }
 enum : uint32_t { T_OUT0 = 0, T_OUT1 = 1, T_DIRECT = 2, T_CFROM = 3 };
 enum : uint32_t { S_N = 0, S_ENC = 1, S_LL0 = 2, S_TAIL = 3, S_OUT = 4, S_CARRY = 5,
                   S_END = 6,      // where the strip's last match ends when it runs past the strip (else 0)
                   S_FIRST = 7,    // first record that is emitted (the ones before it were covered by an earlier strip's match)
-                  S_P = 8 };      // first source position the strip emits
+                  S_P = 8,        // first source position the strip emits
+                  S_ORD = 9 };    // sequences of the block before the strip's first one
 
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t len_minus_nibble_base) {
     // bytes needed after the token for a length field whose value is >= 15 (block format doc)
@@ -476,6 +480,26 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
     }
 }
 
+// ------------------------------------------------------------------------------ entry-point table (optional output)
+// Every kHintEvery-th sequence of the block leaves a ROW: {where its token sits in the block, where its literals start in
+// the source, how many sequences precede it} (lz4amd_params.h: lz4amd_hint_entry).  A decoder that is handed the table
+// parses the block from all those rows at once, every lane the same number of sequences, instead of discovering the token
+// chain (lz4_decompress_kernel.h: PARSER); the block itself is an ordinary LZ4 block.  The rows are written where the
+// sequences are written out: a lane of the emit knows its sequence's place in the output and in the source.
+struct HintOut { lz4amd_gdst table; uint32_t cap_rows, pre; uint32_t* over; uint32_t ord0, row0, k; };      // table == null: none wanted; ord0 / row0 / k: the tile's first ordinal, first row, log2 of its row distance
+__device__ __forceinline__ void st_hint(lz4amd_gdst hints, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord, uint32_t w3 = 0) {
+    U32x4 v; v[0] = tok; v[1] = out; v[2] = ord; v[3] = w3;
+    st_global16(hints + 16 * (uint64_t)(r + 1), v);                 // (row 0 of the memory is the header)
+}
+__device__ __forceinline__ void hint_row(const HintOut& H, bool on, uint32_t ord, uint32_t tok, uint32_t src_pos) {
+    const uint32_t x = ord - H.ord0;
+    if (on && (x & ((1u << H.k) - 1u)) == 0) {
+        const uint32_t r = H.row0 + (x >> H.k);
+        if (r < H.cap_rows) { if (r) st_hint(H.table, r, tok, src_pos - H.pre, ord); }      // (row 0 is written at the block's end: it also carries the number of rows)
+        else *H.over = 1u;
+    }
+}
+
 // wave copy of `len` literal bytes from block position sp to dst + d: out of the ring when the
 // bytes are still there, else from HBM
 __device__ __forceinline__ void copy_literals(lz4amd_gdst dst, uint32_t d, lz4amd_gsrc src, const uint8_t* ring,
@@ -554,7 +578,7 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
 // For the rare tile whose encoded bytes do not fit the staging buffer (it ends a literal run of many KB): one sequence
 // after the other, lane 0 writes the token / length / offset bytes, the wave copies the literals from the source in HBM.
 // Small and slow on purpose: it must not cost the staged path registers.
-__device__ __forceinline__ void emit_strip_plain(const MatchRec* recs, const uint32_t* strip, uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t cs) {
+__device__ __forceinline__ void emit_strip_plain(const MatchRec* recs, const uint32_t* strip, uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t cs, const HintOut& H) {
     const uint32_t lane = lane_id();
     const uint32_t nk = strip[S_N * kCmpWaves + w];
     uint32_t ipos = cs - strip[S_CARRY * kCmpWaves + w];      // source position of the next sequence's literals (the first one's include the carried ones)
@@ -565,6 +589,7 @@ __device__ __forceinline__ void emit_strip_plain(const MatchRec* recs, const uin
         const uint32_t mlm4 = r.mo >> 16, off = r.mo & 0xFFFFu;
         const uint32_t tl = i == 0 ? cs + r.ll - ipos : r.ll;
         const uint32_t lit_d = opos + 1 + lit_hdr_ext(tl);
+        if (H.table) hint_row(H, lane == 0, strip[S_ORD * kCmpWaves + w] + i, opos, ipos);
         if (lane == 0) {
             lz4amd_gdst p = dst + opos;
             *p++ = (uint8_t)(((tl >= 15 ? 15u : tl) << 4) | (mlm4 >= 15 ? 15u : mlm4));
@@ -586,7 +611,7 @@ __device__ __forceinline__ void emit_strip_plain(const MatchRec* recs, const uin
 // (tools/exp/lds_prims.hip); the bytes then leave for HBM as whole aligned 16-byte chunks (flush_begin, flush_end).  Literals always
 // come out of the source ring here: a staged tile's literals are at most kStageBytes old.
 __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchRec* recs, const uint32_t* strip, uint32_t w,
-                                               uint8_t* stage, uint32_t dbase, uint32_t cs, uint32_t* scr) {
+                                               uint8_t* stage, uint32_t dbase, uint32_t cs, uint32_t* scr, const HintOut& H) {
     const uint32_t lane = lane_id();
     const uint32_t nk = strip[S_N * kCmpWaves + w];
     const uint32_t carry = strip[S_CARRY * kCmpWaves + w];
@@ -607,6 +632,7 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
         const uint32_t rel = ipos + a_incl - adv;        // my own literals start here (from cs); the carried ones lie before
         const uint32_t so = rel >= extra ? ring_fwd(cs_off, rel - extra) : ring_back(cs_off, extra - rel);
         const uint32_t my_o = opos + e_incl - e, lit_d = my_o + lhdr;
+        if (H.table) hint_row(H, have, strip[S_ORD * kCmpWaves + w] + i, my_o + dbase, cs + rel - extra);
         // ---- the literal runs, in pieces of 8 bytes, lane = piece: pieces are numbered by a wave scan, a piece finds its
         //      sequence through a scatter of the sequences' first piece numbers + a running maximum (no walk over the
         //      sequences: a wave that hands itself one sequence after the other spends its time on LDS round trips)
@@ -800,9 +826,9 @@ __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs
     }
 }
 
-struct StripTotals { uint32_t out, carry, fail; };
+struct StripTotals { uint32_t out, carry, fail, seqs; };
 __device__ __forceinline__ StripTotals strip_offsets(uint32_t* strip, uint32_t nstrips, uint32_t out0, uint32_t carry0,
-                                                     uint32_t fail, uint32_t cap) {
+                                                     uint32_t fail, uint32_t cap, uint32_t seq0 = 0, bool with_ordinals = false) {
     const uint32_t lane = lane_id();
     const bool mine = lane < nstrips;
     const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, en = mine ? strip[S_ENC * kCmpWaves + lane] : 0;
@@ -819,11 +845,14 @@ __device__ __forceinline__ StripTotals strip_offsets(uint32_t* strip, uint32_t n
     if (__ballot(nk != 0 && (uint64_t)out0 + o_incl > cap)) fail = 1;
     const uint32_t total = wave_readlane(o_incl, 63), t_total = wave_readlane(t_incl, 63);
     const uint32_t last = ne ? 63u - (uint32_t)__clzll(ne) : 0u;
+    const uint32_t n_incl = wave_incl_sum(nk);
     if (mine) { strip[S_OUT * kCmpWaves + lane] = out0 + o_incl - sz; strip[S_CARRY * kCmpWaves + lane] = my_carry; }
+    if (mine && with_ordinals) strip[S_ORD * kCmpWaves + lane] = seq0 + n_incl - nk;      // (the HC kernel's strip array has no such row)
     StripTotals r;
     r.out = fail ? out0 : out0 + total;
     r.carry = ne ? t_total - wave_readlane(t_excl, last) : carry0 + t_total;
     r.fail = fail;
+    r.seqs = seq0 + wave_readlane(n_incl, 63);
     return r;
 }
 
@@ -847,9 +876,18 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
     const uint64_t ts1 = clock_ticks();
 #endif
     const uint32_t out0 = misc[CM_OUT];
-    const StripTotals t = strip_offsets(strip_p, nstrips, out0, misc[CM_CARRY], misc[CM_FAIL], cap);
+    const uint32_t seq0 = misc[CM_SEQS];
+    const StripTotals t = strip_offsets(strip_p, nstrips, out0, misc[CM_CARRY], misc[CM_FAIL], cap, seq0, true);
     if (lane_id() == 0) {
-        misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail;
+        misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; misc[CM_SEQS] = t.seqs;
+        // the tile's rows of the entry-point table: one per 2^k sequences, k from the tile before - about one row per 512
+        // bytes of source, never more than 8 sequences apart (a lane of the decoder's parser walks a row's sequences one by one)
+        const uint32_t prevseq = misc[CM_PREVSEQ], want = prevseq >> 4;               // (tiles are 8 KB: 16 rows)
+        const uint32_t k = want >= 8 ? 3u : want >= 4 ? 2u : want >= 2 ? 1u : 0u;
+        uint32_t* HT = misc + CM_HTILE + 4 * pp;
+        HT[0] = seq0; HT[1] = misc[CM_ROWS]; HT[2] = k;
+        misc[CM_ROWS] += (t.seqs - seq0 + (1u << k) - 1) >> k;
+        misc[CM_PREVSEQ] = (t.seqs - seq0) * (kTileMax / (t1 - t0 ? t1 - t0 : 1u));     // (scaled to a full tile: the first tiles of a block are smaller)
         uint32_t* T = misc + CM_TILE + 4 * pp;
         T[T_OUT0] = out0; T[T_OUT1] = t.out;
         T[T_DIRECT] = (t.out + a0) - ((out0 + a0) & ~15u) > kStageBytes - 16 ? 1u : 0u;
@@ -861,59 +899,18 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
 }
 // every wave: its strip of the settled tile (parity pp), into the staging buffer or straight to HBM
 // (w: the strip; sw: the wave that does it - any wave may, the strip's place in the output was fixed when the tile was settled)
-__device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, uint32_t sw, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo) {
+__device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, uint32_t sw, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo, const HintOut& H0) {
     const uint32_t* misc = (const uint32_t*)(smem + kCOffMisc);
     const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
     if (misc[CM_FAIL] || !strip_p[S_N * kCmpWaves + w]) return;
     const uint8_t* ring = (const uint8_t*)(smem + kCOffRing);
     const MatchRec* recs_w = (const MatchRec*)(smem + kCOffRecs) + (pp * kStrips + w) * kRecsPerStrip + strip_p[S_FIRST * kCmpWaves + w];
     const uint32_t* T = misc + CM_TILE + 4 * pp;
-    if (T[T_DIRECT]) emit_strip_plain(recs_w, strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w]);
+    HintOut H = H0;
+    if (H.table) { const uint32_t* HT = misc + CM_HTILE + 4 * pp; H.ord0 = HT[0]; H.row0 = HT[1]; H.k = HT[2]; }
+    if (T[T_DIRECT]) emit_strip_plain(recs_w, strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], H);
     else emit_strip_lds(ring, recs_w, strip_p, w, (uint8_t*)(smem + kCOffStage), ((T[T_OUT0] + a0) & ~15u) - a0, strip_p[S_P * kCmpWaves + w],
-                        (uint32_t*)(smem + kCOffCandS) + sw * kCandPerPass);    // (scratch: the executing wave's candidate list, idle now; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
-}
-
-// ------------------------------------------------------------------------------ entry-point table (optional output)
-// For every 512 bytes (a ROW) of the source, the first sequence that the strips from the row's first byte on emitted:
-// {where its token sits in the block, where its literals start in the source, how many sequences precede it}
-// (lz4amd_params.h: lz4amd_hint_entry).  A decoder that is handed the table parses the block from all those entries at
-// once instead of discovering the token chain (lz4_decompress_kernel.h: PARSER); the block itself is an ordinary LZ4 block.
-// One wave per tile, whichever is free first once the tile is settled: lane = strip.
-__device__ __forceinline__ void st_hint(lz4amd_gdst hints, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord) {
-    U32x4 v; v[0] = tok; v[1] = out; v[2] = ord; v[3] = 0;
-    st_global16(hints + 16 * (uint64_t)(r + 1), v);                 // (row 0 is the header)
-}
-__device__ __forceinline__ void hint_tile(char* smem, uint32_t pp, uint32_t nstrips, uint32_t t0, uint32_t strip_len, uint32_t t1,
-                                          uint32_t pre, lz4amd_gdst hints) {
-    uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
-    const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
-    const uint32_t lane = lane_id();
-    const bool mine = lane < nstrips;
-    const uint32_t nk = mine ? strip_p[S_N * kCmpWaves + lane] : 0u;
-    const unsigned long long m = __ballot(nk != 0);                 // strips with sequences
-    const uint32_t incl = wave_incl_sum(nk), seq0 = misc[CM_SEQS], pend = misc[CM_HPEND];
-    const uint32_t nseq_tile = wave_readlane(incl, 63);
-    wave_lds_fence();
-    if (lane == 0) misc[CM_SEQS] = seq0 + nseq_tile;
-    if (!m) return;                                                 // (the regions of this tile stay pending)
-    const uint32_t ord = seq0 + incl - nk;
-    const uint32_t tok = mine ? strip_p[S_OUT * kCmpWaves + lane] : 0u;
-    const uint32_t start = mine ? strip_p[S_P * kCmpWaves + lane] - strip_p[S_CARRY * kCmpWaves + lane] - pre : 0u;     // first literal of the strip's first sequence
-    // regions before this tile that had no sequence behind them so far: the tile's first one
-    const uint32_t F = (uint32_t)__ffsll((long long)m) - 1;
-    const uint32_t ra = (t0 - pre) >> LZ4AMD_HINT_ROW_SHIFT, nr = (t1 - t0 + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT;     // the tile's rows (tiles start on the 1 KB grid of the block, strips on its 256-byte grid)
-    {
-        const uint32_t ft = wave_readlane(tok, F), fs = wave_readlane(start, F), fo = wave_readlane(ord, F);
-        for (uint32_t r = pend + lane; r < ra; r += 64) st_hint(hints, r, ft, fs, fo);
-    }
-    // rows of this tile, lane = row (at most 16): the first strip with sequences from the row's first strip on
-    const uint32_t s = (lane << LZ4AMD_HINT_ROW_SHIFT) >> (31 - __clz((int)strip_len));
-    const unsigned long long rest = (lane < nr && s < 64) ? m >> s : 0ull;
-    const uint32_t nv = rest ? s + (uint32_t)__ffsll((long long)rest) - 1 : 0u;
-    const uint32_t et = (uint32_t)__shfl((int)tok, (int)nv), es = (uint32_t)__shfl((int)start, (int)nv), eo = (uint32_t)__shfl((int)ord, (int)nv);
-    if (rest) st_hint(hints, ra + lane, et, es, eo);
-    const uint32_t done = (uint32_t)__popcll(__ballot(rest != 0));    // (a region without a strip behind it: so are all later ones)
-    if (lane == 0) misc[CM_HPEND] = ra + done;
+                        (uint32_t*)(smem + kCOffCandS) + sw * kCandPerPass, H);    // (scratch: the executing wave's candidate list, idle now; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
 }
 
 // ------------------------------------------------------------------------------ one block
@@ -950,11 +947,12 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const bool stride4 = !small && P.acceleration >= LZ4AMD_STRIDE4_FROM;      // LZ4_compress_fast's speed / ratio knob: every fourth position is probed instead of every second
     const uint32_t a0 = (uint32_t)((uintptr_t)P.dst[b] & 15u);        // dst's place on HBM's 16-byte grid
     const lz4amd_gdst hints = P.hints ? LZ4AMD_TO_GDST(P.hints + (uint64_t)b * P.hint_stride) : (lz4amd_gdst)nullptr;      // optional entry-point table
+    HintOut H; H.table = hints; H.cap_rows = P.hint_stride >= 48 ? (uint32_t)(P.hint_stride / 16 - 2) : 0u; H.pre = pre; H.over = &misc[CM_HOVER]; H.ord0 = H.row0 = H.k = 0;
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
-        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_SEQS] = 0; misc[CM_HPEND] = 0;
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_SEQS] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0; misc[CM_PREVSEQ] = 128;
 #ifdef LZ4AMD_PROF_TILE
         for (uint32_t i = 24; i < 30; i++) misc[i] = 0;
 #endif
@@ -1029,12 +1027,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 uint32_t sx = 0;
                 if (lane_id() == 0) sx = atomicAdd(&misc[CM_EMITQ], 1u);
                 sx = __builtin_amdgcn_readfirstlane(sx);
-                if (sx >= prev_nstrips) {
-                    // (the first wave to find the queue empty writes the settled tile's rows of the entry-point table)
-                    if (hints && sx == prev_nstrips) hint_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, pre, hints);
-                    break;
-                }
-                emit_tile_strip(smem, par ^ 1, sx, w, src, dst, a0, ring_lo);
+                if (sx >= prev_nstrips) break;
+                emit_tile_strip(smem, par ^ 1, sx, w, src, dst, a0, ring_lo, H);
             }
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
@@ -1095,13 +1089,10 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     __syncthreads();
     // -- the last tile's sequences (settled by wave 0 first)
     if (prev_nstrips) {
-        if (w == kSettleWave) {
-            settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
-            if (hints) hint_tile(smem, par ^ 1, prev_nstrips, prev_t0, prev_strip_len, prev_t1, pre, hints);
-        }
+        if (w == kSettleWave) settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
         __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
-        if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, w, src, dst, a0, ring_lo);
+        if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, w, src, dst, a0, ring_lo, H);
         __syncthreads();
         if (!misc[CM_FAIL]) { const FlushCtx fc = flush_begin(smem, par ^ 1, a0); flush_end(smem, fc, dst, a0); }
     }
@@ -1133,16 +1124,17 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const uint32_t out = misc[CM_OUT], run = misc[CM_CARRY];
     const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;
     if (misc[CM_FAIL] || total > cap) { if (tid == 0) { P.result[b] = 0; if (hints) *(uint32_t*)hints = 0; } return; }
-    if (hints && w == kCmpWaves - 1) {
-        // the table's last rows: regions without a sequence at or behind them name the block's last sequence (its final
-        // literals), the row behind the last region is the block's end; the header makes the table valid
-        const uint32_t seqs = misc[CM_SEQS], nreg = ((uint32_t)n_i + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT;
-        for (uint32_t r = misc[CM_HPEND] + lane_id(); r < nreg; r += 64) st_hint(hints, r, out, n - run - pre, seqs);
-        if (lane_id() == 0) {
-            st_hint(hints, nreg, (uint32_t)total, (uint32_t)n_i, seqs + 1);
-            U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = (uint32_t)n_i; h[2] = (uint32_t)total; h[3] = seqs + 1;
+    if (hints && tid == 0) {
+        // the block's last sequence (its final literals) is a sequence like the others; the row behind the last one is the
+        // block's end; row 0 (the block's first sequence) carries the number of rows; the header makes the table valid
+        const uint32_t seqs = misc[CM_SEQS], nseq = seqs + 1, last_row = misc[CM_ROWS], nrows = last_row + 1;      // (the last sequence has a row of its own)
+        if (last_row && last_row < H.cap_rows) st_hint(hints, last_row, out, n - run - pre, seqs);
+        if (nrows <= H.cap_rows && !misc[CM_HOVER]) {
+            st_hint(hints, nrows, (uint32_t)total, (uint32_t)n_i, nseq);
+            st_hint(hints, 0, 0, 0, 0, nrows);
+            U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = (uint32_t)n_i; h[2] = (uint32_t)total; h[3] = nseq;
             st_global16(hints, h);
-        }
+        } else *(uint32_t*)hints = 0;                                 // (more sequences than the table has room for: no table)
     }
     {
         const uint32_t r = (out + a0) & 15u, cfrom = misc[CM_TILE + 4 * par + T_CFROM];

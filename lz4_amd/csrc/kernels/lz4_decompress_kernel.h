@@ -75,7 +75,7 @@ enum : uint32_t {
     kIdxMask = kIdxRing - 1,
     kEntRing = 256,                             // rows of the block's entry-point table (16 B each), ring
     kEntMask = kEntRing - 1,
-    kLaneSeqMax = 1024,                         // sequences between two rows of a table (a row is 512 bytes of source: at most 129)
+    kLaneSeqMax = 1024,                         // sequences between two rows of a table (lz4amd_k_compress writes a row every 8)
     kDmaDepth = 16,                             // LDS-DMA instructions (1 KB each) the mover keeps in flight
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
     kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
@@ -339,7 +339,7 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
 
 // ------------------------------------------------------------------------------ PARSER (blocks that come with an entry-point table)
 // An entry-point table (lz4amd_params.h: lz4amd_hint_entry; written by lz4amd_k_compress next to the block it made, or by
-// anybody else) names one sequence of the token chain per 512 bytes of output.  With it the serial chain is cut in pieces that
+// anybody else) names one sequence of the token chain every few sequences (lz4amd_k_compress: every eighth).  With it the serial chain is cut in pieces that
 // are parsed side by side: LANE k of this wave walks the sequences from row r0 + k up to row r0 + k + 1 out of the
 // compressed ring in LDS - token, literal length, offset, match length, the same rules as the pre-parse's P5
 // (read_variable_length lz4.c:1979-2014; lz4.c:2279, 2312-2318, 2356, 2423) - and writes their records and the region
@@ -1032,7 +1032,7 @@ out: ;
 // the table turned out not to fit the stream (the block must then be decoded again without it).
 __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz4amd_gdst dst, uint32_t cap, uint32_t prefix,
                                              const SeqRec* rectab, const uint32_t* ridx, uint32_t nseq, uint32_t total, char* smem, uint64_t* prof,
-                                             lz4amd_gsrc hint) {
+                                             lz4amd_gsrc hint, uint32_t nreg) {
     const uint32_t tid = threadIdx.x, w = wave_id();
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
 
     const uint32_t rend = (kBias + total + kRegion - 1) >> kRegionShift;          // regions [kFirstRegion, rend)
     const bool hinted = hint != nullptr;
-    const uint32_t nreg = (total + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT;      // rows of the table: nreg + 1, behind its 16-byte header
+    // (nreg: rows of the table; nreg + 1 entries behind its 16-byte header)
     if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem, hinted ? hint + 16 : hint, nreg + 1);
     else if (hinted && w >= kFirstParseWave) parser_role(src, csize, cap, prefix, total, nseq, nreg, rend, smem, prof);
     else copy_role(w, src, dst, nseq, total, rend, smem, prof, hinted);
@@ -1116,12 +1116,14 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     uint32_t nseq = 0, total = stored ? csize : 0u;
     uint32_t* ridx = nullptr;
     lz4amd_gsrc hint = nullptr;
-    if (use_hints && !chained && P.hints) {
+    uint32_t nrows = 0;
+    if (use_hints && !chained && P.hints && P.hint_stride >= 48) {
         const lz4amd_gsrc hp = LZ4AMD_TO_GSRC(P.hints + (uint64_t)b * P.hint_stride);
         const U32x4 h = ld_global16(hp);                     // { magic, output bytes, compressed bytes, sequences }
-        const uint64_t rows = (((uint64_t)h[1] + LZ4AMD_HINT_ROW_BYTES - 1) >> LZ4AMD_HINT_ROW_SHIFT) + 2;
-        if (h[0] == LZ4AMD_HINT_MAGIC && h[2] == csize && h[1] != 0 && h[1] <= cap && h[3] != 0 && h[3] <= csize && rows * 16 <= P.hint_stride) {
-            hint = hp; total = h[1]; nseq = h[3];
+        const U32x4 e0 = ld_global16(hp + 16);               // the first row { 0, 0, 0, rows }
+        if (h[0] == LZ4AMD_HINT_MAGIC && h[2] == csize && h[1] != 0 && h[1] <= cap && h[3] != 0 && h[3] <= csize
+            && (e0[0] | e0[1] | e0[2]) == 0 && e0[3] != 0 && ((uint64_t)e0[3] + 2) * 16 <= P.hint_stride) {
+            hint = hp; total = h[1]; nseq = h[3]; nrows = e0[3];
         }
     }
     // ---- stage A: the record table (a malformed block ends here, nothing written)
@@ -1156,7 +1158,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         if (stored) for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
     }
 
-    if (!stored && !stream_block(src, csize, dst, cap, prefix, rectab, ridx, nseq, total, smem, prof, hint)) {
+    if (!stored && !stream_block(src, csize, dst, cap, prefix, rectab, ridx, nseq, total, smem, prof, hint, nrows)) {
         if (tid == 0 && P.hint_stats) atomicAdd(&P.hint_stats[1], 1u);
         return false;
     }

@@ -88,17 +88,18 @@ static int dest_size_search(prefix_fn f, void* arg, const char* src, char* dst, 
     *srcSizePtr = lo;
     return r;
 }
-static int fast_prefix(void* arg, const char* src, char* dst, int n, int cap) { (void)arg; return LZ4_compress_default(src, dst, n, cap); }
+static int fast_prefix(void* arg, const char* src, char* dst, int n, int cap) { return LZ4_compress_fast(src, dst, n, cap, *(const int*)arg); }
 int LZ4_compress_destSize(const char* src, char* dst, int* srcSizePtr, int targetDstSize)
 {
+    int accel = 1;
     if (srcSizePtr == NULL) return 0;
-    return dest_size_search(fast_prefix, NULL, src, dst, srcSizePtr, targetDstSize);
+    return dest_size_search(fast_prefix, &accel, src, dst, srcSizePtr, targetDstSize);
 }
 int LZ4_compress_destSize_extState(void* state, const char* src, char* dst, int* srcSizePtr, int targetDstSize, int acceleration)
-{   /* lz4.c:1506 */
-    (void)acceleration;
+{   /* lz4.c:1506: the same parse as LZ4_compress_fast_extState at this acceleration (fuzzer.c:488-492: one byte less room than that
+     * call needed must take less than the whole input) */
     if (state == NULL || srcSizePtr == NULL) return 0;
-    return dest_size_search(fast_prefix, NULL, src, dst, srcSizePtr, targetDstSize);
+    return dest_size_search(fast_prefix, &acceleration, src, dst, srcSizePtr, targetDstSize);
 }
 static int hc_prefix(void* arg, const char* src, char* dst, int n, int cap) { return LZ4_compress_HC(src, dst, n, cap, *(const int*)arg); }
 int LZ4_compress_HC_destSize(void* stateHC, const char* src, char* dst, int* srcSizePtr, int targetDstSize, int compressionLevel)

@@ -258,9 +258,10 @@ int lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, in
 }
 
 size_t lz4amd_hint_bytes(int src_size)
-{   /* header + one row per started 512 bytes + the end row (lz4amd_params.h) */
+{   /* header + room for one row per 128 bytes of source (a row is 8 sequences: blocks that average less than 16 bytes per
+     * sequence get no table) + the end row (lz4amd_params.h) */
     if (src_size < 0) return 0;
-    return 16u * (((size_t)src_size + LZ4AMD_HINT_ROW_BYTES - 1u) / LZ4AMD_HINT_ROW_BYTES + 2u);
+    return 16u * (((size_t)src_size + 127u) / 128u + 3u);
 }
 
 int lz4amd_plan_attach_hints(lz4amd_plan* p, void* d_hints, size_t stride)

@@ -29,14 +29,18 @@ typedef struct lz4amd_dec_params {
     uint32_t* hint_stats;           /* optional: [0] += blocks decoded from their table, [1] += tables that did not fit their block */
 } lz4amd_dec_params;
 
-/* One block's entry-point table: a 16-byte header followed by rows + 1 entries of 16 bytes, rows = ceil(out_size / 512).
+/* One block's entry-point table: a 16-byte header { magic, out_size, csize, nseq } followed by rows + 1 entries of 16 bytes.
  * Entry r names a sequence of the block's token chain: where its token sits in the compressed block, where its literals
- * start in the output, how many sequences precede it.  Entry 0 is the first sequence, entry `regions` the block's end
- * {csize, out_size, nseq}; entries never decrease.  The compressor picks, for region r, the first sequence that the source
- * strips from byte 1024 r on emitted. */
+ * start in the output, how many sequences precede it.  Entry 0 is the block's first sequence { 0, 0, 0 } and carries the number
+ * of rows in its fourth word; entry `rows` is the block's end { csize, out_size, nseq }; entries never decrease.  The
+ * compressor writes about one row per 512 bytes of source and never fewer than one per 8 sequences (the distance, a power
+ * of two of sequences, is set tile by tile from the tile before): every lane of the decoder's parser walks a row's
+ * sequences one after the other, ~1000 cycles each, so rows must be short in sequences - and they must be short in bytes,
+ * because the lanes' rows must lie in the 32 KB of the stream that are resident.  (Rows at fixed distances in the output -
+ * an earlier layout - left two thirds of the lanes' steps idle: the sequences per KB vary threefold.)  Any table whose rows
+ * lie on the chain works; one that does not is found out and costs time only. */
 #define LZ4AMD_HINT_MAGIC 0x48345A4Cu           /* "LZ4H" */
-#define LZ4AMD_HINT_ROW_SHIFT 9
-#define LZ4AMD_HINT_ROW_BYTES (1u << LZ4AMD_HINT_ROW_SHIFT)
+#define LZ4AMD_HINT_EVERY_MAX 8u             /* sequences between two rows of a table lz4amd_k_compress writes, at most */
 typedef struct lz4amd_hint_entry { uint32_t tok, out, ord, zero; } lz4amd_hint_entry;      /* header: { magic, out_size, csize, nseq } */
 
 typedef struct lz4amd_comp_params {

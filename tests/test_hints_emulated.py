@@ -15,11 +15,11 @@ MAGIC = 0x48345A4C
 CANARY = 0xEE
 
 
-ROW = 512
+EVERY = 8                      # lz4amd_k_compress's rows are at most 8 sequences apart (LZ4AMD_HINT_EVERY_MAX)
 
 
 def hint_bytes(n):
-    return 16 * ((n + ROW - 1) // ROW + 2)
+    return 16 * ((n + 127) // 128 + 3)
 
 
 def token_chain(comp):
@@ -46,52 +46,53 @@ def token_chain(comp):
         o += ll + ml + 4; p = nx
 
 
-def make_table(comp, every=1):
-    """A valid table for any legal block: row r = the first sequence that starts at or behind byte 512 r of the output (the
-    last sequence when there is none); `every` > 1 thins the rows out (row r then names what row r - r % every would)."""
+def make_table(comp, every=EVERY, by_bytes=0):
+    """A valid table for any legal block: a row per `every` sequences, or (by_bytes) a row per `by_bytes` bytes of output - row r
+    then names the first sequence that starts at or behind byte by_bytes * r (the last sequence when there is none)."""
     ch, n = token_chain(comp)
-    nreg = (n + ROW - 1) // ROW
-    rows, j = [], 0
-    for r in range(nreg):
-        want = (r - r % every) * ROW
-        while j + 1 < len(ch) and ch[j][1] < want:
-            j += 1
-        k = j
-        if ch[k][1] < want:
-            k = len(ch) - 1
-        rows.append((ch[k][0], ch[k][1], k))
-    rows.append((len(comp), n, len(ch)))
-    if nreg:
-        rows[0] = (0, 0, 0)
-        for r in range(1, nreg):            # never decreasing
-            if rows[r] < rows[r - 1]:
-                rows[r] = rows[r - 1]
+    rows = []
+    if by_bytes:
+        j = 0
+        for r in range((n + by_bytes - 1) // by_bytes):
+            want = r * by_bytes
+            while j + 1 < len(ch) and ch[j][1] < want:
+                j += 1
+            k = j if ch[j][1] >= want else len(ch) - 1
+            rows.append((ch[k][0], ch[k][1], k))
+        if rows:
+            rows[0] = (0, 0, 0)
+            for r in range(1, len(rows)):       # never decreasing
+                if rows[r] < rows[r - 1]:
+                    rows[r] = rows[r - 1]
+    else:
+        rows = [(ch[k][0], ch[k][1], k) for k in range(0, len(ch), every)]
+    if not rows:
+        rows = [(0, 0, 0)]
     t = struct.pack("<4I", MAGIC, n, len(comp), len(ch))
-    for tok, out, ordn in rows:
-        t += struct.pack("<4I", tok, out, ordn, 0)
+    for r, (tok, out, ordn) in enumerate(rows):
+        t += struct.pack("<4I", tok, out, ordn, len(rows) if r == 0 else 0)
+    t += struct.pack("<4I", len(comp), n, len(ch), 0)
     return t
 
 
 def check_table(comp, table, n):
+    """a table lz4amd_k_compress wrote: every row is a sequence of the block's real token chain, rows are at most 8 sequences
+    apart, the block's last sequence has a row, the first row carries the number of rows"""
     magic, osz, csz, nseq = struct.unpack_from("<4I", table, 0)
     assert (magic, osz, csz) == (MAGIC, n, len(comp))
     ch, total = token_chain(comp)
     assert total == n and nseq == len(ch)
-    where = {t: (o, i) for i, (t, o) in enumerate(ch)}
-    nreg = (n + ROW - 1) // ROW
-    prev = (0, 0, 0)
-    for r in range(nreg + 1):
+    z0 = struct.unpack_from("<4I", table, 16)
+    nrows = z0[3]
+    assert z0[:3] == (0, 0, 0) and 1 <= nrows <= nseq and 16 * (nrows + 2) <= len(table)
+    prev = 0
+    for r in range(1, nrows):
         tok, out, ordn, z = struct.unpack_from("<4I", table, 16 * (r + 1))
-        assert z == 0
-        if r == nreg:
-            assert (tok, out, ordn) == (len(comp), n, nseq)
-        else:
-            assert where.get(tok) == (out, ordn), (r, tok, out, ordn)
-            # the row is near its region: its sequence starts inside the strips of region r or is the first one behind them
-            assert out < (r + 1) * ROW or ordn == 0 or ch[ordn - 1][1] < r * ROW + ROW
-        assert (tok, out, ordn) >= prev
-        prev = (tok, out, ordn)
-    assert struct.unpack_from("<3I", table, 16) == (0, 0, 0)
+        assert z == 0 and prev < ordn <= prev + EVERY and ordn < nseq and (tok, out) == ch[ordn], (r, tok, out, ordn)
+        prev = ordn
+    assert prev == nseq - 1 or nrows == 1 and nseq <= EVERY + 1, (prev, nseq)
+    assert struct.unpack_from("<4I", table, 16 * (nrows + 1)) == (len(comp), n, nseq, 0)
+    return nrows
 
 
 def emu_compress_tables(emu, datas, accel=1):
@@ -174,13 +175,13 @@ def foreign(ocodec, reflib, datagen):
 def test_tables_made_for_foreign_blocks_decode_every_corpus(emu, foreign):
     blocks = [c for _, c in foreign]
     wants = [d for d, _ in foreign]
-    for every, sal in ((1, 0), (1, 5), (3, 0), (40, 0)):
-        tables = [make_table(c, every) for c in blocks]
+    for every, by_bytes, sal in ((8, 0, 0), (8, 0, 5), (1, 0, 0), (50, 0, 0), (0, 512, 0), (0, 3000, 3), (2000, 0, 0)):
+        tables = [make_table(c, every, by_bytes) for c in blocks]
         outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], tables, salign=sal)
         for d, (r, o) in zip(wants, outs):
-            assert r == len(d) and o == d, (every, sal, len(d))
-        # (rows 20 KB apart: a lane of the parser may then own more sequences than it accepts - such a table is rejected, not wrong)
-        assert used + rejected == len(blocks) and (rejected == 0 or every == 40) and used >= 50, (every, used, rejected)
+            assert r == len(d) and o == d, (every, by_bytes, sal, len(d))
+        # (rows 2000 sequences apart: a lane of the parser then owns more sequences than it accepts - such a table is rejected, not wrong)
+        assert used + rejected == len(blocks) and (rejected == 0 or every == 2000) and used >= 40, (every, by_bytes, used, rejected)
 
 
 def test_compressor_tables_name_real_sequences_and_are_used(emu, ocodec, datagen):
@@ -244,7 +245,7 @@ def test_tables_that_lie_only_cost_time(emu, ocodec, datagen):
     outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d)] * len(blocks), tables)
     for r, o in outs:
         assert r == len(d) and o == d
-    assert used + rejected >= 40 and rejected >= 30               # (tables with a broken header are not even tried)
+    assert used + rejected >= 30 and rejected >= 25               # (tables with a broken header or first row are not even tried)
 
 
 def test_hostile_streams_with_true_looking_tables_match_the_oracle(emu, ocodec, datagen, golden):
@@ -290,3 +291,30 @@ def test_tables_with_history_before_the_block(emu, oracle, datagen):
     # the same block without its history: offsets reach before the output, with or without the table
     outs, used, rejected = emu_decompress_tables(emu, [comp], [len(body)], [table])
     assert outs[0][0] < 0
+
+
+def test_a_table_without_room_for_its_rows_is_left_invalid(emu, ocodec, datagen):
+    """lz4amd_hint_bytes leaves room for a row per 128 bytes of source (a row is 8 sequences).  A block with more rows than its table
+    has room for - here: a stride an eighth of that - gets no table: the header stays invalid, nothing is written behind the
+    table's end, and the decoder decodes the block the ordinary way."""
+    d = datagen(1 << 20, 90, 2)
+    n = 1
+    cap = len(d) + len(d) // 255 + 16
+    src = ctypes.create_string_buffer(d, len(d)); dst = ctypes.create_string_buffer(cap + 64)
+    stride = (hint_bytes(len(d)) // 8) & ~15
+    hraw = ctypes.create_string_buffer(b"\xEE" * (stride + 4096 + 16), stride + 4096 + 16)
+    hbase = (ctypes.addressof(hraw) + 15) & ~15
+    sp = (ctypes.c_void_p * 1)(ctypes.addressof(src)); dp = (ctypes.c_void_p * 1)(ctypes.addressof(dst))
+    ss = (ctypes.c_int32 * 1)(len(d)); dc = (ctypes.c_int32 * 1)(cap); res = (ctypes.c_int32 * 1)()
+    emu.emu_compress_batch_hints(sp, ss, dp, dc, res, 1, 1, None, ctypes.c_void_p(hbase), ctypes.c_uint64(stride), 1)
+    comp = dst.raw[:res[0]]
+    ro, o = ocodec.decompress(comp, len(d))
+    assert ro == len(d) and o == d
+    ch, _ = token_chain(comp)
+    assert (len(ch) + EVERY - 1) // EVERY + 2 > stride // 16            # (the premise: more rows than room, even at 8 sequences a row)
+    off = hbase - ctypes.addressof(hraw)
+    table = hraw.raw[off:off + stride]
+    assert struct.unpack_from("<I", table, 0)[0] != MAGIC
+    assert hraw.raw[off + stride:off + stride + 4096] == b"\xEE" * 4096   # nothing behind the table's end
+    outs, used, rejected = emu_decompress_tables(emu, [comp], [len(d)], [table])
+    assert outs[0] == (len(d), d) and (used, rejected) == (0, 0)
