@@ -249,22 +249,22 @@ __device__ __forceinline__ Pair32 ring_ld8_32(const uint8_t* ring, uint32_t o) {
 #endif
 // one probe round: the four positions of a lane's kLaneBytes source bytes from p + lane * kLaneBytes on
 struct Round { uint32_t dd[4]; uint32_t sb, eb; uint32_t hh[2]; };      // distance of the candidate that holds at slot j (0: none); run starts / ends; the four table indices probed (two per word)
-template <uint32_t SH>
-__device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi) {
-    constexpr bool small = SH == 0;
+template <bool SMALL>
+__device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi, uint32_t SH) {
+    constexpr bool small = SMALL;      // (SH: 0 for a small block; 1 or 2 - wave-uniform, the same for the whole launch - for a big one: only the bytes' extraction differs)
     Round R;
     uint32_t R0, R1, R2 = 0, R3 = 0, R4 = 0;
-    if (SH == 2) { const U32x4 v = *(const U32x4*)(ring + o0); R0 = v[0]; R1 = v[1]; R2 = v[2]; R3 = v[3]; R4 = *(const uint32_t*)(ring + o0 + 16); }      // (o0 is a multiple of 16)
-    else if (SH == 1) { const uint64_t v = *(const uint64_t*)(ring + o0); R0 = (uint32_t)v; R1 = (uint32_t)(v >> 32); R2 = *(const uint32_t*)(ring + o0 + 8); }
+    if (!SMALL && SH == 2) { const U32x4 v = *(const U32x4*)(ring + o0); R0 = v[0]; R1 = v[1]; R2 = v[2]; R3 = v[3]; R4 = *(const uint32_t*)(ring + o0 + 16); }      // (o0 is a multiple of 16)
+    else if (!SMALL) { const uint64_t v = *(const uint64_t*)(ring + o0); R0 = (uint32_t)v; R1 = (uint32_t)(v >> 32); R2 = *(const uint32_t*)(ring + o0 + 8); }
     else { R0 = *(const uint32_t*)(ring + o0); R1 = *(const uint32_t*)(ring + o0 + 4); }
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t q = q0 + (j << SH);
         uint32_t f0, f4 = 0;
-        if (SH == 2) {                                  // every fourth position: whole dwords
+        if (!SMALL && SH == 2) {                        // every fourth position: whole dwords
             f0 = j == 0 ? R0 : j == 1 ? R1 : j == 2 ? R2 : R3;
             f4 = j == 0 ? R1 : j == 1 ? R2 : j == 2 ? R3 : R4;
-        } else if (SH == 1) {
+        } else if (!SMALL) {
             f0 = j == 0 ? R0 : j == 1 ? align_bytes(R1, R0, 2) : j == 2 ? R1 : align_bytes(R2, R1, 2);
             f4 = j == 0 ? R1 : j == 1 ? R1 >> 16 : j == 2 ? R2 : R2 >> 16;
         } else f0 = j == 0 ? R0 : align_bytes(R1, R0, j);
@@ -292,8 +292,7 @@ __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t
 // the compiler keep dd[] in scratch memory and load from it: a trip to HBM in the middle of the match)
 __device__ __forceinline__ uint32_t slot_of(uint32_t low) { return (low >> 1) - (low >> 3); }           // 1, 2, 4, 8 -> 0, 1, 2, 3
 __device__ __forceinline__ uint32_t dist_of(const Round& R, uint32_t low) { return (low & 1u) ? R.dd[0] : (low & 2u) ? R.dd[1] : (low & 4u) ? R.dd[2] : R.dd[3]; }
-template <uint32_t SH>
-__device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t iE, uint32_t rel, uint32_t* candS, uint16_t* candE) {
+__device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t iE, uint32_t rel, uint32_t* candS, uint16_t* candE, uint32_t SH) {
     uint32_t s = R.sb, e2 = R.eb;
     {   // a lane's first start and first end (nearly always its only ones) without a trip around the loop
         const uint32_t ls = s & (0u - s), le = e2 & (0u - e2);
@@ -311,14 +310,14 @@ __device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t
     }
 }
 
-template <uint32_t SH>
+template <bool SMALL>
 __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
-                                            uint32_t* candS, uint16_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend, uint32_t (&probe_h)[2] MPROF_ARGS) {
+                                            uint32_t* candS, uint16_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend, uint32_t (&probe_h)[2], uint32_t SH MPROF_ARGS) {
     const uint32_t lane = lane_id();
 #ifdef LZ4AMD_PROF_MATCH
     uint64_t mtq = clock_ticks();
 #endif
-    constexpr uint32_t kSpan = 256u << SH, kLaneBytes = 4u << SH;      // a round covers kSpan bytes; a strip is at most two rounds long
+    const uint32_t kSpan = 256u << SH, kLaneBytes = 4u << SH;      // a round covers kSpan bytes; a strip is at most two rounds long
     uint32_t nseq = 0, enc = 0, ll0 = 0, cur = cs;             // cur: end of the last match taken (first byte not yet covered)
     // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= tend
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
@@ -337,19 +336,19 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                 //      position order: round A's, then round B's.  More than 64 runs in a strip are rare: the rounds are simply
                 //      probed again for the next 64 (the table is frozen: same answers), which keeps one round's registers live.
                 {
-                    const Round A = probe_round<SH>(ring, tab, ring_fwd(cs_off, rel0), cs + rel0, q_hi);
+                    const Round A = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, rel0), cs + rel0, q_hi, SH);
                     if (lo == 0) { probe_h[0] = A.hh[0]; probe_h[1] = A.hh[1]; }      // (the insert of this tile uses them again)
                     const uint32_t cntA = (uint32_t)__popc(A.sb) | ((uint32_t)__popc(A.eb) << 16);
                     const uint32_t inclA = wave_incl_sum(cntA), exA = inclA - cntA;
                     total = wave_readlane(inclA, 63);
-                    list_round<SH>(A, (exA & 0xFFFFu) - lo, (exA >> 16) - lo, rel0, candS, candE);      // (indices below lo wrap and are dropped)
+                    list_round(A, (exA & 0xFFFFu) - lo, (exA >> 16) - lo, rel0, candS, candE, SH);      // (indices below lo wrap and are dropped)
                 }
                 if (two) {
-                    const Round B = probe_round<SH>(ring, tab, ring_fwd(cs_off, rel1), cs + rel1, q_hi);
+                    const Round B = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, rel1), cs + rel1, q_hi, SH);
                     const uint32_t cntB = (uint32_t)__popc(B.sb) | ((uint32_t)__popc(B.eb) << 16);
                     const uint32_t inclB = wave_incl_sum(cntB), exB = inclB - cntB + total;
                     total += wave_readlane(inclB, 63);
-                    list_round<SH>(B, (exB & 0xFFFFu) - lo, (exB >> 16) - lo, rel1, candS, candE);
+                    list_round(B, (exB & 0xFFFFu) - lo, (exB >> 16) - lo, rel1, candS, candE, SH);
                 }
                 total &= 0xFFFFu;
                 MPROF(0);
@@ -887,7 +886,8 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
         uint32_t* HT = misc + CM_HTILE + 4 * pp;
         HT[0] = seq0; HT[1] = misc[CM_ROWS]; HT[2] = k;
         misc[CM_ROWS] += (t.seqs - seq0 + (1u << k) - 1) >> k;
-        misc[CM_PREVSEQ] = (t.seqs - seq0) * (kTileMax / (t1 - t0 ? t1 - t0 : 1u));     // (scaled to a full tile: the first tiles of a block are smaller)
+        const uint32_t lg = 31u - (uint32_t)__clz((int)(t1 - t0 ? t1 - t0 : 1u));       // (scaled to a full tile: the first tiles of a block are smaller)
+        misc[CM_PREVSEQ] = lg >= 13 ? t.seqs - seq0 : (t.seqs - seq0) << (13 - lg);
         uint32_t* T = misc + CM_TILE + 4 * pp;
         T[T_OUT0] = out0; T[T_OUT1] = t.out;
         T[T_DIRECT] = (t.out + a0) - ((out0 + a0) & ~15u) > kStageBytes - 16 ? 1u : 0u;
@@ -1010,9 +1010,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (w < nstrips) {
             const uint32_t cs = strip_lo(g0, t0, w, strip_len);
             uint32_t ce = g0 + (w + 1) * strip_len; if (ce > t1) ce = t1;
-            if (small) match_strip<0>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
-            else if (stride4) match_strip<2>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
-            else match_strip<1>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h MPROF_PASS);
+            if (small) match_strip<true>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, 0u MPROF_PASS);
+            else match_strip<false>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, stride4 ? 2u : 1u MPROF_PASS);
             // the lane probed positions cs + 8 * lane + {0, 2, 4, 6}: with 512-byte strips those are this thread's insert positions
             probe_h_valid = !small && !stride4 && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
         }

@@ -711,12 +711,14 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     if (!is_lit && dist == 0) { fprintf(stderr, "ZERO OFFSET item: R=%u d=%u lo=%u n=%u rec{%u,%u,%u,%u} ms=%u j0=%u nrec=%u\n", C.R, d, lo, n, rec.outpos, rec.litpos, rec.ll, rec.off, ms, C.j0, C.nrec); return false; }
 #endif
     if (!is_lit && into >= dist) {
-        // the source lies inside this very match (it overlaps itself): every earlier period holds the same
-        // bytes; read the farthest one the 64 KB window holds, long final, instead of the bytes just written
-        uint32_t k = into / dist + 1;
-        const uint32_t kmax = kMaxDistance / dist;
-        if (k > kmax) k = kmax;
-        dist *= k;
+        // the source lies inside this very match (it overlaps itself): every earlier period holds the same bytes; read one
+        // far back - the period times the largest power of two that stays inside the match's own source and the 64 KB
+        // window: at least half as far as the farthest, long final - instead of the bytes just written (no division: two
+        // of them were 70 instructions of this function)
+        const uint32_t lim = umin32(into + dist, kMaxDistance);                  // dist << j <= lim
+        uint32_t j = (uint32_t)__clz((int)dist) - (uint32_t)__clz((int)lim);     // floor(log2 lim) - floor(log2 dist) >= 0
+        j -= ((dist << j) > lim) ? 1u : 0u;
+        dist <<= j;
     }
     const uint32_t s = d - dist;
     // sources below my chunk must be final; sources inside my own chunk (a match that starts inside a chunk,
@@ -867,6 +869,7 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
         if (pendA || pendBc) {
             const uint64_t tr0 = timed ? clock_ticks() : 0;
             uint64_t published = 0;
+            uint32_t idle_polls = 0;
             const uint64_t actm = __ballot(actA);
             for (;;) {
                 // chunks without a pending piece are final: tell the other waves
@@ -903,7 +906,12 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                     const bool hard = __any((((pendA >> lane) & 1ull) && keyA == kKeyAlways) || (((left0 >> lane) & 1ull) && keyB0 == kKeyAlways));
                     if (!hard && !later) {
                         pendBc = left0 ? chunks_of(left0, packB0 >> 9) : 0;
-                        if (!(doneA | doneB)) { spin_pause(); if (uload(&misc[M_ABORT])) return; }
+                        if (!(doneA | doneB)) {
+                            // (nothing came in: the sources are a region or more away from being final - a poll costs ~80 instructions of
+                            //  the SIMD the other waves need; after two short naps the naps get long)
+                            if (++idle_polls > 2) spin_pause_long(); else spin_pause();
+                            if (uload(&misc[M_ABORT])) return;
+                        } else idle_polls = 0;
                         continue;
                     }
                 }

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+for shape in "256 4194304 60" "256 4194304 90" "256 4194304 20" "4096 262144 60" "16384 65536 60"; do
+  ( NOPROF=1 timeout 120 python tools/prof_dec.py $shape ) 2>&1 | grep -E "^decoder|Error|error"
+done
+( NOPROF=1 NOHINTS=1 timeout 120 python tools/prof_dec.py 256 4194304 60 ) 2>&1 | grep -E "^decoder|Error|error"
+timeout 300 python bench.py --steps 10 --warmup 2 --no-hc --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('value','ms_per_step','compress_GBps','decompress_GBps')}); print([(k['kernel'],k['avg_ms']) for k in d['kernels']])"
+timeout 300 python bench.py --steps 10 --warmup 2 --no-hc --no-extras --no-cpu-baseline --no-hints 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('no tables:', {k: d[k] for k in ('value','ms_per_step','compress_GBps','decompress_GBps')}); print([(k['kernel'],k['avg_ms']) for k in d['kernels']])"
