@@ -13,30 +13,40 @@
 //   A PRE-PARSE  (all 16 waves, lz4_preparse_kernel.h) turns the serial token chain into a table of
 //       sequence records {output position, literal source, literal length, offset} in the
 //       workgroup's scratch, applying every format rule on the way: a malformed block is rejected
-//       before a byte of output is written.
+//       before a byte of output is written.  A block that comes with an ENTRY-POINT TABLE
+//       (include/lz4amd.h: rows that name every few sequences of the chain, written by
+//       lz4amd_k_compress or anybody else) skips this stage: see PARSER below.
 //
 //   B STREAM     a dataflow pipeline through LDS rings and counters only - no workgroup barrier
 //       between the first and the last byte of the block:
-//       MOVER (wave 15)  moves everything the copy reads into LDS and does nothing else: the
-//           compressed block -> a 32 KB ring (coalesced 16-byte loads, 4 KB a trip), the record
-//           table -> a 2048-row ring (256 rows a trip), the pre-parse's region index (for every
-//           1 KB REGION of output the record that holds its first byte) -> a 512-entry ring; the
-//           next batch of each is in flight while the copy works; as far ahead as the rings allow.
-//       COPY (waves 0-14)  output-stationary: regions are handed out in order to whichever wave is free.  A region is
-//           composed in its slot of a 80 KB LDS ring that always holds the 64 KB LZ4 window, from
-//           PIECES (the literal run or the match of a record, cut at 16-byte chunk borders) in two
-//           lane-uniform rounds: round A, lane = chunk, writes the piece that covers the chunk's
+//       MOVER (wave 15)  moves everything the others read into LDS by LDS-DMA (global_load_lds_dwordx4:
+//           1 KB per instruction, no registers in between, up to 16 KB in flight) and does nothing
+//           else: the compressed block -> a 32 KB ring, in the aligned 16-byte granules of its memory;
+//           without a table the record table -> a 2048-row ring and the pre-parse's region index (for
+//           every 1 KB REGION of output the record that holds its first byte) -> a 512-entry ring; with
+//           a table its rows -> a 256-row ring.  It also moves the first-open-region word over the
+//           complete marks of the regions in flight.
+//       PARSER (waves 12-14, blocks with a table)  claim batches of rows under a lock, walk them - lane =
+//           row, every lane the sequences up to the next row, out of the compressed ring, with the
+//           pre-parse's rules - write records and region index straight into the rings and publish in
+//           claim order: a row is trusted only because the lane before it arrived exactly there.
+//       COPY (the other waves)  output-stationary: regions are handed out in order to whichever wave is
+//           free.  A region is composed in its slot of a 80 KB LDS ring that always holds the 64 KB LZ4
+//           window, from PIECES (the literal run or the match of a record, cut at 16-byte chunk borders)
+//           in two lane-uniform rounds: round A, lane = chunk, writes the piece that covers the chunk's
 //           first byte; round B, lane = piece, ORs in the head of every piece that starts inside a
 //           chunk.  Literals are unaligned 16-byte reads from the compressed ring, matches from
-//           the output ring (a match that overlaps itself reads any earlier period - the farthest
-//           the window holds - so long runs do not serialise and never read a recycled slot).
-//           Sources still in flight on another wave are waited for through per-chunk done bits;
-//           finished regions go to HBM with one 16-byte store per lane (1 KB contiguous per wave).
+//           the output ring (a match that overlaps itself reads an earlier period, far back, so long
+//           runs do not serialise and never read a recycled slot).  Whether a source is final says one
+//           byte per 16-byte chunk of the output ring: the tag of the ring lap whose bytes are final
+//           there; a piece whose source is not is retried after the others.  Finished regions go to HBM
+//           with one 16-byte store per lane (1 KB contiguous per wave).
 //
-// HBM/L2 traffic per block: compressed bytes read by the pre-parse and once more by the mover,
-// the record table written and read once (16 B per sequence) and the region index (4 B per KB of
-// output), output written once; matches and
-// literals never touch HBM during the copy.  No MFMA: byte moves.
+// HBM/L2 traffic per block: without a table the compressed bytes are read by the pre-parse and once more
+// by the mover, the record table is written and read once (16 B per sequence) and so are the token list
+// and the region index; with a table the compressed bytes and the table (~3 % of the output) are read
+// once, nothing is written but the output.  Matches and literals never touch HBM during the copy.
+// No MFMA: byte moves.
 #pragma once
 #include "lz4_common.h"
 #include "../lz4amd_params.h"

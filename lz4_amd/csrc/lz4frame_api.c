@@ -66,8 +66,44 @@ static unsigned optimal_bsid(unsigned requested, size_t srcSize)
 }
 
 /* ---------------------------------------------------------------- device helpers */
+/* Device staging and a stream per calling THREAD (the reference's frame functions are re-entrant; its CLI compresses and
+ * decodes with -T4 workers): no lock is held while a frame's blocks are uploaded, coded and downloaded - the frames of
+ * different threads overlap on the device.  (Rounds 1-3 kept one staging area behind the library's lock.) */
 typedef struct { void* in; size_t in_cap; void* out; size_t out_cap; void* pack; size_t pack_cap; } dev_stage;
-static dev_stage g_stage;                           /* guarded by lz4amd_default_lock */
+typedef struct { dev_stage st; void* stream; } frame_tls;
+static pthread_key_t g_ftls_key;
+static pthread_once_t g_ftls_once = PTHREAD_ONCE_INIT;
+static void ftls_free(void* v)
+{
+    frame_tls* t = (frame_tls*)v;
+    if (!t) return;
+    lz4amd_hip_free(t->st.in); lz4amd_hip_free(t->st.out); lz4amd_hip_free(t->st.pack);
+    lz4amd_hip_stream_destroy(t->stream);
+    free(t);
+}
+static void ftls_key_init(void) { (void)pthread_key_create(&g_ftls_key, ftls_free); }
+static frame_tls* ftls_get(void)
+{   /* (after the default context exists: the stream belongs to its device) */
+    frame_tls* t;
+    pthread_once(&g_ftls_once, ftls_key_init);
+    t = (frame_tls*)pthread_getspecific(g_ftls_key);
+    if (!t) {
+        t = (frame_tls*)calloc(1, sizeof *t);
+        if (!t) return NULL;
+        t->stream = lz4amd_hip_stream_create();
+        if (!t->stream || pthread_setspecific(g_ftls_key, t)) { ftls_free(t); return NULL; }
+    }
+    return t;
+}
+static lz4amd_ctx* frame_ctx(void)
+{
+    lz4amd_ctx* c;
+    pthread_mutex_lock(&lz4amd_default_lock);       /* (only the first call creates the context) */
+    c = lz4amd_default_ctx();
+    pthread_mutex_unlock(&lz4amd_default_lock);
+    if (c && lz4amd_hip_use_device(c->device)) return NULL;
+    return c;
+}
 static int stage_fit(void** buf, size_t* cap, size_t need)
 {
     if (need <= *cap) return 0;
@@ -105,6 +141,7 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     size_t bs, nb, stride, i, result = ERR(GENERIC);
     unsigned bsid;
     lz4amd_ctx* ctx;
+    frame_tls* ts; dev_stage* S; void* strm;
     lz4amd_plan *cplan = NULL, *xplan = NULL, *gplan = NULL;
     const void** d_src = NULL; void** d_dst = NULL; int *sizes = NULL, *caps = NULL, *csz = NULL, *sums = NULL, *pres = NULL;
     uint32_t content_sum = 0;
@@ -146,15 +183,16 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     csz = (int*)malloc(nb * sizeof *csz); sums = (int*)malloc(nb * sizeof *sums); pres = (int*)malloc(nb * sizeof *pres);
     if (!d_src || !d_dst || !sizes || !caps || !csz || !sums || !pres) { result = ERR(allocation_failed); goto done_unlocked; }
 
-    pthread_mutex_lock(&lz4amd_default_lock);
-    ctx = lz4amd_default_ctx();
-    if (!ctx) goto done;
-    if (stage_fit(&g_stage.in, &g_stage.in_cap, srcSize + 64) || stage_fit(&g_stage.out, &g_stage.out_cap, nb * stride)) { result = ERR(allocation_failed); goto done; }
-    if (lz4amd_hip_h2d(g_stage.in, src, srcSize, NULL)) goto done;
+    ctx = frame_ctx();
+    ts = ctx ? ftls_get() : NULL;
+    if (!ts) goto done;
+    S = &ts->st; strm = ts->stream;
+    if (stage_fit(&S->in, &S->in_cap, srcSize + 64) || stage_fit(&S->out, &S->out_cap, nb * stride)) { result = ERR(allocation_failed); goto done; }
+    if (lz4amd_hip_h2d(S->in, src, srcSize, strm)) goto done;
     for (i = 0; i < nb; i++) {
         const size_t chunk = (i + 1 < nb) ? bs : srcSize - i * bs;
-        d_src[i] = (const char*)g_stage.in + i * bs; sizes[i] = (int)chunk;
-        d_dst[i] = (char*)g_stage.out + i * stride; caps[i] = (int)chunk - 1;      /* lz4frame.c:891-899: must gain a byte */
+        d_src[i] = (const char*)S->in + i * bs; sizes[i] = (int)chunk;
+        d_dst[i] = (char*)S->out + i * stride; caps[i] = (int)chunk - 1;      /* lz4frame.c:891-899: must gain a byte */
         if (caps[i] < 1) caps[i] = 1;
         pres[i] = linked ? (int)(i * bs < 65536 ? i * bs : 65536) : 0;     /* the history is the source itself */
     }
@@ -165,13 +203,13 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     } else
     if (lz4amd_plan_create_compress_prefix(ctx, &cplan, (int)nb, d_src, sizes, d_dst, caps, linked ? pres : NULL)) goto done;
     if (p.compressionLevel < 0) (void)lz4amd_plan_set_acceleration(cplan, -p.compressionLevel + 1);      /* lz4frame.c:924-927: negative levels are accelerations */
-    if (lz4amd_plan_launch(cplan, NULL)) goto done;
-    if (lz4amd_plan_results(cplan, csz, NULL)) goto done;
+    if (lz4amd_plan_launch(cplan, strm)) goto done;
+    if (lz4amd_plan_results(cplan, csz, strm)) goto done;
     for (i = 0; i < nb; i++) if (csz[i] <= 0 || csz[i] >= sizes[i]) csz[i] = 0;   /* stored raw */
     if (p.frameInfo.blockChecksumFlag) {          /* lz4frame.c:904: XXH32 of the block as stored */
         for (i = 0; i < nb; i++) { if (csz[i]) { d_src[i] = d_dst[i]; caps[i] = csz[i]; } else caps[i] = sizes[i]; }
         if (lz4amd_plan_create(ctx, &xplan, LZ4AMD_OP_XXH32, (int)nb, d_src, caps, NULL, NULL, 0)) goto done;
-        if (lz4amd_plan_launch(xplan, NULL) || lz4amd_plan_results(xplan, sums, NULL)) goto done;
+        if (lz4amd_plan_launch(xplan, strm) || lz4amd_plan_results(xplan, sums, strm)) goto done;
     }
     {   /* The blocks sit in bound-sized slots; their sizes say where each goes in the frame (lz4frame.c:883-914 appends
          * them one behind the other).  One gather launch packs them on the device - stored blocks straight from the
@@ -181,29 +219,27 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
         size_t total = 0;
         for (i = 0; i < nb; i++) {
             const size_t n = csz[i] ? (size_t)csz[i] : (size_t)sizes[i];
-            d_src[i] = csz[i] ? (const char*)g_stage.out + i * stride : (const char*)g_stage.in + i * bs;
+            d_src[i] = csz[i] ? (const char*)S->out + i * stride : (const char*)S->in + i * bs;
             caps[i] = (int)n;                                   /* rows: (source, size) -> body offset + 4 */
             pres[i] = (int)n;
             total += 4 + n + tailsz;
         }
-        if (stage_fit(&g_stage.pack, &g_stage.pack_cap, total + 64)) { result = ERR(allocation_failed); goto done; }
+        if (stage_fit(&S->pack, &S->pack_cap, total + 64)) { result = ERR(allocation_failed); goto done; }
         {   size_t off = 0;
-            for (i = 0; i < nb; i++) { d_dst[i] = (char*)g_stage.pack + off + 4; off += 4 + (size_t)caps[i] + tailsz; }
+            for (i = 0; i < nb; i++) { d_dst[i] = (char*)S->pack + off + 4; off += 4 + (size_t)caps[i] + tailsz; }
         }
-        if (lz4amd_plan_create(ctx, &gplan, LZ4AMD_OP_GATHER, (int)nb, d_src, caps, d_dst, pres, 0) || lz4amd_plan_launch(gplan, NULL)) goto done;
-        if (lz4amd_hip_d2h(op, g_stage.pack, total, NULL) || lz4amd_hip_sync(NULL)) goto done;
+        if (lz4amd_plan_create(ctx, &gplan, LZ4AMD_OP_GATHER, (int)nb, d_src, caps, d_dst, pres, 0) || lz4amd_plan_launch(gplan, strm)) goto done;
+        if (lz4amd_hip_d2h(op, S->pack, total, strm) || lz4amd_hip_sync(strm)) goto done;
         for (i = 0; i < nb; i++) {
             const uint32_t n = (uint32_t)caps[i];
             wr32(op, csz[i] ? n : (n | 0x80000000u)); op += 4 + n;          /* lz4frame.c:896-903 */
             if (tailsz) { wr32(op, (uint32_t)sums[i]); op += 4; }           /* lz4frame.c:904-908 */
         }
     }
-    if (lz4amd_hip_sync(NULL)) goto done;
-    pthread_mutex_unlock(&lz4amd_default_lock);
+    if (lz4amd_hip_sync(strm)) goto done;
     lz4amd_plan_destroy(cplan); lz4amd_plan_destroy(xplan); lz4amd_plan_destroy(gplan); cplan = xplan = gplan = NULL;
     goto finish_frame_free;
 done:
-    pthread_mutex_unlock(&lz4amd_default_lock);
 done_unlocked:
     if (hashing) pthread_join(hthread, NULL);
     lz4amd_plan_destroy(cplan); lz4amd_plan_destroy(xplan); lz4amd_plan_destroy(gplan);
@@ -392,6 +428,7 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
     const int linked = d->info.blockMode == LZ4F_blockLinked;
     const size_t h0 = linked ? d->hist_len : 0;
     lz4amd_ctx* ctx;
+    frame_tls* ts; dev_stage* S; void* strm;
     lz4amd_plan *dplan = NULL, *xplan = NULL;
     const void** d_src = NULL; void** d_dst = NULL; int *sizes = NULL, *caps = NULL, *res = NULL, *sums = NULL, *prefix = NULL;
     size_t* in_off = NULL; uint8_t* raw = NULL;
@@ -422,16 +459,17 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         }
     }
 
-    pthread_mutex_lock(&lz4amd_default_lock);
-    ctx = lz4amd_default_ctx();
-    if (!ctx) goto done;
-    if (stage_fit(&g_stage.in, &g_stage.in_cap, end + 64) || stage_fit(&g_stage.out, &g_stage.out_cap, h0 + nb * d->block_max + 64)) { result = ERR(allocation_failed); goto done; }
-    if (lz4amd_hip_h2d(g_stage.in, base, end, NULL)) goto done;
+    ctx = frame_ctx();
+    ts = ctx ? ftls_get() : NULL;
+    if (!ts) goto done;
+    S = &ts->st; strm = ts->stream;
+    if (stage_fit(&S->in, &S->in_cap, end + 64) || stage_fit(&S->out, &S->out_cap, h0 + nb * d->block_max + 64)) { result = ERR(allocation_failed); goto done; }
+    if (lz4amd_hip_h2d(S->in, base, end, strm)) goto done;
     /* block checksums: XXH32 of every block as stored (lz4frame.c:1878), one launch */
     if (bchk && !skip_checksums) {
-        for (i = 0; i < nb; i++) d_src[i] = (const char*)g_stage.in + in_off[i];
+        for (i = 0; i < nb; i++) d_src[i] = (const char*)S->in + in_off[i];
         if (lz4amd_plan_create(ctx, &xplan, LZ4AMD_OP_XXH32, (int)nb, d_src, sizes, NULL, NULL, 0)) goto done;
-        if (lz4amd_plan_launch(xplan, NULL) || lz4amd_plan_results(xplan, sums, NULL)) goto done;
+        if (lz4amd_plan_launch(xplan, strm) || lz4amd_plan_results(xplan, sums, strm)) goto done;
         for (i = 0; i < nb; i++) if ((uint32_t)sums[i] != rd32(base + in_off[i] + (size_t)sizes[i])) { result = ERR(blockChecksum_invalid); goto done; }
     }
     if (linked) {
@@ -440,15 +478,15 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         size_t o = h0;
         unsigned char* st = (unsigned char*)malloc(nb);
         if (!st) { result = ERR(allocation_failed); goto done; }
-        if (h0 && lz4amd_hip_h2d(g_stage.out, d->hist, h0, NULL)) { free(st); goto done; }
+        if (h0 && lz4amd_hip_h2d(S->out, d->hist, h0, strm)) { free(st); goto done; }
         for (i = 0; i < nb; i++) {
-            d_src[i] = (const char*)g_stage.in + in_off[i]; caps[i] = (int)d->block_max; st[i] = raw[i];
+            d_src[i] = (const char*)S->in + in_off[i]; caps[i] = (int)d->block_max; st[i] = raw[i];
             if (raw[i] && (size_t)sizes[i] > d->block_max) { free(st); result = ERR(decompressionFailed); goto done; }
         }
         /* one launch for the whole batch: every workgroup pre-parses its block at once, only the copy stages run one after
          * the other (lz4amd_plan_create_decompress_chained); stored blocks are copied in place by the same launch */
-        if (lz4amd_plan_create_decompress_chained(ctx, &dplan, (int)nb, d_src, sizes, (char*)g_stage.out + h0, caps, st, (int)h0)
-            || lz4amd_plan_launch(dplan, NULL) || lz4amd_plan_results(dplan, res, NULL)) { free(st); goto done; }
+        if (lz4amd_plan_create_decompress_chained(ctx, &dplan, (int)nb, d_src, sizes, (char*)S->out + h0, caps, st, (int)h0)
+            || lz4amd_plan_launch(dplan, strm) || lz4amd_plan_results(dplan, res, strm)) { free(st); goto done; }
         free(st);
         for (i = 0; i < nb; i++) {
             if (res[i] < 0) {
@@ -464,20 +502,20 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
              * (one upload, one gather launch), the decoder's prefix mode does the rest */
             lz4amd_plan* cp = NULL;
             int* dls = (int*)malloc(nb * sizeof *dls);
-            int ok = dls != NULL && !stage_fit(&g_stage.out, &g_stage.out_cap, nb * slot + 64) && !stage_fit(&g_stage.pack, &g_stage.pack_cap, dl + 64)
-                     && !lz4amd_hip_h2d(g_stage.pack, d->dict, dl, NULL);
-            for (i = 0; ok && i < nb; i++) { d_src[i] = g_stage.pack; dls[i] = (int)dl; d_dst[i] = (char*)g_stage.out + i * slot + (65536 - dl); }
-            ok = ok && !lz4amd_plan_create(ctx, &cp, LZ4AMD_OP_GATHER, (int)nb, d_src, dls, d_dst, dls, 0) && !lz4amd_plan_launch(cp, NULL);
+            int ok = dls != NULL && !stage_fit(&S->out, &S->out_cap, nb * slot + 64) && !stage_fit(&S->pack, &S->pack_cap, dl + 64)
+                     && !lz4amd_hip_h2d(S->pack, d->dict, dl, strm);
+            for (i = 0; ok && i < nb; i++) { d_src[i] = S->pack; dls[i] = (int)dl; d_dst[i] = (char*)S->out + i * slot + (65536 - dl); }
+            ok = ok && !lz4amd_plan_create(ctx, &cp, LZ4AMD_OP_GATHER, (int)nb, d_src, dls, d_dst, dls, 0) && !lz4amd_plan_launch(cp, strm);
             lz4amd_plan_destroy(cp); free(dls);
             if (!ok) { result = ERR(allocation_failed); goto done; }
         }
         for (i = 0; i < nb; i++) {
-            d_dst[i] = (char*)g_stage.out + i * slot + (dl ? 65536 : 0);
+            d_dst[i] = (char*)S->out + i * slot + (dl ? 65536 : 0);
             if (raw[i]) {
                 if ((size_t)sizes[i] > d->block_max) { result = ERR(decompressionFailed); goto done; }
                 res[i] = sizes[i];
             } else {
-                d_src[ncomp] = (const char*)g_stage.in + in_off[i]; caps[ncomp] = (int)d->block_max;
+                d_src[ncomp] = (const char*)S->in + in_off[i]; caps[ncomp] = (int)d->block_max;
                 sums[ncomp] = sizes[i]; prefix[ncomp] = (int)i; ncomp++;
             }
         }
@@ -488,7 +526,7 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
             for (i = 0; dl && i < ncomp; i++) rr[i] = (int)dl;              /* (prefix lengths; rr[] takes the results afterwards) */
             if ((dl ? lz4amd_plan_create_prefix(ctx, &dplan, (int)ncomp, d_src, sums, dd, caps, rr)
                     : lz4amd_plan_create(ctx, &dplan, LZ4AMD_OP_DECOMPRESS, (int)ncomp, d_src, sums, dd, caps, 0)) ||
-                lz4amd_plan_launch(dplan, NULL) || lz4amd_plan_results(dplan, rr, NULL)) { free(dd); free(rr); goto done; }
+                lz4amd_plan_launch(dplan, strm) || lz4amd_plan_results(dplan, rr, strm)) { free(dd); free(rr); goto done; }
             for (i = 0; i < ncomp; i++) {
                 if (rr[i] < 0) { free(dd); free(rr); result = ERR(decompressionFailed); goto done; }
                 res[prefix[i]] = rr[i];
@@ -498,7 +536,7 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         for (i = 0; i < nb; i++) out_total += (size_t)res[i];
     }
     if (grow(&d->out, &d->out_cap, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done; }
-    if (linked) { if (out_total && lz4amd_hip_d2h(d->out, (char*)g_stage.out + h0, out_total, NULL)) goto done; }
+    if (linked) { if (out_total && lz4amd_hip_d2h(d->out, (char*)S->out + h0, out_total, strm)) goto done; }
     else {
         /* every block but the last is normally full, so the block_max-strided slots ARE the content: one transfer
          * (stored blocks are then laid over their slots from the input); ragged tables go block by block */
@@ -506,15 +544,14 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         int dense = 1;
         if (d->dict_len) dense = 0;                  /* (the slots are 64 KB apart then) */
         for (i = 0; i + 1 < nb; i++) if ((size_t)res[i] != d->block_max) { dense = 0; break; }
-        if (dense && out_total && lz4amd_hip_d2h(d->out, g_stage.out, out_total, NULL)) goto done;
+        if (dense && out_total && lz4amd_hip_d2h(d->out, S->out, out_total, strm)) goto done;
         for (i = 0; i < nb; i++) {
             if (raw[i]) memcpy(d->out + o, base + in_off[i], (size_t)res[i]);
-            else if (!dense && lz4amd_hip_d2h(d->out + o, d_dst[i], (size_t)res[i], NULL)) goto done;
+            else if (!dense && lz4amd_hip_d2h(d->out + o, d_dst[i], (size_t)res[i], strm)) goto done;
             o += (size_t)res[i];
         }
     }
-    if (lz4amd_hip_sync(NULL)) goto done;
-    pthread_mutex_unlock(&lz4amd_default_lock);
+    if (lz4amd_hip_sync(strm)) goto done;
 host_tail:
     d->out_size = out_total; d->total_out += out_total;
     if (d->info.contentChecksumFlag && !skip_checksums) {                   /* lz4frame.c:1896, 1967 */
@@ -535,7 +572,6 @@ host_tail:
     result = 0;
     goto done_unlocked;
 done:
-    pthread_mutex_unlock(&lz4amd_default_lock);
 done_unlocked:
     lz4amd_plan_destroy(dplan); lz4amd_plan_destroy(xplan);
     free(d_src); free(d_dst); free(sizes); free(caps); free(res); free(sums); free(prefix); free(in_off); free(raw);

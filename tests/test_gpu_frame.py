@@ -389,3 +389,32 @@ def test_a_dictionary_counts_for_one_frame_and_after_get_frame_info(L, datagen, 
     assert run(d, frame, True) == body
     assert run(d, plain, False) == body
     L.LZ4F_freeDecompressionContext(d)
+
+
+def test_frames_from_many_threads_at_once(L, oracle, datagen):
+    """The frame entry points keep their device staging and stream per calling thread (csrc/lz4frame_api.c): eight threads compress
+    and decode different frames at the same time - linked and independent blocks, with and without checksums - and every
+    frame is what it is when made alone."""
+    import threading
+    kws = [dict(blockSizeID=4), dict(blockSizeID=5, blockMode=1, contentChecksumFlag=1), dict(blockSizeID=4, blockChecksumFlag=1), dict(blockSizeID=6, contentChecksumFlag=1)]
+    jobs = [(datagen(700000 + 100000 * k, 60, 30 + k), kws[k % 4]) for k in range(8)]
+    alone = [compress_frame(L, d, **kw) for d, kw in jobs]
+    errs, frames = [], [None] * len(jobs)
+
+    def work(k):
+        try:
+            d, kw = jobs[k]
+            for _ in range(3):
+                f = compress_frame(L, d, **kw)
+                out, used = decompress_frame(L, f, len(d))
+                assert out == d and used == len(f)
+            frames[k] = f
+        except Exception as e:                                        # noqa: BLE001
+            errs.append((k, repr(e)))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert frames == alone
