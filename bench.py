@@ -587,6 +587,7 @@ def main():
     ap.add_argument("--no-hc", action="store_true", help="skip the LZ4_compress_HC (configs[3]) side measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the 2048-block shape and the configs[2] frame object")
     ap.add_argument("--no-data-path", action="store_true", help="N>1: skip the RCCL scatter / gather measurement")
+    ap.add_argument("--no-foreign", action="store_true", help="skip the decode of the same blocks without tables and of reference-compressed blocks (profiling runs: the decompress kernel's average then is the step's)")
     ap.add_argument("--no-hints", action="store_true",
                     help="do not pass the compressor's entry-point tables to the decoder (include/lz4amd.h): every block is decoded the way a foreign block is")
     args = ap.parse_args()
@@ -698,7 +699,7 @@ def main():
     # ---- not part of the step: the same blocks decoded WITHOUT their tables (what a block of foreign origin costs: the
     #      decoder first discovers the token chain), and blocks the reference compressor made (oracle/_ref, on the host)
     foreign = {}
-    if rank == 0:
+    if rank == 0 and not args.no_foreign:
         fplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
         out.zero_()
         fplan.launch(stream)

@@ -26,7 +26,7 @@
 //           every 1 KB REGION of output the record that holds its first byte) -> a 512-entry ring; with
 //           a table its rows -> a 256-row ring.  It also moves the first-open-region word over the
 //           complete marks of the regions in flight.
-//       PARSER (waves 12-14, blocks with a table)  claim batches of rows under a lock, walk them - lane =
+//       PARSER (waves 13-14, blocks with a table)  claim batches of rows under a lock, walk them - lane =
 //           row, every lane the sequences up to the next row, out of the compressed ring, with the
 //           pre-parse's rules - write records and region index straight into the rings and publish in
 //           claim order: a row is trusted only because the lane before it arrived exactly there.
@@ -480,10 +480,13 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
 // kParsers waves parse side by side.  A wave CLAIMS the next batch of rows under a lock (as many rows as are resident and
 // fit the rings, one per lane), walks it, and PUBLISHES it when every earlier batch is published (a ticket per claim):
 // publication in order is what makes the induction work - a batch's first row is true because the batch before arrived
-// at it.  A wave's walk is a chain of dependent steps of ~1000 cycles that leaves its SIMD nearly idle: three of them
-// cost the copy waves little and triple what the parser delivers (one wave alone set the decoder's pace).
+// at it.  A wave's walk is a chain of dependent steps of ~1000 cycles each (its SIMD's VALU is kept busy by the copy waves
+// it shares it with: an instruction of the lone walker waits for theirs).  Measured on 256 x 4 MiB with the compressor's
+// tables (rows of at most 8 sequences): two parser waves 1.18 / 1.47 / 1.54 ms per GiB at P60 / P90 / P20, three 1.22 /
+// 1.54 / 1.50, four 1.24 / 1.61 / 1.55: the decoder is bound by VALU issue, and a third walker's instructions cost the
+// twelve copy waves more than its rows bring.
 #ifndef LZ4AMD_PARSERS
-#define LZ4AMD_PARSERS 3
+#define LZ4AMD_PARSERS 2
 #endif
 enum : uint32_t { kParsers = LZ4AMD_PARSERS, kFirstParseWave = kDecWaves - 1 - kParsers };
 enum : uint32_t { P_LOCK = 16, P_NEXT, P_RZ, P_TICKET, P_TURN, P_ICARRY };      // shared words of the parser waves (misc[])
