@@ -109,8 +109,8 @@ int  lz4amd_plan_attach_hints(lz4amd_plan* plan, void* d_hints, size_t stride);
  * rejected (those blocks were decoded without); synchronises the device */
 int  lz4amd_plan_hint_stats(lz4amd_plan* plan, unsigned* used, unsigned* rejected);
 /* LZ4_compress_fast's `acceleration` (lz4.h:236, lz4.c:1382-1400) for the blocks of a LZ4AMD_OP_COMPRESS plan: 1 = default
- * (every second position of a block of 64 KB or more is probed), 2 and above = every fourth position: faster, larger
- * output; clamped to 65537 like the reference (lz4.c:1386-1387). */
+ * (every second position of a block of 64 KB or more is probed), 2 and above = every fourth position: larger output, faster on
+ * highly compressible data; clamped to 65537 like the reference (lz4.c:1386-1387). */
 int  lz4amd_plan_set_acceleration(lz4amd_plan* plan, int acceleration);
 void lz4amd_plan_destroy(lz4amd_plan* plan);
 /* enqueue the whole table on `stream` (asynchronous) */
