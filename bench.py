@@ -319,7 +319,7 @@ def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, copy_gbps, level
     return res
 
 
-def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps):
+def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps, use_hints=True):
     """The per-GPU shape of configs[4]: 2048 x 4 MiB blocks (the GiB eight times over), blocks queue on the CUs."""
     reps = (2048 * bs) // data.numel()
     big = data.repeat(reps)
@@ -330,17 +330,22 @@ def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps):
     ctab = lz4_amd.BlockTable([big.data_ptr() + i * bs for i in range(nb)], [bs] * nb,
                               [comp.data_ptr() + i * stride for i in range(nb)], [stride] * nb)
     cplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, ctab)
+    hints = torch.zeros((nb, lz4_amd.hint_bytes(bs)), dtype=torch.uint8, device=data.device) if use_hints else None
+    if hints is not None:
+        cplan.attach_hints(hints.data_ptr(), hints.stride(0))
     cplan.launch(stream)
     cs = cplan.results(stream)
     dtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nb)], cs,
                               [out.data_ptr() + i * bs for i in range(nb)], [bs] * nb)
     dplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+    if hints is not None:
+        dplan.attach_hints(hints.data_ptr(), hints.stride(0))
     dplan.launch(stream)
     assert dplan.results(stream) == [bs] * nb and torch.equal(out, big), "2048-block round trip is not bit exact"
     cms = min(cplan.launch_timed(stream)[0][0] for _ in range(2))
     dms = min(dplan.launch_timed(stream)[0][0] for _ in range(3))
     U, C = big.numel(), sum(cs)
-    return {"workload": "configs[4] per-GPU shape: %d independent %d-byte blocks (%.0f GiB: the GiB of configs[1] x %d), device resident" % (nb, bs, U / 2**30, reps),
+    return {"workload": "configs[4] per-GPU shape: %d independent %d-byte blocks (%.0f GiB: the GiB of configs[1] x %d), device resident%s" % (nb, bs, U / 2**30, reps, ", entry-point tables as in the step" if use_hints else ""),
             "compress_GBps": round(U / (cms * 1e-3) / 1e9, 2), "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 2),
             "roundtrip_GBps": round(U / ((cms + dms) * 1e-3) / 1e9, 2),
             "roofline_compress": roofline_obj("compress", cms, U + C, copy_gbps, None),
@@ -869,7 +874,7 @@ def main():
         foreign.pop("_ref_ratio", None)
         if world == 1 and not args.no_extras and nb == 256 and bs == 4 << 20:
             try:
-                result["shape_2048"] = bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps)
+                result["shape_2048"] = bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps, hints is not None)
             except Exception as e:
                 result["shape_2048"] = {"error": str(e)}
             try:
