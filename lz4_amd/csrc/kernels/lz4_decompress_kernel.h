@@ -920,9 +920,20 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                     if (!hard && !later) {
                         pendBc = left0 ? chunks_of(left0, packB0 >> 9) : 0;
                         if (!(doneA | doneB)) {
-                            // (nothing came in: the sources are a region or more away from being final - a poll costs ~80 instructions of
-                            //  the SIMD the other waves need; after two short naps the naps get long)
-                            if (++idle_polls > 2) spin_pause_long(); else spin_pause();
+                            // Nothing came in: the sources belong to regions other waves are still composing.  A poll of the chunk
+                            // flags costs ~80 instructions of a SIMD the other waves need; instead the wave sleeps on ONE word - the
+                            // complete mark of the highest region below its own that a waiting piece reads from (a region's chunks
+                            // are flagged before its mark is set; its slot is not recycled while this region is open) - and looks at
+                            // the flags again when that region is done.  Pieces that read from this region's own chunks follow
+                            // from the ones they wait for.
+                            uint32_t wr = 0;                                  // (region + 1)
+                            if (sa_ && !rdyA) { const uint32_t r = (keyA + an - 1) >> kRegionShift; wr = r < C.R ? r + 1 : 0u; }
+                            if (sb_ && !rdyB) { const uint32_t r = (keyB0 + ((packB0 >> 4) & 31u) - 1) >> kRegionShift; if (r < C.R && r + 1 > wr) wr = r + 1; }
+                            wr = wave_readlane(wave_incl_max_u32(wr), 63);
+                            if (wr) {
+                                const uint32_t* mark = (const uint32_t*)(smem + kOffRegDone) + (wr - 1) % kSlots;
+                                while (uload(mark) != wr) { if (uload(&misc[M_ABORT])) return; spin_pause(); }
+                            } else { if (++idle_polls > 2) spin_pause_long(); else spin_pause(); }
                             if (uload(&misc[M_ABORT])) return;
                         } else idle_polls = 0;
                         continue;
