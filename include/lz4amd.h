@@ -108,6 +108,12 @@ int  lz4amd_plan_attach_hints(lz4amd_plan* plan, void* d_hints, size_t stride);
 /* a decompress plan's count, since the tables were attached, of blocks decoded from their table and of tables that were
  * rejected (those blocks were decoded without); synchronises the device */
 int  lz4amd_plan_hint_stats(lz4amd_plan* plan, unsigned* used, unsigned* rejected);
+/* Tables for blocks of foreign origin (reference-compressed, out of a frame ...): with `on`, a decompress plan that has tables
+ * attached writes the table of every block whose table is missing or unusable while it decodes the block the ordinary way (the
+ * decoder's first stage knows every token then); the next launch - or any later plan over the same blocks and tables - parses
+ * from it.  The hints memory must be writable.  lz4amd_plan_hints_made: tables written since they were attached. */
+int  lz4amd_plan_make_hints(lz4amd_plan* plan, int on);
+int  lz4amd_plan_hints_made(lz4amd_plan* plan, unsigned* made);
 /* LZ4_compress_fast's `acceleration` (lz4.h:236, lz4.c:1382-1400) for the blocks of a LZ4AMD_OP_COMPRESS plan: 1 = default
  * (every second position of a block of 64 KB or more is probed), 2 and above = every fourth position: larger output, faster on
  * highly compressible data; clamped to 65537 like the reference (lz4.c:1386-1387). */

@@ -58,6 +58,8 @@ def lib():
     L.lz4amd_plan_attach_hints.argtypes = [vp, vp, ctypes.c_size_t]
     L.lz4amd_plan_hint_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
     L.lz4amd_plan_set_acceleration.argtypes = [vp, i]
+    L.lz4amd_plan_make_hints.argtypes = [vp, i]
+    L.lz4amd_plan_hints_made.argtypes = [vp, ctypes.POINTER(ctypes.c_uint)]
     _LIB = L
     return L
 
@@ -146,6 +148,15 @@ class Plan:
         u, r = ctypes.c_uint(), ctypes.c_uint()
         _check(lib().lz4amd_plan_hint_stats(self._h, ctypes.byref(u), ctypes.byref(r)), "lz4amd_plan_hint_stats")
         return u.value, r.value
+
+    def make_hints(self, on=True):
+        """Decompress plan with tables attached: blocks without a usable table get theirs written while they are decoded."""
+        _check(lib().lz4amd_plan_make_hints(self._h, 1 if on else 0), "lz4amd_plan_make_hints")
+
+    def hints_made(self):
+        m = ctypes.c_uint()
+        _check(lib().lz4amd_plan_hints_made(self._h, ctypes.byref(m)), "lz4amd_plan_hints_made")
+        return m.value
 
     def set_acceleration(self, acceleration):
         _check(lib().lz4amd_plan_set_acceleration(self._h, int(acceleration)), "lz4amd_plan_set_acceleration")

@@ -1158,8 +1158,16 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
             hint = hp; total = h[1]; nseq = h[3]; nrows = e0[3];
         }
     }
-    // ---- stage A: the record table (a malformed block ends here, nothing written)
-    if (!hint && ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx)) {
+    // ---- stage A: the record table (a malformed block ends here, nothing written).  On request it also writes the block's
+    //      entry-point table, for the next decode of the same block.
+    lz4amd_gdst make = nullptr;
+    uint32_t make_rows = 0;
+    if (!hint && ok && !stored && !chained && P.hint_make && P.hints && P.hint_stride >= 48) {
+        make = LZ4AMD_TO_GDST((uint8_t*)P.hints + (uint64_t)b * P.hint_stride);
+        make_rows = (uint32_t)(P.hint_stride / 16 - 2);
+        if (tid == 0) *(uint32_t*)make = 0;                      // (no table until it is whole)
+    }
+    if (!hint && ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx, make, make_rows)) {
         if (!chained) { if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]); return true; }
         ok = false;
     }
@@ -1195,6 +1203,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         return false;
     }
     if (hint && tid == 0 && P.hint_stats) atomicAdd(&P.hint_stats[0], 1u);
+    if (make && tid == 0 && P.hint_stats) atomicAdd(&P.hint_stats[2], 1u);       // (a block that had more rows than room is counted too: its table stays invalid)
 
     __syncthreads();
     if (tid == 0) {

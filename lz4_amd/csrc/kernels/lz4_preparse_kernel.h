@@ -25,6 +25,7 @@
 // A malformed block is rejected here, before a byte of output is written.
 #pragma once
 #include "lz4_common.h"
+#include "../lz4amd_params.h"
 
 namespace lz4amd { namespace pre {
 
@@ -54,7 +55,7 @@ enum : uint32_t {
     kPreLdsBytes = kOffBitmap + kSpanMax / 8,
 };
 static_assert(kPreLdsBytes <= 152u * 1024u, "LDS budget");
-enum : uint32_t { M_ERR = 1, M_MINREF = 2, M_TERM = 8, M_NX, M_OBASE, M_NREC, M_RC };   // M_MINREF: lowest (biased) position any match reads
+enum : uint32_t { M_ERR = 1, M_MINREF = 2, M_TERM = 8, M_NX, M_OBASE, M_NREC, M_RC, M_HOVER, M_HROWS };     // M_HOVER / M_HROWS: entry-point table being made: a row did not fit / rows so far   // M_MINREF: lowest (biased) position any match reads
 
 // scratch of one workgroup: the record table (every sequence but the last takes >= 3 stream bytes; +1 last, +1 sentinel)
 // followed by the token list of one span
@@ -258,9 +259,17 @@ __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_
 
 // ------------------------------------------------------------------------------ stage A
 // Returns false (uniformly) when the block is malformed (position in misc[M_ERR]); nseq_out / total_out otherwise.
+// hint_out (optional): the block's entry-point table is written on the way (include/lz4amd.h; layout csrc/lz4amd_params.h) - a row
+// per 2^k tokens, k <= 3 set per trip of P5 so that rows are ~512 bytes of output apart, one row per token of the slow path - so
+// that the next decode of the same block can skip this stage; hint_cap_rows: rows the table has room for.
+__device__ __forceinline__ void st_hint_row(lz4amd_gdst t, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord, uint32_t w3) {
+    U32x4 v; v[0] = tok; v[1] = out; v[2] = ord; v[3] = w3;
+    st_global16(t + 16 * (uint64_t)(r + 1), v);
+}
 __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix,
                                                SeqRec* rectab, char* smem, uint64_t table_size,
-                                               uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof = nullptr, uint32_t** ridx_out = nullptr) {
+                                               uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof = nullptr, uint32_t** ridx_out = nullptr,
+                                               lz4amd_gdst hint_out = nullptr, uint32_t hint_cap_rows = 0) {
     uint64_t pt[6] = {0, 0, 0, 0, 0, 0}, pq = prof ? clock_ticks() : 0;       // developer profile: cycles in P1, P2, P3, P4, list, P5
 #define LZ4AMD_PSTAMP(i) do { if (prof) { const uint64_t t_ = clock_ticks(); pt[i] += t_ - pq; pq = t_; } } while (0)
     const uint32_t tid = threadIdx.x;
@@ -276,7 +285,8 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     uint32_t* ridx = (uint32_t*)((char*)toks + toks_bytes(csize));       // region (from the block's first) -> record
     if (ridx_out) *ridx_out = ridx;
     const uint32_t capB = cap + kBias, low = kBias - prefix;
-    if (tid == 0) { misc[M_ERR] = kNone; misc[M_MINREF] = kNone; }
+    if (tid == 0) { misc[M_ERR] = kNone; misc[M_MINREF] = kNone; misc[M_HOVER] = 0; }
+    uint32_t hrows = 0;                               // uniform: rows of the entry-point table written so far
     for (uint32_t i = tid, n = (uint32_t)max_regions(csize, cap); i < n; i += kThreads) ridx[i] = 0;    // (ordered before P5's notes by the barriers between)
 
     uint32_t e = 0, obase = kBias, nrec = 0;          // uniform: next true token, output position, records written
@@ -491,6 +501,10 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
             uint32_t e2, t2; uint64_t eo, to;
             block_excl_sum2(0u, (tid & 63) == 0 ? (uint64_t)wsum : 0ull, scan, e2, eo, t2, to);
             const uint64_t wbase = (uint64_t)obase + wave_readlane64(eo, 0);
+            // the trip's rows of the table: ~512 bytes of output apart, at most 8 tokens
+            const uint32_t ntrip = N - base < kThreads * kTokPerThread ? N - base : kThreads * kTokPerThread;
+            uint32_t hk = 3;
+            if (hint_out) { const uint32_t tpr = to ? (uint32_t)(((uint64_t)ntrip << 9) / to) : 8u; hk = tpr >= 8 ? 3u : tpr >= 4 ? 2u : tpr >= 2 ? 1u : 0u; }
 #pragma unroll
             for (uint32_t j = 0; j < kTokPerThread; j++) {
                 if (i0 + 64 * j < N) {
@@ -504,16 +518,28 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
                     if (!b) {
                         SeqRec r; r.outpos = o; r.litpos = ti[j].q; r.ll = ti[j].ll; r.off = ti[j].off; rectab[nrec + i0 + 64 * j] = r;
                         region_note(ridx, o, o + ti[j].ll + ti[j].ml, nrec + i0 + 64 * j, true);
+                        const uint32_t x = i0 + 64 * j - base;
+                        if (hint_out && (x & ((1u << hk) - 1u)) == 0) {
+                            const uint32_t row = hrows + (x >> hk);
+                            if (row >= hint_cap_rows) misc[M_HOVER] = 1u;
+                            else if (row) st_hint_row(hint_out, row, tp[j], o - kBias, nrec + i0 + 64 * j, 0);      // (row 0 is written at the end: it carries the number of rows)
+                        }
                     }
                 }
             }
             if (__syncthreads_or(bad)) return false;
             obase += (uint32_t)to;
+            hrows += (ntrip + (1u << hk) - 1u) >> hk;
         }
         nrec += N;
         LZ4AMD_PSTAMP(5);
         // ---- a token the walk could not pass: the slow path takes it (wave 0), then the next span starts behind it
         if (stop) {
+            if (hint_out && tid == 0) {             // (the slow path's token gets a row of its own)
+                if (hrows >= hint_cap_rows) misc[M_HOVER] = 1u;
+                else if (hrows) st_hint_row(hint_out, hrows, tend, obase - kBias, nrec, 0);
+            }
+            hrows++;
             if (tid < 64) {
                 uint32_t nx = 0, ep = 0, mr = kNone;
                 const int rc = slow_token(src, csize, capB, low, tend, obase, nrec, rectab, ridx, nx, ep, mr);
@@ -531,6 +557,17 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     }
     if (tid == 0) { SeqRec r; r.outpos = obase; r.litpos = csize; r.ll = 0; r.off = 0; rectab[nrec] = r; }      // sentinel row
     nseq_out = nrec; total_out = obase - kBias;
+    if (hint_out) {
+        __syncthreads();                                      // (M_HOVER)
+        if (tid == 0) {
+            if (!misc[M_HOVER] && hrows && hrows <= hint_cap_rows) {
+                st_hint_row(hint_out, hrows, csize, obase - kBias, nrec, 0);              // the block's end
+                st_hint_row(hint_out, 0, 0, 0, 0, hrows);                                  // the first sequence, and the number of rows
+                U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = obase - kBias; h[2] = csize; h[3] = nrec;
+                st_global16(hint_out, h);
+            }
+        }
+    }
     if (prof && tid == 0) { prof[2] = pt[0] | (pt[1] << 32); prof[3] = pt[2] | (pt[3] << 32); prof[4] = pt[4] | (pt[5] << 32); }
 #undef LZ4AMD_PSTAMP
     return true;

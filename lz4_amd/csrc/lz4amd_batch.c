@@ -129,7 +129,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->src = (const uint8_t* const*)dsrc; q->src_size = (const int32_t*)dssz;
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
-        q->prefix = NULL; q->hints = NULL; q->hint_stride = 0; q->hint_stats = NULL;
+        q->prefix = NULL; q->hints = NULL; q->hint_stride = 0; q->hint_stats = NULL; q->hint_make = 0;
         q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c, max_cap) + 255) & ~(uint64_t)255;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase timestamps */
@@ -294,6 +294,23 @@ int lz4amd_plan_hint_stats(lz4amd_plan* p, unsigned* used, unsigned* rejected)
     if (lz4amd_hip_d2h(v, p->dec.hint_stats, sizeof v, NULL) || lz4amd_hip_sync(NULL)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
     if (used) *used = v[0];
     if (rejected) *rejected = v[1];
+    return LZ4AMD_OK;
+}
+
+int lz4amd_plan_make_hints(lz4amd_plan* p, int on)
+{   /* a decompress plan with tables attached: blocks whose table is missing or unusable get theirs written while they are decoded */
+    if (!p || p->op != LZ4AMD_OP_DECOMPRESS || p->dec.chain || (on && !p->dec.hints)) return LZ4AMD_E_ARG;
+    p->dec.hint_make = on ? 1u : 0u;
+    return LZ4AMD_OK;
+}
+
+int lz4amd_plan_hints_made(lz4amd_plan* p, unsigned* made)
+{
+    unsigned v[3] = {0, 0, 0};
+    if (!p || p->op != LZ4AMD_OP_DECOMPRESS || !p->dec.hint_stats || !made) return LZ4AMD_E_ARG;
+    (void)lz4amd_hip_use_device(p->ctx->device);
+    if (lz4amd_hip_d2h(v, p->dec.hint_stats, sizeof v, NULL) || lz4amd_hip_sync(NULL)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
+    *made = v[2];
     return LZ4AMD_OK;
 }
 

@@ -26,7 +26,9 @@ typedef struct lz4amd_dec_params {
      * Read only, never trusted: every entry is checked against the stream before a byte that depends on it is final. */
     const uint8_t* hints;
     uint64_t hint_stride;
-    uint32_t* hint_stats;           /* optional: [0] += blocks decoded from their table, [1] += tables that did not fit their block */
+    uint32_t* hint_stats;           /* optional: [0] += blocks decoded from their table, [1] += tables that did not fit their block, [2] += tables made */
+    uint32_t hint_make;             /* != 0: a block whose table is missing or unusable is decoded the ordinary way AND gets its table written (the
+                                     * hints memory must then be writable): the next decode of the same block parses from it */
 } lz4amd_dec_params;
 
 /* One block's entry-point table: a 16-byte header { magic, out_size, csize, nseq } followed by rows + 1 entries of 16 bytes.

@@ -135,8 +135,14 @@ extern "C" int emu_compress_batch_hints(const uint8_t* const* src, const int32_t
     if (n) simt::launch(grid, kCmpThreads, kCmpLdsBytes, [&] { compress_batch_body(P); });
     return 0;
 }
+extern "C" int emu_decompress_batch_hints_make(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
+                                               int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix, const uint8_t* hints, uint64_t stride, uint32_t* stats, uint32_t make);
 extern "C" int emu_decompress_batch_hints(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
                                           int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix, const uint8_t* hints, uint64_t stride, uint32_t* stats) {
+    return emu_decompress_batch_hints_make(src, src_size, dst, dst_cap, result, n, grid, prefix, hints, stride, stats, 0);
+}
+extern "C" int emu_decompress_batch_hints_make(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
+                                               int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix, const uint8_t* hints, uint64_t stride, uint32_t* stats, uint32_t make) {
     using namespace lz4amd;
     uint32_t max_c = 0, max_cap = 0;
     for (uint32_t i = 0; i < n; i++) if (src_size[i] > 0 && (uint32_t)src_size[i] > max_c) max_c = src_size[i];
@@ -147,7 +153,7 @@ extern "C" int emu_decompress_batch_hints(const uint8_t* const* src, const int32
     uint32_t ticket = 0;
     DecBatch P = {};
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
-    P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix; P.hints = hints; P.hint_stride = stride; P.hint_stats = stats;
+    P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix; P.hints = hints; P.hint_stride = stride; P.hint_stats = stats; P.hint_make = make;
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = sstride;
     if (n) simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
     return 0;

@@ -53,7 +53,7 @@ def gpu_compress_tables(ctx, datas, acceleration=1):
     return comps, [h[i].tobytes() for i in range(len(datas))]
 
 
-def gpu_decompress_tables(ctx, blocks, caps, tables, salign=0, guard=64):
+def gpu_decompress_tables(ctx, blocks, caps, tables, salign=0, guard=64, make=None):
     import lz4_amd
     s = torch.cuda.current_stream().cuda_stream
     srcs = [_dev(b"\xA5" * salign + c, pad=16) for c in blocks]
@@ -65,9 +65,14 @@ def gpu_decompress_tables(ctx, blocks, caps, tables, salign=0, guard=64):
     plan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, lz4_amd.BlockTable([x.data_ptr() + salign for x in srcs], [len(c) for c in blocks],
                                                                       [x.data_ptr() for x in dsts], caps))
     plan.attach_hints(hints.data_ptr(), stride)
+    if make is not None:
+        plan.make_hints(True)
     plan.launch(s)
     res = plan.results(s)
     used, rejected = plan.hint_stats()
+    if make is not None:
+        h = hints.cpu().numpy()
+        make[:] = [[h[i].tobytes() for i in range(len(blocks))], plan.hints_made()]
     outs = []
     for r, d, cap in zip(res, dsts, caps):
         raw = d.cpu().numpy().tobytes()
@@ -179,3 +184,32 @@ def test_full_size_round_trip_with_tables(ctx, oracle, datagen):
     for i in range(nb):
         r = oracle.lz4o_decompress_safe(hc[i, :csizes[i]].tobytes(), dst, csizes[i], bs)
         assert r == bs and dst.raw == host[i * bs:(i + 1) * bs]
+
+
+def test_tables_made_while_decoding_foreign_blocks(ctx, ocodec, reflib, datagen):
+    """lz4amd_plan_make_hints: twin of the interpreter test - plus 4 MiB reference-compressed blocks at three compressibilities"""
+    import ctypes
+    foreign = th.foreign_cases(ocodec, reflib, datagen)
+    for spec in ((4 << 20, 60, 7), (4 << 20, 20, 8), (4 << 20, 90, 9)):
+        d = datagen(*spec)
+        cap = len(d) + len(d) // 255 + 16
+        cb = ctypes.create_string_buffer(cap)
+        n = reflib.LZ4_compress_default(d, cb, len(d), cap)
+        foreign.append((d, cb.raw[:n]))
+    blocks = [c for _, c in foreign]
+    wants = [d for d, _ in foreign]
+    empty = [bytes(th.hint_bytes(len(d))) for d in wants]
+    made = []
+    outs, used, rejected = gpu_decompress_tables(ctx, blocks, [len(d) for d in wants], empty, make=made)
+    for d, (r, o) in zip(wants, outs):
+        assert r == len(d) and o == d, len(d)
+    assert used == 0 and rejected == 0 and made[1] >= len(blocks) - 4, (used, rejected, made[1])
+    good = 0
+    for d, c, t in zip(wants, blocks, made[0]):
+        if struct.unpack_from("<I", t, 0)[0] == th.MAGIC:
+            th.check_table(c, t, len(d)); good += 1
+    assert good >= len(blocks) - 6, good
+    outs, used, rejected = gpu_decompress_tables(ctx, blocks, [len(d) for d in wants], made[0], salign=3)
+    for d, (r, o) in zip(wants, outs):
+        assert r == len(d) and o == d, len(d)
+    assert used == good and rejected == 0, (used, rejected, good)

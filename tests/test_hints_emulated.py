@@ -111,8 +111,9 @@ def emu_compress_tables(emu, datas, accel=1):
     return [dsts[i].raw[:res[i]] for i in range(n)], [hraw.raw[off + i * stride: off + (i + 1) * stride] for i in range(n)]
 
 
-def emu_decompress_tables(emu, blocks, caps, tables, salign=0, align=0, prefixes=None):
-    """-> ([(result, bytes)], blocks decoded from their table, tables rejected); canaries around every output."""
+def emu_decompress_tables(emu, blocks, caps, tables, salign=0, align=0, prefixes=None, make=None):
+    """-> ([(result, bytes)], blocks decoded from their table, tables rejected); canaries around every output.
+    make (a list): the decoder writes the tables of blocks that have none; the list receives [tables afterwards, tables made]."""
     n = len(blocks)
     srcs = [ctypes.create_string_buffer(len(b) + 64 + salign) for b in blocks]
     sptr = lambda buf: ((ctypes.addressof(buf) + 15) & ~15) + salign
@@ -132,8 +133,11 @@ def emu_decompress_tables(emu, blocks, caps, tables, salign=0, align=0, prefixes
     sp = (ctypes.c_void_p * n)(*[sptr(s) for s in srcs]); dp = (ctypes.c_void_p * n)(*[ptr(i) for i in range(n)])
     ss = (ctypes.c_int32 * n)(*[len(b) for b in blocks]); dc = (ctypes.c_int32 * n)(*caps); res = (ctypes.c_int32 * n)()
     pre = (ctypes.c_int32 * n)(*[len(p) for p in pres]) if prefixes else None
-    stats = (ctypes.c_uint32 * 2)()
-    emu.emu_decompress_batch_hints(sp, ss, dp, dc, res, n, 0, pre, ctypes.c_void_p(hbase), ctypes.c_uint64(stride), stats)
+    stats = (ctypes.c_uint32 * 3)()
+    emu.emu_decompress_batch_hints_make(sp, ss, dp, dc, res, n, 0, pre, ctypes.c_void_p(hbase), ctypes.c_uint64(stride), stats, 1 if make is not None else 0)
+    if make is not None:
+        off = hbase - ctypes.addressof(hraw)
+        make[:] = [[hraw.raw[off + i * stride: off + (i + 1) * stride] for i in range(n)], stats[2]]
     outs = []
     for i in range(n):
         off = ptr(i) - ctypes.addressof(dsts[i])
@@ -318,3 +322,40 @@ def test_a_table_without_room_for_its_rows_is_left_invalid(emu, ocodec, datagen)
     assert hraw.raw[off + stride:off + stride + 4096] == b"\xEE" * 4096   # nothing behind the table's end
     outs, used, rejected = emu_decompress_tables(emu, [comp], [len(d)], [table])
     assert outs[0] == (len(d), d) and (used, rejected) == (0, 0)
+
+
+def test_tables_made_while_decoding_foreign_blocks(emu, foreign):
+    """lz4amd_plan_make_hints: the first decode of blocks nobody made a table for writes their tables (stage A knows every token
+    then); they hold to the same rules as the compressor's, and the second decode parses from them"""
+    blocks = [c for _, c in foreign]
+    wants = [d for d, _ in foreign]
+    empty = [bytes(hint_bytes(len(d))) for d in wants]
+    made = []
+    outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], empty, make=made)
+    for d, (r, o) in zip(wants, outs):
+        assert r == len(d) and o == d, len(d)
+    assert used == 0 and rejected == 0 and made[1] >= len(blocks) - 4, (used, rejected, made[1])
+    good = 0
+    for d, c, t in zip(wants, blocks, made[0]):
+        if struct.unpack_from("<I", t, 0)[0] == MAGIC:
+            check_table(c, t, len(d)); good += 1
+        else:
+            assert t == bytes(len(t)) or struct.unpack_from("<I", t, 0)[0] == 0        # (left invalid: more rows than room)
+    assert good >= len(blocks) - 6, good
+    outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], made[0], salign=3)
+    for d, (r, o) in zip(wants, outs):
+        assert r == len(d) and o == d, len(d)
+    assert used == good and rejected == 0, (used, rejected, good)
+    # a table that lies is replaced by a true one on the way
+    liars = []
+    for t in made[0]:
+        b = bytearray(t)
+        if struct.unpack_from("<I", t, 0)[0] == MAGIC and struct.unpack_from("<4I", t, 16)[3] > 2:
+            struct.pack_into("<I", b, 32 + 4, struct.unpack_from("<I", t, 32 + 4)[0] + 1)     # row 1: output position off by one
+        liars.append(bytes(b))
+    made2 = []
+    outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], liars, make=made2)
+    for d, (r, o) in zip(wants, outs):
+        assert r == len(d) and o == d, len(d)
+    assert rejected > 0 and made2[1] >= rejected
+    assert [t for t in made2[0]] == [t for t in made[0]]
