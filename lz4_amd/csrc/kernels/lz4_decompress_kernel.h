@@ -370,6 +370,13 @@ __device__ __forceinline__ uint32_t cr_fetch4(const char* cr, uint32_t x, uint32
     const uint32_t* d = (const uint32_t*)(cr + (a & ~3u));
     return align_bytes(d[1], d[0], a & 3u);
 }
+// eight stream bytes from position x on (three aligned dwords and two byte alignments; the pad covers the dwords behind the ring's end)
+__device__ __forceinline__ uint64_t cr_fetch8(const char* cr, uint32_t x, uint32_t mis) {
+    const uint32_t a = mod_cr(x + mis);
+    const uint32_t* d = (const uint32_t*)(cr + (a & ~3u));
+    const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
+    return (uint64_t)align_bytes(d1, d0, a & 3u) | ((uint64_t)align_bytes(d2, d1, a & 3u) << 32);
+}
 // one stream byte at position x (x < csize): out of the compressed ring when it is resident, else from memory
 __device__ __forceinline__ uint32_t pbyte(const char* cr, lz4amd_gsrc src, uint32_t x, uint32_t mis, uint32_t chi) {
     if (x < chi) return (uint32_t)*(const uint8_t*)(cr + mod_cr(x + mis));
@@ -411,11 +418,12 @@ __device__ __forceinline__ void ext_field(bool need, uint32_t& pos, uint32_t& ac
 }
 
 // One step of a lane's walk: the sequence whose token is at W.p, by the decoder's rules.  The FAST form covers what nearly
-// every sequence is - length fields of at most two extension bytes (lengths below 525), not in the block's last 24 bytes,
-// every byte in the ring: the token and the three bytes behind it in one look, the offset and the two bytes behind it in
-// another (two aligned dwords + a byte alignment each).  Whatever it does not cover takes the CAREFUL form: the same
+// every sequence is - a literal length of at most seven extension bytes (below 1800: poorly compressible data is made of
+// literal runs of hundreds of bytes, and ONE lane that needs the careful form sends the whole wave through it), a match
+// length of at most two (below 529), not in the block's last 24 bytes, every byte in the ring: the token and the seven bytes
+// behind it in one look (three aligned dwords), the offset and the two bytes behind it in another.  Whatever it does not cover takes the CAREFUL form: the same
 // rules, any field length, bytes from memory when they are not resident, the block's last sequence.
-struct Walk { uint32_t p, o, i, end, oend, iend, W; bool act, res, bad; };      // res: every byte of the lane's row is in the ring; W: the four stream bytes at p (asked for as soon as p is known: the walk is a chain of dependent LDS round trips)
+struct Walk { uint32_t p, o, i, end, oend, iend; uint64_t W; bool act, res, bad; };      // res: every byte of the lane's row is in the ring; W: the eight stream bytes at p (asked for as soon as p is known: the walk is a chain of dependent LDS round trips)
 struct StepOut { SeqRec r; uint32_t oe; bool ok; };
 struct PCtx { const char* cr; lz4amd_gsrc src; uint32_t csize, mis, chi, capB, low; };
 __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t& n_careful) {
@@ -423,13 +431,17 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
     uint32_t pn = w.p;
     bool careful = w.act && !w.res;
     {
-        const uint32_t W = w.W;
-        const uint32_t b = W & 0xFFu, e1 = (W >> 8) & 0xFFu, e2 = (W >> 16) & 0xFFu;
-        const bool lx = (b >> 4) == 15, lx2 = lx && e1 == 255;
-        const uint32_t ll = (b >> 4) + (lx ? e1 : 0u) + (lx2 ? e2 : 0u);
-        const uint32_t q = w.p + 1 + (lx ? 1u : 0u) + (lx2 ? 1u : 0u), m = q + ll;
+        const uint64_t W = w.W;
+        const uint32_t b = (uint32_t)W & 0xFFu;
+        const bool lx = (b >> 4) == 15;
+        // the literal length's extension bytes: k bytes of 255 (of the seven behind the token), then the one that ends the field
+        const uint64_t ext = W >> 8, nz = ~ext & 0x00FFFFFFFFFFFFFFull;
+        const uint32_t k = nz ? ((uint32_t)__ffsll((long long)nz) - 1u) >> 3 : 7u;
+        const uint32_t ek = (uint32_t)(ext >> (8u * k)) & 0xFFu;                  // (k == 7: the field goes on - the careful form)
+        const uint32_t ll = (b >> 4) + (lx ? 255u * k + ek : 0u);
+        const uint32_t q = w.p + 1 + (lx ? k + 1u : 0u), m = q + ll;
         // (m + 24 <= csize: not the last sequence, lz4.c:2279, and every length byte looked at may be read, lz4.c:1986-2006)
-        careful = careful || (w.act && ((lx2 && e2 == 255) || m + 24 > X.csize || X.capB - w.o < ll + kMfLimit));
+        careful = careful || (w.act && ((lx && k == 7) || m + 24 > X.csize || X.capB - w.o < ll + kMfLimit));
         const uint32_t V = cr_fetch4(X.cr, m, X.mis);
         const uint32_t off = V & 0xFFFFu, f1 = (V >> 16) & 0xFFu, f2 = V >> 24;
         const bool mx = (b & 15u) == 15, mx2 = mx && f1 == 255;
@@ -443,7 +455,7 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
         S.r.litpos = q; S.r.ll = ll; S.r.off = off;
         S.oe = S.ok ? ms + ml : S.oe;
         pn = S.ok ? m + 2 + (mx ? 1u : 0u) + (mx2 ? 1u : 0u) : pn;
-        w.W = cr_fetch4(X.cr, pn, X.mis);                  // the next token, on its way while this sequence's record is written
+        w.W = cr_fetch8(X.cr, pn, X.mis);                  // the next token, on its way while this sequence's record is written
     }
     if (__any(careful)) {
         n_careful++;
@@ -471,7 +483,7 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
         go = on && !cbad;
         w.bad = w.bad || (on && cbad);
         if (go) { S.r.litpos = q; S.r.ll = ll; S.r.off = last ? 0u : off; S.oe = last ? ms : ms + ml; pn = last ? X.csize : nx; S.ok = true; }
-        if (on) w.W = cr_fetch4(X.cr, pn, X.mis);
+        if (on) w.W = cr_fetch8(X.cr, pn, X.mis);
     }
     w.p = pn;
     return S;
@@ -579,7 +591,7 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         // ---- walk
         Walk w; w.p = A.tok; w.o = A.out + kBias; w.i = A.ord; w.end = B.tok; w.oend = B.out + kBias; w.iend = B.ord;
         w.act = lane < nl && w.p < w.end; w.res = allres; w.bad = false;
-        w.W = cr_fetch4(X.cr, w.p, X.mis);
+        w.W = cr_fetch8(X.cr, w.p, X.mis);
         uint32_t head = 0, sRa = Ra, scarry = 0;
         while (__any(w.act)) {
             n_steps++;

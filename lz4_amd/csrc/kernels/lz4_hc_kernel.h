@@ -257,8 +257,13 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
 }
 
 __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
-                                               uint32_t band, uint32_t attempts, bool favor, char* smem) {
+                                               uint32_t band, uint32_t attempts, bool favor, char* smem, uint64_t* prof = nullptr) {
     const uint32_t tid = opaque_u32(threadIdx.x);
+#ifdef LZ4AMD_PROF_HC
+    uint64_t hp_trips = 0, hp_lanes = 0, hp_loop = 0, hp_wait = 0, hp_hits = 0, hp_hit_lanes = 0, hp_t0x = 0;
+#else
+    (void)prof;
+#endif
     uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
     uint16_t* cring = (uint16_t*)(smem + kHOffChain);
     uint8_t* mine = (uint8_t*)(smem + kHOffMine);
@@ -339,6 +344,9 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
             bool active = false;
             int32_t p = 0;
             uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0, best_in = 3;
+#ifdef LZ4AMD_PROF_HC
+            hp_t0x = clock_ticks();
+#endif
             for (;;) {
                 // ---- hand out runs of kHcRun consecutive positions to idle lanes, from one pool for the whole tile
                 //      (an LDS counter; asked only when a quarter of the wave is idle, or nobody works)
@@ -394,6 +402,9 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                     else if (!kept) inh_len = 0;                        // nothing to hand to the next position
                 }
                 if (!__ballot(active)) { if (pool_dry && !__ballot(run_left != 0)) break; continue; }
+#ifdef LZ4AMD_PROF_HC
+                hp_trips++; hp_lanes += (uint32_t)__popcll(__ballot(active));
+#endif
                 // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
                 uint32_t cd[kHcBatch];
                 uint32_t next = 0;                                      // where the next band resumes
@@ -425,6 +436,9 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
 #pragma unroll
                 for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                 while (__ballot(hits != 0)) {
+#ifdef LZ4AMD_PROF_HC
+                    hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(hits != 0));
+#endif
                     if (hits) {
                         const uint32_t k = (uint32_t)__ffs((int)hits) - 1;
                         hits &= hits - 1;
@@ -453,7 +467,14 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                 }
             }
         }
+#ifdef LZ4AMD_PROF_HC
+        const uint64_t hp_t1 = clock_ticks();
+        hp_loop += hp_t1 - hp_t0x;
+#endif
         __syncthreads();
+#ifdef LZ4AMD_PROF_HC
+        { const uint64_t t2 = clock_ticks(); hp_wait += t2 - hp_t1; }
+#endif
         // -- flush the tile's state (coalesced), commit the prefetched granules: they replace positions
         //    below the next tile's band
         *(U32x4*)(st0_g + t0 + 4 * tid) = *(const U32x4*)(res0 + 4 * tid);
@@ -464,6 +485,9 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
         if (have_m) *(U32x4*)(mine + 16 * tid) = pm;
     }
     __syncthreads();
+#ifdef LZ4AMD_PROF_HC
+    if (prof && band == 0 && tid == 0) { prof[3] += hp_trips | (hp_lanes << 32); prof[6] += hp_hits | (hp_hit_lanes << 32); prof[7] += (hp_loop >> 4) | ((hp_wait >> 4) << 32); }
+#endif
 }
 
 // ------------------------------------------------------------------------------ phase 3: parse (one strip)
@@ -755,7 +779,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         const uint32_t attempts = hc_attempts(level);
 
         for (uint32_t band = 0; band < kHcBands; band++) {
-            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, favor, smem);
+            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, favor, smem, prof);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         }
         // -- parse: one wave per strip of the block proper

@@ -25,3 +25,11 @@ blocks_per_wg = nb / (n // 8) * (runs + 1)
 for k, name in enumerate(names):
     d = [w[i * 8 + k] for i in range(n // 8)]
     print("%-16s cycles per block: median %.0f  max %.0f" % (name, statistics.median(d) / blocks_per_wg, max(d) / blocks_per_wg))
+
+if "hcprof" in os.environ.get("LZ4AMD_LIB", ""):     # tools/build_variant.sh hcprof -DLZ4AMD_PROF_HC
+    med = lambda f: statistics.median([f(i) for i in range(n // 8)]) / blocks_per_wg
+    trips = med(lambda i: w[i * 8 + 3] & 0xFFFFFFFF); lanes = med(lambda i: w[i * 8 + 3] >> 32)
+    hits = med(lambda i: w[i * 8 + 6] & 0xFFFFFFFF); hlanes = med(lambda i: w[i * 8 + 6] >> 32)
+    loop = med(lambda i: (w[i * 8 + 7] & 0xFFFFFFFF) << 4); wait = med(lambda i: (w[i * 8 + 7] >> 32) << 4)
+    print("band 0, wave 0, per block: loop trips %.0f, active lanes per trip %.1f; measure trips %.0f, lanes per measure trip %.1f; cycles in the loop %.0f, at the tile's barrier %.0f" % (
+        trips, lanes / max(trips, 1), hits, hlanes / max(hits, 1), loop, wait))
