@@ -320,11 +320,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
     const uint32_t kSpan = 256u << SH, kLaneBytes = 4u << SH;      // a round covers kSpan bytes; a strip is at most two rounds long
     uint32_t nseq = 0, enc = 0, ll0 = 0, cur = cs;             // cur: end of the last match taken (first byte not yet covered)
     // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= tend
-#ifdef LZ4AMD_X_NOPROBE
-    if (false) {
-#else
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
-#endif
         const uint32_t last_q = n - kMfLimit;                  // inclusive
         // a match may run past the strip up to the tile's end: the strips it covers give way (resolve_overruns)
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
@@ -357,9 +353,6 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
                 total &= 0xFFFFu;
                 MPROF(0);
                 if (lo >= total) break;
-#ifdef LZ4AMD_X_NOSELECT
-                break;
-#endif
                 wave_lds_fence();
                 MPROF(2);
                 // ---- measure: lane = run
@@ -910,9 +903,6 @@ __device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_
     const uint32_t* misc = (const uint32_t*)(smem + kCOffMisc);
     const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
     if (misc[CM_FAIL] || !strip_p[S_N * kCmpWaves + w]) return;
-#ifdef LZ4AMD_X_NOEMIT
-    return;
-#endif
     const uint8_t* ring = (const uint8_t*)(smem + kCOffRing);
     const MatchRec* recs_w = (const MatchRec*)(smem + kCOffRecs) + (pp * kStrips + w) * kRecsPerStrip + strip_p[S_FIRST * kCmpWaves + w];
     const uint32_t* T = misc + CM_TILE + 4 * pp;

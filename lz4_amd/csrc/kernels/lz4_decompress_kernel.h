@@ -501,7 +501,8 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
 #define LZ4AMD_PARSERS 2
 #endif
 enum : uint32_t { kParsers = LZ4AMD_PARSERS, kFirstParseWave = kDecWaves - 1 - kParsers };
-enum : uint32_t { P_LOCK = 16, P_NEXT, P_RZ, P_TICKET, P_TURN, P_ICARRY };      // shared words of the parser waves (misc[])
+enum : uint32_t { P_NEXT = 16, P_RZ, P_TICKET, P_TURN, P_LOCK, P_ICARRY };      // shared words of the parser waves (misc[]); the first four are
+static_assert(M_EHEAD == M_ABORT + 8 && P_NEXT == M_ABORT + 12, "the words a claim looks at are 64 consecutive bytes");      // read with M_ABORT .. M_PBAD in one trip to the LDS
 __device__ __forceinline__ void parser_unlock(uint32_t* misc) { wave_lds_fence(); if (lane_here() == 0) lds_store_release(&misc[P_LOCK], 0u); }
 __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix, uint32_t total, uint32_t nseq,
                                             uint32_t nreg, uint32_t rend, char* smem, uint64_t* prof) {
@@ -533,11 +534,16 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         }
         wave_lds_fence();
         PSTAMP(t_lock);
-        const Ctl c = ctl_snapshot(smem);
-        const uint32_t r0 = uload(&misc[P_NEXT]);
+        // (everything a claim looks at - M_ABORT .. M_PBAD and the parsers' own four words - in ONE trip to the LDS: the claim is a
+        //  chain of dependent round trips of a wave whose every instruction waits for the copy waves', and it is made under the lock)
+        U32x4 qa, qb, qc, qd;
+        lds_load_quad16((const U32x4*)(smem + kOffMisc + 4 * M_ABORT), qa, qb, qc, qd);
+        const Ctl c = ctl_unpack(qa, qb);
+        const uint32_t r0 = __builtin_amdgcn_readfirstlane(qd[0]);
         if (c.abort_ || r0 >= nreg) { parser_unlock(misc); break; }
-        const uint32_t Ra = uload(&misc[P_RZ]);            // regions below Ra belong to the batches claimed before
-        const uint32_t ehead = uload(&misc[M_EHEAD]);
+        const uint32_t Ra = __builtin_amdgcn_readfirstlane(qd[1]);            // regions below Ra belong to the batches claimed before
+        const uint32_t ticket = __builtin_amdgcn_readfirstlane(qd[2]), turn = __builtin_amdgcn_readfirstlane(qd[3]);
+        const uint32_t ehead = __builtin_amdgcn_readfirstlane(qc[0]);
         const uint32_t g = c.open;
         X.chi = c.chi;
         // how many lanes?  Rows [r0, r0 + nl] must be resident; the lanes' records must fit the record ring behind the first
@@ -547,19 +553,20 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         if (er < nlmax) nlmax = er;
         HintEnt A, B; A.tok = A.out = A.ord = A.zero = 0; B = A;
         if (lane < nlmax) { A = ent[(r0 + lane) & kEntMask]; B = ent[(r0 + lane + 1) & kEntMask]; }
+        const uint32_t tail_now = idx[g & kIdxMask];       // (asked for with the rows: one trip; it counts only if the entry is there)
         // the rows themselves: never decreasing, inside the block, no more sequences between two of them than 512 bytes of output can start
         bool rowbad = lane < nlmax && (A.tok > B.tok || A.out > B.out || A.ord > B.ord || B.tok > csize || B.out > total || B.ord - A.ord > kLaneSeqMax
                                        || (A.tok == B.tok) != (A.ord == B.ord) || (A.tok == B.tok && A.out != B.out));
         if (r0 == 0 && lane == 0 && nlmax && (A.tok | A.out | A.ord)) rowbad = true;
         if (r0 + lane + 1 == nreg && lane < nlmax && (B.tok != csize || B.out != total || B.ord != nseq)) rowbad = true;
         if (__any(rowbad)) { fail = true; parser_unlock(misc); break; }
-        if (g < c.ihead) tail = __builtin_amdgcn_readfirstlane(idx[g & kIdxMask]);      // first record an open region needs (only ever grows)
+        if (g < c.ihead) tail = __builtin_amdgcn_readfirstlane(tail_now);               // first record an open region needs (only ever grows)
         const uint32_t Rb = (B.out + kBias + kRegion - 1) >> kRegionShift;              // regions below Rb have their first byte before my lane's end
         const bool okrec = B.ord + 1 - tail <= kRecCap;
         const bool okidx = Rb + 1 <= g + kIdxRing;
         const unsigned long long mh = __ballot(lane < nlmax && okrec && okidx), mr = __ballot(lane < nlmax && okrec && okidx && B.tok <= X.chi);
         const uint32_t nl_hard = ~mh ? (uint32_t)__ffsll((long long)~mh) - 1 : 64u, nl_res = ~mr ? (uint32_t)__ffsll((long long)~mr) - 1 : 64u;      // leading lanes that may go
-        const bool drained = uload(&misc[P_TURN]) == uload(&misc[P_TICKET]);            // every claimed batch is published
+        const bool drained = turn == ticket;                                            // every claimed batch is published
         uint32_t nl = nl_res;
         bool smode = false;                             // a lane whose regions do not fit the index ring at once: alone, filling the index as it goes
         if (!nl && nl_hard && drained) {
@@ -576,7 +583,6 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
             parser_unlock(misc); spin_pause_long(); PSTAMP(t_sel); continue; }
         stall = 0;
         const uint32_t RbN = wave_readlane(Rb, nl - 1);
-        const uint32_t ticket = uload(&misc[P_TICKET]);
         const bool allres = nl_res != 0;
         wave_lds_fence();
         if (lane == 0) {
@@ -637,8 +643,10 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         // ---- publish, once every earlier batch is published
         if (!smode) {
             for (;;) {
-                if (uload(&misc[P_TURN]) == ticket) break;
-                if (uload(&misc[M_ABORT])) return;
+                uint32_t tn, ab;
+                lds_load_2(&misc[P_TURN], &misc[M_ABORT], tn, ab);
+                if (__builtin_amdgcn_readfirstlane(tn) == ticket) break;
+                if (__builtin_amdgcn_readfirstlane(ab)) return;
                 spin_pause();
             }
         }

@@ -64,6 +64,18 @@ __device__ __forceinline__ void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u3
     a = q[0]; b = q[1];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// four consecutive 16-byte LDS reads issued back to back (one wait for all)
+__device__ __forceinline__ void lds_load_quad16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b, lz4amd_u32x4& c, lz4amd_u32x4& d) {
+    const volatile __attribute__((address_space(3))) lz4amd_u32x4* q = (const volatile __attribute__((address_space(3))) lz4amd_u32x4*)p;
+    a = q[0]; b = q[1]; c = q[2]; d = q[3];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// two control words in one trip
+__device__ __forceinline__ void lds_load_2(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) {
+    v0 = *(const volatile __attribute__((address_space(3))) uint32_t*)p0;
+    v1 = *(const volatile __attribute__((address_space(3))) uint32_t*)p1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // ... followed, in this order and in the same trip to the LDS, by two dwords (the DS unit serves one wave's reads in
 // issue order: what the two dwords hold was published before the words in a and b were)
 __device__ __forceinline__ void lds_load_pair16_then2(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b, const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) {

@@ -39,6 +39,9 @@ typedef uint32_t lz4amd_u32x4 __attribute__((vector_size(16)));
 static inline void lds_load_flags2(const uint8_t* p0, const uint8_t* p1, uint32_t& v0, uint32_t& v1) { v0 = *(const volatile uint8_t*)p0; v1 = *(const volatile uint8_t*)p1; }
 static inline void lds_store_flag(uint8_t* p, uint32_t v) { *(volatile uint8_t*)p = (uint8_t)v; }
 static inline void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b) { memcpy(&a, (const void*)p, 16); memcpy(&b, (const void*)(p + 1), 16); }
+static inline void lds_load_quad16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b, lz4amd_u32x4& c, lz4amd_u32x4& d) {
+    memcpy(&a, (const void*)p, 16); memcpy(&b, (const void*)(p + 1), 16); memcpy(&c, (const void*)(p + 2), 16); memcpy(&d, (const void*)(p + 3), 16); }
+static inline void lds_load_2(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) { v0 = *(const volatile uint32_t*)p0; v1 = *(const volatile uint32_t*)p1; }
 static inline void lds_load_pair16_then2(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b, const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) {
     lds_load_pair16(p, a, b);
     v0 = *(const volatile uint32_t*)p0; v1 = *(const volatile uint32_t*)p1;
