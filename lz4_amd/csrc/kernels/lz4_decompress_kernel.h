@@ -431,17 +431,24 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
     uint32_t pn = w.p;
     bool careful = w.act && !w.res;
     {
-        const uint64_t W = w.W;
-        const uint32_t b = (uint32_t)W & 0xFFu;
-        const bool lx = (b >> 4) == 15;
-        // the literal length's extension bytes: k bytes of 255 (of the seven behind the token), then the one that ends the field
-        const uint64_t ext = W >> 8, nz = ~ext & 0x00FFFFFFFFFFFFFFull;
-        const uint32_t k = nz ? ((uint32_t)__ffsll((long long)nz) - 1u) >> 3 : 7u;
-        const uint32_t ek = (uint32_t)(ext >> (8u * k)) & 0xFFu;                  // (k == 7: the field goes on - the careful form)
-        const uint32_t ll = (b >> 4) + (lx ? 255u * k + ek : 0u);
-        const uint32_t q = w.p + 1 + (lx ? k + 1u : 0u), m = q + ll;
+        const uint32_t W = (uint32_t)w.W;
+        const uint32_t b = W & 0xFFu, e1 = (W >> 8) & 0xFFu, e2 = (W >> 16) & 0xFFu, e3 = W >> 24;
+        const bool lx = (b >> 4) == 15, lx2 = lx && e1 == 255, lx3 = lx2 && e2 == 255;
+        uint32_t ll = (b >> 4) + (lx ? e1 : 0u) + (lx2 ? e2 : 0u) + (lx3 ? e3 : 0u);
+        uint32_t q = w.p + 1 + (lx ? 1u : 0u) + (lx2 ? 1u : 0u) + (lx3 ? 1u : 0u);
+        bool lmore = lx3 && e3 == 255;                                           // the field goes on behind the token's dword
+        if (__any(w.act && lmore)) {
+            // ... into the four bytes behind: k of them 255, then the one that ends the field (none of the four: the careful form)
+            const uint32_t W1 = (uint32_t)(w.W >> 32), nz = ~W1;
+            const uint32_t k = nz ? ((uint32_t)__ffs((int)nz) - 1u) >> 3 : 4u;
+            const uint32_t ek = k < 4 ? (W1 >> (8u * k)) & 0xFFu : 0u;
+            ll += lmore ? 255u * k + ek : 0u;
+            q += lmore ? (k < 4 ? k + 1u : 4u) : 0u;
+            lmore = lmore && k == 4;
+        }
+        const uint32_t m = q + ll;
         // (m + 24 <= csize: not the last sequence, lz4.c:2279, and every length byte looked at may be read, lz4.c:1986-2006)
-        careful = careful || (w.act && ((lx && k == 7) || m + 24 > X.csize || X.capB - w.o < ll + kMfLimit));
+        careful = careful || (w.act && (lmore || m + 24 > X.csize || X.capB - w.o < ll + kMfLimit));
         const uint32_t V = cr_fetch4(X.cr, m, X.mis);
         const uint32_t off = V & 0xFFFFu, f1 = (V >> 16) & 0xFFu, f2 = V >> 24;
         const bool mx = (b & 15u) == 15, mx2 = mx && f1 == 255;
