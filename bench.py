@@ -502,8 +502,11 @@ def bench_frame(lz4_amd, host):
     except Exception as e:
         d64["cpu_baseline"] = {"error": str(e)}
     r["independent_64K"] = d64
-    r["note"] = ("PCIe inclusive and single-threaded on the host side: a parity path, not the HBM-resident rate; second of two calls. "
-                 "Linked blocks decode chained inside one launch per 64 MiB batch (only their copy stages run one after the other); independent blocks decode 1024 per launch")
+    r["note"] = ("PCIe inclusive (host buffers in, host buffers out): a parity path, not the HBM-resident rate; second of two calls. "
+                 "The decoder works in batches of up to 32 MiB of input / 1024 blocks: a batch is on the device (a helper thread) while the one before is handed "
+                 "to the caller and the next is taken in, through page-locked buffers.  Linked blocks decode chained inside one launch per batch: only their copy "
+                 "stages run one after the other, ~1.2 ms per 4 MiB block on one CU, which bounds a linked frame at ~3.4 GB/s whatever else overlaps; "
+                 "frames with a content checksum are bound by the one serial XXH32 over the content on the host (~6.3 GB/s on this box)")
     return r
 
 

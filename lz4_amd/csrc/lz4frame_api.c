@@ -264,12 +264,18 @@ finish_frame:
  * (lz4frame.c:1901-1915) keep the last 64 KB of output on the host between batches. */
 enum { ST_HEADER = 0, ST_SKIP, ST_BLOCKS, ST_TAIL, ST_DONE };
 enum { kBatchBlocks = 1024 };
-static const size_t kBatchBytes = (size_t)64 << 20;
-static const size_t kBatchDecoded = (size_t)256 << 20;     /* decoded bytes a batch may need (its blocks x the frame's block size): a
+static const size_t kAsyncDecoded = (size_t)8 << 20;       /* a batch that may decode to this much runs on a helper thread, beside the caller's copies */
+static const size_t kBatchBytes = (size_t)32 << 20;
+static const size_t kBatchDecoded = (size_t)128 << 20;     /* decoded bytes a batch may need (its blocks x the frame's block size): a
                                                              * few MB of highly compressible 4 MiB blocks must not ask for GBs of memory */
 struct LZ4F_dctx_s {
     int stage;
-    uint8_t* in; size_t in_size, in_cap;          /* bytes of the item(s) being collected */
+    uint8_t* in; size_t in_size, in_cap; int in_pin;   /* bytes of the item(s) being collected (_pin: page-locked memory) */
+    uint8_t* in2; size_t in2_cap; int in2_pin;    /* the batch that is being decoded */
+    uint8_t* out2; size_t out2_cap; int out2_pin; /* ... and where its bytes go (the two output buffers swap when it is done) */
+    int out_pin;
+    /* a large batch is decoded by a helper thread while the caller's thread hands out the batch before and takes in the next */
+    int busy; pthread_t bthread; size_t b_nb, b_end, b_out_size, b_result; int b_skip; void* b_ts;
     size_t scan_pos; size_t nready;               /* complete blocks in in[0, scan_pos) */
     int end_seen;                                 /* in[scan_pos, scan_pos+4) is the end mark */
     uint8_t* out; size_t out_size, out_pos, out_cap;   /* decoded bytes of the last batch, and how many were delivered */
@@ -283,10 +289,39 @@ struct LZ4F_dctx_s {
     const uint8_t* dict; size_t dict_len;         /* LZ4F_decompress_usingDict: what the frame's first bytes (every block of an independent-block frame) may reference */
     int dict_keep;                                /* ... installed by the call that is running: the reset between two frames inside that call leaves it */
     /* the content checksum of a batch runs on a helper thread while its bytes are delivered and the next input is taken */
-    int hashing; pthread_t hthread; size_t hash_n;
+    int hashing; pthread_t hthread; size_t hash_n; const uint8_t* hash_p;
 };
-static void* dctx_hash_thread(void* arg) { LZ4F_dctx* d = (LZ4F_dctx*)arg; xxh32_update(&d->xxh, d->out, d->hash_n); return NULL; }
+static void* dctx_hash_thread(void* arg) { LZ4F_dctx* d = (LZ4F_dctx*)arg; xxh32_update(&d->xxh, d->hash_p, d->hash_n); return NULL; }
 static void dctx_hash_join(LZ4F_dctx* d) { if (d->hashing) { pthread_join(d->hthread, NULL); d->hashing = 0; } }
+static void dctx_batch_drop(LZ4F_dctx* d) { if (d->busy > 0) pthread_join(d->bthread, NULL); d->busy = 0; }      /* (a batch nobody waits for any more) */
+/* Page-locked buffers are expensive to make (the pages are pinned one by one): the ones a context lets go of wait here for
+ * the next context that needs one - a decoder per frame, as the reference's own programs create them, then costs no pinning. */
+enum { kPinCache = 8 };
+static struct { uint8_t* p; size_t cap; } g_pin_cache[kPinCache];
+static pthread_mutex_t g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
+static uint8_t* pin_take(size_t need, size_t* cap)
+{
+    int i, best = -1;
+    uint8_t* p = NULL;
+    pthread_mutex_lock(&g_pin_lock);
+    for (i = 0; i < kPinCache; i++) if (g_pin_cache[i].p && g_pin_cache[i].cap >= need && (best < 0 || g_pin_cache[i].cap < g_pin_cache[best].cap)) best = i;
+    if (best >= 0) { p = g_pin_cache[best].p; *cap = g_pin_cache[best].cap; g_pin_cache[best].p = NULL; }
+    pthread_mutex_unlock(&g_pin_lock);
+    return p;
+}
+static void hfree_cap(uint8_t* p, int pinned, size_t cap)
+{
+    if (!p) return;
+    if (pinned) {
+        int i, slot = -1;
+        pthread_mutex_lock(&g_pin_lock);
+        for (i = 0; i < kPinCache; i++) if (!g_pin_cache[i].p) { slot = i; break; }
+        if (slot < 0) for (i = 0; i < kPinCache; i++) if (g_pin_cache[i].cap < cap && (slot < 0 || g_pin_cache[i].cap < g_pin_cache[slot].cap)) slot = i;     /* (the smallest one makes room) */
+        if (slot >= 0) { uint8_t* old = g_pin_cache[slot].p; g_pin_cache[slot].p = p; g_pin_cache[slot].cap = cap; p = old; }
+        pthread_mutex_unlock(&g_pin_lock);
+        lz4amd_hip_host_free(p);
+    } else free(p);
+}
 
 LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version)
 {   /* lz4frame.c:1284-1310 */
@@ -298,6 +333,7 @@ LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned v
 void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
 {   /* lz4frame.c:1322-1330; the buffers are kept */
     if (!d) return;
+    dctx_batch_drop(d);
     dctx_hash_join(d);
     d->stage = ST_HEADER;
     d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
@@ -308,7 +344,8 @@ void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
 LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* d)
 {
     if (d) {
-        dctx_hash_join(d); free(d->in); free(d->out); free(d->hist);
+        dctx_batch_drop(d);
+        dctx_hash_join(d); hfree_cap(d->in, d->in_pin, d->in_cap); hfree_cap(d->in2, d->in2_pin, d->in2_cap); hfree_cap(d->out, d->out_pin, d->out_cap); hfree_cap(d->out2, d->out2_pin, d->out2_cap); free(d->hist);
         if (d->has_cmem && d->cmem.customFree) d->cmem.customFree(d->cmem.opaqueState, d); else free(d);
     }
     return 0;
@@ -407,35 +444,44 @@ size_t LZ4F_getFrameInfo(LZ4F_dctx* d, LZ4F_frameInfo_t* info, const void* srcBu
     return 4;                                                            /* next: a block header */
 }
 
-static int grow(uint8_t** buf, size_t* cap, size_t need, size_t keep)
+/* The batch buffers: page-locked once they are large (the transfers then run at the bus's speed, and the device copies
+ * straight out of / into them); small ones - headers, the frames of the unit tests - are ordinary memory. */
+static int grow(uint8_t** buf, size_t* cap, int* pin, size_t need, size_t keep)
 {
-    uint8_t* nb;
+    uint8_t* nb = NULL;
+    int np = 0;
     if (need <= *cap) return 0;
-    need += (need >> 2) + 4096;
-    nb = (uint8_t*)malloc(need);
+    if (need >= ((size_t)1 << 20)) {
+        nb = pin_take(need, &need);
+        if (nb) np = 1;
+        else {
+            need += need + 4096;                            /* (few re-allocations: pinning pages is slow) */
+            if (frame_ctx()) { nb = (uint8_t*)lz4amd_hip_host_alloc(need); np = nb != NULL; }
+        }
+    } else need += (need >> 2) + 4096;
+    if (!nb) nb = (uint8_t*)malloc(need);
     if (!nb) return -1;
     if (keep) memcpy(nb, *buf, keep);
-    free(*buf); *buf = nb; *cap = need;
+    hfree_cap(*buf, *pin, *cap); *buf = nb; *cap = need; *pin = np;
     return 0;
 }
 
-/* decode the nb complete blocks held in d->in[0, end) into d->out */
-static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksums)
+/* decode the nb complete blocks held in base[0, end) (d->in2) into d->out2; d->b_out_size: how many bytes that made.
+ * Runs on the caller's thread or on the batch's helper thread (ts: the staging area and stream of the thread that owns the context). */
+static size_t decode_batch(LZ4F_dctx* d, const uint8_t* const base, size_t nb, size_t end, int skip_checksums, frame_tls* ts_given)
 {
-    const uint8_t* const base = d->in;
     size_t pos, i, out_total = 0, result = ERR(GENERIC);
     const int bchk = d->info.blockChecksumFlag == LZ4F_blockChecksumEnabled;
     const int linked = d->info.blockMode == LZ4F_blockLinked;
     const size_t h0 = linked ? d->hist_len : 0;
     lz4amd_ctx* ctx;
-    frame_tls* ts; dev_stage* S; void* strm;
+    frame_tls* ts = NULL; dev_stage* S; void* strm = NULL;
     lz4amd_plan *dplan = NULL, *xplan = NULL;
     const void** d_src = NULL; void** d_dst = NULL; int *sizes = NULL, *caps = NULL, *res = NULL, *sums = NULL, *prefix = NULL;
     size_t* in_off = NULL; uint8_t* raw = NULL;
     size_t ncomp = 0;
 
-    dctx_hash_join(d);                              /* the previous batch's bytes are about to be overwritten */
-    d->out_size = d->out_pos = 0;
+    d->b_out_size = 0;
     d_src = (const void**)malloc(nb * sizeof *d_src); d_dst = (void**)malloc(nb * sizeof *d_dst);
     sizes = (int*)malloc(nb * sizeof *sizes); caps = (int*)malloc(nb * sizeof *caps); res = (int*)malloc(nb * sizeof *res);
     sums = (int*)malloc(nb * sizeof *sums); prefix = (int*)malloc(nb * sizeof *prefix);
@@ -453,14 +499,14 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         if (all_raw) {
             size_t o = 0;
             for (i = 0; i < nb; i++) { if ((size_t)sizes[i] > d->block_max) { result = ERR(decompressionFailed); goto done_unlocked; } out_total += (size_t)sizes[i]; }
-            if (grow(&d->out, &d->out_cap, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done_unlocked; }
-            for (i = 0; i < nb; i++) { memcpy(d->out + o, base + in_off[i], (size_t)sizes[i]); o += (size_t)sizes[i]; }
+            if (grow(&d->out2, &d->out2_cap, &d->out2_pin, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done_unlocked; }
+            for (i = 0; i < nb; i++) { memcpy(d->out2 + o, base + in_off[i], (size_t)sizes[i]); o += (size_t)sizes[i]; }
             goto host_tail;
         }
     }
 
     ctx = frame_ctx();
-    ts = ctx ? ftls_get() : NULL;
+    ts = ctx ? (ts_given ? ts_given : ftls_get()) : NULL;
     if (!ts) goto done;
     S = &ts->st; strm = ts->stream;
     if (stage_fit(&S->in, &S->in_cap, end + 64) || stage_fit(&S->out, &S->out_cap, h0 + nb * d->block_max + 64)) { result = ERR(allocation_failed); goto done; }
@@ -535,8 +581,8 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         }
         for (i = 0; i < nb; i++) out_total += (size_t)res[i];
     }
-    if (grow(&d->out, &d->out_cap, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done; }
-    if (linked) { if (out_total && lz4amd_hip_d2h(d->out, (char*)S->out + h0, out_total, strm)) goto done; }
+    if (grow(&d->out2, &d->out2_cap, &d->out2_pin, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done; }
+    if (linked) { if (out_total && lz4amd_hip_d2h(d->out2, (char*)S->out + h0, out_total, strm)) goto done; }
     else {
         /* every block but the last is normally full, so the block_max-strided slots ARE the content: one transfer
          * (stored blocks are then laid over their slots from the input); ragged tables go block by block */
@@ -544,34 +590,39 @@ static size_t decode_batch(LZ4F_dctx* d, size_t nb, size_t end, int skip_checksu
         int dense = 1;
         if (d->dict_len) dense = 0;                  /* (the slots are 64 KB apart then) */
         for (i = 0; i + 1 < nb; i++) if ((size_t)res[i] != d->block_max) { dense = 0; break; }
-        if (dense && out_total && lz4amd_hip_d2h(d->out, S->out, out_total, strm)) goto done;
+        if (dense && out_total && lz4amd_hip_d2h(d->out2, S->out, out_total, strm)) goto done;
         for (i = 0; i < nb; i++) {
-            if (raw[i]) memcpy(d->out + o, base + in_off[i], (size_t)res[i]);
-            else if (!dense && lz4amd_hip_d2h(d->out + o, d_dst[i], (size_t)res[i], strm)) goto done;
+            if (!raw[i] && !dense && lz4amd_hip_d2h(d->out2 + o, d_dst[i], (size_t)res[i], strm)) goto done;
             o += (size_t)res[i];
         }
     }
     if (lz4amd_hip_sync(strm)) goto done;
+    if (!linked) {          /* (after the transfers have landed: the buffer is page-locked memory, a copy into it is still on its way when the call returns) */
+        size_t o = 0;
+        for (i = 0; i < nb; i++) { if (raw[i]) memcpy(d->out2 + o, base + in_off[i], (size_t)res[i]); o += (size_t)res[i]; }
+    }
 host_tail:
-    d->out_size = out_total; d->total_out += out_total;
+    d->b_out_size = out_total; d->total_out += out_total;
     if (d->info.contentChecksumFlag && !skip_checksums) {                   /* lz4frame.c:1896, 1967 */
-        d->hash_n = out_total;
+        dctx_hash_join(d);                          /* (the batch before: one serial hash, batch after batch; its buffer is the one written next) */
+        d->hash_n = out_total; d->hash_p = d->out2;
         d->hashing = out_total >= (1u << 20) && pthread_create(&d->hthread, NULL, dctx_hash_thread, d) == 0;
-        if (!d->hashing) xxh32_update(&d->xxh, d->out, out_total);
+        if (!d->hashing) xxh32_update(&d->xxh, d->out2, out_total);
     }
     if (linked) {                                   /* the 64 KB the next batch may reference */
         if (!d->hist && !(d->hist = (uint8_t*)malloc(65536))) { result = ERR(allocation_failed); goto done_unlocked; }
-        if (out_total >= 65536) { memcpy(d->hist, d->out + out_total - 65536, 65536); d->hist_len = 65536; }
+        if (out_total >= 65536) { memcpy(d->hist, d->out2 + out_total - 65536, 65536); d->hist_len = 65536; }
         else {
             const size_t keep = d->hist_len + out_total > 65536 ? 65536 - out_total : d->hist_len;
             memmove(d->hist, d->hist + d->hist_len - keep, keep);
-            memcpy(d->hist + keep, d->out, out_total);
+            memcpy(d->hist + keep, d->out2, out_total);
             d->hist_len = keep + out_total;
         }
     }
     result = 0;
     goto done_unlocked;
 done:
+    if (ts && strm) (void)lz4amd_hip_sync(strm);     /* (nothing may still be on its way into or out of the page-locked buffers) */
 done_unlocked:
     lz4amd_plan_destroy(dplan); lz4amd_plan_destroy(xplan);
     free(d_src); free(d_dst); free(sizes); free(caps); free(res); free(sums); free(prefix); free(in_off); free(raw);
@@ -585,7 +636,7 @@ static int take_input(LZ4F_dctx* d, size_t want, const uint8_t* src, size_t avai
     if (d->in_size >= want) return 1;
     need = want - d->in_size; take = avail - *used < need ? avail - *used : need;
     if (take) {
-        if (grow(&d->in, &d->in_cap, d->in_size + take, d->in_size)) { *err = ERR(allocation_failed); return 0; }
+        if (grow(&d->in, &d->in_cap, &d->in_pin, d->in_size + take, d->in_size)) { *err = ERR(allocation_failed); return 0; }
         memcpy(d->in + d->in_size, src + *used, take);
         d->in_size += take; *used += take;
     }
@@ -609,6 +660,24 @@ static size_t size_hint(const LZ4F_dctx* d)
     case ST_TAIL:   return 4 - d->in_size;
     default:        return 0;
     }
+}
+
+static void* batch_thread(void* arg)
+{
+    LZ4F_dctx* d = (LZ4F_dctx*)arg;
+    d->b_result = decode_batch(d, d->in2, d->b_nb, d->b_end, d->b_skip, (frame_tls*)d->b_ts);
+    return NULL;
+}
+/* the batch in flight is done: its bytes become the ones to hand out (every byte of the batch before has been handed out) */
+static size_t batch_finish(LZ4F_dctx* d)
+{
+    if (d->busy > 0) pthread_join(d->bthread, NULL);
+    d->busy = 0;
+    if (LZ4F_isError(d->b_result)) return d->b_result;
+    { uint8_t* t = d->out; const size_t c = d->out_cap; const int pn = d->out_pin;
+      d->out = d->out2; d->out_cap = d->out2_cap; d->out_pin = d->out2_pin; d->out2 = t; d->out2_cap = c; d->out2_pin = pn; }
+    d->out_size = d->b_out_size; d->out_pos = 0;
+    return 0;
 }
 
 size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
@@ -673,10 +742,31 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
                 d->scan_pos += 4 + (f & 0x7FFFFFFFu) + tail; d->nready++;
             }
             if (d->nready) {                                                 /* starved, end of frame or a full batch */
-                const size_t r = decode_batch(d, d->nready, d->scan_pos, d->skipc);
+                /* The batch goes to the device - a large one on a helper thread, so that this thread hands out the batch
+                 * before it and takes in the one after it meanwhile (its input and output buffers are the spare pair). */
+                const int large = d->nready * d->block_max >= kAsyncDecoded ;
+                size_t rest, r;
+                if (d->busy) { r = batch_finish(d); if (LZ4F_isError(r)) { err = r; goto fail; } }
+                if (!large && d->out_pos < d->out_size) continue;             /* (its bytes would take this buffer: the pending ones go out first) */
+                rest = d->in_size - d->scan_pos;                              /* the item that is still incomplete stays with the collector */
+                if (grow(&d->in2, &d->in2_cap, &d->in2_pin, rest ? rest : 1, 0)) { err = ERR(allocation_failed); goto fail; }
+                memcpy(d->in2, d->in + d->scan_pos, rest);
+                { uint8_t* t = d->in; const size_t c = d->in_cap; const int pn = d->in_pin;
+                  d->in = d->in2; d->in_cap = d->in2_cap; d->in_pin = d->in2_pin; d->in2 = t; d->in2_cap = c; d->in2_pin = pn; }
+                d->b_nb = d->nready; d->b_end = d->scan_pos; d->b_skip = d->skipc; d->b_ts = NULL;
+                d->in_size = rest; d->scan_pos = 0; d->nready = 0;
+                if (large && frame_ctx() && (d->b_ts = ftls_get()) != NULL && pthread_create(&d->bthread, NULL, batch_thread, d) == 0) d->busy = 1;
+                else {
+                    d->b_result = decode_batch(d, d->in2, d->b_nb, d->b_end, d->b_skip, NULL);
+                    d->busy = -1;                                             /* (done already: nothing to join) */
+                    r = batch_finish(d);
+                    if (LZ4F_isError(r)) { err = r; goto fail; }
+                }
+                continue;
+            }
+            if (d->busy) {                                                   /* nothing else to do before its bytes are there */
+                const size_t r = batch_finish(d);
                 if (LZ4F_isError(r)) { err = r; goto fail; }
-                memmove(d->in, d->in + d->scan_pos, d->in_size - d->scan_pos);
-                d->in_size -= d->scan_pos; d->scan_pos = 0; d->nready = 0;
                 continue;
             }
             if (d->end_seen) {
@@ -724,7 +814,7 @@ size_t LZ4F_decompress_usingDict(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSi
     int fresh;
     if (dctx == NULL) return ERR(parameter_null);
     if (dctx->stage == ST_DONE && dctx->out_pos >= dctx->out_size) LZ4F_resetDecompressionContext(dctx);      /* the frame before is complete and delivered */
-    fresh = dctx->stage == ST_BLOCKS && dctx->total_out == 0 && dctx->in_size == 0 && dctx->nready == 0 && dctx->out_size == 0 && !dctx->end_seen;
+    fresh = dctx->stage == ST_BLOCKS && !dctx->busy && dctx->total_out == 0 && dctx->in_size == 0 && dctx->nready == 0 && dctx->out_size == 0 && !dctx->end_seen;
     if (dctx->stage == ST_HEADER || dctx->stage == ST_DONE || fresh) {
         if (dict && dictSize) {
             if (dictSize > 65536) { dict = (const uint8_t*)dict + (dictSize - 65536); dictSize = 65536; }
