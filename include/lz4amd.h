@@ -47,8 +47,8 @@ const char* lz4amd_last_error(void);
 /* Arguments the reference acts on and this library accepts without acting on them are not errors, but they are not silent
  * either: the call records a notice (thread local, like the error text; "" when the last such call had nothing to say).
  * Today: LZ4_compress_fast* with acceleration > 2 (lz4.c:1389: the GPU parse knows two settings, 1 and 2) and
- * LZ4_compress_HC* with compressionLevel > 10 (lz4hc.c:92-106: levels 10-12 all run ONE optimal parse - 256 candidates per
- * position like level 9, 64-byte sufficient length like level 10). */
+ * LZ4_compress_HC* with compressionLevel > 10 (lz4hc.c:92-106: levels 10 / 11 / 12 search 96 / 512 / 2048 candidates per position -
+ * the reference's level 12: 16384 - and all three use level 10's 64-byte sufficient length). */
 const char* lz4amd_last_notice(void);
 int         lz4amd_device_cus(const lz4amd_ctx* ctx);
 

@@ -21,11 +21,10 @@
  *    "acceleration" levels are served by the fast kernel as level 0.
  *  - LZ4F_decompress is a streaming state machine like the reference's (lz4frame.c:1613-2060): input is taken item by
  *    item, never past the frame; the complete blocks it holds are decoded as one table on the device as soon as the
- *    caller's input runs dry, the end mark shows up or a batch is full (64 MiB of input, 1024 blocks or 256 MiB of
- *    output), and their bytes are delivered before more input is read.  Return values are the reference's size hints.
- *    One deviation: a block is delivered when it is complete - a stored block is not streamed through in parts as
- *    lz4frame.c:1790-1830 does - so on truncated or slowly arriving input fewer bytes may have been delivered than
- *    by the reference for the same input consumed.
+ *    caller's input runs dry, the end mark shows up or a batch is full (32 MiB of input, 1024 blocks or 128 MiB of
+ *    output); a large batch is decoded beside the calls that hand out the batch before it.  Return values are the
+ *    reference's size hints.  A stored block that arrives in pieces is handed on piece by piece as lz4frame.c:1790-1830
+ *    does; a compressed block is delivered when it is complete.
  *  - The streaming compression context (LZ4F_compressBegin / Update / flush / End, lz4frame_stream_api.c) sends
  *    one block per call to the device; LZ4F_compressFrame sends the whole frame at once.
  *  - Dictionaries (LZ4F_CDict, *_usingDict, lz4frame.h:560-640): a frame begun with a dictionary compresses its first block

@@ -111,19 +111,24 @@ __host__ __device__ inline uint64_t hc_recs_bytes(uint32_t n) { return (uint64_t
 __host__ __device__ inline uint64_t hc_scratch_bytes(uint32_t n) { return hc_chain_bytes(n) + hc_st0_bytes(n) + hc_st1_bytes(n) + hc_recs_bytes(n); }
 
 __device__ __forceinline__ uint32_t hc_attempts(int level) {
-    // k_clTable lz4hc.c:92-106: levels 3..9 = 4..256 candidates per position; level 10 = 96 (lz4hc.c:103); levels 11 and 12 ask
-    // for 512 and 16384 there (lz4hc.c:104-105) and get 256 here: the walk's state between bands counts them in 8 bits.
+    // k_clTable lz4hc.c:92-106: levels 3..9 = 4..256 candidates per position; 10 / 11 = 96 / 512 (lz4hc.c:103-104); 12 = 2048 here
+    // (lz4hc.c:105: 16384, behind a pattern analysis that keeps runs of a repeated pattern from costing that much - not built: a
+    // position of such a run would hold its whole tile for 16384 dependent links).
     // Levels below 3 (the reference's LZ4MID, lz4hc.c:93-94) are served by the chain search with 4 candidates.
     if (level < 1) level = 9;            // LZ4HC_CLEVEL_DEFAULT (lz4hc.c:110-113)
     if (level < 3) level = 3;
     if (level == 10) return 96u;
-    if (level > 9) level = 9;
+    if (level == 11) return 512u;
+    if (level > 11) return 2048u;
     return 4u << (level - 3);
 }
+// A walk that is parked between two bands keeps its attempts in 8 bits: in units of 1 up to 256, of 2 up to 512, of 8 beyond
+// (what is lost to the rounding is at most one unit per band).
+__device__ __forceinline__ uint32_t hc_att_shift(uint32_t attempts) { return attempts <= 256u ? 0u : attempts <= 512u ? 1u : 3u; }
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHcHashLog); }
 
 // Per-position search state between bands: st0 = best offset | distance of the next candidate << 16 (0 = walk
-// finished), st1 = best length | (attempts left - 1) << 8.  After the last band st0 = best length | offset << 8.
+// finished), st1 = best length | ((attempts left - 1) >> hc_att_shift) << 8.  After the last band st0 = best length | offset << 8.
 
 // ------------------------------------------------------------------------------ phase 1: chains
 // Lanes of the group that share my hash: `below` = how many lower lanes do (-> the previous position with my
@@ -275,6 +280,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
     const int32_t last_q = (int32_t)n - (int32_t)kMfLimit;            // last position that may start a match
     const int32_t shift = (int32_t)(band * kHcBandStep);
     const bool final_band = band + 1 == kHcBands;
+    const uint32_t ash = hc_att_shift(attempts);
     // the rings hold positions [H - kHcRing, H), H = t0 + kHcTile + kHcAhead - shift
     // -- first tile: fill [0, H(0)) directly
     {
@@ -376,7 +382,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                         else { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
                     } else {
                         const uint32_t s0 = res0[pp], s1 = res1[pp];
-                        dist = s0 >> 16; boff = s0 & 0xFFFFu; best = s1 & 0xFFu; att = (s1 >> 8) + 1;
+                        dist = s0 >> 16; boff = s0 & 0xFFFFu; best = s1 & 0xFFu; att = ((s1 >> 8) << ash) + 1;
                         if (dist == 0) { if (final_band) res0[pp] = best | (boff << 8); walk = false; }   // finished earlier
                     }
                     if (walk) {
@@ -460,7 +466,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                 if (full) { over = true; next = 0; }
                 if (active && over) {
                     if (final_band) res0[pp] = best | (boff << 8);
-                    else { res0[pp] = boff | (next << 16); res1[pp] = (uint16_t)(best | ((next ? att - 1 : 0) << 8)); }
+                    else { res0[pp] = boff | (next << 16); res1[pp] = (uint16_t)(best | ((next ? (att - 1) >> ash : 0) << 8)); }
                     // what the next position of my run may start from (farther bands: only a match found in this band)
                     inh_len = best > kMinMatch && (band == 0 || best > best_in) ? best - 1 : 0; inh_off = boff; inh_capped = best >= lim;
                     active = false;

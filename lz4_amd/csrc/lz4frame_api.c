@@ -290,6 +290,8 @@ struct LZ4F_dctx_s {
     int dict_keep;                                /* ... installed by the call that is running: the reset between two frames inside that call leaves it */
     /* the content checksum of a batch runs on a helper thread while its bytes are delivered and the next input is taken */
     int hashing; pthread_t hthread; size_t hash_n; const uint8_t* hash_p;
+    /* a stored block that arrives in pieces goes straight from the caller's input to the caller's output (lz4frame.c:1790-1830) */
+    int raw_on; size_t raw_left, raw_b0, raw_b1; xxh32_state raw_xxh;      /* raw_b0 .. raw_b1: bytes of the block that were buffered before (they go first) */
 };
 static void* dctx_hash_thread(void* arg) { LZ4F_dctx* d = (LZ4F_dctx*)arg; xxh32_update(&d->xxh, d->hash_p, d->hash_n); return NULL; }
 static void dctx_hash_join(LZ4F_dctx* d) { if (d->hashing) { pthread_join(d->hthread, NULL); d->hashing = 0; } }
@@ -336,7 +338,7 @@ void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
     dctx_batch_drop(d);
     dctx_hash_join(d);
     d->stage = ST_HEADER;
-    d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0;
+    d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0; d->raw_on = 0; d->raw_left = 0;
     d->out_size = d->out_pos = 0;
     d->total_out = d->skip_left = 0; d->hist_len = 0;
     if (!d->dict_keep) { d->dict = NULL; d->dict_len = 0; }      /* lz4frame.c:1331-1332: a dictionary counts for one frame */
@@ -466,6 +468,20 @@ static int grow(uint8_t** buf, size_t* cap, int* pin, size_t need, size_t keep)
     return 0;
 }
 
+/* linked frames: the 64 KB before whatever comes next (lz4frame.c:1901-1915) */
+static int hist_append(LZ4F_dctx* d, const uint8_t* p, size_t n)
+{
+    if (!d->hist && !(d->hist = (uint8_t*)malloc(65536))) return -1;
+    if (n >= 65536) { memcpy(d->hist, p + n - 65536, 65536); d->hist_len = 65536; }
+    else {
+        const size_t keep = d->hist_len + n > 65536 ? 65536 - n : d->hist_len;
+        memmove(d->hist, d->hist + d->hist_len - keep, keep);
+        memcpy(d->hist + keep, p, n);
+        d->hist_len = keep + n;
+    }
+    return 0;
+}
+
 /* decode the nb complete blocks held in base[0, end) (d->in2) into d->out2; d->b_out_size: how many bytes that made.
  * Runs on the caller's thread or on the batch's helper thread (ts: the staging area and stream of the thread that owns the context). */
 static size_t decode_batch(LZ4F_dctx* d, const uint8_t* const base, size_t nb, size_t end, int skip_checksums, frame_tls* ts_given)
@@ -494,10 +510,12 @@ static size_t decode_batch(LZ4F_dctx* d, const uint8_t* const base, size_t nb, s
     }
     if (pos != end) goto done_unlocked;
     {   /* a batch of stored blocks only (lz4frame.c:1790-1830 copies them too) never visits the device */
-        int all_raw = !(bchk && !skip_checksums);
+        int all_raw = 1;
         for (i = 0; i < nb && all_raw; i++) if (!raw[i]) all_raw = 0;
         if (all_raw) {
             size_t o = 0;
+            if (bchk && !skip_checksums)            /* (their checksums on the host as well: the bytes are copied here anyway; lz4frame.c:1878) */
+                for (i = 0; i < nb; i++) if (xxh32(base + in_off[i], (size_t)sizes[i]) != rd32(base + in_off[i] + (size_t)sizes[i])) { result = ERR(blockChecksum_invalid); goto done_unlocked; }
             for (i = 0; i < nb; i++) { if ((size_t)sizes[i] > d->block_max) { result = ERR(decompressionFailed); goto done_unlocked; } out_total += (size_t)sizes[i]; }
             if (grow(&d->out2, &d->out2_cap, &d->out2_pin, out_total ? out_total : 1, 0)) { result = ERR(allocation_failed); goto done_unlocked; }
             for (i = 0; i < nb; i++) { memcpy(d->out2 + o, base + in_off[i], (size_t)sizes[i]); o += (size_t)sizes[i]; }
@@ -609,16 +627,7 @@ host_tail:
         d->hashing = out_total >= (1u << 20) && pthread_create(&d->hthread, NULL, dctx_hash_thread, d) == 0;
         if (!d->hashing) xxh32_update(&d->xxh, d->out2, out_total);
     }
-    if (linked) {                                   /* the 64 KB the next batch may reference */
-        if (!d->hist && !(d->hist = (uint8_t*)malloc(65536))) { result = ERR(allocation_failed); goto done_unlocked; }
-        if (out_total >= 65536) { memcpy(d->hist, d->out2 + out_total - 65536, 65536); d->hist_len = 65536; }
-        else {
-            const size_t keep = d->hist_len + out_total > 65536 ? 65536 - out_total : d->hist_len;
-            memmove(d->hist, d->hist + d->hist_len - keep, keep);
-            memcpy(d->hist + keep, d->out2, out_total);
-            d->hist_len = keep + out_total;
-        }
-    }
+    if (linked && hist_append(d, d->out2, out_total)) { result = ERR(allocation_failed); goto done_unlocked; }      /* the 64 KB the next batch may reference */
     result = 0;
     goto done_unlocked;
 done:
@@ -652,6 +661,7 @@ static size_t size_hint(const LZ4F_dctx* d)
     case ST_HEADER: { const size_t w = header_want(d->in, d->in_size); return (w > d->in_size ? w - d->in_size : 0) + 4; }   /* lz4frame.c:1691, 1710: + the first block header */
     case ST_SKIP:   return d->skip_left > ((size_t)1 << 30) ? ((size_t)1 << 30) : (size_t)d->skip_left;
     case ST_BLOCKS:
+        if (d->raw_on) return d->raw_left ? d->raw_left + tail + 4 : (tail - d->in_size) + 4;      /* lz4frame.c:1826: what the stored block misses + the next header */
         if (d->end_seen) return d->info.contentChecksumFlag ? 4 : 0;
         if (d->in_size < d->scan_pos + 4) return d->scan_pos + 4 - d->in_size;
         {   const size_t bsz = rd32(d->in + d->scan_pos) & 0x7FFFFFFFu;
@@ -732,15 +742,58 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
         /* -- ST_BLOCKS: collect whole blocks, decode them when there is no reason to wait for more */
         {   const size_t tail = d->info.blockChecksumFlag == LZ4F_blockChecksumEnabled ? 4 : 0;
             int starved = 0;
+            if (d->raw_on) {
+                /* a stored block in pieces: from the caller's input straight to the caller's output, as far as both reach */
+                while (d->raw_left) {
+                    const int buffered = d->raw_b0 < d->raw_b1;
+                    const uint8_t* from = buffered ? d->in + d->raw_b0 : src + used;
+                    size_t n = d->raw_left;
+                    const size_t have = buffered ? d->raw_b1 - d->raw_b0 : avail - used;
+                    if (n > have) n = have;
+                    if (n > dcap - given) n = dcap - given;
+                    if (!n) break;
+                    if (d->info.contentChecksumFlag && !d->skipc) xxh32_update(&d->xxh, from, n);
+                    if (tail && !d->skipc) xxh32_update(&d->raw_xxh, from, n);
+                    if (d->info.blockMode == LZ4F_blockLinked && hist_append(d, from, n)) { err = ERR(allocation_failed); goto fail; }
+                    memcpy(dst + given, from, n);
+                    if (buffered) {
+                        d->raw_b0 += n;
+                        if (d->raw_b0 == d->raw_b1) {                        /* (what was buffered behind the block's bytes - a piece of its checksum - stays) */
+                            memmove(d->in, d->in + d->raw_b1, d->in_size - d->raw_b1);
+                            d->in_size -= d->raw_b1; d->raw_b0 = d->raw_b1 = 0;
+                        }
+                    } else used += n;
+                    given += n; d->raw_left -= n; d->total_out += n;
+                }
+                if (d->raw_left) break;                                      /* more input, or more room */
+                if (tail) {
+                    if (!take_input(d, 4, src, avail, &used, &err)) { if (err) goto fail; break; }
+                    if (!d->skipc && rd32(d->in) != xxh32_digest(&d->raw_xxh)) { err = ERR(blockChecksum_invalid); goto fail; }   /* lz4frame.c:1878 */
+                    d->in_size = 0;
+                }
+                d->raw_on = 0;
+                continue;
+            }
             while (!d->end_seen && d->nready < (size_t)kBatchBlocks && d->scan_pos < kBatchBytes && (d->nready + 1) * d->block_max <= kBatchDecoded) {
                 uint32_t f;
                 if (!take_input(d, d->scan_pos + 4, src, avail, &used, &err)) { if (err) goto fail; starved = 1; break; }
                 f = rd32(d->in + d->scan_pos);
                 if (f == 0) { d->end_seen = 1; break; }                      /* end mark, lz4frame.c:1730 */
                 if ((f & 0x7FFFFFFFu) > d->block_max) { err = ERR(maxBlockSize_invalid); goto fail; }   /* lz4frame.c:1737 */
+                if ((f >> 31) && d->nready == 0 && !d->busy && (size_t)(f & 0x7FFFFFFFu) + tail > avail - used) {
+                    /* a stored block that is not all here, with nothing before it waiting for the device: its bytes need no buffer
+                     * (lz4frame.c:1790-1830 hands them on as they come; a whole one at hand goes with the batch, one copy either way) */
+                    dctx_hash_join(d);
+                    d->raw_on = 1; d->raw_left = f & 0x7FFFFFFFu;
+                    d->raw_b0 = 4; d->raw_b1 = d->in_size < 4 + d->raw_left ? d->in_size : 4 + d->raw_left;      /* (bytes an earlier call left in the buffer) */
+                    if (d->raw_b0 == d->raw_b1) { d->in_size = 0; d->raw_b0 = d->raw_b1 = 0; }
+                    if (tail) xxh32_reset(&d->raw_xxh);
+                    break;
+                }
                 if (!take_input(d, d->scan_pos + 4 + (f & 0x7FFFFFFFu) + tail, src, avail, &used, &err)) { if (err) goto fail; starved = 1; break; }
                 d->scan_pos += 4 + (f & 0x7FFFFFFFu) + tail; d->nready++;
             }
+            if (d->raw_on) continue;                                         /* (a stored block in pieces: handled at the top) */
             if (d->nready) {                                                 /* starved, end of frame or a full batch */
                 /* The batch goes to the device - a large one on a helper thread, so that this thread hands out the batch
                  * before it and takes in the one after it meanwhile (its input and output buffers are the spare pair). */

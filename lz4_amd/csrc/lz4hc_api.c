@@ -14,7 +14,7 @@
 
 int LZ4_compress_HC(const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel)
 {
-    lz4amd_set_notice(compressionLevel > 10 ? "LZ4_compress_HC: levels 11-12 run the optimal parse of level 10 with 256 candidates per position (the reference: 512 / 16384) and its 64-byte sufficient length" : "");
+    lz4amd_set_notice(compressionLevel > 10 ? "LZ4_compress_HC: levels 11-12 search 512 / 2048 candidates per position (the reference: 512 / 16384) and use the 64-byte sufficient length of level 10" : "");
     if (srcSize < 0 || (unsigned)srcSize > (unsigned)LZ4_MAX_INPUT_SIZE) return 0;   /* lz4hc.c:1403 */
     if (dst == NULL || dstCapacity <= 0) return 0;
     if (src == NULL && srcSize != 0) return 0;

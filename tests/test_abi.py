@@ -120,7 +120,7 @@ def test_ignored_arguments_leave_a_notice():
         L.LZ4_compress_fast(b"abc", dst, -1, 64, accel)
         assert L.lz4amd_last_notice() == b""
     L.LZ4_compress_HC(b"abc", dst, -1, 64, 12)
-    assert b"level 10" in L.lz4amd_last_notice()                       # levels 10-12 share one optimal parse
+    assert b"level 10" in L.lz4amd_last_notice()                       # levels 11-12: their own search depth, level 10's sufficient length
     L.LZ4_compress_HC(b"abc", dst, -1, 64, 10)
     assert L.lz4amd_last_notice() == b""
     L.LZ4_compress_HC(b"abc", dst, -1, 64, 9)

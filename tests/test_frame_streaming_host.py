@@ -17,14 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BSIZE = {4: 65536, 5: 262144, 6: 1 << 20, 7: 4 << 20}
 
 
-def stored_frame(data, bsid=4, linked=False, content_checksum=True, content_size=False, block_size=None):
-    flg = 0x40 | (0 if linked else 0x20) | (4 if content_checksum else 0) | (8 if content_size else 0)
+def stored_frame(data, bsid=4, linked=False, content_checksum=True, content_size=False, block_size=None, block_checksum=False):
+    flg = 0x40 | (0 if linked else 0x20) | (4 if content_checksum else 0) | (8 if content_size else 0) | (0x10 if block_checksum else 0)
     desc = bytes([flg, bsid << 4]) + (struct.pack("<Q", len(data)) if content_size else b"")
     out = bytearray(struct.pack("<I", 0x184D2204) + desc + bytes([(xxhash.xxh32(desc).intdigest() >> 8) & 0xFF]))
     bs = block_size or BSIZE[bsid]
     for o in range(0, len(data), bs):
         blk = data[o:o + bs]
-        out += struct.pack("<I", len(blk) | 0x80000000) + blk
+        out += struct.pack("<I", len(blk) | 0x80000000) + blk + (struct.pack("<I", xxhash.xxh32(blk).intdigest()) if block_checksum else b"")
     out += struct.pack("<I", 0)
     if content_checksum:
         out += struct.pack("<I", xxhash.xxh32(data).intdigest())
@@ -110,19 +110,20 @@ def test_output_is_progressive_and_input_is_taken_item_by_item(L):
     r, used, got = d.call(frame[:7], 1000)
     assert (r, used, got) == (4, 7, b"")
     pos = 7
-    # first block header + half of the block: all taken, nothing out yet, hint = what the block misses + next header
+    # first block header + half of the block: a stored block needs no buffer - its bytes come out as they arrive (lz4frame.c:1790-1830),
+    # hint = what the block misses + next header
     r, used, got = d.call(frame[pos:pos + 4 + 30000], 1 << 20)
-    assert used == 30004 and got == b"" and r == 65536 - 30000 + 4
+    assert used == 30004 and got == data[:30000] and r == 65536 - 30000 + 4
     pos += used
-    # the rest of block 0 and a bit of block 1: block 0 comes out NOW, long before the frame ends
+    # the rest of block 0 and a bit of block 1: the rest of block 0 comes out, and the 100 bytes of block 1 that are there
     r, used, got = d.call(frame[pos:pos + 35536 + 4 + 100], 1 << 20)
-    assert used == 35536 + 4 + 100 and got == data[:65536] and r == 65536 - 100 + 4
+    assert used == 35536 + 4 + 100 and got == data[30000:65636] and r == 65536 - 100 + 4
     pos += used
     # a small destination: the decoder holds the bytes and takes no input until they are delivered
     r, used, got = d.call(frame[pos:pos + 65436], 1 << 20)
-    assert used == 65436 and got == data[65536:131072]
+    assert used == 65436 and got == data[65636:131072]
     pos += used
-    r, used, got = d.call(frame[pos:], 1000)               # block 2, the short block 3, end mark, checksum are all there
+    r, used, got = d.call(frame[pos:], 1000)               # block 2, the short block 3, end mark, checksum are all there: whole blocks go as a batch
     assert got == data[131072:132072] and r != 0
     pos += used
     out = bytearray(data[:132072])
@@ -138,7 +139,7 @@ def test_output_is_progressive_and_input_is_taken_item_by_item(L):
 
 
 @pytest.mark.parametrize("kw", [dict(bsid=4), dict(bsid=5, linked=True), dict(bsid=4, content_checksum=False, content_size=True),
-                                dict(bsid=7, block_size=70001), dict(bsid=4, block_size=1)])
+                                dict(bsid=7, block_size=70001), dict(bsid=4, block_size=1), dict(bsid=4, block_checksum=True), dict(bsid=5, linked=True, block_checksum=True)])
 def test_any_chunking_gives_the_content(L, kw):
     rng = random.Random(7)
     small = kw.get("block_size") == 1
@@ -219,6 +220,27 @@ def test_skippable_frames_errors_and_context_reuse(L):
     d.close()
 
 
+def test_a_stored_block_with_a_wrong_checksum_is_refused_whole_or_in_pieces(L):
+    """Block checksums of stored blocks (lz4frame.c:1878) are verified on the host: over the batch when the blocks arrive whole,
+    over the pieces when a block is handed on as it arrives."""
+    rng = random.Random(3)
+    data = bytes(rng.getrandbits(8) for _ in range(150000))
+    frame = bytearray(stored_frame(data, bsid=4, block_checksum=True))
+    frame[7 + 4 + 70000] ^= 1                                        # a byte of block 1
+    for take in (1 << 24, 5000):
+        d, pos, err = Dctx(L), 0, None
+        for _ in range(1000):
+            r, used, got = d.call(bytes(frame[pos:pos + take]), 1 << 20)
+            pos += used
+            if L.LZ4F_isError(r):
+                err = L.LZ4F_getErrorName(r)
+                break
+            if r == 0:
+                break
+        assert err == b"ERROR_blockChecksum_invalid", (take, err)
+        d.close()
+
+
 def test_memory_is_bounded_by_a_batch_not_by_the_frame(L):
     """512 MiB of stored 4 MiB blocks streamed through a 1 MiB window: the resident set must not grow with the frame."""
     import resource
@@ -248,15 +270,19 @@ def test_memory_is_bounded_by_a_batch_not_by_the_frame(L):
 def test_same_call_sequence_on_the_reference(L, R):
     """Replay identical call sequences on the real lz4frame.c: the content, the bytes consumed in total and the call
     that reports the end of the frame agree; so do the per-call consumed counts when every call offers exactly the
-    bytes the previous one asked for."""
+    bytes the previous one asked for, and the whole per-call trace when the input comes in pieces smaller than a block."""
     rng = random.Random(11)
     data = bytes(rng.getrandbits(8) for _ in range(5000)) * 60
     for kw in (dict(bsid=4), dict(bsid=5, linked=True, content_size=True), dict(bsid=4, content_checksum=False)):
         frame = stored_frame(data, **kw)
-        for schedule in ([(rng.randint(1, 90000), rng.randint(1, 90000)) for _ in range(50)], [(1 << 24, 1 << 24)], [(97, 70000)]):
+        for schedule in ([(rng.randint(1, 90000), rng.randint(1, 90000)) for _ in range(50)], [(1 << 24, 1 << 24)], [(97, 70000)], [(3000, 1000)], [(20000, 30000)]):
             a, pa, ta = drive(L, frame, schedule)
             b, pb, tb = drive(R, frame, schedule)
             assert a == b == data and pa == pb == len(frame)
+            # input offered in pieces smaller than a block: a stored block is handed on as it arrives, call by call like the reference
+            # (lz4frame.c:1790-1830) - the two traces of (consumed, produced, finished) are the same
+            if max(t for t, _ in schedule) < 60000:
+                assert ta == tb, schedule
         # hint-driven on both
         seqs = []
         for lib in (L, R):

@@ -213,10 +213,9 @@ def test_hc_optimal_parse_levels_10_to_12(ctx, ocodec, corpus, datagen):
         o10 = gpu_compress_hc(ctx, blocks, level=10)
         o9 = gpu_compress_hc(ctx, blocks, level=9)
         o11 = gpu_compress_hc(ctx, blocks, level=11)
-        # level 10 searches 96 candidates per position (lz4hc.c:103), 11 and 12 the 256 the walk can count (the reference: 512, 16384)
-        assert [r for r, _ in o11] == [r for r, _ in o12]
-        s12, s10, s9 = sum(r for r, _ in o12), sum(r for r, _ in o10), sum(r for r, _ in o9)
-        assert s12 <= s10 <= s9 * 1.002 and s12 <= s9, (pct, s12, s10, s9)      # deeper never costs bytes; the optimal parse at 96 candidates is at worst a hair above level 9's 256
+        # levels 10 / 11 / 12 search 96 / 512 / 2048 candidates per position (lz4hc.c:103-105: 96 / 512 / 16384)
+        s12, s11, s10, s9 = sum(r for r, _ in o12), sum(r for r, _ in o11), sum(r for r, _ in o10), sum(r for r, _ in o9)
+        assert s12 <= s11 <= s10 <= s9 * 1.002 and s12 <= s9, (pct, s12, s11, s10, s9)      # deeper never costs bytes; the optimal parse at 96 candidates is at worst a hair above level 9's 256
         for b, (r, c) in zip(blocks, o12):
             ro, o = ocodec.decompress(c, len(b))
             assert ro == len(b) and o == b
