@@ -106,12 +106,18 @@ def gen_data(nbytes, pct, seed):
 
 
 def kernel_sources_sha():
-    """Identity of the device code: the traffic file under profiles/ is only quoted when it was measured on these sources."""
+    """Identity of the device code: the traffic file under profiles/ is only quoted when it was measured on these sources.
+    Comments and blank lines do not count (they do not reach the device)."""
+    import re
     h = hashlib.sha256()
     kdir = os.path.join(ROOT, "lz4_amd", "csrc", "kernels")
     for f in sorted(os.listdir(kdir)) + ["../lz4amd_device.hip"]:
-        with open(os.path.join(kdir, f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(kdir, f), "r", encoding="utf-8", errors="replace") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        lines = [" ".join(l.split()) for l in text.split("\n")]
+        h.update("\n".join(l for l in lines if l).encode())
     return h.hexdigest()[:16]
 
 

@@ -9,32 +9,34 @@
 // reference's on the datagen inputs (tests/test_gpu_parity.py asserts the +-3 % window).
 //
 // Not a port: the reference is one serial loop over one block, whose hash table changes after
-// every probe.  Here ONE 1024-thread workgroup (16 waves, one CU, ~150 KB of its LDS) streams
+// every probe.  Here ONE 1024-thread workgroup (16 waves, one CU, ~160 KB of its LDS) streams
 // through a block in TILES of 8 KB, and everything the inner loops touch lives in LDS:
 //
-//   source ring   100 KB of the block around the tile (the 64 KB LZ4 window + the tile + the
+//   source ring   84 KB of the block around the tile (the 64 KB LZ4 window + the tile + the
 //                 prefetched next tile), filled with coalesced 16-byte loads; candidates are
 //                 verified and matches extended against it, never against HBM;
-//   hash table    8192 x u32 (5-byte multiplicative hash of the reference, lz4.c:785-795, 13 bits),
+//   hash table    8192 x u32 (13 bits; 5 bytes hashed, 4 for blocks under 64 KB + 11 like lz4.c:1389),
 //                 FROZEN while a tile is parsed: every position of the tile probes the state left
 //                 by the previous tiles, and the tile's own positions are inserted afterwards with
 //                 atomicMax (order independent, so the output is deterministic).  That decouples
 //                 match FINDING from the parse order, which is what makes the tile parallel:
-//   strips        the tile is cut in 16 strips of 512 bytes, one wave each.  A wave slides a
-//                 64-position window over its strip: every lane hashes its position, probes,
-//                 measures up to 24 matching bytes forwards and 8 backwards (over
-//                 literals that may still be pending) on its own; found matches
-//                 are taken greedily in position order (ballot + ctz), long ones are extended by a
-//                 wave-wide 512-byte compare.  Matches end at the strip's end; literals pending at
-//                 a strip's end are carried into the next sequence (of any later strip or tile).
-//   offsets       after a barrier one thread turns the strips' encoded sizes into output offsets
-//                 (running across tiles), while the other waves insert the tile into the table;
-//   emit          each wave writes the sequences of its strip: lanes place their token / length /
-//                 offset bytes by a wave prefix sum, then the wave copies the literal runs out of
-//                 the source ring (HBM for runs that started more than a window ago).
+//   strips        the tile is cut in 16 strips of 512 bytes, one wave each (match_strip): a lane probes
+//                 four positions of its own 8 source bytes; stretches of probe hits with one distance
+//                 ("runs") are listed, measured lane = run (24 bytes on, 8 back over pending literals),
+//                 and selected by wave scans - no serial walk over the matches; a long match is
+//                 finished by a wave-wide compare.  A match may run past its strip up to the tile's end;
+//   settle        one wave makes the strips of the tile BEFORE consistent (matches that ran over a
+//                 strip's end: resolve_overruns) and turns their encoded sizes into output offsets
+//                 (strip_offsets), while the others already parse the next tile;
+//   emit          the settled tile's sequences are composed in a 12 KB staging buffer in LDS - token,
+//                 length and offset bytes as byte writes, literals in 8-byte pieces numbered by a wave
+//                 scan - by whichever wave is free (emit_strip_lds), and leave for HBM as whole aligned
+//                 16-byte chunks while the next tile is inserted into the table (flush_begin / flush_end).
+//                 The emit lanes also write the optional entry-point table's rows (hint_row; lz4amd_params.h).
 //
 // HBM traffic per block: source read once (plus the final literal run if it is longer than the
-// ring), compressed stream written once.  No scratch, no second kernel.  No MFMA: byte shuffling.
+// ring), compressed stream written once, 16 bytes of table per ~512 bytes of source when a table is
+// asked for.  No scratch, no second kernel.  No MFMA: byte shuffling.
 #pragma once
 #include "lz4_common.h"
 #include "../lz4amd_params.h"

@@ -15,7 +15,8 @@
 //       workgroup's scratch, applying every format rule on the way: a malformed block is rejected
 //       before a byte of output is written.  A block that comes with an ENTRY-POINT TABLE
 //       (include/lz4amd.h: rows that name every few sequences of the chain, written by
-//       lz4amd_k_compress or anybody else) skips this stage: see PARSER below.
+//       lz4amd_k_compress or anybody else) skips this stage: see PARSER below.  On request (hint_make) the
+//       stage writes that table for a block that came without a usable one, for the block's next decode.
 //
 //   B STREAM     a dataflow pipeline through LDS rings and counters only - no workgroup barrier
 //       between the first and the last byte of the block:
@@ -732,7 +733,7 @@ __device__ __forceinline__ U32x4 ring_read16(const RegionCtx& C, uint32_t pos) {
 // (only a match with a period < 16 that starts inside a chunk reads its own chunk).
 // key: a piece that is not ready for the most common reason - a plain match whose source bytes [key, key + n) lie in
 // other chunks that are still in flight - reports where its source starts: it can be finished later with one poll of
-// those chunks' done bits and one ring read.  kKeyAlways: only a full attempt can tell.
+// those chunks' lap tags and one ring read.  kKeyAlways: only a full attempt can tell.
 enum : uint32_t { kKeyAlways = 0xFFFFFFFFu };
 __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint32_t d, uint32_t lo, uint32_t n,
                                            const SeqRec& rec, uint32_t ms, bool own_ok, U32x4& v, uint32_t& key) {
@@ -773,7 +774,7 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     const bool ready = is_lit ? lit_ok : (src_final && !wait_own);
     const bool plain = is_lit || n <= dist;
     {   // (read whether or not the piece is ready: the address is always inside its ring, and the read then does not wait
-        //  for the done bits' own trip to LDS)
+        //  for the lap tags' own trip to LDS)
         const uint32_t addr = is_lit ? kOffCr + a : kOffRing + ring_fold(s - lo - C.ringB);
         v = lds_read16_at((const uint8_t*)C.smem, addr);
     }

@@ -34,6 +34,8 @@
 //              Matches end at the strip's end; pending literals carry over.
 //   4 emit     strip sizes -> output offsets (wave 0), then every wave writes its strip
 //              (emit_strip of the fast compressor).
+// Levels 10-12 (lz4hc.c:92-106, LZ4HC_compress_optimal 1823-2130) replace phase 3's lazy choice by an optimal parse over the
+// same per-position search results (hc_parse_strip_opt), with 96 / 512 / 2048 candidates per position in phase 2.
 //
 // HBM/L2 traffic per block: source read 2 + 2 x bands times, 2 B/position of chain written once and
 // read once per band, 6 B/position of search state written and read once per band, 8 B per sequence

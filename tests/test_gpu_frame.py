@@ -418,3 +418,35 @@ def test_frames_from_many_threads_at_once(L, oracle, datagen):
         t.join()
     assert not errs, errs
     assert frames == alone
+
+
+@pytest.mark.parametrize("kw", [dict(blockSizeID=7, blockMode=0, contentChecksumFlag=1), dict(blockSizeID=4, blockMode=1),
+                                dict(blockSizeID=6, blockMode=1, blockChecksumFlag=1, contentChecksumFlag=1)])
+def test_large_frames_through_overlapping_batches(L, datagen, kw):
+    """Frames of several batches (lz4frame_api.c: a batch that may decode to 8 MiB or more runs on a helper thread while the
+    calling thread hands out the batch before and takes in the next): the content is the same whatever the caller's buffers
+    are - the whole frame at once, pieces of up to 3 MB into destinations of up to 5 MB, and a destination so small that
+    most calls return with a batch still in flight.  Compressible, incompressible (stored blocks, some of them handed on in
+    pieces) and mixed content."""
+    import random
+    rng = random.Random(17)
+    data = datagen(24 << 20, 60, 3) + os.urandom(9 << 20) + datagen(20 << 20, 90, 4) + os.urandom(70000) + datagen(3 << 20, 20, 5)
+    frame = compress_frame(L, data, **kw)
+    for take_max, dcap_max in ((1 << 30, 1 << 30), (3 << 20, 5 << 20), (9 << 20, 300000), (200000, 9 << 20)):
+        d = ctypes.c_void_p()
+        assert L.LZ4F_createDecompressionContext(ctypes.byref(d), 100) == 0
+        out, pos = bytearray(), 0
+        try:
+            for _ in range(200000):
+                take = min(len(frame) - pos, rng.randint(1, take_max))
+                dst = ctypes.create_string_buffer(min(len(data) + 64, rng.randint(1, dcap_max)))
+                dsz, ssz = ctypes.c_size_t(len(dst)), ctypes.c_size_t(take)
+                r = L.LZ4F_decompress(d, dst, ctypes.byref(dsz), frame[pos:pos + take], ctypes.byref(ssz), None)
+                assert not L.LZ4F_isError(r), L.LZ4F_getErrorName(r)
+                out += dst.raw[:dsz.value]
+                pos += ssz.value
+                if r == 0:
+                    break
+        finally:
+            L.LZ4F_freeDecompressionContext(d)
+        assert pos == len(frame) and bytes(out) == data, (kw, take_max, dcap_max, len(out))
