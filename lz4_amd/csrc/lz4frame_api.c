@@ -95,6 +95,36 @@ static frame_tls* ftls_get(void)
     }
     return t;
 }
+/* Staging areas for work that runs BESIDE the calling thread (a decoder's batch on its helper thread): the thread's own area may
+ * be used by whatever the caller does next on that thread - another frame function - so such work takes an area of its own,
+ * from a small pool (device memory is slow to allocate; a decoder per frame then costs none). */
+enum { kStagePool = 4 };
+static frame_tls* g_stage_pool[kStagePool];
+static pthread_mutex_t g_stage_lock = PTHREAD_MUTEX_INITIALIZER;
+static frame_tls* stage_acquire(void)
+{
+    frame_tls* t = NULL;
+    int i;
+    pthread_mutex_lock(&g_stage_lock);
+    for (i = 0; i < kStagePool && !t; i++) if (g_stage_pool[i]) { t = g_stage_pool[i]; g_stage_pool[i] = NULL; }
+    pthread_mutex_unlock(&g_stage_lock);
+    if (t) return t;
+    t = (frame_tls*)calloc(1, sizeof *t);
+    if (!t) return NULL;
+    t->stream = lz4amd_hip_stream_create();
+    if (!t->stream) { free(t); return NULL; }
+    return t;
+}
+static void stage_release(frame_tls* t)
+{
+    int i;
+    if (!t) return;
+    pthread_mutex_lock(&g_stage_lock);
+    for (i = 0; i < kStagePool; i++) if (!g_stage_pool[i]) { g_stage_pool[i] = t; t = NULL; break; }
+    pthread_mutex_unlock(&g_stage_lock);
+    ftls_free(t);                                  /* (the pool is full) */
+}
+
 static lz4amd_ctx* frame_ctx(void)
 {
     lz4amd_ctx* c;
@@ -275,7 +305,7 @@ struct LZ4F_dctx_s {
     uint8_t* out2; size_t out2_cap; int out2_pin; /* ... and where its bytes go (the two output buffers swap when it is done) */
     int out_pin;
     /* a large batch is decoded by a helper thread while the caller's thread hands out the batch before and takes in the next */
-    int busy; pthread_t bthread; size_t b_nb, b_end, b_out_size, b_result; int b_skip; void* b_ts;
+    int busy; pthread_t bthread; size_t b_nb, b_end, b_out_size, b_result; int b_skip; void* b_ts;      /* b_ts: the staging area of this context's helper-thread batches (from a pool) */
     size_t scan_pos; size_t nready;               /* complete blocks in in[0, scan_pos) */
     int end_seen;                                 /* in[scan_pos, scan_pos+4) is the end mark */
     uint8_t* out; size_t out_size, out_pos, out_cap;   /* decoded bytes of the last batch, and how many were delivered */
@@ -347,6 +377,7 @@ LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* d)
 {
     if (d) {
         dctx_batch_drop(d);
+        stage_release((frame_tls*)d->b_ts);
         dctx_hash_join(d); hfree_cap(d->in, d->in_pin, d->in_cap); hfree_cap(d->in2, d->in2_pin, d->in2_cap); hfree_cap(d->out, d->out_pin, d->out_cap); hfree_cap(d->out2, d->out2_pin, d->out2_cap); free(d->hist);
         if (d->has_cmem && d->cmem.customFree) d->cmem.customFree(d->cmem.opaqueState, d); else free(d);
     }
@@ -806,9 +837,9 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
                 memcpy(d->in2, d->in + d->scan_pos, rest);
                 { uint8_t* t = d->in; const size_t c = d->in_cap; const int pn = d->in_pin;
                   d->in = d->in2; d->in_cap = d->in2_cap; d->in_pin = d->in2_pin; d->in2 = t; d->in2_cap = c; d->in2_pin = pn; }
-                d->b_nb = d->nready; d->b_end = d->scan_pos; d->b_skip = d->skipc; d->b_ts = NULL;
+                d->b_nb = d->nready; d->b_end = d->scan_pos; d->b_skip = d->skipc;
                 d->in_size = rest; d->scan_pos = 0; d->nready = 0;
-                if (large && frame_ctx() && (d->b_ts = ftls_get()) != NULL && pthread_create(&d->bthread, NULL, batch_thread, d) == 0) d->busy = 1;
+                if (large && frame_ctx() && (d->b_ts || (d->b_ts = stage_acquire()) != NULL) && pthread_create(&d->bthread, NULL, batch_thread, d) == 0) d->busy = 1;
                 else {
                     d->b_result = decode_batch(d, d->in2, d->b_nb, d->b_end, d->b_skip, NULL);
                     d->busy = -1;                                             /* (done already: nothing to join) */

@@ -427,7 +427,8 @@ def test_large_frames_through_overlapping_batches(L, datagen, kw):
     calling thread hands out the batch before and takes in the next): the content is the same whatever the caller's buffers
     are - the whole frame at once, pieces of up to 3 MB into destinations of up to 5 MB, and a destination so small that
     most calls return with a batch still in flight.  Compressible, incompressible (stored blocks, some of them handed on in
-    pieces) and mixed content."""
+    pieces) and mixed content; other frames are compressed and decoded on the same thread in between (a batch on its helper
+    thread has a staging area of its own)."""
     import random
     rng = random.Random(17)
     data = datagen(24 << 20, 60, 3) + os.urandom(9 << 20) + datagen(20 << 20, 90, 4) + os.urandom(70000) + datagen(3 << 20, 20, 5)
@@ -447,6 +448,11 @@ def test_large_frames_through_overlapping_batches(L, datagen, kw):
                 pos += ssz.value
                 if r == 0:
                     break
+                if dcap_max == 300000 and _ % 40 == 7:
+                    # another frame function on the same thread while a batch of this decoder is on the device: it has its own staging area
+                    other = data[(_ * 4096) % (1 << 20):][:3 << 20]
+                    back = decompress_frame(L, compress_frame(L, other, blockSizeID=5), len(other))
+                    assert back[0] == other
         finally:
             L.LZ4F_freeDecompressionContext(d)
         assert pos == len(frame) and bytes(out) == data, (kw, take_max, dcap_max, len(out))
