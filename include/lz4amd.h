@@ -90,9 +90,9 @@ int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, i
                                            const void* const* d_src, const int* src_sizes,
                                            void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix);
 /* Entry-point tables ("hints") - an optional, out-of-band column of the block table.
- * A compress plan (LZ4AMD_OP_COMPRESS) that has them attached writes, next to every block, a small table that names every
- * eighth sequence of the block's token chain: {position of its token in the block, position of its literals in the source,
- * sequences before it} (16 bytes per 8 sequences + 48, ~2.5 % of a `datagen -P60` block; layout: csrc/lz4amd_params.h).  The block itself is an ordinary
+ * A compress plan (LZ4AMD_OP_COMPRESS) that has them attached writes, next to every block, a small table that names a
+ * sequence of the block's token chain about every 512 bytes of source (every 2nd to 16th sequence): {position of its token in the block, position of its literals in the source,
+ * sequences before it} (16 bytes a row, ~2.5 % of a `datagen -P60` block; layout: csrc/lz4amd_params.h).  The block itself is an ordinary
  * LZ4 block, byte for byte what it is without the table.  A decompress plan (LZ4AMD_OP_DECOMPRESS, lz4amd_plan_create /
  * _prefix) that has the tables attached parses every block from all its entries at once instead of first discovering the
  * serial token chain (what LZ4_decompress_generic's loop does implicitly, lz4.c:2123-2445) - about a third of the decoder's

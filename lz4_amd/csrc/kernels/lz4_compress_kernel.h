@@ -92,7 +92,6 @@ enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY 
                   CM_SEQS = 6,         // sequences of the tiles settled so far
                   CM_HOVER = 7,        // entry-point table: a row did not fit the table's room (the table is then left invalid)
                   CM_ROWS = 32,        // ... rows of the tiles settled so far
-                  CM_PREVSEQ = 33,     // ... sequences of the tile settled last (sets the next tile's row distance)
                   CM_HTILE = 40,       // u32[2][4] per tile in flight: { first ordinal, first row, log2 of the row distance, - }
                   CM_TILE = 8 };       // u32[2][4] per tile in flight: { first output position, end, written directly (not staged),
                                        //   first pending byte of its carry chunk }
@@ -881,15 +880,16 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
     const StripTotals t = strip_offsets(strip_p, nstrips, out0, misc[CM_CARRY], misc[CM_FAIL], cap, seq0, true);
     if (lane_id() == 0) {
         misc[CM_OUT] = t.out; misc[CM_CARRY] = t.carry; misc[CM_FAIL] = t.fail; misc[CM_SEQS] = t.seqs;
-        // the tile's rows of the entry-point table: one per 2^k sequences, k from the tile before - about one row per 512
-        // bytes of source, never more than 8 sequences apart (a lane of the decoder's parser walks a row's sequences one by one)
-        const uint32_t prevseq = misc[CM_PREVSEQ], want = prevseq >> 4;               // (tiles are 8 KB: 16 rows)
-        const uint32_t k = want >= 8 ? 3u : want >= 4 ? 2u : want >= 2 ? 1u : 0u;
+        // the tile's rows of the entry-point table: one per 2^k sequences, k from the tile's own number of sequences - about one
+        // row per 512 bytes of source, never more than 8 sequences apart - 16 where that still is under 512 bytes, or small blocks of such data
+        // would not fit their rows in the table's room (a lane of the decoder's parser walks a row's sequences
+        // one by one).  (The tile before is no guide: a block's first tile, parsed against an empty table, has none.)
+        const uint32_t lg = 31u - (uint32_t)__clz((int)(t1 - t0 ? t1 - t0 : 1u));
+        const uint32_t want = (t.seqs - seq0) >> (lg > 9 ? lg - 9 : 0u);              // sequences per 512 bytes
+        const uint32_t k = want >= LZ4AMD_HINT_EVERY_MAX ? LZ4AMD_HINT_EVERY_LOG2 : want >= 8 ? 3u : want >= 4 ? 2u : want >= 2 ? 1u : 0u;
         uint32_t* HT = misc + CM_HTILE + 4 * pp;
         HT[0] = seq0; HT[1] = misc[CM_ROWS]; HT[2] = k;
         misc[CM_ROWS] += (t.seqs - seq0 + (1u << k) - 1) >> k;
-        const uint32_t lg = 31u - (uint32_t)__clz((int)(t1 - t0 ? t1 - t0 : 1u));       // (scaled to a full tile: the first tiles of a block are smaller)
-        misc[CM_PREVSEQ] = lg >= 13 ? t.seqs - seq0 : (t.seqs - seq0) << (13 - lg);
         uint32_t* T = misc + CM_TILE + 4 * pp;
         T[T_OUT0] = out0; T[T_OUT1] = t.out;
         T[T_DIRECT] = (t.out + a0) - ((out0 + a0) & ~15u) > kStageBytes - 16 ? 1u : 0u;
@@ -954,7 +954,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
-        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_SEQS] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0; misc[CM_PREVSEQ] = 128;
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_SEQS] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0;
 #ifdef LZ4AMD_PROF_TILE
         for (uint32_t i = 24; i < 30; i++) misc[i] = 0;
 #endif

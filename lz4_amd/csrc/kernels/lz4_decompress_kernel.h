@@ -86,7 +86,7 @@ enum : uint32_t {
     kIdxMask = kIdxRing - 1,
     kEntRing = 256,                             // rows of the block's entry-point table (16 B each), ring
     kEntMask = kEntRing - 1,
-    kLaneSeqMax = 1024,                         // sequences between two rows of a table (lz4amd_k_compress writes a row every 8)
+    kLaneSeqMax = 1024,                         // sequences between two rows of a table (lz4amd_k_compress writes a row every 2 to 16)
     kDmaDepth = 16,                             // LDS-DMA instructions (1 KB each) the mover keeps in flight
     kMaxTrips = 10,                             // round-B trips per region (32 records each)
     kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
@@ -350,7 +350,7 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
 
 // ------------------------------------------------------------------------------ PARSER (blocks that come with an entry-point table)
 // An entry-point table (lz4amd_params.h: lz4amd_hint_entry; written by lz4amd_k_compress next to the block it made, or by
-// anybody else) names one sequence of the token chain every few sequences (lz4amd_k_compress: every eighth).  With it the serial chain is cut in pieces that
+// anybody else) names one sequence of the token chain every few sequences (lz4amd_k_compress: about every 512 bytes of output).  With it the serial chain is cut in pieces that
 // are parsed side by side: LANE k of this wave walks the sequences from row r0 + k up to row r0 + k + 1 out of the
 // compressed ring in LDS - token, literal length, offset, match length, the same rules as the pre-parse's P5
 // (read_variable_length lz4.c:1979-2014; lz4.c:2279, 2312-2318, 2356, 2423) - and writes their records and the region

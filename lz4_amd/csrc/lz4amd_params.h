@@ -35,14 +35,17 @@ typedef struct lz4amd_dec_params {
  * Entry r names a sequence of the block's token chain: where its token sits in the compressed block, where its literals
  * start in the output, how many sequences precede it.  Entry 0 is the block's first sequence { 0, 0, 0 } and carries the number
  * of rows in its fourth word; entry `rows` is the block's end { csize, out_size, nseq }; entries never decrease.  The
- * compressor writes about one row per 512 bytes of source and never fewer than one per 8 sequences (the distance, a power
- * of two of sequences, is set tile by tile from the tile before): every lane of the decoder's parser walks a row's
+ * compressor writes about one row per 512 bytes of source and never fewer than one per 8 sequences - per 16 on data of fewer
+ * than 32 bytes per sequence, whose rows would not fit the table's room otherwise (the distance, a power of two of sequences,
+ * is set tile by tile from the tile's own number of sequences): every lane of the decoder's parser walks a row's
  * sequences one after the other, ~1000 cycles each, so rows must be short in sequences - and they must be short in bytes,
  * because the lanes' rows must lie in the 32 KB of the stream that are resident.  (Rows at fixed distances in the output -
  * an earlier layout - left two thirds of the lanes' steps idle: the sequences per KB vary threefold.)  Any table whose rows
  * lie on the chain works; one that does not is found out and costs time only. */
 #define LZ4AMD_HINT_MAGIC 0x48345A4Cu           /* "LZ4H" */
-#define LZ4AMD_HINT_EVERY_MAX 8u             /* sequences between two rows of a table lz4amd_k_compress writes, at most */
+#define LZ4AMD_HINT_EVERY_MAX 16u            /* sequences between two rows of a table lz4amd_k_compress writes, at most (data of fewer than 32 bytes
+                                              * per sequence; 8 and fewer otherwise: about a row per 512 bytes) */
+#define LZ4AMD_HINT_EVERY_LOG2 4u
 typedef struct lz4amd_hint_entry { uint32_t tok, out, ord, zero; } lz4amd_hint_entry;      /* header: { magic, out_size, csize, nseq } */
 
 typedef struct lz4amd_comp_params {

@@ -15,7 +15,7 @@ MAGIC = 0x48345A4C
 CANARY = 0xEE
 
 
-EVERY = 8                      # lz4amd_k_compress's rows are at most 8 sequences apart (LZ4AMD_HINT_EVERY_MAX)
+EVERY = 16                     # lz4amd_k_compress's rows are at most 16 sequences apart (LZ4AMD_HINT_EVERY_MAX; 8 and fewer on data of 32 bytes per sequence and more)
 
 
 def hint_bytes(n):
