@@ -359,3 +359,22 @@ def test_tables_made_while_decoding_foreign_blocks(emu, foreign):
         assert r == len(d) and o == d, len(d)
     assert rejected > 0 and made2[1] >= rejected
     assert [t for t in made2[0]] == [t for t in made[0]]
+
+
+def test_small_blocks_of_compressible_data_get_their_tables(emu, ocodec, datagen):
+    """A block's first tile is parsed against an empty table and has no sequences: the row distance of a tile comes from the
+    tile's OWN number of sequences (from the tile before it, the second tile got a row per sequence and blocks of a few KB ran
+    out of room), and data of fewer than 32 bytes per sequence gets a row per 16 sequences."""
+    datas = []
+    for pct, seed in ((60, 7), (90, 8), (95, 9)):
+        src = datagen(1 << 20, pct, seed)
+        for o in range(0, 900000, 151111):
+            for n in (1500, 2048, 3000, 4095, 8000, 20000):
+                datas.append(src[o:o + n])
+    comps, tables = emu_compress_tables(emu, datas)
+    for d, c, t in zip(datas, comps, tables):
+        check_table(c, t, len(d))
+    outs, used, rejected = emu_decompress_tables(emu, comps, [len(d) for d in datas], tables)
+    assert used == len(datas) and rejected == 0
+    for d, (r, o) in zip(datas, outs):
+        assert r == len(d) and o == d
