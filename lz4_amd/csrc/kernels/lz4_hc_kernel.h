@@ -508,10 +508,15 @@ __device__ __forceinline__ uint64_t hc_ld8(lz4amd_gsrc src, uint32_t n, uint32_t
     return v;
 }
 
+// The lazy rule is local to a position - a match at f is taken unless one of the next two positions has a better one - so every
+// lane decides for its own position at once (`good`), and what is left of the reference's serial loop is a walk over a bit mask:
+// from the end of a taken match to the next good position.  The walk costs a handful of scalar instructions per sequence; the
+// literal runs, the record writes and the encoded sizes of all sequences of the window are then worked out by their own lanes.
 __device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, const uint32_t* best_g, MatchRec* recs,
                                                uint32_t* strip, uint32_t* stage, uint32_t w, uint32_t cs, uint32_t ce) {
     const uint32_t lane = lane_here();
-    uint32_t nseq = 0, enc = 0, ll0 = 0, anchor = cs;
+    uint32_t nseq = 0, anchor = cs;
+    uint32_t enc_l = 0, ll0_l = 0;                                      // per lane; summed over the wave at the end
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         const uint32_t last_q = n - kMfLimit;
         uint32_t mlimit = n - kLastLiterals; if (mlimit > ce) mlimit = ce;
@@ -533,50 +538,84 @@ __device__ __forceinline__ void hc_parse_strip(lz4amd_gsrc src, uint32_t n, cons
                 const uint32_t l = s & 0xFFu;
                 if (l >= kMinMatch) { len = l; off = s >> 8; }
             }
-            unsigned long long m = __ballot(len != 0);
-            uint32_t next_ip = ip + 64;
-            while (m) {
-                const uint32_t f = (uint32_t)__ffsll((long long)m) - 1;
-                if (f > 61) { next_ip = ip + f; break; }                    // the two positions after f must be in the window
-                const uint32_t L0 = wave_readlane(len, f), L1 = wave_readlane(len, f + 1), L2 = wave_readlane(len, f + 2);
-                if (L1 > L0 || L2 > L0 + 1) { m &= m - 1; continue; }      // a later start is better: f becomes a literal
-                const uint32_t x = ip + f;
-                const uint32_t of = wave_readlane(off, f);
-                uint32_t ml = L0;
-                if (ml >= kHcLenCap && x + ml < mlimit) {
-                    // capped by the search: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
-                    for (;;) {
-                        const uint32_t a = x + ml + 8 * lane;
-                        uint32_t same = 0;
-                        if (a < mlimit) {
-                            same = equal_bytes8(hc_ld8(src, n, a), hc_ld8(src, n, a - of));
-                            if (same > mlimit - a) same = mlimit - a;
-                        }
-                        const unsigned long long brk = __ballot(same < 8);
-                        if (brk) {
-                            const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
-                            ml += 8 * fl + wave_readlane(same, fl);
-                            break;
-                        }
-                        ml += 512;
-                    }
+            // -- every position: may a sequence start here (the two positions after it must be in the window), and where would it end
+            const uint32_t l1 = wave_next_u32(len), l2 = wave_next_u32(l1);
+            const bool good = len != 0 && lane < 62 && !(l1 > len || l2 > len + 1);      // a later start is better: the position becomes a literal
+            uint32_t ml = len;
+            if (pos + ml > mlimit) ml = mlimit - pos;                   // (len != 0: at least kMinMatch are left)
+            const bool capped = good && len >= kHcLenCap && pos + len < mlimit;      // the search stopped measuring: see below
+            const uint32_t jend = lane + ml;
+            const unsigned long long G = __ballot(good), C = __ballot(capped), M = __ballot(len != 0);
+            // -- the walk: first good position at or after the end of the match before it
+            unsigned long long T = 0;                                    // the positions whose match is taken
+            uint32_t a = 0;                                              // (ip is never below the anchor)
+            uint32_t capf = 64;
+            for (;;) {
+                const unsigned long long rem = G & (~0ull << a);
+                if (!rem) break;
+                const uint32_t f = (uint32_t)__ffsll((long long)rem) - 1;
+                if ((C >> f) & 1) { capf = f; break; }
+                T |= 1ull << f;
+                a = wave_readlane(jend, f);
+                if (a >= 64) break;
+            }
+            uint32_t next_ip;
+            if (a >= 64) next_ip = ip + a;
+            else {                                                       // positions 62 and 63 are decided by the next window
+                const uint32_t nx = ((M >> 62) & 1) ? 62u : (M >> 63) ? 63u : 64u;
+                next_ip = ip + (a > nx ? a : nx);
+            }
+            // -- the taken sequences, each by its own lane
+            if (T) {
+                const bool taken = (T >> lane) & 1;
+                const uint32_t pm = wave_prev_u32(wave_incl_max_u32(taken ? pos + ml : 0u));      // where the taken match before mine ends
+                if (taken) {
+                    const uint32_t ll = pos - (pm > anchor ? pm : anchor);
+                    const uint32_t idx = nseq + lanes_below(T);
+                    MatchRec r; r.ll = ll; r.mo = off | ((ml - kMinMatch) << 16); recs[idx] = r;
+                    enc_l += enc_size(ll, ml - kMinMatch);
+                    if (idx == 0) ll0_l = ll;
                 }
-                if (x + ml > mlimit) ml = mlimit - x;
-                if (ml > 65535u) ml = 65535u;                               // the record keeps ml - 4 in 16 bits
+                nseq += (uint32_t)__popcll(T);
+                anchor = ip + a;
+            }
+            if (capf < 64) {
+                // capped by the search: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
+                const uint32_t x = ip + capf, of = wave_readlane(off, capf);
+                uint32_t mlx = wave_readlane(len, capf);
+                for (;;) {
+                    const uint32_t p8 = x + mlx + 8 * lane;
+                    uint32_t same = 0;
+                    if (p8 < mlimit) {
+                        same = equal_bytes8(hc_ld8(src, n, p8), hc_ld8(src, n, p8 - of));
+                        if (same > mlimit - p8) same = mlimit - p8;
+                    }
+                    const unsigned long long brk = __ballot(same < 8);
+                    if (brk) {
+                        const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
+                        mlx += 8 * fl + wave_readlane(same, fl);
+                        break;
+                    }
+                    mlx += 512;
+                }
+                if (x + mlx > mlimit) mlx = mlimit - x;
+                if (mlx > 65535u) mlx = 65535u;                           // the record keeps ml - 4 in 16 bits
                 const uint32_t ll = x - anchor;
-                if (lane == 0) { MatchRec r; r.ll = ll; r.mo = of | ((ml - kMinMatch) << 16); recs[nseq] = r; }
-                if (nseq == 0) ll0 = ll;
-                enc += enc_size(ll, ml - kMinMatch);
+                if (lane == 0) {
+                    MatchRec r; r.ll = ll; r.mo = of | ((mlx - kMinMatch) << 16); recs[nseq] = r;
+                    enc_l += enc_size(ll, mlx - kMinMatch);
+                    if (nseq == 0) ll0_l = ll;
+                }
                 nseq++;
-                anchor = x + ml;
-                if (anchor >= ip + 64) { next_ip = anchor; break; }
-                m &= ~0ull << (anchor - ip);
+                anchor = x + mlx;
+                next_ip = anchor;                                        // (at least kHcLenCap past x)
             }
             // a jump past the staged chunks (a long match): restart the staging at the landing chunk
             if (next_ip >= staged + kHcChunk) staged = cs + ((next_ip - cs) & ~(kHcChunk - 1));
             ip = next_ip;
         }
     }
+    const uint32_t enc = wave_readlane(wave_incl_sum_u32(enc_l), 63), ll0 = wave_readlane(wave_incl_sum_u32(ll0_l), 63);
     if (lane == 0) {
         strip[S_N * kCmpWaves + w] = nseq;
         strip[S_ENC * kCmpWaves + w] = enc;
