@@ -140,8 +140,8 @@ int  lz4amd_compress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int*
  * LZ4_favorDecompressionSpeed (lz4hc.h:364; lz4hc.c:926-929, 1816-1818).  Ignored below level 10, as in the reference. */
 #define LZ4AMD_HC_FAVOR_DEC_SPEED 0x100
 
-/* LZ4_compress_HC (lz4hc.h:66) per block; level as in the reference (3..9 = hash chain with 4..256
- * attempts; values outside are mapped to the nearest of those, 0 and below to the default 9) */
+/* LZ4_compress_HC (lz4hc.h:66) per block; level as in the reference (lz4hc.c:92-106): 1..2 = the two-table search (LZ4MID),
+ * 3..9 = hash chain with 4..256 attempts, 10..12 = optimal parse; 0 and below = the default 9, above 12 = 12 */
 int  lz4amd_compress_hc_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,
                               void* const* d_dst, const int* dst_caps, int* results, int n, int level, void* stream);
 int  lz4amd_decompress_batch(lz4amd_ctx* ctx, const void* const* d_src, const int* src_sizes,

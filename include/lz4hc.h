@@ -14,8 +14,8 @@
  * Levels 10-12 (lz4hc.c:92-106, LZ4HC_compress_optimal 1823-2130) run an optimal parse on the device: the level-9 search
  * result of every position, then the cheapest sequence boundaries by price (kernels/lz4_hc_kernel.h: hc_parse_strip_opt).
  * Levels 10 / 11 / 12 search 96 / 512 / 2048 candidates per position (the reference: 96 / 512 / 16384) and share level 10's
- * 64-byte sufficient length; lz4amd_last_notice() says so after a call with level 11 or 12.  LZ4MID (level 2) is served by the
- * hash-chain search with 4 candidates.
+ * 64-byte sufficient length; lz4amd_last_notice() says so after a call with level 11 or 12.  Levels 1-2 are the reference's LZ4MID
+ * (lz4hc.c:93-95, 472-773): two tables keyed by 4 and by 7 bytes, one candidate each (kernels/lz4_hc_kernel.h: hc_search_mid).
  */
 #ifndef LZ4_AMD_LZ4HC_H
 #define LZ4_AMD_LZ4HC_H

@@ -36,6 +36,8 @@
 //              (emit_strip of the fast compressor).
 // Levels 10-12 (lz4hc.c:92-106, LZ4HC_compress_optimal 1823-2130) replace phase 3's lazy choice by an optimal parse over the
 // same per-position search results (hc_parse_strip_opt), with 96 / 512 / 2048 candidates per position in phase 2.
+// Levels 1-2 (LZ4MID, lz4hc.c:472-773) replace phases 1 and 2 by two head tables and a search without chains or bands
+// (hc_build_links_mid, hc_search_mid).
 //
 // HBM/L2 traffic per block: source read 2 + 2 x bands times, 2 B/position of chain written once and
 // read once per band, 6 B/position of search state written and read once per band, 8 B per sequence
@@ -116,7 +118,7 @@ __device__ __forceinline__ uint32_t hc_attempts(int level) {
     // k_clTable lz4hc.c:92-106: levels 3..9 = 4..256 candidates per position; 10 / 11 = 96 / 512 (lz4hc.c:103-104); 12 = 2048 here
     // (lz4hc.c:105: 16384, behind a pattern analysis that keeps runs of a repeated pattern from costing that much - not built: a
     // position of such a run would hold its whole tile for 16384 dependent links).
-    // Levels below 3 (the reference's LZ4MID, lz4hc.c:93-94) are served by the chain search with 4 candidates.
+    // (Levels 1 and 2 do not come here: hc_search_mid.)
     if (level < 1) level = 9;            // LZ4HC_CLEVEL_DEFAULT (lz4hc.c:110-113)
     if (level < 3) level = 3;
     if (level == 10) return 96u;
@@ -784,6 +786,107 @@ __device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, 
     }
 }
 
+// ------------------------------------------------------------------------------ levels 1-2: two tables, one candidate each
+// The reference's LZ4MID (lz4hc.c:472-773, k_clTable rows 0-2 lz4hc.c:93-95): no chains - one table keyed by a hash of 4 bytes and one
+// keyed by a hash of 7 of the 8 bytes at a position (lz4hc.c:141-149: 2^14 entries each), each remembering the latest position, and a
+// position's two candidates are what the tables held when it was reached ("long" candidate first, lz4hc.c:571-601; then the short one,
+// 602-647).  Here, as at the other levels, linking and searching are separate passes over the block and EVERY position is linked and
+// searched (the reference links a match's first and last positions only, lz4hc.c:688-711, and does not search inside a match): the
+// link pass is hc_build_chain's with two head tables in the same 128 KB of LDS and leaves two distances per position; the search pass
+// needs no window in LDS at all - a position has at most two candidates, anywhere in the 64 KB behind it, so lanes read them from
+// L2 / HBM directly (64 consecutive positions per wave: the positions' own bytes and the distances are coalesced) - and there are no
+// bands.  The lazy parse and the emit are phase 3 / 4 above (the reference's one-step look at ip + 1, lz4hc.c:618-634, is the lazy
+// rule's first half).
+enum : uint32_t { kMidHashLog = kHcHashLog - 1 };                        // lz4hc.c:141 LZ4MID_HASHLOG
+__device__ __forceinline__ uint32_t mid_hash4(uint32_t v) { return (v * 2654435761u) >> (32 - kMidHashLog); }                          // lz4hc.c:144
+__device__ __forceinline__ uint32_t mid_hash7(uint64_t v) { return (uint32_t)(((v << 8) * 58295818150454627ull) >> (64 - kMidHashLog)); }   // lz4hc.c:148 (the low 56 bits)
+
+__device__ __forceinline__ void hc_build_links_mid(lz4amd_gsrc src, uint32_t n, uint16_t* d4_g, uint16_t* d8_g, char* smem) {
+    const uint32_t tid = opaque_u32(threadIdx.x), lane = lane_here(), w = wave_id();
+    uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
+    uint32_t* head4 = (uint32_t*)(smem + kHOffHead);
+    uint32_t* head8 = head4 + (1u << kMidHashLog);
+    uint32_t* wtab = (uint32_t*)(smem + kHOffWtab) + w * 256;
+    for (uint32_t i = tid; i < (2u << kMidHashLog); i += kHcThreads) head4[i] = 0;
+    for (uint32_t i = lane; i < 256; i += 64) wtab[i] = 0;
+    if (tid == 0) misc[HM_TOKEN] = 0;
+    __syncthreads();
+    const uint32_t ngroups = (n + 63) / 64;
+    const uint32_t nturns = (ngroups + kHcTurnGroups - 1) / kHcTurnGroups;
+    for (uint32_t turn = w; turn < nturns; turn += kHcWaves) {
+        uint32_t h4[kHcTurnGroups], h8[kHcTurnGroups], q4[kHcTurnGroups], q8[kHcTurnGroups];      // q: previous position + 1, 0 = none
+        bool v4[kHcTurnGroups], v8[kHcTurnGroups], f4[kHcTurnGroups], f8[kHcTurnGroups], l4[kHcTurnGroups], l8[kHcTurnGroups];
+#pragma unroll
+        for (uint32_t j = 0; j < kHcTurnGroups; j++) {
+            const uint32_t g0 = (turn * kHcTurnGroups + j) * 64, p = g0 + lane;
+            v4[j] = p + 4 <= n; v8[j] = p + 8 <= n;                      // (lz4hc.c:548 ilimit: a position is keyed by 8 bytes while 8 are left)
+            const uint64_t v = p < n ? hc_ld8(src, n, p) : 0;
+            h4[j] = mid_hash4((uint32_t)v); h8[j] = mid_hash7(v);
+            int pred;
+            hc_group_links(h4[j], v4[j], wtab, lane, pred, l4[j]);
+            f4[j] = pred < 0; q4[j] = pred >= 0 ? g0 + (uint32_t)pred + 1 : 0;
+            hc_group_links(h8[j], v8[j], wtab, lane, pred, l8[j]);
+            f8[j] = pred < 0; q8[j] = pred >= 0 ? g0 + (uint32_t)pred + 1 : 0;
+        }
+        while (lds_load_acquire(&misc[HM_TOKEN]) != turn) spin_pause();      // groups read and update the tables in position order
+#pragma unroll
+        for (uint32_t j = 0; j < kHcTurnGroups; j++) {
+            const uint32_t p = (turn * kHcTurnGroups + j) * 64 + lane;
+            if (v4[j] && f4[j]) q4[j] = head4[h4[j]];
+            if (v8[j] && f8[j]) q8[j] = head8[h8[j]];
+            wave_lds_order();
+            if (v4[j] && l4[j]) head4[h4[j]] = p + 1;
+            if (v8[j] && l8[j]) head8[h8[j]] = p + 1;
+            wave_lds_order();
+        }
+        if (lane == 0) lds_store_relaxed(&misc[HM_TOKEN], turn + 1);
+#pragma unroll
+        for (uint32_t j = 0; j < kHcTurnGroups; j++) {
+            const uint32_t p = (turn * kHcTurnGroups + j) * 64 + lane;
+            uint32_t d4 = 0, d8 = 0;
+            if (v4[j] && q4[j]) { const uint32_t d = p + 1 - q4[j]; if (d <= kMaxDistance) d4 = d; }
+            if (v8[j] && q8[j]) { const uint32_t d = p + 1 - q8[j]; if (d <= kMaxDistance) d8 = d; }
+            if (p < ngroups * 64) { d4_g[p] = (uint16_t)d4; d8_g[p] = (uint16_t)d8; }      // the arrays are padded to a multiple of 64 entries
+        }
+    }
+    __syncthreads();
+}
+
+// sixteen source bytes at any position (zero filled past the end of the block), from global memory
+__device__ __forceinline__ Q16 hc_ld16g(lz4amd_gsrc src, uint32_t n, uint32_t a) {
+    Q16 r;
+    if (a + 16 <= n) { const U32x4 v = ld_global16_raw(src + a); r.a = v[0]; r.b = v[1]; r.c = v[2]; r.d = v[3]; }
+    else { const uint64_t lo = a < n ? hc_ld8(src, n, a) : 0, hi = a + 8 < n ? hc_ld8(src, n, a + 8) : 0; r.a = (uint32_t)lo; r.b = (uint32_t)(lo >> 32); r.c = (uint32_t)hi; r.d = (uint32_t)(hi >> 32); }
+    return r;
+}
+// common length of the strings at p and at p - d, at most lim
+__device__ __forceinline__ uint32_t mid_count(lz4amd_gsrc src, uint32_t n, uint32_t p, uint32_t d, uint32_t lim) {
+    uint32_t l = 0;
+    for (;;) {
+        const uint32_t e = equal_bytes16(hc_ld16g(src, n, p + l), hc_ld16g(src, n, p - d + l));
+        l += e;
+        if (e < 16 || l >= lim) break;
+    }
+    return l > lim ? lim : l;
+}
+__device__ __forceinline__ void hc_search_mid(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* d4_g, const uint16_t* d8_g, uint32_t* st0_g) {
+    const uint32_t tid = opaque_u32(threadIdx.x);
+    const uint32_t n64 = (n + 63) & ~63u, last_q = n - kMfLimit;
+    for (uint32_t p = tid; p < n64; p += kHcThreads) {
+        uint32_t res = 0;
+        if (p >= first && p <= last_q) {
+            const uint32_t d8 = d8_g[p], d4 = d4_g[p];
+            uint32_t lim = n - kLastLiterals - p; if (lim > kHcLenCap) lim = kHcLenCap;
+            uint32_t best = 0, off = 0;
+            if (d8) { const uint32_t l = mid_count(src, n, p, d8, lim); if (l >= kMinMatch) { best = l; off = d8; } }
+            if (d4 && d4 != d8) { const uint32_t l = mid_count(src, n, p, d4, lim); if (l >= kMinMatch && l > best) { best = l; off = d4; } }
+            res = best | (off << 8);
+        }
+        st0_g[p] = res;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------ one block
 __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char* smem) {
     const uint32_t tid = opaque_u32(threadIdx.x), w = wave_id();
@@ -817,17 +920,21 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     uint32_t nstrips = 0, strip_len = 0;
     if (tid == 0) { misc[HM_OUT] = 0; misc[HM_CARRY] = 0; misc[HM_FAIL] = 0; }
     if ((uint32_t)n_i >= kMfLimit + 1) {
-        hc_build_chain(src, n, chain_g, smem);
-        if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[0] += t - tq; tq = t; }
         // (P.level: the reference's compressionLevel in the low byte; LZ4AMD_HC_FAVOR_DEC_SPEED = 0x100 on top of it asks the optimal
         //  parse of levels 10-12 for the reference's decompression-speed preference, lz4hc.c:926-929, 1816-1818)
         const int level = P.level & 0xFF;
         const bool favor = (P.level & 0x100) != 0 && level >= 10;
+        const bool mid = level >= 1 && level <= 2;                       // lz4hc.c:93-95 (a level below 1 is the default, 9: lz4hc.c:110-113)
+        if (mid) hc_build_links_mid(src, n, chain_g, st1_g, smem); else hc_build_chain(src, n, chain_g, smem);
+        if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[0] += t - tq; tq = t; }
         const uint32_t attempts = hc_attempts(level);
 
-        for (uint32_t band = 0; band < kHcBands; band++) {
+        if (!mid) for (uint32_t band = 0; band < kHcBands; band++) {
             hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, favor, smem, prof);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
+        } else {
+            hc_search_mid(src, n, first, chain_g, st1_g, st0_g);
+            if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1] += t - tq; tq = t; }
         }
         // -- parse: one wave per strip of the block proper
         const uint32_t own = n - first;

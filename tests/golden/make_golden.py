@@ -108,6 +108,10 @@ G["ratio"]["p90_4m_256k_blocks_hc9"] = ratio(["-g4M", "-P90"], 256 << 10, 9)
 G["ratio"]["p20_2m_256k_blocks_hc9"] = ratio(["-g2M", "-P20"], 256 << 10, 9)
 G["ratio"]["p60_8m_4m_blocks_hc9"] = ratio(["-g8M", "-P60"], 4 << 20, 9)
 G["ratio"]["p50_1m_64k_blocks_hc9"] = ratio(["-g1M", "-P50"], 64 << 10, 9)
+# level 2 = LZ4MID (lz4hc.c:93-95, 472-773), and the fast codec on the same blocks
+for pct, size in ((60, "4M"), (90, "4M"), (20, "2M")):
+    G["ratio"]["p%d_%s_256k_blocks_hc2" % (pct, size.lower())] = ratio(["-g" + size, "-P%d" % pct], 256 << 10, 2)
+    G["ratio"]["p%d_%s_256k_blocks_fast" % (pct, size.lower())] = ratio(["-g" + size, "-P%d" % pct], 256 << 10)
 
 with open(os.path.join(HERE, "golden.json"), "w") as f:
     json.dump(G, f, indent=1, sort_keys=True)

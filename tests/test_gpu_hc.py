@@ -75,6 +75,32 @@ def test_hc_levels(ctx, golden, datagen):
         assert abs(sizes[lvl] - g["csize"]) / g["csize"] < 0.03, lvl
 
 
+def test_hc_levels_1_and_2_are_the_two_table_search(ctx, ocodec, golden, corpus, datagen):
+    """SURVEY 8(f) item 3, lz4hc.c:93-95 / LZ4MID 472-773: levels 1 and 2 are the two-table search (hc_search_mid).  Blocks decode
+    with the oracle; sizes between the fast codec's and level 3's, within the window of the reference's level 2 (golden sizes)."""
+    for d, (r, c) in zip(corpus, gpu_compress_hc(ctx, corpus, level=2)):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+    for pct, size, lo in ((60, "4m", 0.97), (90, "4m", 0.92), (20, "2m", 0.97)):
+        g2, gf = golden["ratio"]["p%d_%s_256k_blocks_hc2" % (pct, size)], golden["ratio"]["p%d_%s_256k_blocks_fast" % (pct, size)]
+        data = datagen(g2["src"], pct, 0)
+        blocks = [data[o:o + g2["block"]] for o in range(0, len(data), g2["block"])]
+        two = sum(r for r, _ in gpu_compress_hc(ctx, blocks, level=2))
+        one = sum(r for r, _ in gpu_compress_hc(ctx, blocks, level=1))
+        three = sum(r for r, _ in gpu_compress_hc(ctx, blocks, level=3))
+        assert one == two and three <= two * 1.002 and two < gf["csize"], (pct, three, two, gf["csize"])
+        assert lo <= two / g2["csize"] <= 1.03, (pct, two, g2["csize"])
+    rnd = random.Random(37)
+    sizes = [14, 15, 17, 63, 64, 65, 1023, 1025, 8193, 65535, 65536, 65537, 262143, 262145] + [rnd.randrange(18, 600000) for _ in range(12)]
+    base = datagen(700000, 70, 6)
+    datas = [base[rnd.randrange(0, 9000):][:n] for n in sizes] + [bytes(n) for n in (13, 64, 8193, 70001, 1 << 20)] + [b"ab" * 40000, b"abcdefg" * 100000, datagen(4 << 20, 60, 3)]
+    for d, (r, c) in zip(datas, gpu_compress_hc(ctx, datas, level=2)):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+
+
 def test_hc_far_matches(ctx, ocodec):
     rnd = random.Random(11)
     a = bytes(rnd.randrange(256) for _ in range(3000))

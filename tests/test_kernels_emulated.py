@@ -494,6 +494,37 @@ def test_hc_levels_trade_ratio_for_depth(emu, golden, datagen):
         assert abs(sizes[lvl] - ref) / ref < 0.03
 
 
+def test_hc_levels_1_and_2_are_the_two_table_search(emu, ocodec, golden, corpus, datagen):
+    """k_clTable rows 0-2 (lz4hc.c:93-95) = LZ4MID (lz4hc.c:472-773): two tables (hashes of 4 and of 7 bytes), one candidate
+    each, no chains.  Every block decodes with the pinned decoder; sizes land between the fast codec's and level 3's, within
+    the +-3 % window of the reference's own level 2 on the benchmark streams (its more compressible one: ours is smaller,
+    every position is linked and searched); block sizes around the kernel's geometry take the same paths."""
+    for d, (r, c) in zip(corpus, emu_compress_hc(emu, corpus, level=2)):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+    for pct, size, nblk, lo in ((60, "4m", 4, 0.97), (90, "4m", 16, 0.90), (20, "2m", 2, 0.97)):
+        g2, gf = golden["ratio"]["p%d_%s_256k_blocks_hc2" % (pct, size)], golden["ratio"]["p%d_%s_256k_blocks_fast" % (pct, size)]
+        data = datagen(g2["src"], pct, 0)
+        blocks = [data[o:o + g2["block"]] for o in range(0, len(data), g2["block"])][:nblk]
+        per = len(data) // g2["block"]
+        two = sum(r for r, _ in emu_compress_hc(emu, blocks, level=2))
+        one = sum(r for r, _ in emu_compress_hc(emu, blocks, level=1))
+        three = sum(r for r, _ in emu_compress_hc(emu, blocks, level=3))
+        ref2, fast = g2["csize"] / per * nblk, gf["csize"] / per * nblk
+        assert one == two                                            # rows 1 and 2 of the table are the same
+        assert three <= two * 1.002 and two < fast, (pct, three, two, fast)
+        assert lo <= two / ref2 <= 1.03, (pct, two, ref2)
+    rnd = random.Random(31)
+    sizes = [14, 15, 17, 20, 63, 64, 65, 127, 129, 1023, 1025, 4097, 65535, 65536, 65537, 70001] + [rnd.randrange(18, 150000) for _ in range(8)]
+    base = datagen(160000, 70, 6)
+    datas = [base[rnd.randrange(0, 9000):][:n] for n in sizes] + [bytes(n) for n in (13, 64, 8193, 70001)] + [b"ab" * 40000, b"abcdefg" * 10000]
+    for d, (r, c) in zip(datas, emu_compress_hc(emu, datas, level=2)):
+        assert 0 < r <= ocodec.bound(len(d))
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d, len(d)
+
+
 def test_hc_optimal_parse_levels_10_to_12(emu, ocodec, reflib, corpus, datagen):
     """Levels 10-12 (lz4hc.c:92-106, LZ4HC_compress_optimal 1823-2130): the sequence boundaries are chosen by price instead
     of greedily.  Every block still decodes with the pinned decoder; the output is never larger than level 9's (beyond the
