@@ -47,6 +47,14 @@
 
 namespace lz4amd {
 
+// developer counters of the CPU interpreter's build (tools/exp/hc_emu_stats.py): how many trips the walk loop makes, with how many lanes
+#ifdef LZ4AMD_EMU_STATS
+extern "C" unsigned long long lz4amd_emu_stats[16];
+#define HC_STAT(i, v) __atomic_fetch_add(&lz4amd_emu_stats[i], (unsigned long long)(v), __ATOMIC_RELAXED)
+#else
+#define HC_STAT(i, v) ((void)0)
+#endif
+
 using HcBatch = ::lz4amd_hc_params;     // argument block (lz4amd_params.h)
 
 enum : uint32_t {
@@ -79,7 +87,10 @@ enum : uint32_t {
 #endif
     kHcBatch = LZ4AMD_HC_BATCH,                       // links a lane chases before it verifies the candidates found
     kHcRun = LZ4AMD_HC_RUN,                         // consecutive positions a lane takes at a time (each inherits its predecessor's match)
-    kHcSkipLen = 32,                    // an inherited match this long is kept without searching (tools/exp/hc_sim.c: < 0.1 % of size)
+    // An inherited match this long is kept without searching (the reference does not search inside a match it has taken either).  The
+    // lazy parse loses next to nothing from 8 on (datagen -P60 / -P90 / -P20 blocks at level 9 against 32: +0.01 / +0.4 / +0.0 % bytes
+    // for -14 % walk trips in the nearest band, tools/exp/hc_emu_stats.py); the optimal parse prices every cell and keeps 32.
+    kHcSkipLenLazy = 8, kHcSkipLenOpt = 32,
     kHcRunsPerTile = kHcTile / kHcRun,
 };
 // LDS carve-up (bytes); the chain phase, the search phase and the parse phase reuse the same region
@@ -266,7 +277,7 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
 }
 
 __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
-                                               uint32_t band, uint32_t attempts, bool favor, char* smem, uint64_t* prof = nullptr) {
+                                               uint32_t band, uint32_t attempts, uint32_t skip_len, bool favor, char* smem, uint64_t* prof = nullptr) {
     const uint32_t tid = opaque_u32(threadIdx.x);
 #ifdef LZ4AMD_PROF_HC
     uint64_t hp_trips = 0, hp_lanes = 0, hp_loop = 0, hp_wait = 0, hp_hits = 0, hp_hit_lanes = 0, hp_t0x = 0;
@@ -326,8 +337,17 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
 #pragma unroll
             for (uint32_t k = 0; k < kHcPosPerThread; k++) {
                 const uint32_t q = k * kHcThreads + tid;
-                if ((res0[q] >> 16) != 0) { const uint32_t i = atomicAdd(&misc[HM_NLIST], 1u); if (i < kHcListCap) plist[i] = (uint16_t)q; }
-                else over |= 1u << k;
+                const bool live = (res0[q] >> 16) != 0;
+                const unsigned long long lm = __ballot(live);              // one counter update per wave (same-address LDS atomics of 64 lanes are served one by one)
+                if (lm) {
+                    const uint32_t leader = (uint32_t)__ffsll((long long)lm) - 1;
+                    uint32_t base = 0;
+                    if (lane_here() == leader) base = atomicAdd(&misc[HM_NLIST], (uint32_t)__popcll(lm));
+                    base = wave_readlane(base, leader);
+                    const uint32_t i = base + lanes_below(lm);
+                    if (live && i < kHcListCap) plist[i] = (uint16_t)q;
+                }
+                if (!live) over |= 1u << k;
             }
             __syncthreads();
             nlist = misc[HM_NLIST];
@@ -400,7 +420,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                             if (inh_capped) best = hc_count(ring, mine, (uint32_t)(p - (int32_t)boff) & (kHcRing - 1), pp, best, lim);
                             // nothing can beat a full-length match; and inside a long match the positions after the
                             // first are not searched at all (the reference does not visit them either)
-                            if (best >= lim || best >= kHcSkipLen) {
+                            if (best >= lim || best >= skip_len) {
                                 if (final_band) res0[pp] = best | (boff << 8);
                                 else { res0[pp] = boff; res1[pp] = (uint16_t)best; }
                                 inh_len = best - 1; inh_capped = best >= lim;
@@ -408,13 +428,16 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                             }
                         }
                     }
-                    if (walk) { mt = lds_ld4(mine, pp + best - 3); active = true; }
+                    if (walk) { mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(band ? 5 : 0, 1); }
                     else if (!kept) inh_len = 0;                        // nothing to hand to the next position
+                    if (kept) HC_STAT(band ? 6 : 1, 1);
                 }
                 if (!__ballot(active)) { if (pool_dry && !__ballot(run_left != 0)) break; continue; }
 #ifdef LZ4AMD_PROF_HC
                 hp_trips++; hp_lanes += (uint32_t)__popcll(__ballot(active));
 #endif
+                if (lane == 0) HC_STAT(band ? 7 : 2, 1);
+                if (active) HC_STAT(band ? 8 : 3, 1);
                 // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
                 uint32_t cd[kHcBatch];
                 uint32_t next = 0;                                      // where the next band resumes
@@ -446,6 +469,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
 #pragma unroll
                 for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                 while (__ballot(hits != 0)) {
+                    if (lane == 0) HC_STAT(band ? 9 : 4, 1);
 #ifdef LZ4AMD_PROF_HC
                     hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(hits != 0));
 #endif
@@ -930,7 +954,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         const uint32_t attempts = hc_attempts(level);
 
         if (!mid) for (uint32_t band = 0; band < kHcBands; band++) {
-            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, favor, smem, prof);
+            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, level >= 10 ? kHcSkipLenOpt : kHcSkipLenLazy, favor, smem, prof);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         } else {
             hc_search_mid(src, n, first, chain_g, st1_g, st0_g);

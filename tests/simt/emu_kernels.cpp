@@ -2,12 +2,18 @@
  * (lz4_amd/csrc/kernels/*.h) on the CPU SIMT interpreter so their logic can be unit-tested
  * without a GPU.  Exposes a plain C ABI for ctypes. */
 #include "platform_emu.h"
+#ifdef LZ4AMD_EMU_STATS
+extern "C" { extern unsigned long long lz4amd_emu_stats[16]; }
+#endif
 #include "../../lz4_amd/csrc/kernels/lz4_decompress_kernel.h"
 #include "../../lz4_amd/csrc/kernels/lz4_compress_kernel.h"
 #include "../../lz4_amd/csrc/kernels/lz4_hc_kernel.h"
 #include "../../lz4_amd/csrc/kernels/xxh32_kernel.h"
 #include "../../lz4_amd/csrc/kernels/gather_kernel.h"
 #include <vector>
+#ifdef LZ4AMD_EMU_STATS
+extern "C" { unsigned long long lz4amd_emu_stats[16]; }
+#endif
 
 extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int32_t* src_size,
                                            uint8_t* const* dst, const int32_t* dst_cap,
@@ -157,4 +163,21 @@ extern "C" int emu_decompress_batch_hints_make(const uint8_t* const* src, const 
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = sstride;
     if (n) simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
     return 0;
+}
+
+// one block; returns the per-position search results the parse read (best length | offset << 8) -- developer checks of the search
+extern "C" int emu_hc_search_results(const uint8_t* src, int32_t n, uint8_t* dst, int32_t cap, int level, uint32_t* best_out) {
+    using namespace lz4amd;
+    uint32_t ticket = 0; const uint32_t max_src = (uint32_t)n + 65536;
+    const uint64_t stride = (hc_scratch_bytes(max_src) + 255) & ~255ull;
+    std::vector<uint8_t> scratch((size_t)(stride + 512));
+    int32_t res = 0;
+    const uint8_t* srcs[1] = { src }; uint8_t* dsts[1] = { dst };
+    HcBatch P = {};
+    P.src = srcs; P.src_size = &n; P.dst = dsts; P.dst_cap = &cap; P.result = &res;
+    P.n_blocks = 1; P.ticket = &ticket; P.prof = nullptr; P.level = level; P.max_src = max_src; P.prefix = nullptr;
+    P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 255) & ~(uintptr_t)255); P.scratch_stride = stride;
+    simt::launch(1, kHcThreads, kHcLdsBytes, [&] { hc_batch_body(P); });
+    memcpy(best_out, P.scratch + hc_chain_bytes(max_src), (size_t)n * 4);
+    return res;
 }
