@@ -83,7 +83,7 @@ enum : uint32_t {
 #define LZ4AMD_HC_REFILL 16
 #endif
 #ifndef LZ4AMD_HC_RUN
-#define LZ4AMD_HC_RUN 4
+#define LZ4AMD_HC_RUN 8
 #endif
     kHcBatch = LZ4AMD_HC_BATCH,                       // links a lane chases before it verifies the candidates found
     kHcRun = LZ4AMD_HC_RUN,                         // consecutive positions a lane takes at a time (each inherits its predecessor's match)
@@ -235,14 +235,13 @@ __device__ __forceinline__ Q16 lds_ld16(const uint8_t* base, uint32_t o) {
     Q16 r; r.a = align_bytes(w1, w0, sh); r.b = align_bytes(w2, w1, sh); r.c = align_bytes(w3, w2, sh); r.d = align_bytes(w4, w3, sh);
     return r;
 }
-// number of equal leading bytes of two 16-byte strings (0..16)
+// number of equal leading bytes of two 16-byte strings (0..16).  No branches: the first set bit of every dword's difference (-1, i.e.
+// 0xFFFFFFFF, where there is none: __ffs(0) - 1), as a byte index, and the minimum of the four.
 __device__ __forceinline__ uint32_t equal_bytes16(const Q16& x, const Q16& y) {
-    const uint32_t a = x.a ^ y.a, b = x.b ^ y.b, c = x.c ^ y.c, d = x.d ^ y.d;
-    if (a) return (uint32_t)(__ffs((int)a) - 1) >> 3;
-    if (b) return 4 + ((uint32_t)(__ffs((int)b) - 1) >> 3);
-    if (c) return 8 + ((uint32_t)(__ffs((int)c) - 1) >> 3);
-    if (d) return 12 + ((uint32_t)(__ffs((int)d) - 1) >> 3);
-    return 16;
+    const uint32_t f0 = (uint32_t)(__ffs((int)(x.a ^ y.a)) - 1) >> 3, f1 = ((uint32_t)(__ffs((int)(x.b ^ y.b)) - 1) >> 3) + 4;
+    const uint32_t f2 = ((uint32_t)(__ffs((int)(x.c ^ y.c)) - 1) >> 3) + 8, f3 = ((uint32_t)(__ffs((int)(x.d ^ y.d)) - 1) >> 3) + 12;
+    const uint32_t m01 = f0 < f1 ? f0 : f1, m23 = f2 < f3 ? f2 : f3, m = m01 < m23 ? m01 : m23;
+    return m < 16 ? m : 16;
 }
 // four bytes at any alignment out of an LDS byte array (two aligned dword reads + v_alignbyte)
 __device__ __forceinline__ uint32_t lds_ld4(const uint8_t* base, uint32_t o) {
@@ -374,6 +373,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
             bool active = false;
             int32_t p = 0;
             uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0, best_in = 3;
+            Q16 mw; mw.a = mw.b = mw.c = mw.d = 0;                        // sixteen of my own bytes: the window the candidates are compared in
 #ifdef LZ4AMD_PROF_HC
             hp_t0x = clock_ticks();
 #endif
@@ -428,7 +428,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                             }
                         }
                     }
-                    if (walk) { mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(band ? 5 : 0, 1); }
+                    if (walk) { if (band == 0) mw = lds_ld16(mine, pp + (best > 15 ? best - 15 : 0)); else mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(band ? 5 : 0, 1); }
                     else if (!kept) inh_len = 0;                        // nothing to hand to the next position
                     if (kept) HC_STAT(band ? 6 : 1, 1);
                 }
@@ -455,38 +455,85 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                     att -= take ? 1u : 0u;
                     if (take) { if (d == 0) over = true; else dist += d; }
                 }
-                // ---- verify: a longer match must agree on the four bytes that end at index `best` (for best = 3
-                //      this is the MINMATCH test; lz4hc.c:934-936)
-                uint32_t ct[kHcBatch];
-#pragma unroll
-                for (uint32_t k = 0; k < kHcBatch; k++)
-                    ct[k] = lds_ld4(ring, ((uint32_t)(p - (int32_t)cd[k]) + best - 3) & (kHcRing - 1));
                 bool full = false;
-                const uint32_t best0 = best;                            // what the ct[] were read against
-                // candidates that pass, as a bit mask per lane; the expensive part (measuring a match) is entered
-                // once per trip for every lane's nearest passing candidate, again only for lanes that have another
-                uint32_t hits = 0;
+                if (band == 0) {
+                    // ---- verify: sixteen bytes of every candidate against my own, in the window that ends at index `best` at the latest
+                    //      (w0 = best - 15; 0 while best is below 16, and then the compare IS the measurement: lz4hc.c:934-946).  Only a
+                    //      candidate that agrees on the whole window can be longer than that, and is measured out in the loop below.
+                    const uint32_t w0 = best > 15 ? best - 15 : 0;
+                    Q16 cw[kHcBatch];
 #pragma unroll
-                for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
-                while (__ballot(hits != 0)) {
-                    if (lane == 0) HC_STAT(band ? 9 : 4, 1);
+                    for (uint32_t k = 0; k < kHcBatch; k++)
+                        cw[k] = lds_ld16(ring, ((uint32_t)(p - (int32_t)cd[k]) + w0) & (kHcRing - 1));
+                    uint32_t ext = 0;                                        // candidates that agree on all sixteen, as a bit mask per lane
+#pragma unroll
+                    for (uint32_t k = 0; k < kHcBatch; k++) {
+                        const bool cand = cd[k] != 0 && !(favor && cd[k] < 8);      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
+                        const uint32_t e = cand ? equal_bytes16(cw[k], mw) : 0u;
+                        ext |= e == 16 ? 1u << k : 0u;
+                        const uint32_t ec = e < lim ? e : lim;
+                        if (w0 == 0 && e < 16 && ec > best) { best = ec; boff = cd[k]; if (ec >= lim) full = true; }
+                    }
+                    if (full) ext = 0;
+                    while (__ballot(ext != 0)) {
+                        if (lane == 0) HC_STAT(band ? 9 : 4, 1);
 #ifdef LZ4AMD_PROF_HC
-                    hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(hits != 0));
+                        hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(ext != 0));
 #endif
-                    if (hits) {
-                        const uint32_t k = (uint32_t)__ffs((int)hits) - 1;
-                        hits &= hits - 1;
-                        uint32_t cdk = cd[0];
+                        if (ext) {
+                            const uint32_t k = (uint32_t)__ffs((int)ext) - 1;
+                            ext &= ext - 1;
+                            uint32_t cdk = cd[0];
 #pragma unroll
-                        for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
-                        const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
-                        // an earlier candidate of the batch may have raised `best`: test again at the new index
-                        if (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
-                            const uint32_t l = hc_count(ring, mine, qo, pp, 0, lim);
-                            if (l > best) {
-                                best = l; boff = cdk;
-                                if (l >= lim) { full = true; hits = 0; }
-                                else mt = lds_ld4(mine, pp + best - 3);
+                            for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
+                            const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
+                            // an earlier candidate of the batch may have raised `best` past the window: test again at the new index
+                            if (best <= w0 + 15 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == lds_ld4(mine, pp + best - 3)) {
+                                const uint32_t l = hc_count(ring, mine, qo, pp, w0 == 0 ? 16u : 0u, lim);
+                                if (l > best) {
+                                    best = l; boff = cdk;
+                                    if (l >= lim) { full = true; ext = 0; }
+                                }
+                            }
+                        }
+                    }
+                    {   // my own bytes in the window of the next trip
+                        const uint32_t w1 = best > 15 ? best - 15 : 0;
+                        if (w1 != w0) mw = lds_ld16(mine, pp + w1);
+                    }
+                } else {
+                    // farther bands: a walk that comes this far mostly has its match already, and nearly every candidate fails the
+                    // cheapest test there is - the four bytes that end at index `best` (for best = 3 the MINMATCH test; lz4hc.c:934-936)
+                    uint32_t ct[kHcBatch];
+#pragma unroll
+                    for (uint32_t k = 0; k < kHcBatch; k++)
+                        ct[k] = lds_ld4(ring, ((uint32_t)(p - (int32_t)cd[k]) + best - 3) & (kHcRing - 1));
+                    const uint32_t best0 = best;                            // what the ct[] were read against
+                    // candidates that pass, as a bit mask per lane; the expensive part (measuring a match) is entered
+                    // once per trip for every lane's nearest passing candidate, again only for lanes that have another
+                    uint32_t hits = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
+                    while (__ballot(hits != 0)) {
+                        if (lane == 0) HC_STAT(band ? 9 : 4, 1);
+#ifdef LZ4AMD_PROF_HC
+                        hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(hits != 0));
+#endif
+                        if (hits) {
+                            const uint32_t k = (uint32_t)__ffs((int)hits) - 1;
+                            hits &= hits - 1;
+                            uint32_t cdk = cd[0];
+#pragma unroll
+                            for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
+                            const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
+                            // an earlier candidate of the batch may have raised `best`: test again at the new index
+                            if (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
+                                const uint32_t l = hc_count(ring, mine, qo, pp, 0, lim);
+                                if (l > best) {
+                                    best = l; boff = cdk;
+                                    if (l >= lim) { full = true; hits = 0; }
+                                    else mt = lds_ld4(mine, pp + best - 3);
+                                }
                             }
                         }
                     }
@@ -817,9 +864,7 @@ __device__ __forceinline__ void hc_parse_strip_opt(lz4amd_gsrc src, uint32_t n, 
 // 602-647).  Here, as at the other levels, linking and searching are separate passes over the block and EVERY position is linked and
 // searched (the reference links a match's first and last positions only, lz4hc.c:688-711, and does not search inside a match): the
 // link pass is hc_build_chain's with two head tables in the same 128 KB of LDS and leaves two distances per position; the search pass
-// needs no window in LDS at all - a position has at most two candidates, anywhere in the 64 KB behind it, so lanes read them from
-// L2 / HBM directly (64 consecutive positions per wave: the positions' own bytes and the distances are coalesced) - and there are no
-// bands.  The lazy parse and the emit are phase 3 / 4 above (the reference's one-step look at ip + 1, lz4hc.c:618-634, is the lazy
+// has no chain ring to hold, so the whole 64 KB window fits the LDS at once (hc_search_mid) - and there are no bands.  The lazy parse and the emit are phase 3 / 4 above (the reference's one-step look at ip + 1, lz4hc.c:618-634, is the lazy
 // rule's first half).
 enum : uint32_t { kMidHashLog = kHcHashLog - 1 };                        // lz4hc.c:141 LZ4MID_HASHLOG
 __device__ __forceinline__ uint32_t mid_hash4(uint32_t v) { return (v * 2654435761u) >> (32 - kMidHashLog); }                          // lz4hc.c:144
@@ -876,37 +921,99 @@ __device__ __forceinline__ void hc_build_links_mid(lz4amd_gsrc src, uint32_t n, 
     __syncthreads();
 }
 
-// sixteen source bytes at any position (zero filled past the end of the block), from global memory
-__device__ __forceinline__ Q16 hc_ld16g(lz4amd_gsrc src, uint32_t n, uint32_t a) {
-    Q16 r;
-    if (a + 16 <= n) { const U32x4 v = ld_global16_raw(src + a); r.a = v[0]; r.b = v[1]; r.c = v[2]; r.d = v[3]; }
-    else { const uint64_t lo = a < n ? hc_ld8(src, n, a) : 0, hi = a + 8 < n ? hc_ld8(src, n, a + 8) : 0; r.a = (uint32_t)lo; r.b = (uint32_t)(lo >> 32); r.c = (uint32_t)hi; r.d = (uint32_t)(hi >> 32); }
-    return r;
+// The search: with no chain ring to hold, the LDS takes the whole LZ4 window - a 128 KB source ring, filled once per tile of 32 K
+// positions: [t0 - 64 K, t0 + 32 K + kHcAhead) - and a position reads its own bytes and both candidates from it (reads of the
+// candidates from L2 were tried first: one 16-byte read at an address of its own per lane ran at a fifth of this).  Four positions
+// per lane and trip, so that their twelve reads are in flight together; only matches of sixteen bytes and more go round the
+// measuring loop.
+enum : uint32_t { kMidRing = 131072, kMidTile = 32768 };
+static_assert(kHOffSrc + kMidRing + kHcPad <= kHcLdsBytes, "the two-table search's source ring must fit");
+static_assert(kMidRing >= kMaxDistance + kMidTile + kHcAhead + 16, "the ring holds a tile, its window and the bytes a match is measured over");
+__device__ __forceinline__ void mid_commit_src(uint8_t* ring, uint32_t P, const U32x4& v) {
+    const uint32_t o = P & (kMidRing - 1);
+    *(U32x4*)(ring + o) = v;
+    if (o < kHcPad) *(U32x4*)(ring + kMidRing + o) = v;
 }
-// common length of the strings at p and at p - d, at most lim
-__device__ __forceinline__ uint32_t mid_count(lz4amd_gsrc src, uint32_t n, uint32_t p, uint32_t d, uint32_t lim) {
-    uint32_t l = 0;
-    for (;;) {
-        const uint32_t e = equal_bytes16(hc_ld16g(src, n, p + l), hc_ld16g(src, n, p - d + l));
-        l += e;
-        if (e < 16 || l >= lim) break;
-    }
-    return l > lim ? lim : l;
-}
-__device__ __forceinline__ void hc_search_mid(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* d4_g, const uint16_t* d8_g, uint32_t* st0_g) {
-    const uint32_t tid = opaque_u32(threadIdx.x);
-    const uint32_t n64 = (n + 63) & ~63u, last_q = n - kMfLimit;
-    for (uint32_t p = tid; p < n64; p += kHcThreads) {
-        uint32_t res = 0;
-        if (p >= first && p <= last_q) {
-            const uint32_t d8 = d8_g[p], d4 = d4_g[p];
-            uint32_t lim = n - kLastLiterals - p; if (lim > kHcLenCap) lim = kHcLenCap;
-            uint32_t best = 0, off = 0;
-            if (d8) { const uint32_t l = mid_count(src, n, p, d8, lim); if (l >= kMinMatch) { best = l; off = d8; } }
-            if (d4 && d4 != d8) { const uint32_t l = mid_count(src, n, p, d4, lim); if (l >= kMinMatch && l > best) { best = l; off = d4; } }
-            res = best | (off << 8);
+// Matches of sixteen bytes and more.  The lanes of a wave hold consecutive positions, and a match at p over a distance d is a match
+// one byte shorter at p + 1 over the same distance: so of a stretch of lanes whose first sixteen bytes all matched over one distance
+// only the first (its `head`) is measured - by the whole wave, eight bytes a lane (30 lanes cover kHcLenCap), one step per head
+// instead of a sixteen-byte loop that every lane of the wave sits through - and the others take the head's length less their
+// distance to it.  p0: the position of lane 0; full: my first sixteen bytes equal those d bytes back.  Returns the length (not yet
+// cut to the lane's own limit) for full lanes.
+__device__ __forceinline__ uint32_t mid_extend(const uint8_t* ring, uint32_t p0, uint32_t d, bool full) {
+    const uint32_t lane = lane_here();
+    const uint32_t dkey = full ? d : 0u;                                 // (a candidate's distance is never 0)
+    const uint32_t dprev = wave_prev_u32(dkey);                          // (every lane takes part in the shift)
+    const bool head = full && dprev != dkey;
+    const unsigned long long heads = __ballot(head);
+    uint32_t lh = 16;
+    for (unsigned long long rem = heads; rem; rem &= rem - 1) {
+        const uint32_t f = (uint32_t)__ffsll((long long)rem) - 1;
+        const uint32_t pf = p0 + f, df = wave_readlane(d, f);
+        uint32_t same = 0;
+        if (lane < 30) {                                                  // bytes [16 + 8 lane, 24 + 8 lane) of the two strings: up to 256, all inside the ring's kHcAhead
+            const uint32_t o = (pf + 16 + 8 * lane) & (kMidRing - 1), q = (pf - df + 16 + 8 * lane) & (kMidRing - 1);
+            const uint32_t* a = (const uint32_t*)(ring + (o & ~3u)); const uint32_t* b = (const uint32_t*)(ring + (q & ~3u));
+            const uint32_t a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
+            same = equal_bytes8_32(align_bytes(a1, a0, o & 3u), align_bytes(a2, a1, o & 3u), align_bytes(b1, b0, q & 3u), align_bytes(b2, b1, q & 3u));
         }
-        st0_g[p] = res;
+        const unsigned long long brk = __ballot(same < 8);               // (never empty: lanes 30.. report 0)
+        const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
+        const uint32_t len = 16 + 8 * fl + wave_readlane(same, fl);
+        if (lane == f) lh = len;
+    }
+    // my head: the highest head lane at or below mine
+    const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
+    const uint32_t hl = upto ? 63u - (uint32_t)__clzll((long long)upto) : lane;
+    const uint32_t lhead = (uint32_t)__shfl((int)lh, (int)hl);
+    const uint32_t gone = lane - hl;
+    return lhead > gone + 16 ? lhead - gone : 16;                         // (a lane past its head's measured end still has its own sixteen)
+}
+__device__ __forceinline__ void hc_search_mid(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* d4_g, const uint16_t* d8_g, uint32_t* st0_g, char* smem) {
+    const uint32_t tid = opaque_u32(threadIdx.x);
+    uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
+    const uint32_t n64 = (n + 63) & ~63u, last_q = n - kMfLimit;
+    enum : uint32_t { K = 4 };
+    uint32_t loaded = 0;                                                 // the ring holds [loaded - kMidRing, loaded)
+    for (uint32_t t0 = 0; t0 < n64; t0 += kMidTile) {
+        uint32_t H = t0 + kMidTile + kHcAhead; if (H > n) H = (n + 15) & ~15u;      // (kHcAhead is a multiple of 16; zero filled past n)
+        __syncthreads();                                                 // nobody reads the bytes that are replaced any more
+        for (uint32_t P = loaded + 16 * tid; P < H; P += 16 * kHcThreads) mid_commit_src(ring, P, load_src16(src, n, P));
+        if (H > loaded) loaded = H;
+        __syncthreads();
+        uint32_t t1 = t0 + kMidTile; if (t1 > n64) t1 = n64;
+        for (uint32_t base = t0; base < t1; base += K * kHcThreads) {
+            uint32_t d8[K], d4[K];
+            bool ok[K];
+#pragma unroll
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t p = base + k * kHcThreads + tid;
+                ok[k] = p >= first && p <= last_q;
+                d8[k] = ok[k] ? d8_g[p] : 0u; d4[k] = ok[k] ? d4_g[p] : 0u;
+                if (d4[k] == d8[k]) d4[k] = 0;                           // one candidate
+            }
+            Q16 own[K], c8[K], c4[K];
+#pragma unroll
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t p = base + k * kHcThreads + tid;
+                own[k] = lds_ld16(ring, p & (kMidRing - 1)); c8[k] = lds_ld16(ring, (p - d8[k]) & (kMidRing - 1)); c4[k] = lds_ld16(ring, (p - d4[k]) & (kMidRing - 1));
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t p = base + k * kHcThreads + tid;
+                uint32_t lim = ok[k] ? n - kLastLiterals - p : 0u; if (lim > kHcLenCap) lim = kHcLenCap;
+                uint32_t l8 = d8[k] ? equal_bytes16(own[k], c8[k]) : 0u, l4 = d4[k] ? equal_bytes16(own[k], c4[k]) : 0u;
+                const bool full8 = l8 == 16, full4 = l4 == 16;
+                if (__ballot(full8)) { const uint32_t l = mid_extend(ring, p - lane_here(), d8[k], full8); if (full8) l8 = l; }
+                if (__ballot(full4)) { const uint32_t l = mid_extend(ring, p - lane_here(), d4[k], full4); if (full4) l4 = l; }
+                if (l8 > lim) l8 = lim;
+                if (l4 > lim) l4 = lim;
+                uint32_t best = 0, off = 0;
+                if (l8 >= kMinMatch) { best = l8; off = d8[k]; }
+                if (l4 >= kMinMatch && l4 > best) { best = l4; off = d4[k]; }
+                if (p < t1) st0_g[p] = best | (off << 8);
+            }
+        }
     }
     __syncthreads();
 }
@@ -957,7 +1064,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
             hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, level >= 10 ? kHcSkipLenOpt : kHcSkipLenLazy, favor, smem, prof);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         } else {
-            hc_search_mid(src, n, first, chain_g, st1_g, st0_g);
+            hc_search_mid(src, n, first, chain_g, st1_g, st0_g, smem);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1] += t - tq; tq = t; }
         }
         // -- parse: one wave per strip of the block proper

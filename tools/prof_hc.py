@@ -8,25 +8,26 @@ from bench import gen_data
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 256 << 10
 pct = int(sys.argv[3]) if len(sys.argv) > 3 else 60
-level = int(sys.argv[4]) if len(sys.argv) > 4 else 9
+levels = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [9]      # several levels: "9,2,12"
 ctx = lz4_amd.Context(0)
 data = torch.from_numpy(gen_data(nb * bs, pct, 0)).cuda()
-comp, csizes, plan = lz4_amd.compress_blocks(ctx, data, bs, hc_level=level)
 s = torch.cuda.current_stream().cuda_stream
-runs = 2
-for _ in range(runs):
-    km, tot = plan.launch_timed(s)
-print("HC level %d, %d x %d B P%d: kernel ms %.2f  GB/s in %.2f  ratio %.3f" % (level, nb, bs, pct, km[0], nb * bs / km[0] / 1e6, nb * bs / sum(csizes)))
 L = lz4_amd.lib()
-w = (ctypes.c_ulonglong * (256 * 8))()
-n = L.lz4amd_plan_profile(plan._h, w, len(w))
-names = ["chain build", "search band 0", "search band 1", "optimal parse: forward pass of wave 0 (levels 10-12)", "parse", "offsets + emit"]
-blocks_per_wg = nb / (n // 8) * (runs + 1)
-for k, name in enumerate(names):
+for level in levels:
+  comp, csizes, plan = lz4_amd.compress_blocks(ctx, data, bs, hc_level=level)
+  runs = 2
+  for _ in range(runs):
+    km, tot = plan.launch_timed(s)
+  print("HC level %d, %d x %d B P%d: kernel ms %.2f  GB/s in %.2f  ratio %.3f" % (level, nb, bs, pct, km[0], nb * bs / km[0] / 1e6, nb * bs / sum(csizes)))
+  w = (ctypes.c_ulonglong * (256 * 8))()
+  n = L.lz4amd_plan_profile(plan._h, w, len(w))
+  names = ["chain build", "search band 0", "search band 1", "optimal parse: forward pass of wave 0 (levels 10-12)", "parse", "offsets + emit"]
+  blocks_per_wg = nb / (n // 8) * (runs + 1)
+  for k, name in enumerate(names):
     d = [w[i * 8 + k] for i in range(n // 8)]
     print("%-16s cycles per block: median %.0f  max %.0f" % (name, statistics.median(d) / blocks_per_wg, max(d) / blocks_per_wg))
 
-if "hcprof" in os.environ.get("LZ4AMD_LIB", ""):     # tools/build_variant.sh hcprof -DLZ4AMD_PROF_HC
+  if "hcprof" in os.environ.get("LZ4AMD_LIB", ""):     # tools/build_variant.sh hcprof -DLZ4AMD_PROF_HC
     med = lambda f: statistics.median([f(i) for i in range(n // 8)]) / blocks_per_wg
     trips = med(lambda i: w[i * 8 + 3] & 0xFFFFFFFF); lanes = med(lambda i: w[i * 8 + 3] >> 32)
     hits = med(lambda i: w[i * 8 + 6] & 0xFFFFFFFF); hlanes = med(lambda i: w[i * 8 + 6] >> 32)
