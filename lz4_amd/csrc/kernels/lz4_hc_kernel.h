@@ -22,16 +22,20 @@
 //              = 192 KB, more than a CU's LDS, so the window is searched in BANDS of 32 K positions:
 //              a pass streams the block through a 32 KB source ring + 64 KB chain ring in tiles of
 //              8 K positions, every lane walks the chains of its 8 positions while the candidates are
-//              inside the band, and parks {best length, best offset, distance of the next candidate,
-//              attempts left} (6 bytes, staged in LDS, flushed coalesced); the next pass streams the
-//              band 32 K further back and resumes the walks.  Every probe of the inner loop is an LDS
-//              access.  Lengths are measured up to kHcLenCap bytes.
+//              inside the band; a walk whose next candidate lies beyond the band is parked as a list
+//              entry {position, best length, best offset, distance of the next candidate, attempts
+//              left} (8 bytes; a third of the positions on datagen -P60), and the next pass streams the
+//              band 32 K further back and resumes the listed walks only.  In the nearest band a
+//              candidate is compared over sixteen bytes at once (while the best match is shorter than
+//              that the compare is the measurement); every probe of the inner loop is an LDS access.
+//              Lengths are measured up to kHcLenCap bytes.
 //   3 parse    16 strips, one wave each (the per-position results are staged through LDS in chunks
-//              of 1 K positions): the wave looks at 64 positions at a time, takes the first
-//              match that neither of the next two positions beats (lazy evaluation, the role of the
-//              reference's LZ4HC_InsertAndGetWiderMatch retries, lz4hc.c:1168-1330), extends capped
-//              matches with a wave-wide compare, and records {literal run, offset, length}.
-//              Matches end at the strip's end; pending literals carry over.
+//              of 1 K positions): 64 positions at a time, every lane decides whether a sequence may
+//              start at its position - a match that neither of the next two positions beats (lazy
+//              evaluation, the role of the reference's LZ4HC_InsertAndGetWiderMatch retries,
+//              lz4hc.c:1168-1330) - the wave walks from match end to next start over that bit mask,
+//              extends capped matches with a wave-wide compare, and the taken lanes record {literal
+//              run, offset, length}.  Matches end at the strip's end; pending literals carry over.
 //   4 emit     strip sizes -> output offsets (wave 0), then every wave writes its strip
 //              (emit_strip of the fast compressor).
 // Levels 10-12 (lz4hc.c:92-106, LZ4HC_compress_optimal 1823-2130) replace phase 3's lazy choice by an optimal parse over the
@@ -40,8 +44,11 @@
 // (hc_build_links_mid, hc_search_mid).
 //
 // HBM/L2 traffic per block: source read 2 + 2 x bands times, 2 B/position of chain written once and
-// read once per band, 6 B/position of search state written and read once per band, 8 B per sequence
-// of records, compressed stream written once.  No MFMA: integer / byte work.
+// read once per band, 4 B/position of results written once (patched where a farther band finds better) and read once,
+// 8 B per parked walk written and read per band, 8 B per sequence of records, compressed stream written once.
+// Not built: the reference's handling of long runs of one byte (patternAnalysis, lz4hc.c:960-1060) - blocks that hold such runs spend
+// their attempts inside them and come out larger than the reference's (datagen -P99: up to +20 % at a stream's start).
+// No MFMA: integer / byte work.
 #pragma once
 #include "lz4_compress_kernel.h"
 
@@ -74,7 +81,7 @@ enum : uint32_t {
     kHcBandStep = kHcRing - kHcAhead,   // how much further back the next band starts
     kHcBands = 3,                       // 3 x 32496 >= 65535 + kHcTile + kHcAhead: the whole LZ4 window, for every position
     kHcMinStrip = 1024,
-    kHcListCap = 3584,                  // if more walks than this go on in a tile, all its positions are handed out instead
+    kHcEntCap = 6144,                   // parked walks of a tile a farther band stages at a time
     kHcChunk = 1024,                    // positions of search results a parsing wave stages in LDS at a time
 #ifndef LZ4AMD_HC_BATCH
 #define LZ4AMD_HC_BATCH 4
@@ -103,10 +110,8 @@ enum : uint32_t {
     kHOffChain = kHOffSrc + kHcRing + kHcPad,       //          u16[kHcRing]
     kHOffMine = kHOffChain + 2 * kHcRing,           //          the tile's own bytes
     kHcMineBytes = kHcTile + kHcAhead + 48,           // 36-byte reads at up to kHcLenCap bytes past the tile's last position
-    kHOffRes0 = kHOffMine + kHcMineBytes,           //          u32[kHcTile] per-position state, word 0
-    kHOffRes1 = kHOffRes0 + 4 * kHcTile,            //          u16[kHcTile] per-position state, word 1
-    kHOffList = kHOffRes1 + 2 * kHcTile,            //          u16[kHcListCap] positions of the tile whose walks go on (farther bands)
-    kHcSearchEnd = kHOffList + 2 * kHcListCap,
+    kHOffRes0 = kHOffMine + kHcMineBytes,           //          nearest band: u32[kHcTile] results of the tile; farther bands: HcEnt[kHcEntCap] parked walks
+    kHcSearchEnd = kHOffRes0 + 8 * kHcEntCap,
     kHOffWtab = kHOffBody + (4u << kHcHashLog),     // phase 1: u32[kHcWaves][256] duplicate detection, one table per wave
     kHOffParse = kHOffBody,                         // phase 3: u32[kHcWaves][2 * kHcChunk]
     kHcLdsBytes = kHcSearchEnd,
@@ -115,7 +120,8 @@ static_assert(kHOffWtab + kHcWaves * 256 * 4 <= kHcLdsBytes, "head table + dupli
 static_assert(kHOffParse + kHcWaves * 2 * kHcChunk * 4 <= kHcLdsBytes, "parse staging must fit");
 static_assert(kHcLdsBytes <= 160 * 1024, "one CU's LDS");
 static_assert(kHcBands * kHcBandStep >= 65535 + kHcTile + kHcAhead, "bands must cover the LZ4 window");
-static_assert(kHOffMine % 16 == 0 && kHOffRes0 % 16 == 0 && kHOffRes1 % 16 == 0 && kHOffChain % 16 == 0, "16-byte LDS accesses");
+static_assert(kHOffMine % 16 == 0 && kHOffRes0 % 16 == 0 && kHOffChain % 16 == 0, "16-byte LDS accesses");
+static_assert(8 * kHcEntCap >= 4 * kHcTile, "the results of a tile and the staged entries share one region");
 enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5, HM_NLIST = 6, HM_FIRST0 = 16 /* [16]: first record of each strip's record area */ };
 
 // scratch layout of one workgroup, for blocks of at most n bytes
@@ -123,7 +129,9 @@ __host__ __device__ inline uint64_t hc_chain_bytes(uint32_t n) { return ((uint64
 __host__ __device__ inline uint64_t hc_st0_bytes(uint32_t n) { return ((uint64_t)4 * (n + kHcTile) + 255) & ~255ull; }
 __host__ __device__ inline uint64_t hc_st1_bytes(uint32_t n) { return ((uint64_t)2 * (n + kHcTile) + 255) & ~255ull; }
 __host__ __device__ inline uint64_t hc_recs_bytes(uint32_t n) { return (uint64_t)8 * (n / 4 + 64 * kHcWaves); }
-__host__ __device__ inline uint64_t hc_scratch_bytes(uint32_t n) { return hc_chain_bytes(n) + hc_st0_bytes(n) + hc_st1_bytes(n) + hc_recs_bytes(n); }
+__host__ __device__ inline uint64_t hc_list_bytes(uint32_t n) { return ((uint64_t)8 * (n + kHcTile) + 255) & ~255ull; }      // parked walks: at most one per position
+__host__ __device__ inline uint64_t hc_count_bytes(uint32_t n) { return ((uint64_t)4 * (n / kHcTile + 2) + 255) & ~255ull; }
+__host__ __device__ inline uint64_t hc_scratch_bytes(uint32_t n) { return hc_chain_bytes(n) + hc_st0_bytes(n) + hc_st1_bytes(n) + hc_recs_bytes(n) + hc_list_bytes(n) + hc_count_bytes(n); }
 
 __device__ __forceinline__ uint32_t hc_attempts(int level) {
     // k_clTable lz4hc.c:92-106: levels 3..9 = 4..256 candidates per position; 10 / 11 = 96 / 512 (lz4hc.c:103-104); 12 = 2048 here
@@ -142,8 +150,8 @@ __device__ __forceinline__ uint32_t hc_attempts(int level) {
 __device__ __forceinline__ uint32_t hc_att_shift(uint32_t attempts) { return attempts <= 256u ? 0u : attempts <= 512u ? 1u : 3u; }
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHcHashLog); }
 
-// Per-position search state between bands: st0 = best offset | distance of the next candidate << 16 (0 = walk
-// finished), st1 = best length | ((attempts left - 1) >> hc_att_shift) << 8.  After the last band st0 = best length | offset << 8.
+// Per-position search result: st0 = best length | offset << 8.  A walk that goes on in the next band is a list entry (hc_search_band).
+struct HcEnt { uint32_t x, y; };
 
 // ------------------------------------------------------------------------------ phase 1: chains
 // Lanes of the group that share my hash: `below` = how many lower lanes do (-> the previous position with my
@@ -275,7 +283,13 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
     return l > lim ? lim : l;
 }
 
-__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, uint16_t* st1_g,
+// What a walk leaves behind between two bands is a list entry, not a slot of a per-position array: most walks end in the nearest
+// band, so the farther bands read a third of the positions (and the last one a sixth) instead of streaming 6 bytes of state per
+// position in and out.  Entry (8 bytes): e0 = position in the tile | distance of the next candidate << 16, e1 = best offset |
+// best length << 16 | attempts left (hc_att_shift units) << 24.  A tile's entries sit at list_g[t0 ...], their number in
+// count_g[tile]; a band rewrites a tile's list in place (it has staged what it overwrites).  The per-position results (best
+// length | offset << 8) are written densely by the nearest band and patched by the farther ones where a walk found a longer match.
+__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, HcEnt* list_g, uint32_t* count_g,
                                                uint32_t band, uint32_t attempts, uint32_t skip_len, bool favor, char* smem, uint64_t* prof = nullptr) {
     const uint32_t tid = opaque_u32(threadIdx.x);
 #ifdef LZ4AMD_PROF_HC
@@ -286,9 +300,8 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
     uint8_t* ring = (uint8_t*)(smem + kHOffSrc);
     uint16_t* cring = (uint16_t*)(smem + kHOffChain);
     uint8_t* mine = (uint8_t*)(smem + kHOffMine);
-    uint32_t* res0 = (uint32_t*)(smem + kHOffRes0);
-    uint16_t* res1 = (uint16_t*)(smem + kHOffRes1);
-    uint16_t* plist = (uint16_t*)(smem + kHOffList);
+    uint32_t* res0 = (uint32_t*)(smem + kHOffRes0);                     // nearest band: the tile's results
+    HcEnt* ent = (HcEnt*)(smem + kHOffRes0);                            // farther bands: the staged entries
     uint32_t* misc = (uint32_t*)(smem + kHOffMisc);
     const uint32_t n64 = (n + 63) & ~63u;
     const int32_t last_q = (int32_t)n - (int32_t)kMfLimit;            // last position that may start a match
@@ -305,6 +318,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
             *(U32x4*)(cring + (P & (int32_t)(kHcRing - 1))) = *(const U32x4*)(chain_g + P);
         if (tid < kHcMineBytes / 16) *(U32x4*)(mine + 16 * tid) = load_src16(src, n, 16 * tid);      // zero filled past n
     }
+    if (tid == 0) misc[HM_NLIST] = 0;
     for (uint32_t t0 = 0; t0 < n; t0 += kHcTile) {
         const int32_t H = (int32_t)(t0 + kHcTile + kHcAhead) - shift;
         const int32_t low = H - (int32_t)kHcRing;                     // lowest candidate position of this band
@@ -319,248 +333,247 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
         if (have_s) ps = load_src16(src, n, (uint32_t)Ps);
         if (have_c) pc = *(const U32x4*)(chain_g + Pc);
         if (have_m && Pm < n) pm = load_src16(src, n, Pm);
-        // -- the walks' state left by the previous band
-        if (band != 0) {
-            *(U32x4*)(res0 + 4 * tid) = *(const U32x4*)(st0_g + t0 + 4 * tid);
-            *(U32x4*)(res0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads));
-            *(U32x4*)(res1 + 8 * tid) = *(const U32x4*)(st1_g + t0 + 8 * tid);
-        }
-        if (tid == 0) { misc[HM_POOL] = 0; misc[HM_NLIST] = 0; }
-        __syncthreads();
-        // -- farther bands: most walks are over already.  The positions whose walk goes on are listed and only
-        //    those are handed out (one by one); the others are settled here, eight per thread
-        uint32_t nlist = 0;
-        bool listed = false;
-        if (band != 0) {
-            uint32_t over = 0;                                          // my positions whose walk is over
-#pragma unroll
-            for (uint32_t k = 0; k < kHcPosPerThread; k++) {
-                const uint32_t q = k * kHcThreads + tid;
-                const bool live = (res0[q] >> 16) != 0;
-                const unsigned long long lm = __ballot(live);              // one counter update per wave (same-address LDS atomics of 64 lanes are served one by one)
-                if (lm) {
-                    const uint32_t leader = (uint32_t)__ffsll((long long)lm) - 1;
-                    uint32_t base = 0;
-                    if (lane_here() == leader) base = atomicAdd(&misc[HM_NLIST], (uint32_t)__popcll(lm));
-                    base = wave_readlane(base, leader);
-                    const uint32_t i = base + lanes_below(lm);
-                    if (live && i < kHcListCap) plist[i] = (uint16_t)q;
-                }
-                if (!live) over |= 1u << k;
+        // -- farther bands: the tile's parked walks, staged kHcEntCap at a time (one round, unless nearly every position of the tile
+        //    is still walking); the nearest band: one round over the tile's runs
+        const uint32_t cnt = band ? count_g[t0 / kHcTile] : 0u;
+        uint32_t c0 = 0;
+        do {
+            uint32_t cn = 0;
+            if (band != 0) {
+                cn = cnt - c0 < kHcEntCap ? cnt - c0 : kHcEntCap;
+                for (uint32_t i = tid; i < cn; i += kHcThreads) ent[i] = list_g[t0 + c0 + i];
             }
+            if (tid == 0) misc[HM_POOL] = 0;
             __syncthreads();
-            nlist = misc[HM_NLIST];
-            listed = nlist <= kHcListCap;
-            if (listed && final_band) {                                 // (only entries no walker will touch: see `over`)
-#pragma unroll
-                for (uint32_t k = 0; k < kHcPosPerThread; k++) {
-                    const uint32_t q = k * kHcThreads + tid;
-                    if (over & (1u << k)) res0[q] = (res1[q] & 0xFFu) | ((res0[q] & 0xFFFFu) << 8);
-                }
-            }
-        }
-        const uint32_t nunits = listed ? nlist : kHcRunsPerTile;        // work units of the tile: listed positions, or runs
-        // -- the walks.  The tile is a pool of runs of kHcRun consecutive positions; idle lanes of any wave take
-        //    the next runs (which lane walks a run does not change its result).  The loop is wave-synchronous
-        //    and predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
-        //    nothing else on the path), then VERIFIES the candidates found (independent reads).
-        {
-            const uint32_t lane = lane_here();
-            bool pool_dry = false;                                       // the tile's pool of runs is empty
-            uint32_t run_left = 0;                                       // positions of my run still to start
-            uint32_t inh_len = 0, inh_off = 0;                           // what the previous position of my run leaves to the next
-            bool inh_capped = false;
-            bool active = false;
-            int32_t p = 0;
-            uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0, best_in = 3;
-            Q16 mw; mw.a = mw.b = mw.c = mw.d = 0;                        // sixteen of my own bytes: the window the candidates are compared in
+            const uint32_t nunits = band ? cn : kHcRunsPerTile;          // work units of the round: entries, or runs
+            // -- the walks.  The nearest band's tile is a pool of runs of kHcRun consecutive positions; idle lanes of any wave take
+            //    the next runs (which lane walks a run does not change its result).  The loop is wave-synchronous
+            //    and predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
+            //    nothing else on the path), then VERIFIES the candidates found (independent reads).
+            {
+                const uint32_t lane = lane_here();
+                bool pool_dry = nunits == 0;                                 // the round's pool is empty
+                uint32_t run_left = 0;                                       // positions of my run still to start
+                uint32_t eidx = 0;                                           // (farther bands) my entry
+                uint32_t inh_len = 0, inh_off = 0;                           // what the previous position of my run leaves to the next
+                bool inh_capped = false;
+                bool active = false;
+                int32_t p = 0;
+                uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0, best_in = 3;
+                Q16 mw; mw.a = mw.b = mw.c = mw.d = 0;                        // sixteen of my own bytes: the window the candidates are compared in
 #ifdef LZ4AMD_PROF_HC
-            hp_t0x = clock_ticks();
+                hp_t0x = clock_ticks();
 #endif
-            for (;;) {
-                // ---- hand out runs of kHcRun consecutive positions to idle lanes, from one pool for the whole tile
-                //      (an LDS counter; asked only when a quarter of the wave is idle, or nobody works)
-                const bool want = !active && run_left == 0;
-                const unsigned long long idle = __ballot(want);
-                const uint32_t nidle = (uint32_t)__popcll(idle);
-                if (!pool_dry && (nidle >= LZ4AMD_HC_REFILL || (nidle && !__ballot(active || run_left != 0)))) {
-                    uint32_t base = 0;
-                    if (lane == (uint32_t)__ffsll((long long)idle) - 1) base = atomicAdd(&misc[HM_POOL], nidle);
-                    base = wave_readlane(base, (uint32_t)__ffsll((long long)idle) - 1);
-                    const uint32_t mine_i = base + lanes_below(idle);
-                    if (base + nidle >= nunits) pool_dry = true;
-                    if (want && mine_i < nunits) {
-                        if (listed) { pp = (uint32_t)plist[mine_i] - 1; run_left = 1; } else { pp = mine_i * kHcRun - 1; run_left = kHcRun; }
-                        inh_len = 0;
-                    }
-                }
-                // ---- next position of my run.  In the nearest band it starts from what its predecessor found:
-                //      a match of length L at p is a match of length L - 1 at p + 1 (same offset), so inside a long
-                //      match only the first position pays for measuring it
-                if (!active && run_left) {
-                    pp++; run_left--;
-                    p = (int32_t)(t0 + pp);
-                    bool walk = true, kept = false;
-                    if (band == 0) {
-                        if (p > last_q || (uint32_t)p < first) { res0[pp] = 0; res1[pp] = 3; walk = false; }     // the history, and the slots past the block's end
-                        else { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
-                    } else {
-                        const uint32_t s0 = res0[pp], s1 = res1[pp];
-                        dist = s0 >> 16; boff = s0 & 0xFFFFu; best = s1 & 0xFFu; att = ((s1 >> 8) << ash) + 1;
-                        if (dist == 0) { if (final_band) res0[pp] = best | (boff << 8); walk = false; }   // finished earlier
-                    }
-                    if (walk) {
-                        lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
-                        if (lim > kHcLenCap) lim = kHcLenCap;
-                        best_in = best;
-                        if (inh_len >= kMinMatch && inh_len > best) {
-                            // (in a farther band the predecessor's match was found in this band, so its bytes are in the ring)
-                            best = inh_len; boff = inh_off;
-                            // a capped predecessor may match further than it measured
-                            if (inh_capped) best = hc_count(ring, mine, (uint32_t)(p - (int32_t)boff) & (kHcRing - 1), pp, best, lim);
-                            // nothing can beat a full-length match; and inside a long match the positions after the
-                            // first are not searched at all (the reference does not visit them either)
-                            if (best >= lim || best >= skip_len) {
-                                if (final_band) res0[pp] = best | (boff << 8);
-                                else { res0[pp] = boff; res1[pp] = (uint16_t)best; }
-                                inh_len = best - 1; inh_capped = best >= lim;
-                                walk = false; kept = true;
-                            }
+                for (;;) {
+                    // ---- hand out work to idle lanes, from one pool for the whole round
+                    //      (an LDS counter; asked only when a quarter of the wave is idle, or nobody works)
+                    const bool want = !active && run_left == 0;
+                    const unsigned long long idle = __ballot(want);
+                    const uint32_t nidle = (uint32_t)__popcll(idle);
+                    if (!pool_dry && (nidle >= LZ4AMD_HC_REFILL || (nidle && !__ballot(active || run_left != 0)))) {
+                        uint32_t base = 0;
+                        if (lane == (uint32_t)__ffsll((long long)idle) - 1) base = atomicAdd(&misc[HM_POOL], nidle);
+                        base = wave_readlane(base, (uint32_t)__ffsll((long long)idle) - 1);
+                        const uint32_t mine_i = base + lanes_below(idle);
+                        if (base + nidle >= nunits) pool_dry = true;
+                        if (want && mine_i < nunits) {
+                            if (band != 0) { eidx = mine_i; run_left = 1; } else { pp = mine_i * kHcRun - 1; run_left = kHcRun; }
+                            inh_len = 0;
                         }
                     }
-                    if (walk) { if (band == 0) mw = lds_ld16(mine, pp + (best > 15 ? best - 15 : 0)); else mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(band ? 5 : 0, 1); }
-                    else if (!kept) inh_len = 0;                        // nothing to hand to the next position
-                    if (kept) HC_STAT(band ? 6 : 1, 1);
-                }
-                if (!__ballot(active)) { if (pool_dry && !__ballot(run_left != 0)) break; continue; }
+                    // ---- once the pool is dry, what is still queued is what the lanes hold in their runs (a tile is one run of kHcRun
+                    //      positions per lane on average: without this the tile ends when its slowest lane has walked its run alone).
+                    //      Idle lanes take over the last queued position of lanes that have any, one each per trip.
+                    if (pool_dry && band == 0) {
+                        const uint32_t queued = active ? run_left : (run_left ? run_left - 1 : 0);      // positions behind the one in progress / about to start
+                        unsigned long long donors = __ballot(queued != 0), takers = __ballot(!active && run_left == 0);
+                        while (donors && takers) {
+                            const uint32_t dl = (uint32_t)__ffsll((long long)donors) - 1, tl = (uint32_t)__ffsll((long long)takers) - 1;
+                            donors &= donors - 1; takers &= takers - 1;
+                            const uint32_t last = wave_readlane(pp + run_left, dl);          // the donor's last position (in the tile)
+                            if (lane == dl) run_left--;
+                            if (lane == tl) { pp = last - 1; run_left = 1; inh_len = 0; }
+                        }
+                    }
+                    // ---- next position of my run.  In the nearest band it starts from what its predecessor found:
+                    //      a match of length L at p is a match of length L - 1 at p + 1 (same offset), so inside a long
+                    //      match only the first position pays for measuring it
+                    if (!active && run_left) {
+                        run_left--;
+                        bool walk = true, kept = false;
+                        if (band == 0) {
+                            pp++;
+                            p = (int32_t)(t0 + pp);
+                            if (p > last_q || (uint32_t)p < first) { res0[pp] = 0; walk = false; }     // the history, and the slots past the block's end
+                            else { dist = cring[(uint32_t)p & (kHcRing - 1)]; best = 3; boff = 0; att = attempts; }
+                        } else {
+                            const HcEnt e = ent[eidx];
+                            pp = e.x & 0xFFFFu; p = (int32_t)(t0 + pp);
+                            dist = e.x >> 16; boff = e.y & 0xFFFFu; best = (e.y >> 16) & 0xFFu; att = ((e.y >> 24) << ash) + 1;
+                        }
+                        if (walk) {
+                            lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
+                            if (lim > kHcLenCap) lim = kHcLenCap;
+                            best_in = best;
+                            if (inh_len >= kMinMatch && inh_len > best) {     // (nearest band only: a farther band's work units are single positions)
+                                best = inh_len; boff = inh_off;
+                                // a capped predecessor may match further than it measured
+                                if (inh_capped) best = hc_count(ring, mine, (uint32_t)(p - (int32_t)boff) & (kHcRing - 1), pp, best, lim);
+                                // nothing can beat a full-length match; and inside a long match the positions after the
+                                // first are not searched at all (the reference does not visit them either)
+                                if (best >= lim || best >= skip_len) {
+                                    res0[pp] = best | (boff << 8);
+                                    inh_len = best - 1; inh_capped = best >= lim;
+                                    walk = false; kept = true;
+                                }
+                            }
+                        }
+                        if (walk) { if (band == 0) mw = lds_ld16(mine, pp + (best > 15 ? best - 15 : 0)); else mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(band ? 5 : 0, 1); }
+                        else if (!kept) inh_len = 0;                        // nothing to hand to the next position
+                        if (kept) HC_STAT(band ? 6 : 1, 1);
+                    }
+                    if (!__ballot(active)) { if (pool_dry && !__ballot(run_left != 0)) break; continue; }
 #ifdef LZ4AMD_PROF_HC
-                hp_trips++; hp_lanes += (uint32_t)__popcll(__ballot(active));
+                    hp_trips++; hp_lanes += (uint32_t)__popcll(__ballot(active));
 #endif
-                if (lane == 0) HC_STAT(band ? 7 : 2, 1);
-                if (active) HC_STAT(band ? 8 : 3, 1);
-                // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
-                uint32_t cd[kHcBatch];
-                uint32_t next = 0;                                      // where the next band resumes
-                bool over = !active;
-#pragma unroll
-                for (uint32_t k = 0; k < kHcBatch; k++) {
-                    const int32_t q = p - (int32_t)dist;
-                    const bool in_chain = !over && dist != 0 && dist <= kMaxDistance && att != 0;
-                    const bool in_band = q >= low;
-                    const bool take = in_chain && in_band;
-                    if (in_chain && !in_band) next = final_band ? 0 : dist;
-                    over = over || !take;
-                    cd[k] = take ? dist : 0;
-                    const uint32_t d = cring[(uint32_t)q & (kHcRing - 1)];
-                    att -= take ? 1u : 0u;
-                    if (take) { if (d == 0) over = true; else dist += d; }
-                }
-                bool full = false;
-                if (band == 0) {
-                    // ---- verify: sixteen bytes of every candidate against my own, in the window that ends at index `best` at the latest
-                    //      (w0 = best - 15; 0 while best is below 16, and then the compare IS the measurement: lz4hc.c:934-946).  Only a
-                    //      candidate that agrees on the whole window can be longer than that, and is measured out in the loop below.
-                    const uint32_t w0 = best > 15 ? best - 15 : 0;
-                    Q16 cw[kHcBatch];
-#pragma unroll
-                    for (uint32_t k = 0; k < kHcBatch; k++)
-                        cw[k] = lds_ld16(ring, ((uint32_t)(p - (int32_t)cd[k]) + w0) & (kHcRing - 1));
-                    uint32_t ext = 0;                                        // candidates that agree on all sixteen, as a bit mask per lane
+                    if (lane == 0) HC_STAT(band ? 7 : 2, 1);
+                    if (active) HC_STAT(band ? 8 : 3, 1);
+                    // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
+                    uint32_t cd[kHcBatch];
+                    uint32_t next = 0;                                      // where the next band resumes
+                    bool over = !active;
 #pragma unroll
                     for (uint32_t k = 0; k < kHcBatch; k++) {
-                        const bool cand = cd[k] != 0 && !(favor && cd[k] < 8);      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
-                        const uint32_t e = cand ? equal_bytes16(cw[k], mw) : 0u;
-                        ext |= e == 16 ? 1u << k : 0u;
-                        const uint32_t ec = e < lim ? e : lim;
-                        if (w0 == 0 && e < 16 && ec > best) { best = ec; boff = cd[k]; if (ec >= lim) full = true; }
+                        const int32_t q = p - (int32_t)dist;
+                        const bool in_chain = !over && dist != 0 && dist <= kMaxDistance && att != 0;
+                        const bool in_band = q >= low;
+                        const bool take = in_chain && in_band;
+                        if (in_chain && !in_band) next = final_band ? 0 : dist;
+                        over = over || !take;
+                        cd[k] = take ? dist : 0;
+                        const uint32_t d = cring[(uint32_t)q & (kHcRing - 1)];
+                        att -= take ? 1u : 0u;
+                        if (take) { if (d == 0) over = true; else dist += d; }
                     }
-                    if (full) ext = 0;
-                    while (__ballot(ext != 0)) {
-                        if (lane == 0) HC_STAT(band ? 9 : 4, 1);
-#ifdef LZ4AMD_PROF_HC
-                        hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(ext != 0));
-#endif
-                        if (ext) {
-                            const uint32_t k = (uint32_t)__ffs((int)ext) - 1;
-                            ext &= ext - 1;
-                            uint32_t cdk = cd[0];
+                    bool full = false;
+                    if (band == 0) {
+                        // ---- verify: sixteen bytes of every candidate against my own, in the window that ends at index `best` at the latest
+                        //      (w0 = best - 15; 0 while best is below 16, and then the compare IS the measurement: lz4hc.c:934-946).  Only a
+                        //      candidate that agrees on the whole window can be longer than that, and is measured out in the loop below.
+                        const uint32_t w0 = best > 15 ? best - 15 : 0;
+                        Q16 cw[kHcBatch];
 #pragma unroll
-                            for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
-                            const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
-                            // an earlier candidate of the batch may have raised `best` past the window: test again at the new index
-                            if (best <= w0 + 15 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == lds_ld4(mine, pp + best - 3)) {
-                                const uint32_t l = hc_count(ring, mine, qo, pp, w0 == 0 ? 16u : 0u, lim);
-                                if (l > best) {
-                                    best = l; boff = cdk;
-                                    if (l >= lim) { full = true; ext = 0; }
+                        for (uint32_t k = 0; k < kHcBatch; k++)
+                            cw[k] = lds_ld16(ring, ((uint32_t)(p - (int32_t)cd[k]) + w0) & (kHcRing - 1));
+                        uint32_t ext = 0;                                        // candidates that agree on all sixteen, as a bit mask per lane
+#pragma unroll
+                        for (uint32_t k = 0; k < kHcBatch; k++) {
+                            const bool cand = cd[k] != 0 && !(favor && cd[k] < 8);      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
+                            const uint32_t e = cand ? equal_bytes16(cw[k], mw) : 0u;
+                            ext |= e == 16 ? 1u << k : 0u;
+                            const uint32_t ec = e < lim ? e : lim;
+                            if (w0 == 0 && e < 16 && ec > best) { best = ec; boff = cd[k]; if (ec >= lim) full = true; }
+                        }
+                        if (full) ext = 0;
+                        while (__ballot(ext != 0)) {
+                            if (lane == 0) HC_STAT(band ? 9 : 4, 1);
+#ifdef LZ4AMD_PROF_HC
+                            hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(ext != 0));
+#endif
+                            if (ext) {
+                                const uint32_t k = (uint32_t)__ffs((int)ext) - 1;
+                                ext &= ext - 1;
+                                uint32_t cdk = cd[0];
+#pragma unroll
+                                for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
+                                const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
+                                // an earlier candidate of the batch may have raised `best` past the window: test again at the new index
+                                if (best <= w0 + 15 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == lds_ld4(mine, pp + best - 3)) {
+                                    const uint32_t l = hc_count(ring, mine, qo, pp, w0 == 0 ? 16u : 0u, lim);
+                                    if (l > best) {
+                                        best = l; boff = cdk;
+                                        if (l >= lim) { full = true; ext = 0; }
+                                    }
+                                }
+                            }
+                        }
+                        {   // my own bytes in the window of the next trip
+                            const uint32_t w1 = best > 15 ? best - 15 : 0;
+                            if (w1 != w0) mw = lds_ld16(mine, pp + w1);
+                        }
+                    } else {
+                        // farther bands: a walk that comes this far mostly has its match already, and nearly every candidate fails the
+                        // cheapest test there is - the four bytes that end at index `best` (for best = 3 the MINMATCH test; lz4hc.c:934-936)
+                        uint32_t ct[kHcBatch];
+#pragma unroll
+                        for (uint32_t k = 0; k < kHcBatch; k++)
+                            ct[k] = lds_ld4(ring, ((uint32_t)(p - (int32_t)cd[k]) + best - 3) & (kHcRing - 1));
+                        const uint32_t best0 = best;                            // what the ct[] were read against
+                        // candidates that pass, as a bit mask per lane; the expensive part (measuring a match) is entered
+                        // once per trip for every lane's nearest passing candidate, again only for lanes that have another
+                        uint32_t hits = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
+                        while (__ballot(hits != 0)) {
+                            if (lane == 0) HC_STAT(band ? 9 : 4, 1);
+#ifdef LZ4AMD_PROF_HC
+                            hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(hits != 0));
+#endif
+                            if (hits) {
+                                const uint32_t k = (uint32_t)__ffs((int)hits) - 1;
+                                hits &= hits - 1;
+                                uint32_t cdk = cd[0];
+#pragma unroll
+                                for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
+                                const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
+                                // an earlier candidate of the batch may have raised `best`: test again at the new index
+                                if (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
+                                    const uint32_t l = hc_count(ring, mine, qo, pp, 0, lim);
+                                    if (l > best) {
+                                        best = l; boff = cdk;
+                                        if (l >= lim) { full = true; hits = 0; }
+                                        else mt = lds_ld4(mine, pp + best - 3);
+                                    }
                                 }
                             }
                         }
                     }
-                    {   // my own bytes in the window of the next trip
-                        const uint32_t w1 = best > 15 ? best - 15 : 0;
-                        if (w1 != w0) mw = lds_ld16(mine, pp + w1);
+                    if (full) { over = true; next = 0; }
+                    const bool park = active && over && next != 0;           // the walk goes on in the next band
+                    if (active && over) {
+                        if (band == 0) res0[pp] = best | (boff << 8);
+                        else if (best > best_in) st0_g[p] = best | (boff << 8);
+                        // what the next position of my run may start from
+                        inh_len = best > kMinMatch ? best - 1 : 0; inh_off = boff; inh_capped = best >= lim;
+                        active = false;
                     }
-                } else {
-                    // farther bands: a walk that comes this far mostly has its match already, and nearly every candidate fails the
-                    // cheapest test there is - the four bytes that end at index `best` (for best = 3 the MINMATCH test; lz4hc.c:934-936)
-                    uint32_t ct[kHcBatch];
-#pragma unroll
-                    for (uint32_t k = 0; k < kHcBatch; k++)
-                        ct[k] = lds_ld4(ring, ((uint32_t)(p - (int32_t)cd[k]) + best - 3) & (kHcRing - 1));
-                    const uint32_t best0 = best;                            // what the ct[] were read against
-                    // candidates that pass, as a bit mask per lane; the expensive part (measuring a match) is entered
-                    // once per trip for every lane's nearest passing candidate, again only for lanes that have another
-                    uint32_t hits = 0;
-#pragma unroll
-                    for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
-                    while (__ballot(hits != 0)) {
-                        if (lane == 0) HC_STAT(band ? 9 : 4, 1);
-#ifdef LZ4AMD_PROF_HC
-                        hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(hits != 0));
-#endif
-                        if (hits) {
-                            const uint32_t k = (uint32_t)__ffs((int)hits) - 1;
-                            hits &= hits - 1;
-                            uint32_t cdk = cd[0];
-#pragma unroll
-                            for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
-                            const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
-                            // an earlier candidate of the batch may have raised `best`: test again at the new index
-                            if (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
-                                const uint32_t l = hc_count(ring, mine, qo, pp, 0, lim);
-                                if (l > best) {
-                                    best = l; boff = cdk;
-                                    if (l >= lim) { full = true; hits = 0; }
-                                    else mt = lds_ld4(mine, pp + best - 3);
-                                }
-                            }
-                        }
+                    const unsigned long long parked = __ballot(park);        // (one counter update per wave)
+                    if (parked) {
+                        const uint32_t leader = (uint32_t)__ffsll((long long)parked) - 1;
+                        uint32_t base = 0;
+                        if (lane == leader) base = atomicAdd(&misc[HM_NLIST], (uint32_t)__popcll(parked));
+                        base = wave_readlane(base, leader);
+                        if (park) { HcEnt e; e.x = pp | (next << 16); e.y = boff | (best << 16) | (((att - 1) >> ash) << 24); list_g[t0 + base + lanes_below(parked)] = e; }
                     }
-                }
-                if (full) { over = true; next = 0; }
-                if (active && over) {
-                    if (final_band) res0[pp] = best | (boff << 8);
-                    else { res0[pp] = boff | (next << 16); res1[pp] = (uint16_t)(best | ((next ? (att - 1) >> ash : 0) << 8)); }
-                    // what the next position of my run may start from (farther bands: only a match found in this band)
-                    inh_len = best > kMinMatch && (band == 0 || best > best_in) ? best - 1 : 0; inh_off = boff; inh_capped = best >= lim;
-                    active = false;
                 }
             }
-        }
 #ifdef LZ4AMD_PROF_HC
-        const uint64_t hp_t1 = clock_ticks();
-        hp_loop += hp_t1 - hp_t0x;
+            const uint64_t hp_t1 = clock_ticks();
+            hp_loop += hp_t1 - hp_t0x;
 #endif
-        __syncthreads();
+            __syncthreads();
 #ifdef LZ4AMD_PROF_HC
-        { const uint64_t t2 = clock_ticks(); hp_wait += t2 - hp_t1; }
+            { const uint64_t t2 = clock_ticks(); hp_wait += t2 - hp_t1; }
 #endif
-        // -- flush the tile's state (coalesced), commit the prefetched granules: they replace positions
+            c0 += kHcEntCap;
+        } while (c0 < cnt);
+        // -- the nearest band flushes the tile's results (coalesced); the prefetched granules are committed: they replace positions
         //    below the next tile's band
-        *(U32x4*)(st0_g + t0 + 4 * tid) = *(const U32x4*)(res0 + 4 * tid);
-        *(U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(res0 + 4 * (tid + kHcThreads));
-        if (!final_band) *(U32x4*)(st1_g + t0 + 8 * tid) = *(const U32x4*)(res1 + 8 * tid);
+        if (band == 0) {
+            *(U32x4*)(st0_g + t0 + 4 * tid) = *(const U32x4*)(res0 + 4 * tid);
+            *(U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(res0 + 4 * (tid + kHcThreads));
+        }
+        if (tid == 0) { if (!final_band) count_g[t0 / kHcTile] = misc[HM_NLIST]; misc[HM_NLIST] = 0; }
         if (have_s) hc_commit_src(ring, (uint32_t)Ps, ps);
         if (have_c) *(U32x4*)(cring + ((uint32_t)Pc & (kHcRing - 1))) = pc;
         if (have_m) *(U32x4*)(mine + 16 * tid) = pm;
@@ -1045,6 +1058,8 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     uint32_t* st0_g = (uint32_t*)(scratch + hc_chain_bytes(P.max_src));
     uint16_t* st1_g = (uint16_t*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src));
     MatchRec* recs_g = (MatchRec*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src) + hc_st1_bytes(P.max_src));
+    HcEnt* list_g = (HcEnt*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src) + hc_st1_bytes(P.max_src) + hc_recs_bytes(P.max_src));
+    uint32_t* count_g = (uint32_t*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src) + hc_st1_bytes(P.max_src) + hc_recs_bytes(P.max_src) + hc_list_bytes(P.max_src));
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tq = prof ? clock_ticks() : 0;
 
@@ -1061,7 +1076,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         const uint32_t attempts = hc_attempts(level);
 
         if (!mid) for (uint32_t band = 0; band < kHcBands; band++) {
-            hc_search_band(src, n, first, chain_g, st0_g, st1_g, band, attempts, level >= 10 ? kHcSkipLenOpt : kHcSkipLenLazy, favor, smem, prof);
+            hc_search_band(src, n, first, chain_g, st0_g, list_g, count_g, band, attempts, level >= 10 ? kHcSkipLenOpt : kHcSkipLenLazy, favor, smem, prof);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         } else {
             hc_search_mid(src, n, first, chain_g, st1_g, st0_g, smem);
