@@ -19,7 +19,7 @@ Prints ONE JSON line on rank 0:
   cpu_baseline     the reference lib/lz4.c (oracle/_ref, kind "reference") or the oracle port, timed on this box's
                    host cores (1 thread, one per physical core, one per logical CPU; >= 4 blocks per thread,
                    loops of >= 1 s, best of 3) on a bounded sample of the same workload
-  hc               (N=1) BASELINE configs[3]: LZ4_compress_HC level 9 on 256 KiB blocks of the same GiB
+  hc               (N=1) BASELINE configs[3]: LZ4_compress_HC level 9 on 256 KiB blocks of the same GiB (+ levels 12 and 2)
   shape_2048       (N=1) the per-GPU shape of configs[4]: 2048 x 4 MiB blocks (8 GiB), blocks queue 8 deep per CU
   frame            (N=1) configs[2]: the GiB as ONE frame, 4 MB linked blocks + content checksum, through the
                    host-pointer API LZ4F_compressFrame / LZ4F_decompress (PCIe inclusive)
@@ -105,13 +105,22 @@ def gen_data(nbytes, pct, seed):
     return buf
 
 
-def kernel_sources_sha():
-    """Identity of the device code: the traffic file under profiles/ is only quoted when it was measured on these sources.
-    Comments and blank lines do not count (they do not reach the device)."""
+KERNEL_FILES = {   # the kernel headers each kernel is built from (lz4amd_device.hip instantiates all of them)
+    "compress": ["lz4_common.h", "platform_hip.h", "lz4_compress_kernel.h"],
+    "decompress": ["lz4_common.h", "platform_hip.h", "lz4_decompress_kernel.h", "lz4_preparse_kernel.h"],
+    "compress_hc": ["lz4_common.h", "platform_hip.h", "lz4_compress_kernel.h", "lz4_hc_kernel.h"],
+    "xxh32": ["lz4_common.h", "platform_hip.h", "xxh32_kernel.h"],
+}
+
+
+def kernel_sources_sha(kernel=None):
+    """Identity of the device code (of one kernel, or of all of it): the traffic file under profiles/ is only quoted for a kernel
+    when it was measured on that kernel's sources.  Comments and blank lines do not count (they do not reach the device)."""
     import re
     h = hashlib.sha256()
     kdir = os.path.join(ROOT, "lz4_amd", "csrc", "kernels")
-    for f in sorted(os.listdir(kdir)) + ["../lz4amd_device.hip"]:
+    names = sorted(os.listdir(kdir)) if kernel is None else KERNEL_FILES[kernel]
+    for f in names + ["../lz4amd_device.hip"]:
         with open(os.path.join(kdir, f), "r", encoding="utf-8", errors="replace") as fh:
             text = fh.read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
@@ -122,11 +131,12 @@ def kernel_sources_sha():
 
 
 def measured_traffic():
-    """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); {} when the
-    file was measured on other kernel sources."""
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); a kernel's entry is left
+    out when the file was measured on other sources of that kernel."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return pmc if pmc.get("kernel_sources_sha") == kernel_sources_sha() else {}
+        shas = pmc.get("kernel_sources_sha", {})
+        return {k: v for k, v in pmc.items() if k in KERNEL_FILES and shas.get(k) == kernel_sources_sha(k)}
     except Exception:
         return {}
 
@@ -322,6 +332,28 @@ def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, copy_gbps, level
                                             "ratio": round(U / sum(ocs), 4), "bit_exact": bool(ok)}
         except Exception as e:                               # a side measurement: never takes the line down
             res["optimal_parse_level12"] = {"error": str(e)}
+        # levels 1-2 (LZ4MID, lz4hc.c:93-95: two tables, one candidate each), same blocks; the reference's own level 2 beside it
+        try:
+            mplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS_HC, tab, level=2)
+            mplan.launch(stream)
+            mcs = mplan.results(stream)
+            mdtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nb)], mcs,
+                                       [out.data_ptr() + i * bs for i in range(nb)], [bs] * nb)
+            mdplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, mdtab)
+            out.zero_()
+            mdplan.launch(stream)
+            ok = all(c > 0 for c in mcs) and mdplan.results(stream) == [bs] * nb and torch.equal(out, data)
+            mms = min(mplan.launch_timed(stream)[0][0] for _ in range(2))
+            mid = {"compress_GBps": round(U / (mms * 1e-3) / 1e9, 2), "kernel_ms": round(mms, 3), "ratio": round(U / sum(mcs), 4), "bit_exact": bool(ok),
+                   "roofline_frac": round((U + sum(mcs)) / (mms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
+            if with_cpu:
+                cb2 = cpu_baseline_hc(bs, pct, seed, 2)
+                if cb2 and "ref_comp_bytes" in cb2 and cb2["sample_blocks"] <= len(mcs):
+                    mid["ratio_vs_reference"] = round(cb2["ref_comp_bytes"] / sum(mcs[:cb2["sample_blocks"]]), 4)
+                    mid["cpu_baseline"] = {k: cb2[k] for k in ("value", "unit", "cores", "kind", "single_thread_GBps")}
+            res["two_table_level2"] = mid
+        except Exception as e:
+            res["two_table_level2"] = {"error": str(e)}
     return res
 
 

@@ -34,7 +34,7 @@ def main():
     gib_kib = float(1 << 20)
     fcorr = gib_kib / fe["lz4amd_k_stream_copy"] if "lz4amd_k_stream_copy" in fe else 2.0
     wcorr = gib_kib / wr["lz4amd_k_stream_copy"] if "lz4amd_k_stream_copy" in wr else 1.0
-    doc = {"kernel_sources_sha": bench.kernel_sources_sha(),
+    doc = {"kernel_sources_sha": {k: bench.kernel_sources_sha(k) for k in bench.KERNEL_FILES},
            "source": f"profiles/{name}_rocprof_pmc_fetch.txt, _pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                      f"bench.py --no-hc --no-extras: configs[1]); compress_hc: profiles/{name}_rocprof_hc_pmc_fetch.txt / _write.txt "
                      "(tools/prof_hc.py 4096 262144 60 9: configs[3])",
