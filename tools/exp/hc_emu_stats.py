@@ -23,4 +23,4 @@ st = (ctypes.c_ulonglong * 16).in_dll(emu, "lz4amd_emu_stats")
 v = [x / k for x in st]
 print("P%d level %d: %.0f bytes per block" % (pct, level, sum(res) / k))
 print("band 0 : walks %.0f kept %.0f wave-trips %.0f lane-trips %.0f (%.1f lanes) measuring passes %.0f" % (v[0], v[1], v[2], v[3], v[3] / max(v[2], 1), v[4]))
-print("bands 1+: walks %.0f kept %.0f wave-trips %.0f lane-trips %.0f (%.1f lanes) measuring passes %.0f" % (v[5], v[6], v[7], v[8], v[8] / max(v[7], 1), v[9]))
+print("first step: positions left to the walk loop %.0f" % v[10]); print("bands 1+: walks %.0f kept %.0f wave-trips %.0f lane-trips %.0f (%.1f lanes) measuring passes %.0f" % (v[5], v[6], v[7], v[8], v[8] / max(v[7], 1), v[9]))
