@@ -46,8 +46,9 @@
 // HBM/L2 traffic per block: source read 2 + 2 x bands times, 2 B/position of chain written once and
 // read once per band, 4 B/position of results written once (patched where a farther band finds better) and read once,
 // 8 B per parked walk written and read per band, 8 B per sequence of records, compressed stream written once.
-// Not built: the reference's handling of long runs of one byte (patternAnalysis, lz4hc.c:960-1060) - blocks that hold such runs spend
-// their attempts inside them and come out larger than the reference's (datagen -P99: up to +20 % at a stream's start).
+// Every position searches its own chain only: on copies-of-copies data, where a position's chain holds more true candidates than its
+// attempts cover, the reference finds the far ones through the chains of later positions of the match and extends them backwards
+// (lz4hc.c:885-960, 1168-1330), and its blocks are smaller (datagen -P99: by up to 20 % at a stream's start).
 // No MFMA: integer / byte work.
 #pragma once
 #include "lz4_compress_kernel.h"
