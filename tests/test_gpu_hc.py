@@ -111,6 +111,22 @@ def test_hc_far_matches(ctx, ocodec):
         assert r < len(d) - 2500
 
 
+def test_hc_whole_tiles_of_walks_parked_for_the_next_band(ctx, ocodec):
+    """Every position of several tiles has its first candidate beyond the nearest band (a repeat 40 000 / 50 000 bytes back): whole
+    tiles of walks are parked as list entries (more than a band stages at a time), found by the second band; parked twice, by the third."""
+    rnd = random.Random(12)
+    datas, bounds = [], []
+    for gap, reps in ((40000, 2), (50000, 3), (65000, 4)):
+        a = bytes(rnd.randrange(256) for _ in range(gap))
+        datas.append(a * reps + bytes(rnd.randrange(256) for _ in range(300)))
+        bounds.append(gap + gap // 200 + 600 * reps)
+    for lvl in (9, 3, 12, 2):
+        for d, b, (r, c) in zip(datas, bounds, gpu_compress_hc(ctx, datas, level=lvl)):
+            ro, o = ocodec.decompress(c, len(d))
+            assert ro == len(d) and o == d
+            assert r < b, (len(d), lvl, r, b)
+
+
 def test_hc_classic_host_pointer_api(ctx, ocodec, golden, datagen):
     import lz4_amd
     L = lz4_amd.lib()

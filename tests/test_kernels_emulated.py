@@ -617,6 +617,21 @@ def test_hc_matches_beyond_32k_are_found(emu, ocodec):
         assert r < len(d) - 2500, "the far repeat was not matched"
 
 
+def test_hc_whole_tiles_of_walks_parked_for_the_next_band(emu, ocodec):
+    """A block whose second half repeats its first 40 000 bytes back: every position of several 8 K tiles has its first candidate
+    beyond the nearest band, so whole tiles are parked (8192 list entries a tile: more than a band stages at a time, kHcEntCap) and
+    found by the second band; and the same 50 000 back, twice over (parked again by the second band, found by the third)."""
+    rnd = random.Random(12)
+    for gap, reps in ((40000, 2), (50000, 3)):
+        a = bytes(rnd.randrange(256) for _ in range(gap))
+        d = a * reps + bytes(rnd.randrange(256) for _ in range(300))
+        for lvl in (9, 3):
+            (r, c), = emu_compress_hc(emu, [d], level=lvl)
+            ro, o = ocodec.decompress(c, len(d))
+            assert ro == len(d) and o == d
+            assert r < gap + gap // 200 + 600 * reps, (gap, lvl, r)     # everything behind the first copy is matched
+
+
 def test_hc_4mib_block(emu, ocodec, golden, datagen):
     g = golden["ratio"]["p60_8m_4m_blocks_hc9"]
     d = datagen(4 << 20, 60, 0)
