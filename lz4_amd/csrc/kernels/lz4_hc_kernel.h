@@ -290,7 +290,7 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
 // best length << 16 | attempts left (hc_att_shift units) << 24.  A tile's entries sit at list_g[t0 ...], their number in
 // count_g[tile]; a band rewrites a tile's list in place (it has staged what it overwrites).  The per-position results (best
 // length | offset << 8) are written densely by the nearest band and patched by the farther ones where a walk found a longer match.
-__device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, HcEnt* list_g, uint32_t* count_g,
+template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, HcEnt* list_g, uint32_t* count_g,
                                                uint32_t band, uint32_t attempts, uint32_t skip_len, bool favor, char* smem, uint64_t* prof = nullptr) {
     const uint32_t tid = opaque_u32(threadIdx.x);
 #ifdef LZ4AMD_PROF_HC
@@ -336,17 +336,17 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
         if (have_m && Pm < n) pm = load_src16(src, n, Pm);
         // -- farther bands: the tile's parked walks, staged kHcEntCap at a time (one round, unless nearly every position of the tile
         //    is still walking); the nearest band: one round over the tile's runs
-        const uint32_t cnt = band ? count_g[t0 / kHcTile] : 0u;
+        const uint32_t cnt = NEAR ? 0u : count_g[t0 / kHcTile];
         uint32_t c0 = 0;
         do {
             uint32_t cn = 0;
-            if (band != 0) {
+            if (!NEAR) {
                 cn = cnt - c0 < kHcEntCap ? cnt - c0 : kHcEntCap;
                 for (uint32_t i = tid; i < cn; i += kHcThreads) ent[i] = list_g[t0 + c0 + i];
             }
             if (tid == 0) misc[HM_POOL] = 0;
             __syncthreads();
-            const uint32_t nunits = band ? cn : kHcRunsPerTile;          // work units of the round: entries, or runs
+            const uint32_t nunits = NEAR ? kHcRunsPerTile : cn;          // work units of the round: entries, or runs
             // -- the walks.  The nearest band's tile is a pool of runs of kHcRun consecutive positions; idle lanes of any wave take
             //    the next runs (which lane walks a run does not change its result).  The loop is wave-synchronous
             //    and predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
@@ -378,14 +378,14 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                         const uint32_t mine_i = base + lanes_below(idle);
                         if (base + nidle >= nunits) pool_dry = true;
                         if (want && mine_i < nunits) {
-                            if (band != 0) { eidx = mine_i; run_left = 1; } else { pp = mine_i * kHcRun - 1; run_left = kHcRun; }
+                            if (!NEAR) { eidx = mine_i; run_left = 1; } else { pp = mine_i * kHcRun - 1; run_left = kHcRun; }
                             inh_len = 0;
                         }
                     }
                     // ---- once the pool is dry, what is still queued is what the lanes hold in their runs (a tile is one run of kHcRun
                     //      positions per lane on average: without this the tile ends when its slowest lane has walked its run alone).
                     //      Idle lanes take over the last queued position of lanes that have any, one each per trip.
-                    if (pool_dry && band == 0) {
+                    if (pool_dry && NEAR) {
                         const uint32_t queued = active ? run_left : (run_left ? run_left - 1 : 0);      // positions behind the one in progress / about to start
                         unsigned long long donors = __ballot(queued != 0), takers = __ballot(!active && run_left == 0);
                         while (donors && takers) {
@@ -402,7 +402,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                     if (!active && run_left) {
                         run_left--;
                         bool walk = true, kept = false;
-                        if (band == 0) {
+                        if (NEAR) {
                             pp++;
                             p = (int32_t)(t0 + pp);
                             if (p > last_q || (uint32_t)p < first) { res0[pp] = 0; walk = false; }     // the history, and the slots past the block's end
@@ -416,7 +416,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                             lim = (uint32_t)((int32_t)n - (int32_t)kLastLiterals - p);
                             if (lim > kHcLenCap) lim = kHcLenCap;
                             best_in = best;
-                            if (inh_len >= kMinMatch && inh_len > best) {     // (nearest band only: a farther band's work units are single positions)
+                            if (NEAR && inh_len >= kMinMatch && inh_len > best) {     // (nearest band only: a farther band's work units are single positions)
                                 best = inh_len; boff = inh_off;
                                 // a capped predecessor may match further than it measured
                                 if (inh_capped) best = hc_count(ring, mine, (uint32_t)(p - (int32_t)boff) & (kHcRing - 1), pp, best, lim);
@@ -429,16 +429,16 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                                 }
                             }
                         }
-                        if (walk) { if (band == 0) mw = lds_ld16(mine, pp + (best > 15 ? best - 15 : 0)); else mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(band ? 5 : 0, 1); }
+                        if (walk) { if (NEAR) mw = lds_ld16(mine, pp + (best > 15 ? best - 15 : 0)); else mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(NEAR ? 0 : 5, 1); }
                         else if (!kept) inh_len = 0;                        // nothing to hand to the next position
-                        if (kept) HC_STAT(band ? 6 : 1, 1);
+                        if (kept) HC_STAT(NEAR ? 1 : 6, 1);
                     }
                     if (!__ballot(active)) { if (pool_dry && !__ballot(run_left != 0)) break; continue; }
 #ifdef LZ4AMD_PROF_HC
                     hp_trips++; hp_lanes += (uint32_t)__popcll(__ballot(active));
 #endif
-                    if (lane == 0) HC_STAT(band ? 7 : 2, 1);
-                    if (active) HC_STAT(band ? 8 : 3, 1);
+                    if (lane == 0) HC_STAT(NEAR ? 2 : 7, 1);
+                    if (active) HC_STAT(NEAR ? 3 : 8, 1);
                     // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
                     uint32_t cd[kHcBatch];
                     uint32_t next = 0;                                      // where the next band resumes
@@ -457,7 +457,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                         if (take) { if (d == 0) over = true; else dist += d; }
                     }
                     bool full = false;
-                    if (band == 0) {
+                    if (NEAR) {
                         // ---- verify: sixteen bytes of every candidate against my own, in the window that ends at index `best` at the latest
                         //      (w0 = best - 15; 0 while best is below 16, and then the compare IS the measurement: lz4hc.c:934-946).  Only a
                         //      candidate that agrees on the whole window can be longer than that, and is measured out in the loop below.
@@ -477,7 +477,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                         }
                         if (full) ext = 0;
                         while (__ballot(ext != 0)) {
-                            if (lane == 0) HC_STAT(band ? 9 : 4, 1);
+                            if (lane == 0) HC_STAT(NEAR ? 4 : 9, 1);
 #ifdef LZ4AMD_PROF_HC
                             hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(ext != 0));
 #endif
@@ -516,7 +516,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
 #pragma unroll
                         for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                         while (__ballot(hits != 0)) {
-                            if (lane == 0) HC_STAT(band ? 9 : 4, 1);
+                            if (lane == 0) HC_STAT(NEAR ? 4 : 9, 1);
 #ifdef LZ4AMD_PROF_HC
                             hp_hits++; hp_hit_lanes += (uint32_t)__popcll(__ballot(hits != 0));
 #endif
@@ -542,7 +542,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
                     if (full) { over = true; next = 0; }
                     const bool park = active && over && next != 0;           // the walk goes on in the next band
                     if (active && over) {
-                        if (band == 0) res0[pp] = best | (boff << 8);
+                        if (NEAR) res0[pp] = best | (boff << 8);
                         else if (best > best_in) st0_g[p] = best | (boff << 8);
                         // what the next position of my run may start from
                         inh_len = best > kMinMatch ? best - 1 : 0; inh_off = boff; inh_capped = best >= lim;
@@ -570,7 +570,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
         } while (c0 < cnt);
         // -- the nearest band flushes the tile's results (coalesced); the prefetched granules are committed: they replace positions
         //    below the next tile's band
-        if (band == 0) {
+        if (NEAR) {
             *(U32x4*)(st0_g + t0 + 4 * tid) = *(const U32x4*)(res0 + 4 * tid);
             *(U32x4*)(st0_g + t0 + 4 * (tid + kHcThreads)) = *(const U32x4*)(res0 + 4 * (tid + kHcThreads));
         }
@@ -581,7 +581,7 @@ __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint
     }
     __syncthreads();
 #ifdef LZ4AMD_PROF_HC
-    if (prof && band == 0 && tid == 0) { prof[3] += hp_trips | (hp_lanes << 32); prof[6] += hp_hits | (hp_hit_lanes << 32); prof[7] += (hp_loop >> 4) | ((hp_wait >> 4) << 32); }
+    if (prof && NEAR && tid == 0) { prof[3] += hp_trips | (hp_lanes << 32); prof[6] += hp_hits | (hp_hit_lanes << 32); prof[7] += (hp_loop >> 4) | ((hp_wait >> 4) << 32); }
 #endif
 }
 
@@ -1077,7 +1077,9 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         const uint32_t attempts = hc_attempts(level);
 
         if (!mid) for (uint32_t band = 0; band < kHcBands; band++) {
-            hc_search_band(src, n, first, chain_g, st0_g, list_g, count_g, band, attempts, level >= 10 ? kHcSkipLenOpt : kHcSkipLenLazy, favor, smem, prof);
+            // (the nearest band and the farther ones are two instances of the loop: what one of them never does is not in its code)
+            if (band == 0) hc_search_band<true>(src, n, first, chain_g, st0_g, list_g, count_g, band, attempts, level >= 10 ? kHcSkipLenOpt : kHcSkipLenLazy, favor, smem, prof);
+            else hc_search_band<false>(src, n, first, chain_g, st0_g, list_g, count_g, band, attempts, level >= 10 ? kHcSkipLenOpt : kHcSkipLenLazy, favor, smem, prof);
             if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[1 + (band ? 1 : 0)] += t - tq; tq = t; }
         } else {
             hc_search_mid(src, n, first, chain_g, st1_g, st0_g, smem);
