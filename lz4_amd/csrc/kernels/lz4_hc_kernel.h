@@ -85,7 +85,7 @@ enum : uint32_t {
     kHcEntCap = 6144,                   // parked walks of a tile a farther band stages at a time
     kHcChunk = 1024,                    // positions of search results a parsing wave stages in LDS at a time
 #ifndef LZ4AMD_HC_BATCH
-#define LZ4AMD_HC_BATCH 4
+#define LZ4AMD_HC_BATCH 6
 #endif
 #ifndef LZ4AMD_HC_REFILL
 #define LZ4AMD_HC_REFILL 16
@@ -93,7 +93,11 @@ enum : uint32_t {
 #ifndef LZ4AMD_HC_RUN
 #define LZ4AMD_HC_RUN 8
 #endif
-    kHcBatch = LZ4AMD_HC_BATCH,                       // links a lane chases before it verifies the candidates found
+    kHcBatch = LZ4AMD_HC_BATCH,                       // links a lane chases before it verifies the candidates found (nearest band)
+#ifndef LZ4AMD_HC_BATCH_FAR
+#define LZ4AMD_HC_BATCH_FAR 4
+#endif
+    kHcBatchFar = LZ4AMD_HC_BATCH_FAR,                //   ... in the farther bands
     kHcRun = LZ4AMD_HC_RUN,                         // consecutive positions a lane takes at a time (each inherits its predecessor's match)
     // An inherited match this long is kept without searching (the reference does not search inside a match it has taken either).  The
     // lazy parse loses next to nothing from 8 on (datagen -P60 / -P90 / -P20 blocks at level 9 against 32: +0.01 / +0.4 / +0.0 % bytes
@@ -293,6 +297,7 @@ __device__ __forceinline__ uint32_t hc_count(const uint8_t* ring, const uint8_t*
 template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc src, uint32_t n, uint32_t first, const uint16_t* chain_g, uint32_t* st0_g, HcEnt* list_g, uint32_t* count_g,
                                                uint32_t band, uint32_t attempts, uint32_t skip_len, bool favor, char* smem, uint64_t* prof = nullptr) {
     const uint32_t tid = opaque_u32(threadIdx.x);
+    constexpr uint32_t kB = NEAR ? (uint32_t)kHcBatch : (uint32_t)kHcBatchFar;      // links a lane chases per trip
 #ifdef LZ4AMD_PROF_HC
     uint64_t hp_trips = 0, hp_lanes = 0, hp_loop = 0, hp_wait = 0, hp_hits = 0, hp_hit_lanes = 0, hp_t0x = 0;
 #else
@@ -349,7 +354,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
             const uint32_t nunits = NEAR ? kHcRunsPerTile : cn;          // work units of the round: entries, or runs
             // -- the walks.  The nearest band's tile is a pool of runs of kHcRun consecutive positions; idle lanes of any wave take
             //    the next runs (which lane walks a run does not change its result).  The loop is wave-synchronous
-            //    and predicated: every trip CHASES up to kHcBatch links of each lane's chain (dependent LDS reads,
+            //    and predicated: every trip CHASES up to kB links of each lane's chain (dependent LDS reads,
             //    nothing else on the path), then VERIFIES the candidates found (independent reads).
             {
                 const uint32_t lane = lane_here();
@@ -440,11 +445,11 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                     if (lane == 0) HC_STAT(NEAR ? 2 : 7, 1);
                     if (active) HC_STAT(NEAR ? 3 : 8, 1);
                     // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
-                    uint32_t cd[kHcBatch];
+                    uint32_t cd[kB];
                     uint32_t next = 0;                                      // where the next band resumes
                     bool over = !active;
 #pragma unroll
-                    for (uint32_t k = 0; k < kHcBatch; k++) {
+                    for (uint32_t k = 0; k < kB; k++) {
                         const int32_t q = p - (int32_t)dist;
                         const bool in_chain = !over && dist != 0 && dist <= kMaxDistance && att != 0;
                         const bool in_band = q >= low;
@@ -462,13 +467,13 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                         //      (w0 = best - 15; 0 while best is below 16, and then the compare IS the measurement: lz4hc.c:934-946).  Only a
                         //      candidate that agrees on the whole window can be longer than that, and is measured out in the loop below.
                         const uint32_t w0 = best > 15 ? best - 15 : 0;
-                        Q16 cw[kHcBatch];
+                        Q16 cw[kB];
 #pragma unroll
-                        for (uint32_t k = 0; k < kHcBatch; k++)
+                        for (uint32_t k = 0; k < kB; k++)
                             cw[k] = lds_ld16(ring, ((uint32_t)(p - (int32_t)cd[k]) + w0) & (kHcRing - 1));
                         uint32_t ext = 0;                                        // candidates that agree on all sixteen, as a bit mask per lane
 #pragma unroll
-                        for (uint32_t k = 0; k < kHcBatch; k++) {
+                        for (uint32_t k = 0; k < kB; k++) {
                             const bool cand = cd[k] != 0 && !(favor && cd[k] < 8);      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                             const uint32_t e = cand ? equal_bytes16(cw[k], mw) : 0u;
                             ext |= e == 16 ? 1u << k : 0u;
@@ -486,7 +491,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                                 ext &= ext - 1;
                                 uint32_t cdk = cd[0];
 #pragma unroll
-                                for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
+                                for (uint32_t j = 1; j < kB; j++) cdk = k == j ? cd[j] : cdk;
                                 const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
                                 // an earlier candidate of the batch may have raised `best` past the window: test again at the new index
                                 if (best <= w0 + 15 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == lds_ld4(mine, pp + best - 3)) {
@@ -505,16 +510,16 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                     } else {
                         // farther bands: a walk that comes this far mostly has its match already, and nearly every candidate fails the
                         // cheapest test there is - the four bytes that end at index `best` (for best = 3 the MINMATCH test; lz4hc.c:934-936)
-                        uint32_t ct[kHcBatch];
+                        uint32_t ct[kB];
 #pragma unroll
-                        for (uint32_t k = 0; k < kHcBatch; k++)
+                        for (uint32_t k = 0; k < kB; k++)
                             ct[k] = lds_ld4(ring, ((uint32_t)(p - (int32_t)cd[k]) + best - 3) & (kHcRing - 1));
                         const uint32_t best0 = best;                            // what the ct[] were read against
                         // candidates that pass, as a bit mask per lane; the expensive part (measuring a match) is entered
                         // once per trip for every lane's nearest passing candidate, again only for lanes that have another
                         uint32_t hits = 0;
 #pragma unroll
-                        for (uint32_t k = 0; k < kHcBatch; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
+                        for (uint32_t k = 0; k < kB; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                         while (__ballot(hits != 0)) {
                             if (lane == 0) HC_STAT(NEAR ? 4 : 9, 1);
 #ifdef LZ4AMD_PROF_HC
@@ -525,7 +530,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                                 hits &= hits - 1;
                                 uint32_t cdk = cd[0];
 #pragma unroll
-                                for (uint32_t j = 1; j < kHcBatch; j++) cdk = k == j ? cd[j] : cdk;
+                                for (uint32_t j = 1; j < kB; j++) cdk = k == j ? cd[j] : cdk;
                                 const uint32_t qo = (uint32_t)(p - (int32_t)cdk) & (kHcRing - 1);
                                 // an earlier candidate of the batch may have raised `best`: test again at the new index
                                 if (best == best0 || lds_ld4(ring, (qo + best - 3) & (kHcRing - 1)) == mt) {
