@@ -674,14 +674,15 @@ def test_hc_with_history_decodes_with_prefix_oracle(emu, oracle, datagen):
     emu.emu_compress_hc_batch_prefix.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
     oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
     buf = ctypes.create_string_buffer(data, len(data))
-    for pre, n in ((65536, 200000), (65536, 5000), (1000, 100000), (64, 70000), (30000, 13), (70000, 262144)):
+    for pre, n, level in ((65536, 200000, 9), (65536, 5000, 9), (1000, 100000, 9), (64, 70000, 9), (30000, 13, 9), (70000, 262144, 9),
+                          (65536, 100000, 2), (1000, 40000, 2), (64, 5000, 2), (30000, 13, 2)):      # (level 2: the two-table search links the history too)
         cap = n + n // 255 + 16
         dst = ctypes.create_string_buffer(cap + 32)
         sp = (ctypes.c_void_p * 1)(ctypes.addressof(buf) + pre); dp = (ctypes.c_void_p * 1)(ctypes.addressof(dst))
         ss = (ctypes.c_int32 * 1)(n); dc = (ctypes.c_int32 * 1)(cap); res = (ctypes.c_int32 * 1)(); pr = (ctypes.c_int32 * 1)(pre)
-        emu.emu_compress_hc_batch_prefix(sp, ss, dp, dc, res, 1, 1, 9, pr)
+        emu.emu_compress_hc_batch_prefix(sp, ss, dp, dc, res, 1, 1, level, pr)
         assert res[0] > 0
-        (r0, _), = emu_compress_hc(emu, [data[pre:pre + n]])
+        (r0, _), = emu_compress_hc(emu, [data[pre:pre + n]], level=level)
         if pre >= 1000 and n >= 5000:
             assert res[0] < r0, (pre, n)                       # the history pays
         used = min(pre, 65536)
