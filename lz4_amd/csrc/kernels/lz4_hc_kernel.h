@@ -444,23 +444,27 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
 #endif
                     if (lane == 0) HC_STAT(NEAR ? 2 : 7, 1);
                     if (active) HC_STAT(NEAR ? 3 : 8, 1);
-                    // ---- chase: distances of the next candidates; `dist` = the one to look at next, 0 = walk over
+                    // ---- chase: distances of the next candidates; `dist` = the one to look at next.  A candidate counts while it is inside
+                    //      the window AND the band: one compare against the higher of the two bounds; which of them ended the walk is
+                    //      looked at once, behind the links
                     uint32_t cd[kB];
-                    uint32_t next = 0;                                      // where the next band resumes
-                    bool over = !active;
+                    const int32_t qmin = p - (int32_t)kMaxDistance > low ? p - (int32_t)kMaxDistance : low;
+                    bool alive = active && dist != 0 && att != 0;
 #pragma unroll
                     for (uint32_t k = 0; k < kB; k++) {
                         const int32_t q = p - (int32_t)dist;
-                        const bool in_chain = !over && dist != 0 && dist <= kMaxDistance && att != 0;
-                        const bool in_band = q >= low;
-                        const bool take = in_chain && in_band;
-                        if (in_chain && !in_band) next = final_band ? 0 : dist;
-                        over = over || !take;
+                        const bool take = alive && q >= qmin;
                         cd[k] = take ? dist : 0;
                         const uint32_t d = cring[(uint32_t)q & (kHcRing - 1)];
                         att -= take ? 1u : 0u;
-                        if (take) { if (d == 0) over = true; else dist += d; }
+                        alive = take && d != 0 && att != 0;
+                        dist += take ? d : 0u;
                     }
+                    // the walk is over unless its chain goes on inside the band; a candidate beyond the band (not beyond the window, and
+                    // with attempts left) is where the next band resumes
+                    bool over = !alive;
+                    uint32_t next = 0;
+                    if (!alive && !final_band && att != 0 && dist != 0 && dist <= kMaxDistance && p - (int32_t)dist < low) next = dist;
                     bool full = false;
                     if (NEAR) {
                         // ---- verify: sixteen bytes of every candidate against my own, in the window that ends at index `best` at the latest
