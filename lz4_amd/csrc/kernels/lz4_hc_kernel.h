@@ -314,6 +314,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
     const int32_t shift = (int32_t)(band * kHcBandStep);
     const bool final_band = band + 1 == kHcBands;
     const uint32_t ash = hc_att_shift(attempts);
+    const uint32_t dmin = favor ? 8u : 1u;                              // the smallest distance of a candidate that counts (cd[k] = 0: none)
     // the rings hold positions [H - kHcRing, H), H = t0 + kHcTile + kHcAhead - shift
     // -- first tile: fill [0, H(0)) directly
     {
@@ -341,13 +342,14 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
         if (have_m && Pm < n) pm = load_src16(src, n, Pm);
         // -- farther bands: the tile's parked walks, staged kHcEntCap at a time (one round, unless nearly every position of the tile
         //    is still walking); the nearest band: one round over the tile's runs
+        HcEnt* const list_t = list_g + t0;                           // the tile's entries
         const uint32_t cnt = NEAR ? 0u : count_g[t0 / kHcTile];
         uint32_t c0 = 0;
         do {
             uint32_t cn = 0;
             if (!NEAR) {
                 cn = cnt - c0 < kHcEntCap ? cnt - c0 : kHcEntCap;
-                for (uint32_t i = tid; i < cn; i += kHcThreads) ent[i] = list_g[t0 + c0 + i];
+                for (uint32_t i = tid; i < cn; i += kHcThreads) ent[i] = list_t[c0 + i];
             }
             if (tid == 0) misc[HM_POOL] = 0;
             __syncthreads();
@@ -372,11 +374,11 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
 #endif
                 for (;;) {
                     // ---- hand out work to idle lanes, from one pool for the whole round
-                    //      (an LDS counter; asked only when a quarter of the wave is idle, or nobody works)
+                    //      (an LDS counter; asked only when a quarter of the wave is idle)
                     const bool want = !active && run_left == 0;
                     const unsigned long long idle = __ballot(want);
                     const uint32_t nidle = (uint32_t)__popcll(idle);
-                    if (!pool_dry && (nidle >= LZ4AMD_HC_REFILL || (nidle && !__ballot(active || run_left != 0)))) {
+                    if (!pool_dry && nidle >= LZ4AMD_HC_REFILL) {                   // (when nobody works all 64 lanes are idle: no test of its own)
                         uint32_t base = 0;
                         if (lane == (uint32_t)__ffsll((long long)idle) - 1) base = atomicAdd(&misc[HM_POOL], nidle);
                         base = wave_readlane(base, (uint32_t)__ffsll((long long)idle) - 1);
@@ -478,7 +480,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                         uint32_t ext = 0;                                        // candidates that agree on all sixteen, as a bit mask per lane
 #pragma unroll
                         for (uint32_t k = 0; k < kB; k++) {
-                            const bool cand = cd[k] != 0 && !(favor && cd[k] < 8);      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
+                            const bool cand = cd[k] >= dmin;                        // (a candidate; favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                             const uint32_t e = cand ? equal_bytes16(cw[k], mw) : 0u;
                             ext |= e == 16 ? 1u << k : 0u;
                             const uint32_t ec = e < lim ? e : lim;
@@ -523,7 +525,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                         // once per trip for every lane's nearest passing candidate, again only for lanes that have another
                         uint32_t hits = 0;
 #pragma unroll
-                        for (uint32_t k = 0; k < kB; k++) hits |= (cd[k] != 0 && ct[k] == mt && !(favor && cd[k] < 8)) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
+                        for (uint32_t k = 0; k < kB; k++) hits |= (cd[k] >= dmin && ct[k] == mt) ? 1u << k : 0u;      // (favorDecSpeed skips offsets below 8, lz4hc.c:926-929)
                         while (__ballot(hits != 0)) {
                             if (lane == 0) HC_STAT(NEAR ? 4 : 9, 1);
 #ifdef LZ4AMD_PROF_HC
@@ -563,7 +565,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                         uint32_t base = 0;
                         if (lane == leader) base = atomicAdd(&misc[HM_NLIST], (uint32_t)__popcll(parked));
                         base = wave_readlane(base, leader);
-                        if (park) { HcEnt e; e.x = pp | (next << 16); e.y = boff | (best << 16) | (((att - 1) >> ash) << 24); list_g[t0 + base + lanes_below(parked)] = e; }
+                        if (park) { HcEnt e; e.x = pp | (next << 16); e.y = boff | (best << 16) | (((att - 1) >> ash) << 24); list_t[base + lanes_below(parked)] = e; }
                     }
                 }
             }
