@@ -260,7 +260,7 @@ def stream_copy_gbps(ctx, lz4_amd, torch, nbytes, stream):
     b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     a.fill_(7)
     ms = ctypes.c_float(0)
-    rc = L.lz4amd_stream_copy_ms(ctx._h, b.data_ptr(), a.data_ptr(), nbytes, 10, stream, ctypes.byref(ms))
+    rc = L.lz4amd_stream_copy_ms(ctx._h, b.data_ptr(), a.data_ptr(), nbytes, 4, stream, ctypes.byref(ms))
     if rc != 0 or ms.value <= 0:
         return None
     return 2.0 * nbytes / (ms.value * 1e-3) / 1e9

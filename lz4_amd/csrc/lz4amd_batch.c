@@ -461,21 +461,26 @@ int lz4amd_stream_copy_ms(lz4amd_ctx* ctx, void* d_dst, const void* d_src, size_
 {
     void *e0, *e1;
     float best = -1.f;
-    int r;
+    int r, shape;
     if (!ctx || !d_dst || !d_src || !best_ms || bytes < 16 || reps < 1) return LZ4AMD_E_ARG;
     (void)lz4amd_hip_use_device(ctx->device);
     e0 = lz4amd_hip_event_create(); e1 = lz4amd_hip_event_create();
     if (!e0 || !e1) { lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1); return LZ4AMD_E_RUNTIME; }
-    for (r = 0; r < reps + 1; r++) {                       /* one untimed warm-up launch */
-        float ms;
-        if (lz4amd_hip_event_record(e0, stream) || lz4amd_hip_launch_stream_copy(d_dst, d_src, bytes, (unsigned)ctx->n_cus * 8u, stream)
-            || lz4amd_hip_event_record(e1, stream) || lz4amd_hip_event_sync(e1)) {
-            lz4amd_set_error(lz4amd_hip_errstr());
-            lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1);
-            return LZ4AMD_E_RUNTIME;
+    /* the best of a few shapes of the same copy (granules in flight per lane, non-temporal or not, workgroups per CU): the
+       calibration is this box's stream rate, not one kernel's */
+    for (shape = 0; shape < 15; shape++) {
+        const unsigned variant = (unsigned)(shape % 5), per_cu = shape < 5 ? 8u : shape < 10 ? 16u : 32u;
+        for (r = 0; r < reps + 1; r++) {                   /* one untimed warm-up launch per shape */
+            float ms;
+            if (lz4amd_hip_event_record(e0, stream) || lz4amd_hip_launch_stream_copy(d_dst, d_src, bytes, (unsigned)ctx->n_cus * per_cu, variant, stream)
+                || lz4amd_hip_event_record(e1, stream) || lz4amd_hip_event_sync(e1)) {
+                lz4amd_set_error(lz4amd_hip_errstr());
+                lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1);
+                return LZ4AMD_E_RUNTIME;
+            }
+            ms = lz4amd_hip_event_ms(e0, e1);
+            if (r > 0 && ms > 0.f && (best < 0.f || ms < best)) best = ms;
         }
-        ms = lz4amd_hip_event_ms(e0, e1);
-        if (r > 0 && ms > 0.f && (best < 0.f || ms < best)) best = ms;
     }
     lz4amd_hip_event_destroy(e0); lz4amd_hip_event_destroy(e1);
     *best_ms = best;

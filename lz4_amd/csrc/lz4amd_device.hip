@@ -20,10 +20,20 @@ __global__ void __launch_bounds__(kHcThreads) lz4amd_k_compress_hc(lz4amd_hc_par
 __global__ void __launch_bounds__(64) lz4amd_k_xxh32(lz4amd_xxh_params p) { xxh32_block_body(p); }
 __global__ void __launch_bounds__(256) lz4amd_k_gather(lz4amd_gather_params p) { gather_block_body(p); }
 
-// calibration: a plain 16-bytes-per-lane stream copy, the bandwidth this box's HBM actually delivers to a read+write stream
+// calibration: a plain 16-bytes-per-lane stream copy, the bandwidth this box's HBM actually delivers to a read+write stream.
+// U granules per thread and trip, all loads issued before the first store (U * 16 bytes in flight per lane); NT: non-temporal stores.
+template <int U, bool NT>
 __global__ void __launch_bounds__(256) lz4amd_k_stream_copy(const lz4amd_u32x4* __restrict__ src, lz4amd_u32x4* __restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x * U;
+    size_t i = (size_t)blockIdx.x * blockDim.x * U + threadIdx.x;
+    for (; i + (size_t)(U - 1) * blockDim.x < n16; i += stride) {
+        lz4amd_u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = NT ? __builtin_nontemporal_load(&src[i + (size_t)k * blockDim.x]) : src[i + (size_t)k * blockDim.x];
+#pragma unroll
+        for (int k = 0; k < U; k++) { if (NT) __builtin_nontemporal_store(v[k], &dst[i + (size_t)k * blockDim.x]); else dst[i + (size_t)k * blockDim.x] = v[k]; }
+    }
+    for (int k = 0; k < U; k++) { const size_t j = i + (size_t)k * blockDim.x; if (j < n16) dst[j] = src[j]; }
 }
 
 // ------------------------------------------------------------------------------- runtime glue
@@ -103,9 +113,16 @@ extern "C" int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned
     HIPCHK(hipGetLastError());
     return 0;
 }
-extern "C" int lz4amd_hip_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, unsigned grid, void* s) {
+extern "C" int lz4amd_hip_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, unsigned grid, unsigned variant, void* s) {
     if (bytes < 16 || !grid) return 0;
-    hipLaunchKernelGGL(lz4amd_k_stream_copy, dim3(grid), dim3(256), 0, (hipStream_t)s, (const lz4amd_u32x4*)d_src, (lz4amd_u32x4*)d_dst, bytes / 16);
+    const lz4amd_u32x4* a = (const lz4amd_u32x4*)d_src; lz4amd_u32x4* b = (lz4amd_u32x4*)d_dst;
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((lz4amd_k_stream_copy<1, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, a, b, bytes / 16); break;
+    case 1: hipLaunchKernelGGL((lz4amd_k_stream_copy<4, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, a, b, bytes / 16); break;
+    case 2: hipLaunchKernelGGL((lz4amd_k_stream_copy<4, true>), dim3(grid), dim3(256), 0, (hipStream_t)s, a, b, bytes / 16); break;
+    case 3: hipLaunchKernelGGL((lz4amd_k_stream_copy<8, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, a, b, bytes / 16); break;
+    default: hipLaunchKernelGGL((lz4amd_k_stream_copy<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)s, a, b, bytes / 16); break;
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
