@@ -41,6 +41,18 @@
 #include "lz4_common.h"
 #include "../lz4amd_params.h"
 
+// what a wave does between two looks at a word it waits for inside a tile (the waits are a few thousand cycles long: a look costs the
+// SIMD's other waves issue slots)
+#ifndef LZ4AMD_CMP_WAIT_SLEEP
+#define LZ4AMD_CMP_WAIT_SLEEP 3
+#endif
+#define CMP_WAIT_PAUSE() spin_pause_n<LZ4AMD_CMP_WAIT_SLEEP>()
+#ifndef LZ4AMD_CMP_FLUSH_IN_A
+#define LZ4AMD_CMP_FLUSH_IN_A 1    // developer knob: 0: the tile before leaves after the barrier, one chunk per thread
+#endif
+#ifndef LZ4AMD_CMP_PRIO
+#define LZ4AMD_CMP_PRIO 2          // developer knob: 1: the settling wave runs at high issue priority, 2: the measuring waves at raised priority
+#endif
 #ifndef LZ4AMD_STRIDE4_FROM
 #define LZ4AMD_STRIDE4_FROM 2
 #endif
@@ -57,13 +69,16 @@ enum : uint32_t {
     kTileMaxSmall = 2048,              // smaller blocks (4-byte hash, like the reference: lz4.c:1389)
     kTileMin = 1024,
     kStripMin = 256,
-    kSrcRing = 84u << 10,              // the 64 KB window + the tile + the prefetched next tile + 4 KB
+    kSrcRing = 76u << 10,              // the 64 KB window + the tile that is parsed + 16 bytes, and 4 KB to spare (the next tile waits in registers until the parse is over)
     kSrcPad = 32,                      // mirror of the ring's first bytes: unaligned reads never wrap
     kHashBits = 13,
     kStrips = 16,                      // strips of a tile, one wave each
     kSettleWave = 0,                   // the wave that settles a tile (overrunning matches, strip sizes -> offsets)
-    kRecsPerStrip = 64,                // matches a strip may take (the rest of it becomes literals)
+    kRecsPerPair = 128,                // matches a pair's 1 KB strip may take (the rest of it becomes literals)
+    kRecsPerStrip = kRecsPerPair / 2,  // ... a strip of a small tile
+    kRecsPerTile = 8 * kRecsPerPair,   // record slots of a tile (8 pair strips or 16 small ones)
     kCandPerPass = 64,                 // match candidates (runs of probe positions with one distance) measured at a time
+    kCandCap = 128,                    // ... listed per probe of a piece (512 bytes of datagen -P60 list ~32 of them, of -P90 ~100)
     kShortRun = 16,                    // literal runs up to this long are copied by the sequence's own lane
     kStageBytes = 12288,               // a tile's encoded bytes are composed here (LDS) and leave with 16-byte stores
     kMaxInput = 0x7E000000u,           // lz4.h:214 LZ4_MAX_INPUT_SIZE
@@ -73,22 +88,28 @@ enum : uint32_t {
 // LDS carve-up (bytes)
 enum : uint32_t {
     kCOffMisc = 0,                                        // u32[64]
-    kCOffStrip = kCOffMisc + 64 * 4,                      // u32[2][kStripFields][16] per-strip summaries (two tiles in flight)
+    kCOffPair = kCOffMisc + 64 * 4,                       // u32[16]: a wave's list of the tile is complete (tile number << 16 | runs); u32[16]: [pair] its measuring wave reads the table no more (tile number)
+    kCOffStrip = kCOffPair + 32 * 4,                      // u32[2][kStripFields][16] per-strip summaries (two tiles in flight)
     kCOffTab = kCOffStrip + 2 * kStripFields * kCmpWaves * 4,   // u32[1 << kHashBits]
-    kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kStrips][kRecsPerStrip]
-    kCOffEnds = kCOffRecs + 2 * kStrips * kRecsPerStrip * 8,        // u16[2][kStrips][kRecsPerStrip] where a record's match ends (from the strip's start)
-    kCOffEncp = kCOffEnds + 2 * kStrips * kRecsPerStrip * 2,        // u16[2][kStrips][kRecsPerStrip] encoded bytes of the strip's records before it
-    kCOffCandS = kCOffEncp + 2 * kStrips * kRecsPerStrip * 2,       // u32[kStrips][kCandPerPass] a candidate's first probe position | distance << 10
-    kCOffCandE = kCOffCandS + kStrips * kCandPerPass * 4,           // u16[kStrips][kCandPerPass] its last probe position
-    kCOffCarry = kCOffCandE + kStrips * kCandPerPass * 2,         // u8[2][16]: encoded bytes of the 16-byte chunk a tile's output ends in (they leave with the next tile)
+    kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kRecsPerTile]: a tile's strips behind one another (kRecsPerPair or kRecsPerStrip slots each)
+    kCOffEnds = kCOffRecs + 2 * kRecsPerTile * 8,                   // u16[2][kRecsPerTile] where a record's match ends (from the strip's start)
+    kCOffEncp = kCOffEnds + 2 * kRecsPerTile * 2,                   // u16[2][kRecsPerTile] encoded bytes of the strip's records before it
+    kCOffCandS = kCOffEncp + 2 * kRecsPerTile * 2,                  // u32[kCmpWaves][kCandCap] a candidate's first probe slot | distance << 8
+    kCOffCandE = kCOffCandS + kCmpWaves * kCandCap * 4,             // u8[kCmpWaves][kCandCap] its last probe slot
+    kCOffScr = kCOffCandE + kCmpWaves * kCandCap,                   // u32[kCmpWaves][64] the emit's scatter space
+    kCOffCarry = kCOffScr + kCmpWaves * 64 * 4,                   // u8[2][16]: encoded bytes of the 16-byte chunk a tile's output ends in (they leave with the next tile)
     kCOffStage = kCOffCarry + 32,                                   // u8[kStageBytes]
     kCOffRing = kCOffStage + kStageBytes,
     kCmpLdsBytes = kCOffRing + kSrcRing + kSrcPad,
 };
 static_assert(kCmpLdsBytes <= 160u * 1024u, "LDS budget");
-static_assert(kCOffRing % 16 == 0 && kCOffStage % 16 == 0 && kCOffCarry % 16 == 0 && kSrcRing % 16 == 0, "LDS alignment");
+static_assert(kCOffRing % 16 == 0 && kCOffStage % 16 == 0 && kCOffCarry % 16 == 0 && kSrcRing % 16 == 0 && kCOffRecs % 8 == 0 && kCOffCandS % 4 == 0 && kCOffScr % 4 == 0, "LDS alignment");
+static_assert(kSrcRing >= 65536 + kTileMax + 16 + 1024, "the ring holds the window of the tile that is parsed");
 enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4,     // CM_READY: tiles whose output offsets are fixed
                   CM_EMITQ = 5,        // next strip of the settled tile to write out (handed to whichever wave is free)
+                  CM_INSQ = 48,        // next piece of a full tile to insert into the table (likewise)
+                  CM_EMITDONE = 49,    // strips of the settled tile that are written out (a bit each)
+                  CM_FLUSHQ = 50,      // next 64 chunks of the staging buffer to store (full tiles: whichever wave is free)
                   CM_SEQS = 6,         // sequences of the tiles settled so far
                   CM_HOVER = 7,        // entry-point table: a row did not fit the table's room (the table is then left invalid)
                   CM_ROWS = 32,        // ... rows of the tiles settled so far
@@ -228,27 +249,23 @@ __device__ __forceinline__ Pair32 ring_ld8_32(const uint8_t* ring, uint32_t o) {
     return r;
 }
 
-// One wave parses one strip.  SH = 1: every second position is probed (blocks >= 64 KB + 11), SH = 0: every position.
+// Matching a strip.  SH = 1: every second position is probed (blocks >= 64 KB + 11), SH = 0: every position, SH = 2: every fourth.
 //   probe     a lane owns 4 << SH consecutive source bytes = four probe positions: its bytes come out of ONE aligned
 //             read, the four hashes out of registers, each candidate is checked for its first four bytes only;
 //   runs      consecutive probe positions that hit with the SAME distance are one match seen several times: only the
 //             first and the last probe of such a run matter (where the match may start, up to where it is known to
-//             hold).  Run starts / ends are numbered by a wave scan and written to a 64-entry list;
-//   measure   lane = run: how far does it go on behind its last probe (8 bytes on its own; the rare longer ones are
+//             hold).  Run starts / ends are numbered by a wave scan and written to a list (probe_list);
+//   measure   lane = run: how far does it go on behind its last probe (24 bytes on its own; the rare longer ones are
 //             finished by the whole wave when the run is taken), how far back before its first probe (lz4.c:1105-1109);
 //   select    greedy in position order (a run that starts inside the match taken before it is cut to start at that
-//             match's end - the reference would probe there and find the same distance), scalar bookkeeping only;
-//   records   the taken lanes write {literals, offset, length} and their encoded sizes side by side.
-#ifdef LZ4AMD_PROF_MATCH
-#define MPROF(k) do { const uint64_t t_ = clock_ticks(); mtp[k] += t_ - mtq; mtq = t_; } while (0)
-#define MPROF_ARGS , uint64_t* mtp
-#define MPROF_PASS , mtp
-#else
-#define MPROF(k) do {} while (0)
-#define MPROF_ARGS
-#define MPROF_PASS
-#endif
-// one probe round: the four positions of a lane's kLaneBytes source bytes from p + lane * kLaneBytes on
+//             match's end - the reference would probe there and find the same distance), by wave scans;
+//   records   the taken lanes write {literals, offset, length} and their encoded sizes side by side (parse_pass).
+// Who does what: in the small tiles at a block's start and in small blocks one wave does all of it for its strip
+// (match_strip).  In a full 8 KB tile of a big block the sixteen waves probe and list 512 bytes each, and the two waves of
+// a PAIR then split up: one measures / selects / records the pair's 1 KB as ONE strip - the two lists behind one another,
+// 64 runs at a time: at ~32 runs per 512 bytes that is one full pass where two waves ran a half-empty one each - while
+// the other writes out strips of the tile before (match_pair_strip; the roles swap from tile to tile).
+// one probe round: the four positions of a lane's 4 << SH source bytes from q0 on
 struct Round { uint32_t dd[4]; uint32_t sb, eb; uint32_t hh[2]; };      // distance of the candidate that holds at slot j (0: none); run starts / ends; the four table indices probed (two per word)
 template <bool SMALL>
 __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi, uint32_t SH) {
@@ -287,197 +304,256 @@ __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t
            ((R.dd[2] && R.dd[2] != R.dd[3]) ? 4u : 0u) | ((R.dd[3] && R.dd[3] != nx) ? 8u : 0u);
     return R;
 }
-// the runs of one round whose numbers fall into [0, kCandPerPass) (iS / iE: number of the lane's first start / end, already
-// relative to the pass) into the list; rel: the lane's first probe position from the strip's start
+// the runs of one round whose numbers fall into [0, kCandCap) (iS / iE: number of the lane's first start / end, already
+// relative to the pass) into the list: candS[i] = the run's first slot (4 * lane + j: its position is the slot << SH bytes from
+// the piece's start) | distance << 8, candE[i] = its last slot.
 // slot number / distance of the lowest run start or end in a 4-bit mask, by bit tests (an index computed with ffs makes
 // the compiler keep dd[] in scratch memory and load from it: a trip to HBM in the middle of the match)
 __device__ __forceinline__ uint32_t slot_of(uint32_t low) { return (low >> 1) - (low >> 3); }           // 1, 2, 4, 8 -> 0, 1, 2, 3
 __device__ __forceinline__ uint32_t dist_of(const Round& R, uint32_t low) { return (low & 1u) ? R.dd[0] : (low & 2u) ? R.dd[1] : (low & 4u) ? R.dd[2] : R.dd[3]; }
-__device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t iE, uint32_t rel, uint32_t* candS, uint16_t* candE, uint32_t SH) {
+__device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t iE, uint32_t slot0, uint32_t* candS, uint8_t* candE) {
     uint32_t s = R.sb, e2 = R.eb;
     {   // a lane's first start and first end (nearly always its only ones) without a trip around the loop
         const uint32_t ls = s & (0u - s), le = e2 & (0u - e2);
-        if (s && iS < kCandPerPass) candS[iS] = (rel + (slot_of(ls) << SH)) | (dist_of(R, ls) << 10);
-        if (e2 && iE < kCandPerPass) candE[iE] = (uint16_t)(rel + (slot_of(le) << SH));
+        if (s && iS < kCandCap) candS[iS] = (slot0 + slot_of(ls)) | (dist_of(R, ls) << 8);
+        if (e2 && iE < kCandCap) candE[iE] = (uint8_t)(slot0 + slot_of(le));
         iS += s ? 1u : 0u; iE += e2 ? 1u : 0u;
         s ^= ls; e2 ^= le;
     }
     while (__any((s | e2) != 0)) {
         const uint32_t ls = s & (0u - s), le = e2 & (0u - e2);
-        if (s && iS < kCandPerPass) candS[iS] = (rel + (slot_of(ls) << SH)) | (dist_of(R, ls) << 10);
-        if (e2 && iE < kCandPerPass) candE[iE] = (uint16_t)(rel + (slot_of(le) << SH));
+        if (s && iS < kCandCap) candS[iS] = (slot0 + slot_of(ls)) | (dist_of(R, ls) << 8);
+        if (e2 && iE < kCandCap) candE[iE] = (uint8_t)(slot0 + slot_of(le));
         iS += s ? 1u : 0u; iE += e2 ? 1u : 0u;
         s ^= ls; e2 ^= le;
     }
 }
-
+// probe the piece [cs, cs + (256 << SH)) (positions up to q_hi) and list its runs [lo, lo + kCandCap) in position order; returns the
+// number of runs the piece has.  probe_h: the table indices of the lane's four positions (the insert of this tile uses them again).
 template <bool SMALL>
-__device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t* strip,
-                                            uint32_t* candS, uint16_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend, uint32_t (&probe_h)[2], uint32_t SH MPROF_ARGS) {
+__device__ __forceinline__ uint32_t probe_list(const uint8_t* ring, const uint32_t* tab, uint32_t* candS, uint8_t* candE, uint32_t cs, uint32_t cs_off,
+                                               uint32_t q_hi, uint32_t lo, uint32_t SH, uint32_t (&probe_h)[2]) {
     const uint32_t lane = lane_id();
-#ifdef LZ4AMD_PROF_MATCH
-    uint64_t mtq = clock_ticks();
-#endif
-    const uint32_t kSpan = 256u << SH, kLaneBytes = 4u << SH;      // a round covers kSpan bytes; a strip is at most two rounds long
-    uint32_t nseq = 0, enc = 0, ll0 = 0, cur = cs;             // cur: end of the last match taken (first byte not yet covered)
-    // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= tend
-    if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
-        const uint32_t last_q = n - kMfLimit;                  // inclusive
-        // a match may run past the strip up to the tile's end: the strips it covers give way (resolve_overruns)
-        uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
-        const uint32_t cs_off = src_ring_off(cs);
-        const uint32_t q_hi = ce - 1 < last_q ? ce - 1 : last_q;   // last position of the strip that may start a match
-        {
-            const uint32_t p = cs;
-            const uint32_t rel0 = lane * kLaneBytes, rel1 = kSpan + lane * kLaneBytes;
-            const bool two = cs + kSpan <= q_hi;               // strips of two rounds
-            uint32_t total = 0;
-            for (uint32_t lo = 0; nseq < kRecsPerStrip; lo += kCandPerPass) {
-                // ---- probe, round by round (four positions per lane), the runs [lo, lo + 64) into the list.  Runs are numbered in
-                //      position order: round A's, then round B's.  More than 64 runs in a strip are rare: the rounds are simply
-                //      probed again for the next 64 (the table is frozen: same answers), which keeps one round's registers live.
-                {
-                    const Round A = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, rel0), cs + rel0, q_hi, SH);
-                    if (lo == 0) { probe_h[0] = A.hh[0]; probe_h[1] = A.hh[1]; }      // (the insert of this tile uses them again)
-                    const uint32_t cntA = (uint32_t)__popc(A.sb) | ((uint32_t)__popc(A.eb) << 16);
-                    const uint32_t inclA = wave_incl_sum(cntA), exA = inclA - cntA;
-                    total = wave_readlane(inclA, 63);
-                    list_round(A, (exA & 0xFFFFu) - lo, (exA >> 16) - lo, rel0, candS, candE, SH);      // (indices below lo wrap and are dropped)
-                }
-                if (two) {
-                    const Round B = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, rel1), cs + rel1, q_hi, SH);
-                    const uint32_t cntB = (uint32_t)__popc(B.sb) | ((uint32_t)__popc(B.eb) << 16);
-                    const uint32_t inclB = wave_incl_sum(cntB), exB = inclB - cntB + total;
-                    total += wave_readlane(inclB, 63);
-                    list_round(B, (exB & 0xFFFFu) - lo, (exB >> 16) - lo, rel1, candS, candE, SH);
-                }
-                total &= 0xFFFFu;
-                MPROF(0);
-                if (lo >= total) break;
-                wave_lds_fence();
-                MPROF(2);
-                // ---- measure: lane = run
-                const uint32_t nc = total - lo < kCandPerPass ? total - lo : kCandPerPass;
-                const bool have = lane < nc;
-                uint32_t qs = 0, d = 1, e = 0, back = 0, more = 0;
-                if (have) {
-                    const uint32_t S = candS[lane], E = candE[lane];
-                    qs = p + (S & 1023u); d = S >> 10;
-                    const uint32_t a = p + E + kMinMatch;                    // first byte the probes did not compare
-                    e = mlimit;
-                    if (a < mlimit) {
-                        // the next 24 bytes on the lane's own (seven aligned dwords per side)
-                        const uint32_t ao = ring_fwd(cs_off, a - cs), ko = ring_back(ao, d);
-                        const uint32_t* xa = (const uint32_t*)(ring + (ao & ~3u));
-                        const uint32_t* ya = (const uint32_t*)(ring + (ko & ~3u));
-                        uint32_t xd[7], yd[7];
+    const Round A = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, lane * (4u << SH)), cs + lane * (4u << SH), q_hi, SH);
+    probe_h[0] = A.hh[0]; probe_h[1] = A.hh[1];
+    const uint32_t cntA = (uint32_t)__popc(A.sb) | ((uint32_t)__popc(A.eb) << 16);
+    const uint32_t inclA = wave_incl_sum(cntA), exA = inclA - cntA;
+    list_round(A, (exA & 0xFFFFu) - lo, (exA >> 16) - lo, 4 * lane, candS, candE);      // (indices below lo wrap and are dropped)
+    return wave_readlane(inclA, 63) & 0xFFFFu;
+}
+
+// what a strip's parse carries from pass to pass
+struct ParseState { uint32_t nseq, enc, ll0, cur; };      // records so far, their encoded bytes, the first one's literals, end of the last match taken (first byte not yet covered)
+// One pass of measure / select / records, lane = run: the run's first probe position qs, its distance d, a = the first byte
+// its probes did not compare (last probe + 4).  Runs come in position order; st.cur carries the end of what was taken before.
+__device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap, uint32_t cs, uint32_t cs_off,
+                                           uint32_t mlimit, uint32_t last_q, bool have, uint32_t qs, uint32_t d, uint32_t a, ParseState& st) {
+    const uint32_t lane = lane_id();
+    // ---- measure
+    uint32_t e = 0, back = 0, more = 0;
+    if (have) {
+        e = mlimit;
+        if (a < mlimit) {
+            // the next 24 bytes on the lane's own (seven aligned dwords per side)
+            const uint32_t ao = ring_fwd(cs_off, a - cs), ko = ring_back(ao, d);
+            const uint32_t* xa = (const uint32_t*)(ring + (ao & ~3u));
+            const uint32_t* ya = (const uint32_t*)(ring + (ko & ~3u));
+            uint32_t xd[7], yd[7];
 #pragma unroll
-                        for (uint32_t i = 0; i < 7; i++) { xd[i] = xa[i]; yd[i] = ya[i]; }
-                        uint32_t same = 24;
+            for (uint32_t i = 0; i < 7; i++) { xd[i] = xa[i]; yd[i] = ya[i]; }
+            uint32_t same = 24;
 #pragma unroll
-                        for (int i = 5; i >= 0; i--) {
-                            const uint32_t z = align_bytes(xd[i + 1], xd[i], ao & 3u) ^ align_bytes(yd[i + 1], yd[i], ko & 3u);
-                            same = z ? 4 * (uint32_t)i + ((uint32_t)(__ffs((int)z) - 1) >> 3) : same;
-                        }
-                        more = (same == 24 && a + 24 < mlimit) ? 1u : 0u;
-                        if (same > mlimit - a) same = mlimit - a;
-                        e = a + same;
-                    }
-                    // how far back, over literals that may still be pending (lz4.c:1105-1109)?
-                    if (qs - d >= 8) {
-                        const uint32_t bo = ring_back(ring_fwd(cs_off, qs - cs), 8);
-                        const Pair32 v = ring_ld8_32(ring, bo), k = ring_ld8_32(ring, ring_back(bo, d));
-                        const uint32_t x1 = v.hi ^ k.hi, x0 = v.lo ^ k.lo;
-                        back = x1 ? (uint32_t)__clz((int)x1) >> 3 : (x0 ? 4 + ((uint32_t)__clz((int)x0) >> 3) : 8u);
-                    }
-                }
-                wave_lds_fence();                                            // (the list may be rewritten by the next pass)
-                MPROF(3);
-                // ---- select: a run is taken when it still holds a minimal match behind everything that ends before it - the
-                //      running maximum of the ends of the runs in front of it (a wave scan: no serial walk over the matches; a
-                //      run that is not taken ends less than 4 bytes behind a taken one, so the maximum over all runs is the end
-                //      of the last taken match give or take 3 bytes).  A taken run that went on matching for more than the 24
-                //      bytes its lane compared is finished by the whole wave, and the scan is repeated with its real end
-                //      (finishing every such run before the scan was measured: slower, most of them end up covered).
-                const bool sv = have && e >= qs + kMinMatch;
-                unsigned long long taken;
-                for (;;) {
-                    uint32_t pmx = wave_prev_u32(wave_incl_max(sv ? e : 0u));
-                    if (pmx < cur) pmx = cur;
-                    const uint32_t st = qs > pmx ? qs : pmx;
-                    bool tk = sv && e >= st + kMinMatch && st <= last_q;
-                    taken = __ballot(tk);
-                    const uint32_t room = kRecsPerStrip - nseq;
-                    if ((uint32_t)__popcll(taken) > room) taken = __ballot(tk && lanes_below(taken) < room);
-                    const unsigned long long mm = taken & __ballot(more != 0);
-                    if (!mm) break;
-                    // long match: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
-                    const uint32_t l = (uint32_t)__ffsll((long long)mm) - 1;
-                    uint32_t el = wave_readlane(e, l);
-                    const uint32_t eo = ring_fwd(cs_off, el - cs), ko = ring_back(eo, wave_readlane(d, l));
-                    uint32_t ext = 0;
-                    for (;;) {
-                        const uint32_t a = el + ext + 8 * lane;
-                        uint32_t same = 0;
-                        if (a < mlimit) {
-                            const Pair32 x = ring_ld8_32(ring, ring_fwd(eo, ext + 8 * lane)), y = ring_ld8_32(ring, ring_fwd(ko, ext + 8 * lane));
-                            same = equal_bytes8_32(x.lo, x.hi, y.lo, y.hi);
-                            if (same > mlimit - a) same = mlimit - a;
-                        }
-                        const unsigned long long brk = __ballot(same < 8);
-                        if (brk) {
-                            const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
-                            ext += 8 * fl + wave_readlane(same, fl);
-                            break;
-                        }
-                        ext += 512;
-                    }
-                    el += ext;
-                    e = lane == l ? el : e;
-                    more = lane == l ? 0u : more;
-                }
-                const uint32_t ntaken = (uint32_t)__popcll(taken);
-                uint32_t prev_end = 0;                                       // end of the match taken before mine (taken lanes)
-                if (taken) {
-                    const uint32_t pt = wave_incl_max(((taken >> lane) & 1) ? e : 0u);
-                    prev_end = wave_prev_u32(pt);
-                    if (prev_end < cur) prev_end = cur;
-                    const uint32_t last_e = wave_readlane(pt, 63);
-                    if (last_e > cur) cur = last_e;
-                }
-                MPROF(4);
-                // ---- records
-                if (taken) {
-                    const bool mine = (taken >> lane) & 1;
-                    const uint32_t ri = nseq + lanes_below(taken);
-                    uint32_t my_enc = 0, my_ll = 0;
-                    if (mine) {
-                        uint32_t start = prev_end;
-                        if (qs > prev_end) { uint32_t bk = back; if (bk > qs - prev_end) bk = qs - prev_end; start = qs - bk; }
-                        my_ll = start - prev_end;
-                        const uint32_t mlen = e - start;
-                        MatchRec r; r.ll = my_ll; r.mo = d | ((mlen - kMinMatch) << 16);
-                        recs[ri] = r;
-                        my_enc = enc_size(my_ll, mlen - kMinMatch);
-                    }
-                    if (nseq == 0) ll0 = wave_readlane(my_ll, (uint32_t)__ffsll((long long)taken) - 1);
-                    const uint32_t enc_incl = wave_incl_sum(my_enc);
-                    if (mine) { ends[ri] = (uint16_t)(e - cs); encp[ri] = (uint16_t)(enc + enc_incl - my_enc); }
-                    enc += wave_readlane(enc_incl, 63);
-                    nseq += ntaken;
-                }
-                MPROF(5);
-                if (lo + kCandPerPass >= total) break;
+            for (int i = 5; i >= 0; i--) {
+                const uint32_t z = align_bytes(xd[i + 1], xd[i], ao & 3u) ^ align_bytes(yd[i + 1], yd[i], ko & 3u);
+                same = z ? 4 * (uint32_t)i + ((uint32_t)(__ffs((int)z) - 1) >> 3) : same;
             }
+            more = (same == 24 && a + 24 < mlimit) ? 1u : 0u;
+            if (same > mlimit - a) same = mlimit - a;
+            e = a + same;
+        }
+        // how far back, over literals that may still be pending (lz4.c:1105-1109)?
+        if (qs - d >= 8) {
+            const uint32_t bo = ring_back(ring_fwd(cs_off, qs - cs), 8);
+            const Pair32 v = ring_ld8_32(ring, bo), k = ring_ld8_32(ring, ring_back(bo, d));
+            const uint32_t x1 = v.hi ^ k.hi, x0 = v.lo ^ k.lo;
+            back = x1 ? (uint32_t)__clz((int)x1) >> 3 : (x0 ? 4 + ((uint32_t)__clz((int)x0) >> 3) : 8u);
         }
     }
-    if (lane == 0) {
-        strip[S_N * kCmpWaves + w] = nseq;
-        strip[S_ENC * kCmpWaves + w] = enc;
-        strip[S_LL0 * kCmpWaves + w] = ll0;
-        strip[S_TAIL * kCmpWaves + w] = cur < ce ? ce - cur : 0;
-        strip[S_END * kCmpWaves + w] = cur > ce ? cur : 0;
+    // ---- select: a run is taken when it still holds a minimal match behind everything that ends before it - the
+    //      running maximum of the ends of the runs in front of it (a wave scan: no serial walk over the matches; a
+    //      run that is not taken ends less than 4 bytes behind a taken one, so the maximum over all runs is the end
+    //      of the last taken match give or take 3 bytes).  A taken run that went on matching for more than the 24
+    //      bytes its lane compared is finished by the whole wave, and the scan is repeated with its real end
+    //      (finishing every such run before the scan was measured: slower, most of them end up covered).
+    const bool sv = have && e >= qs + kMinMatch;
+    unsigned long long taken;
+    for (;;) {
+        uint32_t pmx = wave_prev_u32(wave_incl_max(sv ? e : 0u));
+        if (pmx < st.cur) pmx = st.cur;
+        const uint32_t s0 = qs > pmx ? qs : pmx;
+        bool tk = sv && e >= s0 + kMinMatch && s0 <= last_q;
+        taken = __ballot(tk);
+        const uint32_t room = rec_cap - st.nseq;
+        if ((uint32_t)__popcll(taken) > room) taken = __ballot(tk && lanes_below(taken) < room);
+        const unsigned long long mm = taken & __ballot(more != 0);
+        if (!mm) break;
+        // long match: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
+        const uint32_t l = (uint32_t)__ffsll((long long)mm) - 1;
+        uint32_t el = wave_readlane(e, l);
+        const uint32_t eo = ring_fwd(cs_off, el - cs), ko = ring_back(eo, wave_readlane(d, l));
+        uint32_t ext = 0;
+        for (;;) {
+            const uint32_t aa = el + ext + 8 * lane;
+            uint32_t same = 0;
+            if (aa < mlimit) {
+                const Pair32 x = ring_ld8_32(ring, ring_fwd(eo, ext + 8 * lane)), y = ring_ld8_32(ring, ring_fwd(ko, ext + 8 * lane));
+                same = equal_bytes8_32(x.lo, x.hi, y.lo, y.hi);
+                if (same > mlimit - aa) same = mlimit - aa;
+            }
+            const unsigned long long brk = __ballot(same < 8);
+            if (brk) {
+                const uint32_t fl = (uint32_t)__ffsll((long long)brk) - 1;
+                ext += 8 * fl + wave_readlane(same, fl);
+                break;
+            }
+            ext += 512;
+        }
+        el += ext;
+        e = lane == l ? el : e;
+        more = lane == l ? 0u : more;
     }
+    if (!taken) return;
+    const uint32_t ntaken = (uint32_t)__popcll(taken);
+    const bool mine = (taken >> lane) & 1;
+    const uint32_t pt = wave_incl_max(mine ? e : 0u);
+    uint32_t prev_end = wave_prev_u32(pt);                   // end of the match taken before mine (taken lanes)
+    if (prev_end < st.cur) prev_end = st.cur;
+    const uint32_t last_e = wave_readlane(pt, 63);
+    // ---- records
+    const uint32_t ri = st.nseq + lanes_below(taken);
+    uint32_t my_enc = 0, my_ll = 0;
+    if (mine) {
+        uint32_t start = prev_end;
+        if (qs > prev_end) { uint32_t bk = back; if (bk > qs - prev_end) bk = qs - prev_end; start = qs - bk; }
+        my_ll = start - prev_end;
+        const uint32_t mlen = e - start;
+        MatchRec r; r.ll = my_ll; r.mo = d | ((mlen - kMinMatch) << 16);
+        recs[ri] = r;
+        my_enc = enc_size(my_ll, mlen - kMinMatch);
+    }
+    if (st.nseq == 0) st.ll0 = wave_readlane(my_ll, (uint32_t)__ffsll((long long)taken) - 1);
+    const uint32_t enc_incl = wave_incl_sum(my_enc);
+    if (mine) { ends[ri] = (uint16_t)(e - cs); encp[ri] = (uint16_t)(st.enc + enc_incl - my_enc); }
+    st.enc += wave_readlane(enc_incl, 63);
+    st.nseq += ntaken;
+    if (last_e > st.cur) st.cur = last_e;
+}
+
+// the strip's summary for the settle (lane 0)
+__device__ __forceinline__ void strip_summary(uint32_t* strip, uint32_t si, const ParseState& st, uint32_t ce) {
+    if (lane_id() == 0) {
+        strip[S_N * kCmpWaves + si] = st.nseq;
+        strip[S_ENC * kCmpWaves + si] = st.enc;
+        strip[S_LL0 * kCmpWaves + si] = st.ll0;
+        strip[S_TAIL * kCmpWaves + si] = st.cur < ce ? ce - st.cur : 0;
+        strip[S_END * kCmpWaves + si] = st.cur > ce ? st.cur : 0;
+    }
+}
+// One wave parses the piece [pcs, pce) of the strip that starts at cs, all by itself: probe, list, and passes over the list; more
+// runs than the list holds are rare: the piece is simply probed again for the next ones (the table is frozen: same answers).
+template <bool SMALL>
+__device__ __forceinline__ void parse_piece(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap,
+                                            uint32_t* candS, uint8_t* candE, uint32_t cs, uint32_t pcs, uint32_t pce, uint32_t mlimit, uint32_t last_q,
+                                            uint32_t (&probe_h)[2], uint32_t SH, ParseState& st) {
+    const uint32_t lane = lane_id();
+    const uint32_t cs_off = src_ring_off(cs), pcs_off = ring_fwd(cs_off, pcs - cs);
+    const uint32_t q_hi = pce - 1 < last_q ? pce - 1 : last_q;   // last position of the piece that may start a match
+    for (uint32_t lo = 0; st.nseq < rec_cap; lo += kCandCap) {
+        uint32_t ph[2];
+        const uint32_t total = probe_list<SMALL>(ring, tab, candS, candE, pcs, pcs_off, q_hi, lo, SH, ph);
+        if (lo == 0) { probe_h[0] = ph[0]; probe_h[1] = ph[1]; }
+        if (lo >= total) break;
+        wave_lds_fence();
+        const uint32_t nlist = total - lo < kCandCap ? total - lo : kCandCap;
+        for (uint32_t pl = 0; pl < nlist && st.nseq < rec_cap; pl += kCandPerPass) {
+            const bool have = pl + lane < nlist;
+            uint32_t S = 0, E = 0;
+            if (have) { S = candS[pl + lane]; E = candE[pl + lane]; }
+            parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, pcs + ((S & 255u) << SH), have ? S >> 8 : 1u, pcs + (E << SH) + kMinMatch, st);
+        }
+        if (lo + kCandCap >= total) break;
+        wave_lds_fence();                                            // (the list is rewritten by the next probe)
+    }
+}
+// ... a whole strip [cs, ce) of at most 256 << SH bytes: strip `w` of its tile (records, summary)
+template <bool SMALL>
+__device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap, uint32_t* strip,
+                                            uint32_t* candS, uint8_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend, uint32_t (&probe_h)[2], uint32_t SH) {
+    ParseState st; st.nseq = 0; st.enc = 0; st.ll0 = 0; st.cur = cs;
+    // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= tend
+    if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
+        // a match may run past the strip up to the tile's end: the strips it covers give way (resolve_overruns)
+        uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
+        parse_piece<SMALL>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, ce, mlimit, n - kMfLimit, probe_h, SH, st);
+    }
+    strip_summary(strip, w, st, ce);
+}
+// The measuring wave of a pair: the pair's 1 KB [cs, cs + 1024) as one strip (number `si` of its tile).  Its two pieces were probed and
+// listed by the pair's two waves (nA / nB runs, lists LA / LB: the first piece's wave is the even one); the lists are walked
+// behind one another, 64 runs a pass.  A piece with more runs than its list holds is parsed the single-wave way (probed again).
+__device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap, uint32_t* strip,
+                                                 const uint32_t* LAs, const uint8_t* LAe, uint32_t nA, const uint32_t* LBs, const uint8_t* LBe, uint32_t nB,
+                                                 uint32_t* candS, uint8_t* candE, uint32_t si, uint32_t n, uint32_t cs, uint32_t tend,
+                                                 uint32_t* table_free, uint32_t gen, const uint32_t* late_b = nullptr) {      // late_b: the second piece's list comes late (its wave settled the tile before first): the first piece does not wait for it; table_free: told (gen) when this wave probes no more
+    const uint32_t lane = lane_id();
+    const uint32_t ce = cs + 1024;                                   // (full tiles only: the strip lies inside the block)
+    ParseState st; st.nseq = 0; st.enc = 0; st.ll0 = 0; st.cur = cs;
+    if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
+        uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
+        const uint32_t last_q = n - kMfLimit;
+        if (late_b) {
+            // the first piece's runs on their own, then - when its list is there - the second piece's (always in this order for this pair: the bytes do not depend on who was late)
+            const uint32_t cs_off = src_ring_off(cs);
+            if (nA <= kCandCap) {
+                for (uint32_t pl = 0; pl < nA && st.nseq < rec_cap; pl += kCandPerPass) {
+                    const bool have = pl + lane < nA;
+                    uint32_t S = 0, E = 0;
+                    if (have) { S = LAs[pl + lane]; E = LAe[pl + lane]; }
+                    parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, cs + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + (E << 1) + kMinMatch, st);
+                }
+            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st); wave_lds_fence(); }
+            uint32_t pv;
+            while (((pv = __builtin_amdgcn_readfirstlane(lds_load_acquire(late_b))) >> 16) != gen) spin_pause();
+            nB = pv & 0xFFFFu;
+            if (nB <= kCandCap) {
+                if (lane == 0) lds_store_release(table_free, gen);
+                for (uint32_t pl = 0; pl < nB && st.nseq < rec_cap; pl += kCandPerPass) {
+                    const bool have = pl + lane < nB;
+                    uint32_t S = 0, E = 0;
+                    if (have) { S = LBs[pl + lane]; E = LBe[pl + lane]; }
+                    parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, cs + 512 + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + 512 + (E << 1) + kMinMatch, st);
+                }
+            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st); }
+        } else if (nA <= kCandCap && nB <= kCandCap) {
+            if (lane == 0) lds_store_release(table_free, gen);
+            const uint32_t cs_off = src_ring_off(cs), total = nA + nB;
+            for (uint32_t pl = 0; pl < total && st.nseq < rec_cap; pl += kCandPerPass) {
+                const uint32_t i = pl + lane;
+                const bool have = i < total, inB = i >= nA;
+                uint32_t S = 0, E = 0;
+                if (have) { S = inB ? LBs[i - nA] : LAs[i]; E = inB ? LBe[i - nA] : LAe[i]; }
+                const uint32_t base = cs + (inB ? 512u : 0u);
+                parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, base + ((S & 255u) << 1), have ? S >> 8 : 1u, base + (E << 1) + kMinMatch, st);
+            }
+        } else {
+            uint32_t ph[2];
+            parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st);
+            wave_lds_fence();
+            parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st);
+        }
+    }
+    strip_summary(strip, si, st, ce);
+    if (lane == 0) lds_store_release(table_free, gen);                // (at the latest)
 }
 
 // ------------------------------------------------------------------------------ entry-point table (optional output)
@@ -683,15 +759,15 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
     }
 }
 
-// ------------------------------------------------------------------------------ flush (all threads)
-// The staged tile leaves for HBM: every thread stores one ALIGNED 16-byte chunk (the output's own 16-byte grid: a0 is
-// dst's misalignment).  The chunk the tile starts in begins with the last bytes of the tile before: they wait in the
+// ------------------------------------------------------------------------------ flush
+// The staged tile leaves for HBM: a thread stores one ALIGNED 16-byte chunk, number ci of the staging buffer (the output's own
+// 16-byte grid: a0 is dst's misalignment) - every thread its own after a small tile, 64 chunks a wave from a queue after a full one.  The chunk the tile starts in begins with the last bytes of the tile before: they wait in the
 // carry chunk (two of them, by tile parity) and leave now; the bytes behind the tile's last whole chunk wait in turn.
 // cfrom: first byte of the carry chunk that is pending (bytes below it left already, or lie before dst).
 struct FlushCtx { U32x4 v; uint32_t dbase, h, nfull, r, cfrom, direct, pp; };
-static_assert(kStageBytes / 16 <= kCmpThreads, "one staged chunk per thread");
+static_assert(kStageBytes / 16 <= kCmpThreads && kStageBytes % 1024 == 0, "one staged chunk per thread");
 // first half: the tile's numbers and my chunk of the staging buffer into registers (the table inserts run while they arrive)
-__device__ __forceinline__ FlushCtx flush_begin(char* smem, uint32_t pp, uint32_t a0) {
+__device__ __forceinline__ FlushCtx flush_begin(char* smem, uint32_t pp, uint32_t a0, uint32_t ci) {
     const uint32_t* T = (const uint32_t*)(smem + kCOffMisc) + CM_TILE + 4 * pp;
     FlushCtx f;
     const uint32_t out0 = T[T_OUT0], out1 = T[T_OUT1];
@@ -699,12 +775,12 @@ __device__ __forceinline__ FlushCtx flush_begin(char* smem, uint32_t pp, uint32_
     const uint32_t V0 = out0 + a0, V1 = out1 + a0;
     f.dbase = V0 & ~15u; f.h = V0 - f.dbase;
     f.nfull = (V1 - f.dbase) >> 4; f.r = (V1 - f.dbase) & 15u;
-    f.v = *(const U32x4*)(smem + kCOffStage + 16 * threadIdx.x);       // (threads behind the tile's last chunk read bytes nobody uses)
-    if (16 * threadIdx.x < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * threadIdx.x) = z; }   // the next tile ORs its literals into zeros
+    f.v = *(const U32x4*)(smem + kCOffStage + 16 * (ci < kStageBytes / 16 ? ci : 0u));       // (threads behind the tile's last chunk read bytes nobody uses)
+    if (16 * ci < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * ci) = z; }   // the next tile ORs its literals into zeros
     return f;
 }
-__device__ __forceinline__ void flush_end(char* smem, const FlushCtx& f, lz4amd_gdst dst, uint32_t a0) {
-    const uint32_t tid = threadIdx.x;
+__device__ __forceinline__ void flush_end(char* smem, const FlushCtx& f, lz4amd_gdst dst, uint32_t a0, uint32_t ci) {
+    const uint32_t tid = ci;
     uint32_t* Tn = (uint32_t*)(smem + kCOffMisc) + CM_TILE + 4 * (f.pp ^ 1);
     const uint8_t* C = (const uint8_t*)(smem + kCOffCarry) + 16 * f.pp;
     uint8_t* Cn = (uint8_t*)(smem + kCOffCarry) + 16 * (f.pp ^ 1);
@@ -745,16 +821,16 @@ __device__ __forceinline__ void flush_end(char* smem, const FlushCtx& f, lz4amd_
 // (same offset, the bytes are the same), or goes as well when less than a minimal match is left - and its summary is
 // brought up to date.  One wave: a short serial walk over the strips settles where each one starts (a strip's own
 // overrun counts only if its last match survives), then lane k puts strip k right (binary search in the record ends).
-__device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs_tile, const uint16_t* ends_tile, const uint16_t* encp_tile,
-                                                 uint32_t nstrips, uint32_t g0, uint32_t t0, uint32_t strip_len, uint32_t t1, uint32_t n) {
+__device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs_tile, const uint16_t* ends_tile, const uint16_t* encp_tile, uint32_t rps,
+                                                 uint32_t nstrips, uint32_t g0, uint32_t t0, uint32_t strip_len, uint32_t t1, uint32_t n) {      // rps: record slots per strip
     const uint32_t lane = lane_id();
     const bool mine = lane < nstrips;
     const uint32_t cs = strip_lo(g0, t0, lane, strip_len);
     uint32_t ce = g0 + (lane + 1) * strip_len; if (ce > t1) ce = t1;
     const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, own_end = mine ? strip[S_END * kCmpWaves + lane] : 0;
-    MatchRec* rk = recs_tile + lane * kRecsPerStrip;
-    const uint16_t* ek = ends_tile + lane * kRecsPerStrip;
-    const uint16_t* pk = encp_tile + lane * kRecsPerStrip;
+    MatchRec* rk = recs_tile + lane * rps;
+    const uint16_t* ek = ends_tile + lane * rps;
+    const uint16_t* pk = encp_tile + lane * rps;
     uint32_t q_last = 0;                                  // where my last match starts (strips whose last match runs over)
     if (own_end) q_last = own_end - ((rk[nk - 1].mo >> 16) + kMinMatch);
     if (!__any(own_end != 0)) {                           // nothing ran over in this tile
@@ -864,13 +940,14 @@ __device__ __forceinline__ uint32_t uload_cm(const uint32_t* w) { return __built
 // the staging buffer, i.e. when it ends a literal run of more than a few KB - written to HBM directly
 __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t nstrips, uint32_t g0, uint32_t t0, uint32_t strip_len, uint32_t t1,
                                             uint32_t n, uint32_t cap, uint32_t a0) {
+    const uint32_t rps = strip_len == 1024 ? kRecsPerPair : kRecsPerStrip;
     uint32_t* misc = (uint32_t*)(smem + kCOffMisc);
     uint32_t* strip_p = (uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
 #ifdef LZ4AMD_PROF_TILE
     const uint64_t ts0 = clock_ticks();
 #endif
-    resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kStrips * kRecsPerStrip, (const uint16_t*)(smem + kCOffEnds) + pp * kStrips * kRecsPerStrip,
-                     (const uint16_t*)(smem + kCOffEncp) + pp * kStrips * kRecsPerStrip, nstrips, g0, t0, strip_len, t1, n);
+    resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kRecsPerTile, (const uint16_t*)(smem + kCOffEnds) + pp * kRecsPerTile,
+                     (const uint16_t*)(smem + kCOffEncp) + pp * kRecsPerTile, rps, nstrips, g0, t0, strip_len, t1, n);
     wave_lds_fence();
 #ifdef LZ4AMD_PROF_TILE
     const uint64_t ts1 = clock_ticks();
@@ -901,18 +978,52 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
 }
 // every wave: its strip of the settled tile (parity pp), into the staging buffer or straight to HBM
 // (w: the strip; sw: the wave that does it - any wave may, the strip's place in the output was fixed when the tile was settled)
-__device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, uint32_t sw, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo, const HintOut& H0) {
+__device__ __forceinline__ void emit_tile_strip(char* smem, uint32_t pp, uint32_t w, uint32_t sw, uint32_t rps, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t a0, uint32_t ring_lo, const HintOut& H0) {      // rps: record slots per strip of that tile
     const uint32_t* misc = (const uint32_t*)(smem + kCOffMisc);
     const uint32_t* strip_p = (const uint32_t*)(smem + kCOffStrip) + pp * kStripFields * kCmpWaves;
     if (misc[CM_FAIL] || !strip_p[S_N * kCmpWaves + w]) return;
     const uint8_t* ring = (const uint8_t*)(smem + kCOffRing);
-    const MatchRec* recs_w = (const MatchRec*)(smem + kCOffRecs) + (pp * kStrips + w) * kRecsPerStrip + strip_p[S_FIRST * kCmpWaves + w];
+    const MatchRec* recs_w = (const MatchRec*)(smem + kCOffRecs) + pp * kRecsPerTile + w * rps + strip_p[S_FIRST * kCmpWaves + w];
     const uint32_t* T = misc + CM_TILE + 4 * pp;
     HintOut H = H0;
     if (H.table) { const uint32_t* HT = misc + CM_HTILE + 4 * pp; H.ord0 = HT[0]; H.row0 = HT[1]; H.k = HT[2]; }
     if (T[T_DIRECT]) emit_strip_plain(recs_w, strip_p, w, src, dst, strip_p[S_P * kCmpWaves + w], H);
     else emit_strip_lds(ring, recs_w, strip_p, w, (uint8_t*)(smem + kCOffStage), ((T[T_OUT0] + a0) & ~15u) - a0, strip_p[S_P * kCmpWaves + w],
-                        (uint32_t*)(smem + kCOffCandS) + sw * kCandPerPass, H);    // (scratch: the executing wave's candidate list, idle now; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
+                        (uint32_t*)(smem + kCOffScr) + sw * 64, H);    // (scratch: the executing wave's own; stage[0] = the chunk's first byte; wraps for the first chunk of an unaligned dst)
+}
+
+// the 8 positions q0 .. q0 + 7 (q0: a multiple of 8) into the table - those that may start a match (below t1, up to last_q) -,
+// hashed out of four aligned dwords; have_h: the even ones' table indices are in probe_h (the thread probed them)
+__device__ __forceinline__ void insert_unit(const uint8_t* ring, uint32_t* tab, uint32_t q0, uint32_t t1, uint32_t last_q, bool small, bool have_h, const uint32_t (&probe_h)[2]) {
+    if (q0 < t1 && q0 <= last_q) {
+        const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
+        const uint32_t* a = (const uint32_t*)(ring + o);
+        uint32_t dw[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
+        uint32_t h[8];
+#pragma unroll
+        for (uint32_t i = 1; i < 8; i += 2) {
+            const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
+            h[i] = hash_pos32(lo, hi, small);
+        }
+        if (have_h) {                                           // computed when the strip was probed (wave-uniform)
+            h[0] = probe_h[0] & 0xFFFFu; h[2] = probe_h[0] >> 16; h[4] = probe_h[1] & 0xFFFFu; h[6] = probe_h[1] >> 16;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i += 2) {
+                const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
+                h[i] = hash_pos32(lo, hi, small);
+            }
+        }
+        if (q0 + 7 < t1 && q0 + 7 <= last_q) {                  // every thread but the ones at a block's very end: no per-position test
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) atomicMax(&tab[h[i]], q0 + i);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) if (q0 + i < t1 && q0 + i <= last_q) atomicMax(&tab[h[i]], q0 + i);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------ one block
@@ -922,11 +1033,12 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint32_t* strip = (uint32_t*)(smem + kCOffStrip);
     uint32_t* tab = (uint32_t*)(smem + kCOffTab);
     const uint32_t sw = w;
-    MatchRec* recs = (MatchRec*)(smem + kCOffRecs) + sw * kRecsPerStrip;      // + parity * kStrips * kRecsPerStrip
-    uint16_t* ends = (uint16_t*)(smem + kCOffEnds) + sw * kRecsPerStrip;
-    uint16_t* encp = (uint16_t*)(smem + kCOffEncp) + sw * kRecsPerStrip;
-    uint32_t* candS = (uint32_t*)(smem + kCOffCandS) + sw * kCandPerPass;
-    uint16_t* candE = (uint16_t*)(smem + kCOffCandE) + sw * kCandPerPass;
+    MatchRec* recs = (MatchRec*)(smem + kCOffRecs);                            // + parity * kRecsPerTile + strip * its slots
+    uint16_t* ends = (uint16_t*)(smem + kCOffEnds);
+    uint16_t* encp = (uint16_t*)(smem + kCOffEncp);
+    uint32_t* candS = (uint32_t*)(smem + kCOffCandS) + sw * kCandCap;
+    uint8_t* candE = (uint8_t*)(smem + kCOffCandE) + sw * kCandCap;
+    uint32_t* pairw = (uint32_t*)(smem + kCOffPair);
     uint8_t* ring = (uint8_t*)(smem + kCOffRing);
 
     // history (linked blocks, lz4io.c:741-744 / LZ4_compress_fast_continue in prefix mode lz4.c:1707): the
@@ -954,7 +1066,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
-        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_SEQS] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0;
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_INSQ] = 0; misc[CM_EMITDONE] = 0; misc[CM_FLUSHQ] = 0; misc[CM_SEQS] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0;
+        for (uint32_t i = 0; i < 2 * kCmpWaves; i++) pairw[i] = 0;
 #ifdef LZ4AMD_PROF_TILE
         for (uint32_t i = 24; i < 30; i++) misc[i] = 0;
 #endif
@@ -966,8 +1079,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint32_t loaded = 0;                                  // ring holds [.., loaded)
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
-#ifdef LZ4AMD_PROF_MATCH
-    uint64_t mtp[6] = {0, 0, 0, 0, 0, 0};
+#ifdef LZ4AMD_PROF_ROLES
+    uint64_t rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // developer build: one wave's cycles by role: probe + list | measuring: partner wait, measure, wait for the settle, write out | writing: wait for the settle, write out
 #endif
     if (prof) tq = clock_ticks();
     {
@@ -975,20 +1088,22 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         for (uint32_t Pp = 16 * tid; Pp < hi; Pp += 16 * kCmpThreads) ring_commit16(ring, Pp, load_src16(src, n, Pp));
         loaded = (hi + 15) & ~15u;
     }
-    // Two barriers per tile.  Interval A: wave 0 first settles tile k-1 (overrunning matches, then the strips' sizes
+    // Two barriers per tile.  Interval A: one wave settles tile k-1 (overrunning matches, then the strips' sizes
     // into output offsets: ~3.5 K cycles of one wave's dependent work, which used to sit between the barriers with
-    // fifteen waves waiting) and says so in CM_READY; every wave parses its strip of tile k, then - once CM_READY
-    // covers tile k-1, which it long does by then - composes its strip of tile k-1 in the staging buffer.  Interval B:
-    // everybody inserts tile k into the table and stores one 16-byte chunk of tile k-1's bytes.  Records and strip
-    // summaries are double buffered for that.
+    // fifteen waves waiting) and says so in CM_READY; the waves parse tile k - in a full tile all sixteen probe and list, then
+    // one wave of every pair measures and selects - and, once CM_READY covers tile k-1, compose its strips in the staging
+    // buffer, whoever is free.  Interval B: everybody inserts tile k into the table and stores one 16-byte chunk of tile k-1's
+    // bytes.  Records and strip summaries are double buffered for that.
     uint32_t par = 0;                                       // buffer parity of tile k
-    uint32_t prev_t0 = 0, prev_g0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0;      // tile k-1, still to be emitted
+    uint32_t prev_t0 = 0, prev_g0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0, prev_rps = kRecsPerStrip;      // tile k-1, still to be emitted (rps: record slots per strip)
     uint32_t tiles_parsed = 0;                              // tiles whose strips were matched so far (CM_READY counts up to it)
     while (t0 < n) {
         uint32_t t1 = t0 + tile_len; if (t1 > n || t1 < t0) t1 = n;
         if (t0 < pre && t1 > pre) t1 = pre;                    // the block's first tile starts where the history ends
         uint32_t* strip_k = strip + par * kStripFields * kCmpWaves;
-        MatchRec* recs_k = recs + par * kStrips * kRecsPerStrip;
+        MatchRec* recs_k = recs + par * kRecsPerTile;
+        uint16_t* ends_k = ends + par * kRecsPerTile;
+        uint16_t* encp_k = encp + par * kRecsPerTile;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
         tile_geometry(t1 >= pre ? t1 - pre : kTileMax * 4, small, nt_len, nt_strip);
@@ -1002,20 +1117,81 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         const uint32_t g0 = strip_origin(t0, tile_len, strip_len);
         const uint32_t nstrips = parse ? (t1 - g0 + strip_len - 1) >> (31 - __clz((int)strip_len)) : 0;      // (strip lengths are powers of two)
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
-        // -- A0: one wave settles tile k-1 first
-        if (w == kSettleWave && prev_nstrips) {
-            settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
-            if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
-        }
-        // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
+        // a full tile of a big block: 16 pieces of 512 bytes, probed by one wave each, 8 strips of 1 KB, measured by one wave of a pair each
+        const bool paired = parse && !small && !stride4 && strip_len == 512 && t1 - t0 == 8192;
         uint32_t probe_h[2] = {0, 0}; bool probe_h_valid = false;
-        if (w < nstrips) {
-            const uint32_t cs = strip_lo(g0, t0, w, strip_len);
-            uint32_t ce = g0 + (w + 1) * strip_len; if (ce > t1) ce = t1;
-            if (small) match_strip<true>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, 0u MPROF_PASS);
-            else match_strip<false>(ring, tab, recs_k, ends + par * kStrips * kRecsPerStrip, encp + par * kStrips * kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, stride4 ? 2u : 1u MPROF_PASS);
-            // the lane probed positions cs + 8 * lane + {0, 2, 4, 6}: with 512-byte strips those are this thread's insert positions
-            probe_h_valid = !small && !stride4 && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
+#ifdef LZ4AMD_PROF_ROLES
+        uint64_t rq = clock_ticks(); uint32_t rrole = 2;
+#define RSTAMP(k) do { const uint64_t t_ = clock_ticks(); rt[k] += t_ - rq; rq = t_; } while (0)
+#else
+#define RSTAMP(k) do {} while (0)
+#endif
+        if (paired) {
+            // -- A0: one writing wave settles tile k-1, before anything else: the other writing waves wait for it, and so does its
+            //    partner, for its list - which therefore measures its own piece (the pair's first) in the meantime
+            const uint32_t settle_w = (tiles_parsed & 1u) ? 5u : 1u;      // (an odd wave - its piece is its pair's second - whose role this tile is to write)
+            if (w == settle_w && prev_nstrips) {
+#if LZ4AMD_CMP_PRIO & 1
+                wave_priority(3);
+#endif
+                settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
+                if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
+#if LZ4AMD_CMP_PRIO & 1
+                wave_priority(0);
+#endif
+            }
+            // -- A1: probe and list my piece, tell my partner
+            const uint32_t last_q = n - kMfLimit;
+            const uint32_t pcs = t0 + 512 * w, gen = (tiles_parsed & 0x7FFFu) + 1u;
+            const uint32_t q_hi = pcs + 511 < last_q ? pcs + 511 : last_q;
+            uint32_t nw = 0;
+            if (pcs <= last_q) { nw = probe_list<false>(ring, tab, candS, candE, pcs, src_ring_off(pcs), q_hi, 0u, 1u, probe_h); probe_h_valid = true; }
+            wave_lds_fence();
+            if (lane_id() == 0) lds_store_release(&pairw[w], (gen << 16) | nw);
+            RSTAMP(0);
+            // roles: of the two waves of a pair one measures, one writes out; they swap every tile, and a SIMD (waves w, w + 4, w + 8, w + 12) has two of each
+            const uint32_t role = (w ^ (w >> 2) ^ tiles_parsed) & 1u;
+#ifdef LZ4AMD_PROF_ROLES
+            rrole = role;
+#endif
+            if (role == 0) {
+#if LZ4AMD_CMP_PRIO & 2
+                wave_priority(2);
+#endif
+                // -- A1': the pair's 1 KB, from both lists (the even wave's piece comes first)
+                const uint32_t pw = w ^ 1u;
+                const bool late = pw == settle_w;                  // (always measured in two steps, whether or not a tile was there to settle)
+                uint32_t pv = 0;
+                if (!late) while (((pv = uload_cm(&pairw[pw])) >> 16) != gen) spin_pause();
+                RSTAMP(1);
+                const uint32_t np = pv & 0xFFFFu;
+                const uint32_t* pS = (const uint32_t*)(smem + kCOffCandS) + pw * kCandCap;
+                const uint8_t* pE = (const uint8_t*)(smem + kCOffCandE) + pw * kCandCap;
+                const uint32_t si = w >> 1;
+                if (w & 1u) match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, encp_k + si * kRecsPerPair, kRecsPerPair, strip_k,
+                                             pS, pE, np, candS, candE, nw, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen);
+                else match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, encp_k + si * kRecsPerPair, kRecsPerPair, strip_k,
+                                      candS, candE, nw, pS, pE, np, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen, late ? &pairw[pw] : nullptr);
+#if LZ4AMD_CMP_PRIO & 2
+                wave_priority(0);
+#endif
+                RSTAMP(2);
+            }
+        } else {
+            // -- A0: one wave settles tile k-1 first
+            if (w == kSettleWave && prev_nstrips) {
+                settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
+                if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
+            }
+            // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
+            if (w < nstrips) {
+                const uint32_t cs = strip_lo(g0, t0, w, strip_len);
+                uint32_t ce = g0 + (w + 1) * strip_len; if (ce > t1) ce = t1;
+                if (small) match_strip<true>(ring, tab, recs_k + w * kRecsPerStrip, ends_k + w * kRecsPerStrip, encp_k + w * kRecsPerStrip, kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, 0u);
+                else match_strip<false>(ring, tab, recs_k + w * kRecsPerStrip, ends_k + w * kRecsPerStrip, encp_k + w * kRecsPerStrip, kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, stride4 ? 2u : 1u);
+                // the lane probed positions cs + 8 * lane + {0, 2, 4, 6}: with 512-byte strips those are this thread's insert positions
+                probe_h_valid = !small && !stride4 && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
+            }
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: write out tile k-1 (into the staging buffer)
@@ -1023,57 +1199,68 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         //    (the wave that settled the tile starts late, and the arbiter serves a SIMD's low wave slots first), and the barrier
         //    below waits for the last one.
         if (prev_nstrips) {
-            while (uload_cm(&misc[CM_READY]) < tiles_parsed) spin_pause();
+            while (uload_cm(&misc[CM_READY]) < tiles_parsed) CMP_WAIT_PAUSE();
+#ifdef LZ4AMD_PROF_ROLES
+            if (rrole < 2) RSTAMP(rrole ? 5 : 3);
+#endif
             for (;;) {
                 uint32_t sx = 0;
                 if (lane_id() == 0) sx = atomicAdd(&misc[CM_EMITQ], 1u);
                 sx = __builtin_amdgcn_readfirstlane(sx);
                 if (sx >= prev_nstrips) break;
-                emit_tile_strip(smem, par ^ 1, sx, w, src, dst, a0, ring_lo, H);
+                emit_tile_strip(smem, par ^ 1, sx, w, prev_rps, src, dst, a0, ring_lo, H);
+                wave_lds_fence();
+                lds_or_release(&misc[CM_EMITDONE], 1u << sx);          // (every lane the same bit: a store by lane 0 alone, in this loop, hung the kernel on the device)
             }
+        }
+#ifdef LZ4AMD_PROF_ROLES
+        if (rrole < 2) RSTAMP(rrole ? 6 : 4);
+#endif
+        if (paired) {
+            // -- A3: the tile goes into the table, piece by piece, by whichever wave is free (the writing waves mostly: the measuring ones have the
+            //    longer way to the barrier) - once all sixteen pieces were probed and no measuring wave has to probe one again: the table is
+            //    frozen while it is read
+            const uint32_t gen = (tiles_parsed & 0x7FFFu) + 1u;
+            for (;;) {
+                const uint32_t l = lane_id();
+                const uint32_t f = l < kCmpWaves ? lds_load_acquire(&pairw[l]) >> 16 : l < kCmpWaves + 8 ? lds_load_acquire(&pairw[l]) : gen;
+                if (__all(f == gen)) break;
+                CMP_WAIT_PAUSE();
+            }
+            for (;;) {
+                uint32_t px = 0;
+                if (lane_id() == 0) px = atomicAdd(&misc[CM_INSQ], 1u);
+                px = __builtin_amdgcn_readfirstlane(px);
+                if (px >= kCmpWaves) break;
+                insert_unit(ring, tab, t0 + 512 * px + 8 * lane_id(), t1, n - kMfLimit, false, px == w && probe_h_valid, probe_h);
+            }
+            // -- A4: tile k-1's bytes leave, 64 chunks a time, once all its strips are written out
+            if (LZ4AMD_CMP_FLUSH_IN_A && prev_nstrips && !misc[CM_FAIL]) {
+                while (uload_cm(&misc[CM_EMITDONE]) != (1u << prev_nstrips) - 1u) CMP_WAIT_PAUSE();
+                for (;;) {
+                    uint32_t fx = 0;
+                    if (lane_id() == 0) fx = atomicAdd(&misc[CM_FLUSHQ], 1u);
+                    fx = __builtin_amdgcn_readfirstlane(fx);
+                    if (fx >= kStageBytes / 1024) break;
+                    const FlushCtx fj = flush_begin(smem, par ^ 1, a0, 64 * fx + lane_id());
+                    if (64 * fx > fj.nfull) break;                      // (nothing of the tile that far: the chunks are clean)
+                    flush_end(smem, fj, dst, a0, 64 * fx + lane_id());
+                }
+            }
+#ifdef LZ4AMD_PROF_ROLES
+            RSTAMP(7);
+#endif
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
-        // -- B: tile k-1's bytes leave; everybody inserts tile k into the table (positions that may start a match):
-        //    8 consecutive positions per thread, hashed out of four aligned dwords
-        const bool do_flush = prev_nstrips && !misc[CM_FAIL];
-        if (tid == 0) misc[CM_EMITQ] = 0;                           // (nobody looks at it between the two barriers)
+        // -- B: tile k-1's bytes leave; everybody inserts tile k into the table (positions that may start a match) - unless it was a full
+        //    tile, which its writing waves inserted while the measuring ones were still at it
+        const bool do_flush = prev_nstrips && !misc[CM_FAIL] && !(LZ4AMD_CMP_FLUSH_IN_A && paired);      // (a full tile's waves stored the tile before already)
+        if (tid == 0) { misc[CM_EMITQ] = 0; misc[CM_INSQ] = 0; misc[CM_EMITDONE] = 0; misc[CM_FLUSHQ] = 0; }      // (nobody looks at them between the two barriers)
         FlushCtx fc;
-        if (do_flush) fc = flush_begin(smem, par ^ 1, a0);
-        if (n >= kMfLimit + 1) {
-            const uint32_t last_q = n - kMfLimit;
-            const uint32_t q0 = t0 + 8 * tid;                       // t0 is a multiple of 16; tiles are at most 8 * kCmpThreads long
-            if (q0 < t1 && q0 <= last_q) {
-                const uint32_t o = src_ring_off(q0);                // multiple of 8: o + 16 <= ring + pad
-                const uint32_t* a = (const uint32_t*)(ring + o);
-                uint32_t dw[4];
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
-                uint32_t h[8];
-#pragma unroll
-                for (uint32_t i = 1; i < 8; i += 2) {
-                    const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
-                    h[i] = hash_pos32(lo, hi, small);
-                }
-                if (probe_h_valid) {                                    // the even ones were computed when the strip was probed (wave-uniform)
-                    h[0] = probe_h[0] & 0xFFFFu; h[2] = probe_h[0] >> 16; h[4] = probe_h[1] & 0xFFFFu; h[6] = probe_h[1] >> 16;
-                } else {
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; i += 2) {
-                        const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
-                        h[i] = hash_pos32(lo, hi, small);
-                    }
-                }
-                if (q0 + 7 < t1 && q0 + 7 <= last_q) {                  // every thread but the ones at a block's very end: no per-position test
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; i++) atomicMax(&tab[h[i]], q0 + i);
-                } else {
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; i++) if (q0 + i < t1 && q0 + i <= last_q) atomicMax(&tab[h[i]], q0 + i);
-                }
-            }
-        }
+        if (do_flush) fc = flush_begin(smem, par ^ 1, a0, tid);
+        if (!paired && n >= kMfLimit + 1) insert_unit(ring, tab, t0 + 8 * tid, t1, n - kMfLimit, small, probe_h_valid, probe_h);      // (t0 is a multiple of 16; tiles are at most 8 * kCmpThreads long; a full tile was inserted by its writing waves)
 #ifdef LZ4AMD_PROF_TILE
         if (prof) { const uint64_t t = clock_ticks(); if (tid == 0) ((uint64_t*)(smem + kCOffMisc))[14] += t - tq; }
 #endif
@@ -1081,9 +1268,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         // the wait for the load would wait for the store's acknowledgement as well - the counter is in order)
         if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
-        if (do_flush) flush_end(smem, fc, dst, a0);
+        if (do_flush) flush_end(smem, fc, dst, a0, tid);
         if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
-        prev_t0 = t0; prev_g0 = g0; prev_t1 = t1; prev_strip_len = strip_len; prev_nstrips = nstrips; par ^= 1;
+        prev_t0 = t0; prev_g0 = g0; prev_t1 = t1; prev_strip_len = paired ? 1024u : strip_len; prev_nstrips = paired ? 8u : nstrips; prev_rps = paired ? kRecsPerPair : kRecsPerStrip; par ^= 1;
         if (nstrips) tiles_parsed++;
         t0 = t1; tile_len = nt_len; strip_len = nt_strip;
     }
@@ -1093,9 +1280,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         if (w == kSettleWave) settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
         __syncthreads();
         const uint32_t ring_lo = loaded > kSrcRing ? loaded - kSrcRing : 0;
-        if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, w, src, dst, a0, ring_lo, H);
+        if (w < prev_nstrips) emit_tile_strip(smem, par ^ 1, w, w, prev_rps, src, dst, a0, ring_lo, H);
         __syncthreads();
-        if (!misc[CM_FAIL]) { const FlushCtx fc = flush_begin(smem, par ^ 1, a0); flush_end(smem, fc, dst, a0); }
+        if (!misc[CM_FAIL]) { const FlushCtx fc = flush_begin(smem, par ^ 1, a0, tid); flush_end(smem, fc, dst, a0, tid); }
     }
     __syncthreads();
     if (prof) {
@@ -1112,12 +1299,15 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             { const uint64_t* m64 = (const uint64_t*)(smem + kCOffMisc); mx = m64[12]; mn = m64[13]; sm = m64[14] * kCmpWaves; }
 #endif
             prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = (uint64_t)misc[CM_EMITQ] << 4; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
+#ifdef LZ4AMD_PROF_ROLES
+        }
+        if (w == LZ4AMD_PROF_ROLES && lane_id() == 0) {
+            for (uint32_t i = 0; i < 8; i++) prof[i] = rt[i];
+        }
+        if (tid == 0) {
+#endif
 #ifdef LZ4AMD_PROF_WAVES
             for (uint32_t i = 0; i < 8; i++) prof[i] = (uint64_t)misc[16 + 2 * i] | ((uint64_t)misc[17 + 2 * i] << 32);      // developer build: match + emit time of each wave (>> 4)
-#endif
-#ifdef LZ4AMD_PROF_MATCH
-            // developer build: wave 0's match time by phase (probe, runs, list, measure, select, records)
-            prof[2] = mtp[0]; prof[3] = mtp[1]; prof[5] = mtp[2]; prof[6] = mtp[3]; prof[7] = mtp[4]; prof[0] = mtp[5];
 #endif
         }
     }

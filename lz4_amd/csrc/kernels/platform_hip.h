@@ -122,6 +122,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
 template <int N> __device__ __forceinline__ void vmem_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8); }
+template <int N> __device__ __forceinline__ void spin_pause_n() { __builtin_amdgcn_s_sleep(N); }      // (64 * N cycles)
 __device__ __forceinline__ void chain_wait_pause() { __builtin_amdgcn_s_sleep(32); }      // waiting for another workgroup
 // issue priority of this wave among the waves of its SIMD (0..3)
 __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }

@@ -30,6 +30,7 @@ static inline void spin_pause() { simt::yield_to_sched(); }
 static inline long long chain_load_acquire(const long long* w) { return __atomic_load_n(w, __ATOMIC_ACQUIRE); }
 static inline void chain_store_release(long long* w, long long v) { __atomic_store_n(w, v, __ATOMIC_RELEASE); }
 static inline void spin_pause_long() { simt::yield_to_sched(); }
+template <int N> static inline void spin_pause_n() { simt::yield_to_sched(); }
 static inline void chain_wait_pause() { simt::external_wait(); }
 static inline void wave_priority_high() {}
 static inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {

@@ -1,6 +1,7 @@
 /* simt_emu.cpp -- TEST INFRASTRUCTURE ONLY (see simt_emu.h): fiber scheduler. */
 #include "simt_emu.h"
 #include <mutex>
+#include <algorithm>
 
 namespace simt {
 
@@ -51,14 +52,25 @@ static void run_block(Block& b, size_t stack_bytes, char* stacks) {
         for (int i = 0; i < 6; i++) *--sp = nullptr;   // rbp rbx r12-r15
         f.sp = sp;
     }
-    // scheduler: wave by wave, several rounds per wave while it makes progress
+    // scheduler: wave by wave, several rounds per wave while it makes progress.  SIMT_SEED=<n>: the waves of a pass in a pseudo-random
+    // order, a pseudo-random number of rounds each - protocols between waves must not depend on who runs first
     unsigned long long last_progress = ~0ull;
     unsigned idle_passes = 0;
+    static const char* seed_env = getenv("SIMT_SEED");
+    unsigned long long rng = seed_env ? 0x9E3779B97F4A7C15ull * (unsigned long long)(atoll(seed_env) + 1) + b.bIdx.x : 0;
+    std::vector<unsigned> order(nw);
+    for (unsigned w = 0; w < nw; w++) order[w] = w;
     while (b.live_threads) {
         last_progress = b.progress;
-        for (unsigned w = 0; w < nw && b.live_threads; w++) {
+        int max_rounds = 16;
+        if (seed_env) {
+            for (unsigned i = nw; i > 1; i--) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(rng >> 33) % i]); }
+            rng = rng * 6364136223846793005ull + 1442695040888963407ull; max_rounds = 1 + (int)((rng >> 33) % 16);
+        }
+        for (unsigned wi = 0; wi < nw && b.live_threads; wi++) {
+            const unsigned w = order[wi];
             if (!b.waves[w].live) continue;
-            for (int round = 0; round < 16; round++) {
+            for (int round = 0; round < max_rounds; round++) {
                 unsigned long long before = b.progress;
                 for (unsigned l = 0; l < 64; l++) {
                     Fiber& f = b.fibers[w * 64 + l];
