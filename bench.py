@@ -3,6 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no launcher around it (no WORLD_SIZE in the environment) this process starts the N ranks itself (one per
+GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) and waits for them; under torchrun it is a rank.
+
 Workload (BASELINE.json configs[1]): per GPU, 1 GiB of independent 4 MiB blocks of
 `datagen -P60 -s<rank>` data, resident in HBM.  A "step" is one pass of the hot path over that
 batch: LZ4 block compression of every block (LZ4_compress_default semantics) followed by
@@ -276,7 +279,8 @@ def roofline_obj(kernel, ms, alg_bytes, copy_gbps, traffic):
     # what holds the kernel below that roofline today: VALU issue (committed SQ counters of the same kernel sources)
     v = measured_traffic().get(kernel, {}).get("valu")
     if v:
-        r["limited_by"] = {"what": "VALU issue (one wave64 instruction per 4 cycles per SIMD)", **v}
+        r["limited_by"] = {"what": "VALU issue: a SIMD takes one wave64 instruction per ~4.2 cycles in mixed code (measured: profiles/r05_valu_issue.txt - "
+                                   "VOP3 / DPP / compare / min-max / multiply 4.2-4.6, runs of plain add / logic / shift 2.4, any mix ~4.2)", **v}
     return r
 
 
@@ -388,6 +392,52 @@ def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps, use_hints
             "roundtrip_GBps": round(U / ((cms + dms) * 1e-3) / 1e9, 2),
             "roofline_compress": roofline_obj("compress", cms, U + C, copy_gbps, None),
             "roofline_decompress": roofline_obj("decompress", dms, U + C, copy_gbps, None)}
+
+
+def table_bytes_written(torch, hints):
+    """Bytes of the entry-point tables the compressor actually wrote (header + rows + end row of every valid table), from the
+    tables themselves: word 7 of a table (row 0's last word) is its number of rows."""
+    if hints is None:
+        return 0
+    w = hints.view(torch.int32).view(hints.shape[0], -1)[:, :8].cpu()
+    valid = w[:, 0] == 0x48345A4C
+    return int(((w[:, 7][valid].to(torch.int64) + 2) * 16).sum().item())
+
+
+def bench_shape_small(ctx, lz4_amd, torch, data, stream, bs=64 << 10):
+    """The small end of north_star's block range: the same GiB as 16384 independent 64 KiB blocks (the frame format's default block
+    size): compress, decode with the tables, decode without."""
+    U = data.numel()
+    nb = U // bs
+    stride = (lz4_amd.compress_bound(bs) + 255) & ~255
+    comp = torch.empty((nb, stride), dtype=torch.uint8, device=data.device)
+    out = torch.empty(U, dtype=torch.uint8, device=data.device)
+    ctab = lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb, [comp.data_ptr() + i * stride for i in range(nb)], [stride] * nb)
+    cplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, ctab)
+    hints = torch.zeros((nb, lz4_amd.hint_bytes(bs)), dtype=torch.uint8, device=data.device)
+    cplan.attach_hints(hints.data_ptr(), hints.stride(0))
+    cplan.launch(stream)
+    cs = cplan.results(stream)
+    dtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nb)], cs, [out.data_ptr() + i * bs for i in range(nb)], [bs] * nb)
+    dplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+    dplan.attach_hints(hints.data_ptr(), hints.stride(0))
+    dplan.launch(stream)
+    ok = all(c > 0 for c in cs) and dplan.results(stream) == [bs] * nb and bool(torch.equal(out, data))
+    fplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+    out.zero_()
+    fplan.launch(stream)
+    ok = ok and fplan.results(stream) == [bs] * nb and bool(torch.equal(out, data))
+    cms = min(cplan.launch_timed(stream)[0][0] for _ in range(3))
+    dms = min(dplan.launch_timed(stream)[0][0] for _ in range(3))
+    fms = min(fplan.launch_timed(stream)[0][0] for _ in range(3))
+    C = sum(cs)
+    return {"workload": "%d independent %d-byte blocks (%.2f GiB, the same data), device resident" % (nb, bs, U / 2**30), "bit_exact": ok, "ratio": round(U / C, 4),
+            "compress_GBps": round(U / (cms * 1e-3) / 1e9, 2), "decompress_GBps_with_tables": round(U / (dms * 1e-3) / 1e9, 2),
+            "decompress_GBps_without_tables": round(U / (fms * 1e-3) / 1e9, 2),
+            "compress_frac_of_hbm_peak": round((U + C) / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "decompress_frac_of_hbm_peak_with_tables": round((U + C) / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "decompress_frac_of_hbm_peak_without_tables": round((U + C) / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "one 1024-thread workgroup per block whatever its size: a 64 KiB block's matches reach into the block itself only, its regions wait for the ones just before them"}
 
 
 def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(20, 90), nblk=256, nref=16):
@@ -563,7 +613,15 @@ def pack_python(torch, dev, comp, csizes):
     return packed
 
 
-def data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=None):
+def gather_corpus(dist, torch, rank, world, data):
+    """Setup of data_path, untimed: the corpus lives on the root, so rank 0 first collects every rank's shard (each rank generated
+    its own).  Returns the list of shards on rank 0, None elsewhere."""
+    shards = [torch.empty_like(data) for _ in range(world)] if rank == 0 else None
+    dist.gather(data, gather_list=shards, dst=0)
+    return shards
+
+
+def data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=None, shards="gather"):
     """configs[4]'s movement with torch.distributed (backend nccl = RCCL over xGMI on the GPU box, gloo in
     the CPU test).  Setup, untimed: the corpus lives on the root, so rank 0 first collects every rank's shard (each
     rank generated its own, `datagen -s<rank>`).  Timed: (1) scatter of the DISTINCT shards from rank 0, (2) all_gather
@@ -572,8 +630,8 @@ def data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=None):
     every shard and the payloads cut back into (rank, block) order with the sizes table."""
     U = data.numel()
     pack = pack or (lambda c, z: pack_python(torch, dev, c, z))
-    shards = [torch.empty_like(data) for _ in range(world)] if rank == 0 else None
-    dist.gather(data, gather_list=shards, dst=0)                       # setup: the root holds the whole corpus
+    if isinstance(shards, str):
+        shards = gather_corpus(dist, torch, rank, world, data)         # setup: the root holds the whole corpus
     recv = torch.empty_like(data)
     _sync(torch, dev); dist.barrier()
     t0 = time.perf_counter()
@@ -620,6 +678,66 @@ def data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=None):
             "scatter_bytes": U * (world - 1), "gather_bytes": sum(totals) - totals[0], "blocks": blocks, "sizes": [t.tolist() for t in allsz]}
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start the N ranks (this file again, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), wait for them; rank 0 prints the JSON line on the stdout it inherits.  Returns the worst exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:                                                   # a rank died: do not leave the others at a rendezvous
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run(args, world, rank):
+    """`--dry-run`: the N-rank plumbing of this file WITHOUT the codec and without a GPU (the CPU container's check of the command
+    line: launcher, rendezvous, shard plan, the scatter / all_gather / gather movement over gloo with every block "stored", the
+    aggregation).  Prints a line with n_gpus and no value: it measures nothing."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    nb, bs = args.blocks or 4, args.block_bytes
+    plan_s = shard_plan(nb, rank, world)
+    host = gen_data(nb * bs, args.pct, plan_s["seed"])
+    data = torch.from_numpy(host)
+    comp = data.view(nb, bs)                                  # every block "stored": the movement is what is exercised
+    csizes = [bs] * nb
+    t_max, bytes_all = aggregate(dist if world > 1 else None, 1.0, nb * bs)
+    dp = None
+    if world > 1:
+        r = data_path(dist, torch, torch.device("cpu"), rank, world, data, comp, csizes)
+        ok = bool(torch.equal(r["received"], data))
+        if rank == 0:
+            ok = ok and len(r["blocks"]) == world * nb and all(bool(torch.equal(r["blocks"][rr * nb + i], r["shards"][rr][i * bs:(i + 1) * bs]))
+                                                               for rr in range(world) for i in range(nb))
+        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        dp = {"ok": bool(okt.item() == 1.0), "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+              "scatter_bytes": r["scatter_bytes"], "gather_bytes": r["gather_bytes"]}
+    if rank == 0:
+        print(json.dumps({"metric": "GB/s compress + decompress, 4 MB independent blocks", "value": None, "unit": "GB/s", "dry_run": True,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                          "config": {"workload": "dry run: %d x %d-byte blocks per rank, no codec, no GPU" % (nb, bs), "blocks_per_gpu": nb, "block_bytes": bs},
+                          "bytes_all_ranks": bytes_all, "data_path": dp,
+                          "note": "plumbing check of `bench.py --gpus N` (launcher, rendezvous, sharding, collectives over gloo): nothing is measured"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -636,7 +754,14 @@ def main():
     ap.add_argument("--no-foreign", action="store_true", help="skip the decode of the same blocks without tables and of reference-compressed blocks (profiling runs: the decompress kernel's average then is the step's)")
     ap.add_argument("--no-hints", action="store_true",
                     help="do not pass the compressor's entry-point tables to the decoder (include/lz4amd.h): every block is decoded the way a foreign block is")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without codec and GPU: launcher, rendezvous, sharding and the collectives over gloo (prints n_gpus, measures nothing)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # no launcher around us: be the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run or os.environ.get("LZ4AMD_BENCH_DRYRUN") == "1":
+        return dry_run(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
 
     import torch
     import torch.distributed as dist
@@ -653,6 +778,8 @@ def main():
         loopback = os.environ.get("LZ4AMD_BENCH_LOOPBACK") == "1"
         if loopback:
             local_rank = 0
+        elif torch.cuda.device_count() < world:
+            sys.exit("bench.py: %d ranks asked for, %d GPU(s) visible (rank %d)" % (world, torch.cuda.device_count(), rank))
         torch.cuda.set_device(local_rank)
         if loopback:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -800,7 +927,8 @@ def main():
     result = None
     if rank == 0:
         copy_gbps = stream_copy_gbps(ctx, lz4_amd, torch, 1 << 30, stream)
-        alg = {"compress": U + C, "decompress": U + C}        # U read + C written / C read + U written
+        tbytes = table_bytes_written(torch, hints)
+        alg = {"compress": U + C + tbytes, "decompress": U + C + tbytes}        # U read + C written / C read + U written; the tables' rows are bytes written / read as well
         pmc = measured_traffic() if (nb == 256 and bs == 4 << 20 and args.pct == 60) else {}
         traffic = {k: pmc.get(k, {}).get("hbm_bytes_per_launch") for k in ("compress", "decompress")}
         kernels = []
@@ -824,10 +952,24 @@ def main():
             "compress_GBps": round(U / (c_total * 1e-3) / 1e9, 2),
             "decompress_GBps": round(U / (d_total * 1e-3) / 1e9, 2),
             "ratio": round(U / C, 4), "compressed_bytes": C,
+            # the step's decode is handed the compressor's entry-point tables (an interface of this library, out of band: plain LZ4
+            # blocks - frames, LZ4_decompress_safe, foreign data - come without).  The same round trip without them, and with blocks
+            # the reference compressed, beside it:
+            "value_note": "`value` = compress (writes the tables) + decompress from the tables; `value_without_tables` = the same compress + decode of "
+                          "the same blocks as plain LZ4 blocks; `value_reference_input` = the same compress + decode of blocks made by the reference's "
+                          "LZ4_compress_default (what LZ4_decompress_safe / LZ4F_decompress callers get)",
+            "value_without_tables": (round(U / ((c_total + foreign["own_blocks_without_table"]["avg_ms"]) * 1e-3) / 1e9, 3)
+                                     if "own_blocks_without_table" in foreign else None),
+            "value_reference_input": (round(U / ((c_total + foreign["reference_compressed_blocks"]["avg_ms"]) * 1e-3) / 1e9, 3)
+                                      if "avg_ms" in foreign.get("reference_compressed_blocks", {}) else None),
+            "decompress_GBps_without_tables": foreign.get("own_blocks_without_table", {}).get("decompress_GBps"),
+            "decompress_GBps_reference_input": foreign.get("reference_compressed_blocks", {}).get("decompress_GBps"),
+            "ratio_with_tables": round(U / (C + tbytes), 4) if hints is not None else None,
             "roofline": roofline_obj(dom["kernel"], dom["avg_ms"], dom["algorithmic_bytes"], copy_gbps, traffic.get(dom["kernel"])),
             "roofline_decompress": roofline_obj("decompress", k_ms["decompress"], alg["decompress"], copy_gbps, traffic.get("decompress")),
             "kernels": kernels,
-            "entry_point_tables": ({"used": True, "bytes_per_block": hstride, "bytes_per_launch": hstride * nb,
+            "entry_point_tables": ({"used": True, "room_bytes_per_block": hstride, "room_bytes_per_launch": hstride * nb,
+                                    "bytes_written_per_launch": tbytes, "bytes_written_per_block": tbytes // nb, "fraction_of_compressed_bytes": round(tbytes / C, 4),
                                     "blocks_decoded_from_their_table": table_stats[0], "tables_rejected": table_stats[1],
                                     "launches_counted": 1 + args.warmup + 2 * args.steps,
                                     "note": "optional out-of-band column of the block table (include/lz4amd.h): written by lz4amd_k_compress, checked row by row by the decoder; "
@@ -841,6 +983,21 @@ def main():
     # ---- N > 1: the movement configs[4] names, over RCCL (not part of `value`, which stays the kernel-only rate)
     dp = None
     if world > 1 and not args.no_data_path:
+        # setup, untimed and outside the watchdog below: rank 0 collects every rank's shard (8 GiB each at the default size: tens of GiB over
+        # xGMI); a collective that never returns must still not cost the bench line, so it has a (long) watchdog of its own
+        def bail_setup():
+            if rank == 0:
+                result["data_path"] = {"error": "the setup gather of the shards did not finish within 600 s"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        w0 = threading.Timer(600.0, bail_setup)
+        w0.daemon = True
+        w0.start()
+        try:
+            corpus = gather_corpus(dist, torch, rank, world, data)
+            torch.cuda.synchronize()
+        finally:
+            w0.cancel()
         # a collective that never returns must not cost the bench line: after 120 s rank 0 prints what it has and every rank leaves
         def bail():
             if rank == 0:
@@ -863,7 +1020,7 @@ def main():
                 gp.launch(stream)
                 assert gp.results(stream) == cs_, "gather op failed"
                 return packed
-            r = data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=pack_gpu)
+            r = data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=pack_gpu, shards=corpus)
             ok = bool(torch.equal(r["received"], data))               # every rank got its own shard back from the root
             if rank == 0:
                 # the root decodes a sample of EVERY rank's gathered blocks with its own decoder and compares with the shard it holds
@@ -899,7 +1056,8 @@ def main():
                 backend = dist.get_backend()
                 dp = {"experiment": "configs[4]: %d GPUs x %d blocks of %d bytes (%.1f GiB per GPU, %.1f GiB in all), shards datagen -s0..%d held by rank 0"
                                     % (world, nb, bs, U / 2**30, U * world / 2**30, world - 1),
-                      "world_size": dist.get_world_size(), "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (loopback check of the code path, not a measurement)"),
+                      "world_size": dist.get_world_size(), "launched_by": "torchrun / external launcher" if os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("GROUP_RANK") else "bench.py --gpus N (launch_ranks) or an external launcher",
+                      "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (loopback check of the code path, not a measurement)"),
                       "devices": dp["devices"],
                       "collectives": "scatter of the %d distinct shards from rank 0; all_gather of int32 csize[%d]; payloads packed by LZ4AMD_OP_GATHER and sent to rank 0 with their exact lengths" % (world, nb),
                       "scatter_s": round(dp["scatter_s"], 5), "sizes_s": round(dp["sizes_s"], 5), "pack_s": round(dp["pack_s"], 5), "gather_s": round(dp["gather_s"], 5),
@@ -930,6 +1088,10 @@ def main():
                 result["by_compressibility"] = {"error": str(e)}
         foreign.pop("_ref_ratio", None)
         if world == 1 and not args.no_extras and nb == 256 and bs == 4 << 20:
+            try:
+                result["shape_64K"] = bench_shape_small(ctx, lz4_amd, torch, data, stream)
+            except Exception as e:
+                result["shape_64K"] = {"error": str(e)}
             try:
                 result["shape_2048"] = bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps, hints is not None)
             except Exception as e:

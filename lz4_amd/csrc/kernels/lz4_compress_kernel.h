@@ -50,6 +50,9 @@
 #ifndef LZ4AMD_CMP_FLUSH_IN_A
 #define LZ4AMD_CMP_FLUSH_IN_A 1    // developer knob: 0: the tile before leaves after the barrier, one chunk per thread
 #endif
+#ifndef LZ4AMD_CMP_LDS_BARRIER
+#define LZ4AMD_CMP_LDS_BARRIER 0      // developer knob: 1: the tile barrier waits for LDS operations only (measured: no difference)
+#endif
 #ifndef LZ4AMD_CMP_PRIO
 #define LZ4AMD_CMP_PRIO 2          // developer knob: 1: the settling wave runs at high issue priority, 2: the measuring waves at raised priority
 #endif
@@ -473,7 +476,7 @@ __device__ __forceinline__ void parse_piece(const uint8_t* ring, const uint32_t*
         const uint32_t total = probe_list<SMALL>(ring, tab, candS, candE, pcs, pcs_off, q_hi, lo, SH, ph);
         if (lo == 0) { probe_h[0] = ph[0]; probe_h[1] = ph[1]; }
         if (lo >= total) break;
-        wave_lds_fence();
+        wave_lds_fence_local();
         const uint32_t nlist = total - lo < kCandCap ? total - lo : kCandCap;
         for (uint32_t pl = 0; pl < nlist && st.nseq < rec_cap; pl += kCandPerPass) {
             const bool have = pl + lane < nlist;
@@ -482,7 +485,7 @@ __device__ __forceinline__ void parse_piece(const uint8_t* ring, const uint32_t*
             parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, pcs + ((S & 255u) << SH), have ? S >> 8 : 1u, pcs + (E << SH) + kMinMatch, st);
         }
         if (lo + kCandCap >= total) break;
-        wave_lds_fence();                                            // (the list is rewritten by the next probe)
+        wave_lds_fence_local();                                            // (the list is rewritten by the next probe)
     }
 }
 // ... a whole strip [cs, ce) of at most 256 << SH bytes: strip `w` of its tile (records, summary)
@@ -521,12 +524,12 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
                     if (have) { S = LAs[pl + lane]; E = LAe[pl + lane]; }
                     parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, cs + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + (E << 1) + kMinMatch, st);
                 }
-            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st); wave_lds_fence(); }
+            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st); wave_lds_fence_local(); }
             uint32_t pv;
-            while (((pv = __builtin_amdgcn_readfirstlane(lds_load_acquire(late_b))) >> 16) != gen) spin_pause();
+            while (((pv = __builtin_amdgcn_readfirstlane(lds_load_acquire_local(late_b))) >> 16) != gen) spin_pause();
             nB = pv & 0xFFFFu;
             if (nB <= kCandCap) {
-                if (lane == 0) lds_store_release(table_free, gen);
+                if (lane == 0) lds_store_release_local(table_free, gen);
                 for (uint32_t pl = 0; pl < nB && st.nseq < rec_cap; pl += kCandPerPass) {
                     const bool have = pl + lane < nB;
                     uint32_t S = 0, E = 0;
@@ -535,7 +538,7 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
                 }
             } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st); }
         } else if (nA <= kCandCap && nB <= kCandCap) {
-            if (lane == 0) lds_store_release(table_free, gen);
+            if (lane == 0) lds_store_release_local(table_free, gen);
             const uint32_t cs_off = src_ring_off(cs), total = nA + nB;
             for (uint32_t pl = 0; pl < total && st.nseq < rec_cap; pl += kCandPerPass) {
                 const uint32_t i = pl + lane;
@@ -548,12 +551,12 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
         } else {
             uint32_t ph[2];
             parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st);
-            wave_lds_fence();
+            wave_lds_fence_local();
             parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st);
         }
     }
     strip_summary(strip, si, st, ce);
-    if (lane == 0) lds_store_release(table_free, gen);                // (at the latest)
+    if (lane == 0) lds_store_release_local(table_free, gen);                // (at the latest)
 }
 
 // ------------------------------------------------------------------------------ entry-point table (optional output)
@@ -716,11 +719,11 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
         const uint32_t p_incl = wave_incl_sum(cnt), pbase = p_incl - cnt, npieces = wave_readlane(p_incl, 63);
         for (uint32_t W = 0; W < npieces; W += 64) {
             scr[lane] = 0;
-            wave_lds_fence();
+            wave_lds_fence_local();
             if (cnt && pbase < W + 64 && pbase + cnt > W) scr[pbase > W ? pbase - W : 0u] = lane + 1;
-            wave_lds_fence();
+            wave_lds_fence_local();
             const uint32_t own = wave_incl_max(scr[lane]);
-            wave_lds_fence();
+            wave_lds_fence_local();
             const uint32_t ol = own ? own - 1 : 0u;
             const uint32_t o_so = (uint32_t)__shfl((int)so, (int)ol), o_d = (uint32_t)__shfl((int)lit_d, (int)ol);
             const uint32_t o_tl = (uint32_t)__shfl((int)tl, (int)ol), o_pb = (uint32_t)__shfl((int)pbase, (int)ol);
@@ -933,7 +936,7 @@ __device__ __forceinline__ StripTotals strip_offsets(uint32_t* strip, uint32_t n
 }
 
 // a control word every lane of the wave agrees on
-__device__ __forceinline__ uint32_t uload_cm(const uint32_t* w) { return __builtin_amdgcn_readfirstlane(lds_load_acquire(w)); }
+__device__ __forceinline__ uint32_t uload_cm(const uint32_t* w) { return __builtin_amdgcn_readfirstlane(lds_load_acquire_local(w)); }
 
 // ------------------------------------------------------------------------------ one tile settled / written (helpers of one block)
 // wave 0: tile (parity pp) gets its output offsets; whether it is composed in LDS or - when its encoded bytes do not fit
@@ -948,7 +951,7 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
 #endif
     resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kRecsPerTile, (const uint16_t*)(smem + kCOffEnds) + pp * kRecsPerTile,
                      (const uint16_t*)(smem + kCOffEncp) + pp * kRecsPerTile, rps, nstrips, g0, t0, strip_len, t1, n);
-    wave_lds_fence();
+    wave_lds_fence_local();
 #ifdef LZ4AMD_PROF_TILE
     const uint64_t ts1 = clock_ticks();
 #endif
@@ -971,7 +974,7 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
         T[T_OUT0] = out0; T[T_OUT1] = t.out;
         T[T_DIRECT] = (t.out + a0) - ((out0 + a0) & ~15u) > kStageBytes - 16 ? 1u : 0u;
     }
-    wave_lds_fence();
+    wave_lds_fence_local();
 #ifdef LZ4AMD_PROF_TILE
     { const uint64_t ts2 = clock_ticks(); if (lane_id() == 0) { ((uint64_t*)(smem + kCOffMisc))[12] += ts1 - ts0; ((uint64_t*)(smem + kCOffMisc))[13] += ts2 - ts1; } }
 #endif
@@ -1108,10 +1111,16 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         uint32_t nt_len, nt_strip;
         tile_geometry(t1 >= pre ? t1 - pre : kTileMax * 4, small, nt_len, nt_strip);
         uint32_t pf_hi = loaded + nt_len; if (pf_hi > n || pf_hi < loaded) pf_hi = n;     // stays 16 bytes ahead of the tile
-        const uint32_t Pp = loaded + 16 * tid;
+        // (a tile is at most 512 granules: the upper eight waves fetch them - not the wave that settles the tile before: wherever the
+        //  compiler waits for the granule, that wave would wait at the head of the chain everybody else waits for)
+        const uint32_t Pp = loaded + 16 * (tid ^ 512u);
         U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;
-        if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 16 * kCmpThreads
+        if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 8 * kCmpThreads
+#if LZ4AMD_CMP_LDS_BARRIER
+        lds_barrier();                                         // ring, table and tile k-1's records ready (all of it LDS: the fetch just issued, and the stores of the tile before, may still be on their way)
+#else
         __syncthreads();                                       // ring, table and tile k-1's records ready
+#endif
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
         const bool parse = t0 >= pre;
         const uint32_t g0 = strip_origin(t0, tile_len, strip_len);
@@ -1135,7 +1144,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 wave_priority(3);
 #endif
                 settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
-                if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
+                if (lane_id() == 0) lds_store_release_local(&misc[CM_READY], tiles_parsed);
 #if LZ4AMD_CMP_PRIO & 1
                 wave_priority(0);
 #endif
@@ -1146,8 +1155,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             const uint32_t q_hi = pcs + 511 < last_q ? pcs + 511 : last_q;
             uint32_t nw = 0;
             if (pcs <= last_q) { nw = probe_list<false>(ring, tab, candS, candE, pcs, src_ring_off(pcs), q_hi, 0u, 1u, probe_h); probe_h_valid = true; }
-            wave_lds_fence();
-            if (lane_id() == 0) lds_store_release(&pairw[w], (gen << 16) | nw);
+            wave_lds_fence_local();
+            if (lane_id() == 0) lds_store_release_local(&pairw[w], (gen << 16) | nw);
             RSTAMP(0);
             // roles: of the two waves of a pair one measures, one writes out; they swap every tile, and a SIMD (waves w, w + 4, w + 8, w + 12) has two of each
             const uint32_t role = (w ^ (w >> 2) ^ tiles_parsed) & 1u;
@@ -1181,7 +1190,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             // -- A0: one wave settles tile k-1 first
             if (w == kSettleWave && prev_nstrips) {
                 settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
-                if (lane_id() == 0) lds_store_release(&misc[CM_READY], tiles_parsed);
+                if (lane_id() == 0) lds_store_release_local(&misc[CM_READY], tiles_parsed);
             }
             // -- A1: match, one wave per strip (tiles of the history are only inserted into the table)
             if (w < nstrips) {
@@ -1209,8 +1218,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 sx = __builtin_amdgcn_readfirstlane(sx);
                 if (sx >= prev_nstrips) break;
                 emit_tile_strip(smem, par ^ 1, sx, w, prev_rps, src, dst, a0, ring_lo, H);
-                wave_lds_fence();
-                lds_or_release(&misc[CM_EMITDONE], 1u << sx);          // (every lane the same bit: a store by lane 0 alone, in this loop, hung the kernel on the device)
+                wave_lds_fence_local();
+                lds_or_release_local(&misc[CM_EMITDONE], 1u << sx);          // (every lane the same bit: a store by lane 0 alone, in this loop, hung the kernel on the device)
             }
         }
 #ifdef LZ4AMD_PROF_ROLES
@@ -1223,7 +1232,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             const uint32_t gen = (tiles_parsed & 0x7FFFu) + 1u;
             for (;;) {
                 const uint32_t l = lane_id();
-                const uint32_t f = l < kCmpWaves ? lds_load_acquire(&pairw[l]) >> 16 : l < kCmpWaves + 8 ? lds_load_acquire(&pairw[l]) : gen;
+                const uint32_t f = l < kCmpWaves ? lds_load_acquire_local(&pairw[l]) >> 16 : l < kCmpWaves + 8 ? lds_load_acquire_local(&pairw[l]) : gen;
                 if (__all(f == gen)) break;
                 CMP_WAIT_PAUSE();
             }

@@ -187,6 +187,29 @@ __device__ __forceinline__ uint32_t take_ticket(uint32_t* counter) {
     return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- the same hand-offs for kernels whose waves exchange nothing but LDS data (the fast compressor): no wait for the wave's global
+// loads and stores.  (A release / acquire at workgroup scope, and __builtin_amdgcn_fence, cover every address space: they wait for the
+// acknowledgement of global stores nobody in the workgroup reads, and for prefetches that are wanted a tile later.)  The DS unit serves
+// one wave's LDS instructions in issue order: a flag stored after the data is seen after the data; the reader's data reads are issued
+// after the flag's value came back.  What is left to do is to keep the compiler from reordering.
+__device__ __forceinline__ void wave_lds_fence_local() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void lds_store_release_local(uint32_t* w, uint32_t v) {
+    asm volatile("" ::: "memory"); __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_or_release_local(uint32_t* w, uint32_t bits) {
+    asm volatile("" ::: "memory"); __hip_atomic_fetch_or(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ uint32_t lds_load_acquire_local(const uint32_t* w) {
+    asm volatile("" ::: "memory"); const uint32_t v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return v;
+}
+// Workgroup barrier for data that travels through LDS only: the wave's LDS operations are complete (lgkmcnt), its global loads and
+// stores may still be in flight - __syncthreads() also waits for those (its release fence covers every address space), i.e. for the
+// acknowledgement of stores nobody in the workgroup reads and for prefetches that are only wanted a tile later.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the registers of a global load, complete from here on (the compiler waits for the load at this point, not at a later use behind
+// stores whose number it cannot know: the memory counter is in order)
+__device__ __forceinline__ void settle_load16(lz4amd_u32x4& v) { asm volatile("" : "+v"(v)); }
+
 // lanes of a wave run in lockstep on the hardware; this only pins the compiler's schedule
 // (and gives the CPU interpreter used by the unit tests a rendezvous point).
 __device__ __forceinline__ void wave_converge() { __builtin_amdgcn_wave_barrier(); }

@@ -69,3 +69,9 @@ static inline uint32_t row16_min_u32(uint32_t v) {
     return v;
 }
 static inline void wave_converge() { (void)__ballot(1); }
+static inline void lds_barrier() { __syncthreads(); }
+static inline void wave_lds_fence_local() { (void)__ballot(1); }
+static inline void lds_store_release_local(uint32_t* w, uint32_t v) { *(volatile uint32_t*)w = v; }
+static inline void lds_or_release_local(uint32_t* w, uint32_t bits) { *w |= bits; }
+static inline uint32_t lds_load_acquire_local(const uint32_t* w) { return *(volatile const uint32_t*)w; }
+static inline void settle_load16(lz4amd_u32x4&) {}

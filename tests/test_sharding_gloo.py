@@ -97,3 +97,27 @@ def test_two_rank_sharding_movement_and_aggregation():
         assert len(sizes) == world and all(len(s) == NB for s in sizes) and sizes[rank] == csizes   # every rank knows every size
         assert sizes[0] != sizes[1]                        # distinct shards: ragged payloads, exact-length transfers
     assert res[0][7] == world * NB                         # rank 0 put every payload back in order and decoded it
+
+
+def test_bench_command_line_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (bench.launch_ranks: RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* per rank, rendezvous on 127.0.0.1) - here in its dry-run mode (no codec, no GPU: the launcher, the
+    rendezvous, the shard plan and the scatter / all_gather / exact-length gather over gloo with real bytes), through the
+    command line, not through an import."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--blocks", "5", "--block-bytes", "30000"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                           # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None
+    assert d["data_path"]["ok"] is True and d["data_path"]["world_size"] == 2
+    assert d["data_path"]["scatter_bytes"] == 5 * 30000 and d["data_path"]["gather_bytes"] == 5 * 30000
+    assert d["bytes_all_ranks"] == 2 * 5 * 30000
+    # one rank: no launcher, no process group
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--blocks", "2", "--block-bytes", "4096"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
