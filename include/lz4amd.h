@@ -56,7 +56,12 @@ int         lz4amd_device_cus(const lz4amd_ctx* ctx);
 int         lz4amd_compress_bound(int src_size);
 
 /* Bind a table of n blocks.  d_src[i]/d_dst[i] are device pointers, src_sizes/dst_caps host
- * arrays (copied).  level is used by LZ4AMD_OP_COMPRESS_HC only. */
+ * arrays (copied).  level is used by LZ4AMD_OP_COMPRESS_HC only.
+ * Device memory a plan holds besides the table itself: LZ4AMD_OP_COMPRESS none; LZ4AMD_OP_DECOMPRESS ~1/3 of the largest
+ * compressed block per workgroup (one workgroup per CU at most; none of it is touched for blocks that come with an entry-point
+ * table); LZ4AMD_OP_COMPRESS_HC ~18 bytes per byte of the largest source block per workgroup (chain, search state, parked walks,
+ * records) - the number of workgroups is cut down so that this stays within 16 GiB (environment LZ4AMD_HC_SCRATCH_MB overrides):
+ * 256 blocks of 4 MiB are compressed by ~220 workgroups, the rest of the table queues. */
 int  lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
                         const void* const* d_src, const int* src_sizes,
                         void* const* d_dst, const int* dst_caps, int level);

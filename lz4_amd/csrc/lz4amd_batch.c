@@ -170,6 +170,16 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->level = hc_level_norm(level); q->max_src = max_n + 65536;           /* room for a block's history (lz4amd_plan_create_compress_hc_prefix) */
         q->prefix = NULL;
         q->scratch_stride = (lz4amd_hip_hc_scratch_bytes(q->max_src) + 255) & ~(uint64_t)255;
+        /* ~18 bytes of scratch per source byte of the largest block and workgroup (include/lz4amd.h): a table of large blocks is
+         * compressed by as many workgroups as fit a budget (16 GiB, or LZ4AMD_HC_SCRATCH_MB) - the blocks queue on them - and never by
+         * fewer than one */
+        {   const char* e = getenv("LZ4AMD_HC_SCRATCH_MB");
+            unsigned long long budget = e && atoll(e) > 0 ? (unsigned long long)atoll(e) << 20 : (unsigned long long)16 << 30;
+            unsigned long long fit = budget / (q->scratch_stride ? q->scratch_stride : 1);
+            if (fit < 1) fit = 1;
+            if (grid > fit) grid = (unsigned)fit;
+            p->grid = grid;
+        }
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {
             q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));

@@ -305,7 +305,8 @@ struct LZ4F_dctx_s {
     uint8_t* out2; size_t out2_cap; int out2_pin; /* ... and where its bytes go (the two output buffers swap when it is done) */
     int out_pin;
     /* a large batch is decoded by a helper thread while the caller's thread hands out the batch before and takes in the next */
-    int busy; pthread_t bthread; size_t b_nb, b_end, b_out_size, b_result; int b_skip; void* b_ts;      /* b_ts: the staging area of this context's helper-thread batches (from a pool) */
+    int busy; pthread_t bthread; size_t b_nb, b_end, b_out_size, b_result; int b_skip; void* b_ts; int deferred;      /* deferred: the prepared batch (in2, b_nb, b_end) could not get a helper thread and waits for the bytes before it to be handed out */
+     /* b_ts: the staging area of this context's helper-thread batches (from a pool) */
     size_t scan_pos; size_t nready;               /* complete blocks in in[0, scan_pos) */
     int end_seen;                                 /* in[scan_pos, scan_pos+4) is the end mark */
     uint8_t* out; size_t out_size, out_pos, out_cap;   /* decoded bytes of the last batch, and how many were delivered */
@@ -329,6 +330,7 @@ static void dctx_batch_drop(LZ4F_dctx* d) { if (d->busy > 0) pthread_join(d->bth
 /* Page-locked buffers are expensive to make (the pages are pinned one by one): the ones a context lets go of wait here for
  * the next context that needs one - a decoder per frame, as the reference's own programs create them, then costs no pinning. */
 enum { kPinCache = 8 };
+static const size_t kPinCacheBytes = (size_t)384 << 20;      /* page-locked bytes the cache may hold in all */
 static struct { uint8_t* p; size_t cap; } g_pin_cache[kPinCache];
 static pthread_mutex_t g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
 static uint8_t* pin_take(size_t need, size_t* cap)
@@ -347,8 +349,10 @@ static void hfree_cap(uint8_t* p, int pinned, size_t cap)
     if (pinned) {
         int i, slot = -1;
         pthread_mutex_lock(&g_pin_lock);
-        for (i = 0; i < kPinCache; i++) if (!g_pin_cache[i].p) { slot = i; break; }
-        if (slot < 0) for (i = 0; i < kPinCache; i++) if (g_pin_cache[i].cap < cap && (slot < 0 || g_pin_cache[i].cap < g_pin_cache[slot].cap)) slot = i;     /* (the smallest one makes room) */
+        size_t held = 0;
+        for (i = 0; i < kPinCache; i++) if (g_pin_cache[i].p) held += g_pin_cache[i].cap;
+        for (i = 0; i < kPinCache && held + cap <= kPinCacheBytes; i++) if (!g_pin_cache[i].p) { slot = i; break; }
+        if (slot < 0 && held + cap <= kPinCacheBytes) for (i = 0; i < kPinCache; i++) if (g_pin_cache[i].cap < cap && (slot < 0 || g_pin_cache[i].cap < g_pin_cache[slot].cap)) slot = i;     /* (the smallest one makes room) */
         if (slot >= 0) { uint8_t* old = g_pin_cache[slot].p; g_pin_cache[slot].p = p; g_pin_cache[slot].cap = cap; p = old; }
         pthread_mutex_unlock(&g_pin_lock);
         lz4amd_hip_host_free(p);
@@ -368,7 +372,7 @@ void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
     dctx_batch_drop(d);
     dctx_hash_join(d);
     d->stage = ST_HEADER;
-    d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0; d->raw_on = 0; d->raw_left = 0;
+    d->in_size = d->scan_pos = d->nready = 0; d->end_seen = 0; d->raw_on = 0; d->raw_left = 0; d->deferred = 0;
     d->out_size = d->out_pos = 0;
     d->total_out = d->skip_left = 0; d->hist_len = 0;
     if (!d->dict_keep) { d->dict = NULL; d->dict_len = 0; }      /* lz4frame.c:1331-1332: a dictionary counts for one frame */
@@ -488,7 +492,7 @@ static int grow(uint8_t** buf, size_t* cap, int* pin, size_t need, size_t keep)
         nb = pin_take(need, &need);
         if (nb) np = 1;
         else {
-            need += need + 4096;                            /* (few re-allocations: pinning pages is slow) */
+            need += (need >> 2) + 4096;                     /* (a quarter of slack: pinning pages is slow, but a context holds four such buffers) */
             if (frame_ctx()) { nb = (uint8_t*)lz4amd_hip_host_alloc(need); np = nb != NULL; }
         }
     } else need += (need >> 2) + 4096;
@@ -703,6 +707,14 @@ static size_t size_hint(const LZ4F_dctx* d)
     }
 }
 
+/* (test hook: LZ4AMD_TEST_NO_BATCH_THREAD=1 makes the helper thread of a large batch fail to start, the way pthread_create does
+ *  when the process is out of threads) */
+static int batch_thread_start(LZ4F_dctx* d, void* (*fn)(void*))
+{
+    const char* e = getenv("LZ4AMD_TEST_NO_BATCH_THREAD");
+    if (e && e[0] == '1') return -1;
+    return pthread_create(&d->bthread, NULL, fn, d);
+}
 static void* batch_thread(void* arg)
 {
     LZ4F_dctx* d = (LZ4F_dctx*)arg;
@@ -811,13 +823,16 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
                 f = rd32(d->in + d->scan_pos);
                 if (f == 0) { d->end_seen = 1; break; }                      /* end mark, lz4frame.c:1730 */
                 if ((f & 0x7FFFFFFFu) > d->block_max) { err = ERR(maxBlockSize_invalid); goto fail; }   /* lz4frame.c:1737 */
-                if ((f >> 31) && d->nready == 0 && !d->busy && (size_t)(f & 0x7FFFFFFFu) + tail > avail - used) {
+                if ((f >> 31) && d->nready == 0 && !d->busy && !d->deferred && (size_t)(f & 0x7FFFFFFFu) + tail > avail - used) {
                     /* a stored block that is not all here, with nothing before it waiting for the device: its bytes need no buffer
                      * (lz4frame.c:1790-1830 hands them on as they come; a whole one at hand goes with the batch, one copy either way) */
                     dctx_hash_join(d);
                     d->raw_on = 1; d->raw_left = f & 0x7FFFFFFFu;
                     d->raw_b0 = 4; d->raw_b1 = d->in_size < 4 + d->raw_left ? d->in_size : 4 + d->raw_left;      /* (bytes an earlier call left in the buffer) */
-                    if (d->raw_b0 == d->raw_b1) { d->in_size = 0; d->raw_b0 = d->raw_b1 = 0; }
+                    if (d->raw_b0 == d->raw_b1) {                             /* nothing of the block's bytes is buffered - but a piece of its checksum may be (an empty stored block) */
+                        memmove(d->in, d->in + 4, d->in_size - 4);
+                        d->in_size -= 4; d->raw_b0 = d->raw_b1 = 0;
+                    }
                     if (tail) xxh32_reset(&d->raw_xxh);
                     break;
                 }
@@ -825,13 +840,28 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
                 d->scan_pos += 4 + (f & 0x7FFFFFFFu) + tail; d->nready++;
             }
             if (d->raw_on) continue;                                         /* (a stored block in pieces: handled at the top) */
+            if (d->deferred) {
+                /* a prepared batch whose helper thread could not be started: it is decoded here, once every byte before it has been
+                 * handed out (decoding it now would put its bytes where those still wait) */
+                size_t r;
+                if (d->busy) { r = batch_finish(d); if (LZ4F_isError(r)) { err = r; goto fail; } }
+                if (d->out_pos < d->out_size) continue;
+                d->deferred = 0;
+                d->b_result = decode_batch(d, d->in2, d->b_nb, d->b_end, d->b_skip, NULL);
+                d->busy = -1;
+                r = batch_finish(d);
+                if (LZ4F_isError(r)) { err = r; goto fail; }
+                continue;
+            }
             if (d->nready) {                                                 /* starved, end of frame or a full batch */
                 /* The batch goes to the device - a large one on a helper thread, so that this thread hands out the batch
                  * before it and takes in the one after it meanwhile (its input and output buffers are the spare pair). */
                 const int large = d->nready * d->block_max >= kAsyncDecoded ;
+                int can_async;
                 size_t rest, r;
                 if (d->busy) { r = batch_finish(d); if (LZ4F_isError(r)) { err = r; goto fail; } }
-                if (!large && d->out_pos < d->out_size) continue;             /* (its bytes would take this buffer: the pending ones go out first) */
+                can_async = large && frame_ctx() && (d->b_ts || (d->b_ts = stage_acquire()) != NULL);
+                if (!can_async && d->out_pos < d->out_size) continue;         /* (its bytes would take this buffer: the pending ones go out first) */
                 rest = d->in_size - d->scan_pos;                              /* the item that is still incomplete stays with the collector */
                 if (grow(&d->in2, &d->in2_cap, &d->in2_pin, rest ? rest : 1, 0)) { err = ERR(allocation_failed); goto fail; }
                 memcpy(d->in2, d->in + d->scan_pos, rest);
@@ -839,7 +869,8 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr,
                   d->in = d->in2; d->in_cap = d->in2_cap; d->in_pin = d->in2_pin; d->in2 = t; d->in2_cap = c; d->in2_pin = pn; }
                 d->b_nb = d->nready; d->b_end = d->scan_pos; d->b_skip = d->skipc;
                 d->in_size = rest; d->scan_pos = 0; d->nready = 0;
-                if (large && frame_ctx() && (d->b_ts || (d->b_ts = stage_acquire()) != NULL) && pthread_create(&d->bthread, NULL, batch_thread, d) == 0) d->busy = 1;
+                if (can_async && batch_thread_start(d, batch_thread) == 0) d->busy = 1;
+                else if (d->out_pos < d->out_size) d->deferred = 1;           /* (no thread to be had, and the batch before is not handed out yet: see above) */
                 else {
                     d->b_result = decode_batch(d, d->in2, d->b_nb, d->b_end, d->b_skip, NULL);
                     d->busy = -1;                                             /* (done already: nothing to join) */

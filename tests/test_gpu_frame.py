@@ -456,3 +456,88 @@ def test_large_frames_through_overlapping_batches(L, datagen, kw):
         finally:
             L.LZ4F_freeDecompressionContext(d)
         assert pos == len(frame) and bytes(out) == data, (kw, take_max, dcap_max, len(out))
+
+
+@pytest.mark.parametrize("kw", [dict(blockSizeID=7, blockMode=0, contentChecksumFlag=1), dict(blockSizeID=6, blockMode=1, blockChecksumFlag=1)])
+def test_large_batches_when_no_helper_thread_can_be_started(L, datagen, kw):
+    """A large batch normally runs on a helper thread while the batch before it is handed out.  When that thread cannot be
+    started (LZ4AMD_TEST_NO_BATCH_THREAD=1: the way pthread_create fails in a process that is out of threads) the batch is
+    decoded on the calling thread - but only after every byte of the batch before has been handed out: decoding it at once
+    would put its bytes where those still wait (they were silently lost: round 4's advisor finding).  Small destinations, so
+    that a batch is pending whenever the next one is ready."""
+    import random
+    rng = random.Random(23)
+    data = datagen(40 << 20, 60, 9) + os.urandom(5 << 20) + datagen(30 << 20, 90, 10)
+    frame = compress_frame(L, data, **kw)
+    for env in ("1", "0"):
+        os.environ["LZ4AMD_TEST_NO_BATCH_THREAD"] = env
+        try:
+            for take_max, dcap_max in ((9 << 20, 300000), (1 << 30, 1 << 20), (40 << 20, 64 << 20)):
+                d = ctypes.c_void_p()
+                assert L.LZ4F_createDecompressionContext(ctypes.byref(d), 100) == 0
+                out, pos = bytearray(), 0
+                try:
+                    for _ in range(200000):
+                        take = min(len(frame) - pos, rng.randint(1, take_max))
+                        dst = ctypes.create_string_buffer(min(len(data) + 64, rng.randint(1, dcap_max)))
+                        dsz, ssz = ctypes.c_size_t(len(dst)), ctypes.c_size_t(take)
+                        r = L.LZ4F_decompress(d, dst, ctypes.byref(dsz), frame[pos:pos + take], ctypes.byref(ssz), None)
+                        assert not L.LZ4F_isError(r), L.LZ4F_getErrorName(r)
+                        out += dst.raw[:dsz.value]
+                        pos += ssz.value
+                        if r == 0:
+                            break
+                finally:
+                    L.LZ4F_freeDecompressionContext(d)
+                assert pos == len(frame) and bytes(out) == data, (kw, env, take_max, dcap_max, len(out))
+        finally:
+            os.environ.pop("LZ4AMD_TEST_NO_BATCH_THREAD", None)
+
+
+def test_empty_stored_blocks_with_checksums_between_large_batches(L, datagen):
+    """tests/frametest.c splices empty stored blocks (header 0x80000000, then - with block checksums - the XXH32 of nothing)
+    into frames.  One that arrives right behind a large batch, its checksum cut in two by the caller's chunking while the batch
+    is still on the device, must not lose the checksum bytes already taken in (lz4frame_api.c: the piecewise path of stored blocks)."""
+    import struct
+    import random
+    data = datagen(20 << 20, 60, 21)
+    frame = compress_frame(L, data, blockSizeID=7, blockMode=1, blockChecksumFlag=1, contentChecksumFlag=1)
+    # walk the blocks (header 7 bytes: no content size, no dictID), put an empty stored block behind every one of them
+    pos, out, cuts = 7, bytearray(frame[:7]), []
+    empty = struct.pack("<I", 0x80000000) + struct.pack("<I", 0x02CC5D05)
+    while True:
+        f = struct.unpack_from("<I", frame, pos)[0]
+        if f == 0:
+            break
+        n = 4 + (f & 0x7FFFFFFF) + 4
+        out += frame[pos:pos + n]
+        cuts.append(len(out))
+        out += empty
+        pos += n
+    out += frame[pos:]
+    spliced = bytes(out)
+    assert len(cuts) >= 5
+    rng = random.Random(5)
+    for trial in range(12):
+        d = ctypes.c_void_p()
+        assert L.LZ4F_createDecompressionContext(ctypes.byref(d), 100) == 0
+        got, p = bytearray(), 0
+        # input is handed over up to a point 5, 6 or 7 bytes into an empty block (its header and a piece of its checksum), then in small steps
+        stops = sorted(c + rng.choice((4, 5, 6, 7)) for c in rng.sample(cuts, 3))
+        try:
+            for _ in range(400000):
+                nxt = next((s for s in stops if s > p), len(spliced))
+                take = min(nxt - p, rng.randint(1, 6 << 20)) if nxt > p else 0
+                dst = ctypes.create_string_buffer(rng.choice((1 << 16, 300000, 5 << 20)))
+                dsz, ssz = ctypes.c_size_t(len(dst)), ctypes.c_size_t(take)
+                r = L.LZ4F_decompress(d, dst, ctypes.byref(dsz), spliced[p:p + take], ctypes.byref(ssz), None)
+                assert not L.LZ4F_isError(r), (trial, L.LZ4F_getErrorName(r))
+                got += dst.raw[:dsz.value]
+                p += ssz.value
+                if r == 0:
+                    break
+                if p in stops and ssz.value == 0 and dsz.value == 0:
+                    stops.remove(p)                               # nothing moves any more at the stop: go on
+        finally:
+            L.LZ4F_freeDecompressionContext(d)
+        assert p == len(spliced) and bytes(got) == data, (trial, len(got))
