@@ -294,23 +294,33 @@ def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, copy_gbps, level
     tab = lz4_amd.BlockTable([data.data_ptr() + i * bs for i in range(nb)], [bs] * nb,
                              [comp.data_ptr() + i * stride for i in range(nb)], [stride] * nb)
     plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS_HC, tab, level=level)
+    hints = torch.zeros((nb, lz4_amd.hint_bytes(bs)), dtype=torch.uint8, device=data.device)      # the HC compressor writes the entry-point tables too
+    plan.attach_hints(hints.data_ptr(), hints.stride(0))
     plan.launch(stream)
     cs = plan.results(stream)
     assert all(c > 0 for c in cs), "HC compression failed"
     dtab = lz4_amd.BlockTable([comp.data_ptr() + i * stride for i in range(nb)], cs,
                               [out.data_ptr() + i * bs for i in range(nb)], [bs] * nb)
     dplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)
+    dplan.attach_hints(hints.data_ptr(), hints.stride(0))
     out.zero_()
     dplan.launch(stream)
     assert dplan.results(stream) == [bs] * nb and torch.equal(out, data), "HC round trip is not bit exact"
+    fplan = lz4_amd.Plan(ctx, lz4_amd.OP_DECOMPRESS, dtab)      # the same blocks as plain LZ4 blocks
+    out.zero_()
+    fplan.launch(stream)
+    assert fplan.results(stream) == [bs] * nb and torch.equal(out, data), "HC round trip without tables is not bit exact"
     ms = min(plan.launch_timed(stream)[0][0] for _ in range(3))
     dms = min(dplan.launch_timed(stream)[0][0] for _ in range(3))
+    fms = min(fplan.launch_timed(stream)[0][0] for _ in range(3))
     C = sum(cs)
     tr = measured_traffic().get("compress_hc", {}).get("hbm_bytes_per_launch") if (nb == 4096 and pct == 60 and level == 9) else None
     res = {"workload": "configs[3]: %d independent %d-byte blocks (%.2f GiB), datagen -P%d, LZ4_compress_HC level %d, device resident"
                        % (nb, bs, U / 2**30, pct, level),
            "compress_GBps": round(U / (ms * 1e-3) / 1e9, 2), "kernel_ms": round(ms, 3),
-           "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 2), "ratio": round(U / C, 4), "compressed_bytes": C,
+           "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 2), "decompress_GBps_without_tables": round(U / (fms * 1e-3) / 1e9, 2),
+           "tables": {"blocks_decoded_from_their_table": dplan.hint_stats()[0], "tables_rejected": dplan.hint_stats()[1], "bytes_written": table_bytes_written(torch, hints)},
+           "ratio": round(U / C, 4), "compressed_bytes": C,
            "roofline": roofline_obj("compress_hc", ms, U + C, copy_gbps, tr)}
     if with_cpu:
         cb = cpu_baseline_hc(bs, pct, seed, level)

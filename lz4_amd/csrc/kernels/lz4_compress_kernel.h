@@ -594,7 +594,7 @@ __device__ __forceinline__ void copy_literals(lz4amd_gdst dst, uint32_t d, lz4am
 
 // ------------------------------------------------------------------------------ emit (one strip)
 __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* recs, const uint32_t* strip,
-                                           uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t cs, uint32_t ring_lo) {
+                                           uint32_t w, lz4amd_gsrc src, lz4amd_gdst dst, uint32_t cs, uint32_t ring_lo, const HintOut* H = nullptr, uint32_t ord0 = 0) {      // H: the entry-point table's rows are written on the way (ord0: sequences of the block before this strip)
     const uint32_t lane = lane_id();
     const uint32_t nk = strip[S_N * kCmpWaves + w];
     const uint32_t carry = strip[S_CARRY * kCmpWaves + w];
@@ -613,6 +613,7 @@ __device__ __forceinline__ void emit_strip(const uint8_t* ring, const MatchRec* 
         const uint32_t my_i = ipos + a_incl - adv - extra;   // source pos of my literals (carried ones included)
         uint32_t lit_dst = 0;
         const uint32_t tl = ll + extra;
+        if (H) hint_row(*H, have, ord0 + i, my_o, my_i);
         if (have) {
             lz4amd_gdst p = dst + my_o;
             const uint32_t tok_ll = tl >= 15 ? 15u : tl, tok_ml = mlm4 >= 15 ? 15u : mlm4;

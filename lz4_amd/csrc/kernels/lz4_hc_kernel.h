@@ -108,8 +108,8 @@ enum : uint32_t {
 // LDS carve-up (bytes); the chain phase, the search phase and the parse phase reuse the same region
 enum : uint32_t {
     kHOffMisc = 0,                                  // u32[32]
-    kHOffStrip = 128,                               // u32[6][16] strip summaries
-    kHOffBody = 512,
+    kHOffStrip = 128,                               // u32[8][16] strip summaries (rows S_N .. S_CARRY of the fast compressor's, row 6: sequences of the block before the strip)
+    kHOffBody = 640,
     kHOffHead = kHOffBody,                          // phase 1: u32[1 << 15]
     kHOffSrc = kHOffBody,                           // phase 2: source ring + pad
     kHOffChain = kHOffSrc + kHcRing + kHcPad,       //          u16[kHcRing]
@@ -127,7 +127,7 @@ static_assert(kHcLdsBytes <= 160 * 1024, "one CU's LDS");
 static_assert(kHcBands * kHcBandStep >= 65535 + kHcTile + kHcAhead, "bands must cover the LZ4 window");
 static_assert(kHOffMine % 16 == 0 && kHOffRes0 % 16 == 0 && kHOffChain % 16 == 0, "16-byte LDS accesses");
 static_assert(8 * kHcEntCap >= 4 * kHcTile, "the results of a tile and the staged entries share one region");
-enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5, HM_NLIST = 6, HM_FIRST0 = 16 /* [16]: first record of each strip's record area */ };
+enum : uint32_t { HM_BLOCK = 0, HM_TOKEN = 1, HM_OUT = 2, HM_CARRY = 3, HM_FAIL = 4, HM_POOL = 5, HM_NLIST = 6, HM_HOVER = 7 /* a row of the entry-point table did not fit its room */, HM_SEQS = 8, HM_HK = 9 /* log2 of the table's row distance */, HM_FIRST0 = 16 /* [16]: first record of each strip's record area */ };
 
 // scratch layout of one workgroup, for blocks of at most n bytes
 __host__ __device__ inline uint64_t hc_chain_bytes(uint32_t n) { return ((uint64_t)2 * (n + 64) + 255) & ~255ull; }
@@ -1052,11 +1052,12 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     const lz4amd_gdst dst = LZ4AMD_TO_GDST(P.dst[b]);
     const int32_t n_i = P.src_size[b];
     const int32_t cap_i = P.dst_cap[b];
+    const lz4amd_gdst hints = P.hints ? LZ4AMD_TO_GDST(P.hints + (uint64_t)b * P.hint_stride) : (lz4amd_gdst)nullptr;      // optional entry-point table
     if (n_i < 0 || (uint32_t)n_i > kMaxInput || cap_i <= 0 || P.dst[b] == nullptr || (P.src[b] == nullptr && n_i != 0)) {
-        if (tid == 0) P.result[b] = 0;                               // lz4hc.c:1403-1404
+        if (tid == 0) { P.result[b] = 0; if (hints) *(uint32_t*)hints = 0; }                               // lz4hc.c:1403-1404
         return;
     }
-    if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; } return; }
+    if (n_i == 0) { if (tid == 0) { dst[0] = 0; P.result[b] = 1; if (hints) *(uint32_t*)hints = 0; } return; }      // (no table for an empty block)
     // history (linked blocks / LZ4_compress_HC_continue in prefix mode, lz4hc.c:1666-1700): the `first` bytes right
     // before the block are linked into the chains like the block itself, but neither searched nor emitted.  From
     // here on positions count from the start of the history.  (A multiple of 64 keeps every per-position array aligned.)
@@ -1114,12 +1115,24 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         // -- offsets (wave 0; limitedOutput: a block that does not fit fails as a whole, lz4hc.c:297-300)
         if (w == 0) {
             const StripTotals t = strip_offsets(strip, nstrips, 0, 0, 0, cap);
-            if (lane_here() == 0) { misc[HM_OUT] = t.out; misc[HM_CARRY] = t.carry; misc[HM_FAIL] = t.fail; }
+            // the strips' first sequence numbers, and the entry-point table's row distance: one row per 2^k sequences, about one per 512 bytes
+            // of source (as lz4amd_k_compress chooses it tile by tile: settle_tile)
+            const uint32_t l = lane_here();
+            const uint32_t nk = l < nstrips ? strip[S_N * kCmpWaves + l] : 0u;
+            const uint32_t n_incl = wave_incl_sum(nk);
+            if (l < kCmpWaves) strip[6 * kCmpWaves + l] = n_incl - nk;
+            if (l == 0) {
+                misc[HM_OUT] = t.out; misc[HM_CARRY] = t.carry; misc[HM_FAIL] = t.fail; misc[HM_SEQS] = t.seqs; misc[HM_HOVER] = 0;
+                const uint32_t want = (uint32_t)(((uint64_t)t.seqs << 9) / (own ? own : 1u));              // sequences per 512 bytes
+                misc[HM_HK] = want >= LZ4AMD_HINT_EVERY_MAX ? LZ4AMD_HINT_EVERY_LOG2 : want >= 8 ? 3u : want >= 4 ? 2u : want >= 2 ? 1u : 0u;
+            }
         }
         __syncthreads();
-        // -- emit
-        if (w < nstrips && !misc[HM_FAIL] && strip[S_N * kCmpWaves + w])
-            emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap + misc[HM_FIRST0 + w], strip, w, src, dst, first + w * strip_len, 0xFFFFFFFFu);
+        // -- emit (the emit lanes also write the optional entry-point table's rows: lz4amd_params.h)
+        if (w < nstrips && !misc[HM_FAIL] && strip[S_N * kCmpWaves + w]) {
+            HintOut H; H.table = hints; H.cap_rows = P.hint_stride >= 48 ? (uint32_t)(P.hint_stride / 16 - 2) : 0u; H.pre = first; H.over = &misc[HM_HOVER]; H.ord0 = 0; H.row0 = 0; H.k = misc[HM_HK];
+            emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap + misc[HM_FIRST0 + w], strip, w, src, dst, first + w * strip_len, 0xFFFFFFFFu, hints ? &H : nullptr, strip[6 * kCmpWaves + w]);
+        }
         __syncthreads();
         if (prof && tid == 0) { const uint64_t t = clock_ticks(); prof[5] += t - tq; tq = t; }
     } else {
@@ -1130,7 +1143,21 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     // -- final literal run (lz4hc.c:1336-1357)
     const uint32_t out = misc[HM_OUT], run = misc[HM_CARRY];
     const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;
-    if (misc[HM_FAIL] || total > cap) { if (tid == 0) P.result[b] = 0; return; }
+    if (misc[HM_FAIL] || total > cap) { if (tid == 0) { P.result[b] = 0; if (hints) *(uint32_t*)hints = 0; } return; }
+    if (hints && tid == 0) {
+        // as lz4amd_k_compress ends its tables: the block's last sequence (its final literals) has a row of its own, the row behind it is the
+        // block's end, row 0 carries the number of rows, the header makes the table valid
+        const uint32_t cap_rows = P.hint_stride >= 48 ? (uint32_t)(P.hint_stride / 16 - 2) : 0u;
+        const uint32_t seqs = n > first && n - first >= kMfLimit + 1 ? misc[HM_SEQS] : 0u, k = seqs ? misc[HM_HK] : 0u;
+        const uint32_t last_row = (seqs + (1u << k) - 1) >> k, nrows = last_row + 1;
+        if (last_row && last_row < cap_rows) st_hint(hints, last_row, out, n - run - first, seqs);
+        if (nrows <= cap_rows && !(seqs && misc[HM_HOVER])) {
+            st_hint(hints, nrows, (uint32_t)total, (uint32_t)n_i, seqs + 1);
+            st_hint(hints, 0, 0, 0, 0, nrows);
+            U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = (uint32_t)n_i; h[2] = (uint32_t)total; h[3] = seqs + 1;
+            st_global16(hints, h);
+        } else *(uint32_t*)hints = 0;
+    }
     const uint32_t lit_dst = out + 1 + lit_hdr_ext(run);
     if (tid == 0) {
         lz4amd_gdst p = dst + out;

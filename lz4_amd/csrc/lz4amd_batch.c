@@ -168,7 +168,7 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->dst = (uint8_t* const*)ddst; q->dst_cap = (const int32_t*)dcap;
         q->result = (int32_t*)dres; q->n_blocks = (uint32_t)n;
         q->level = hc_level_norm(level); q->max_src = max_n + 65536;           /* room for a block's history (lz4amd_plan_create_compress_hc_prefix) */
-        q->prefix = NULL;
+        q->prefix = NULL; q->hints = NULL; q->hint_stride = 0;
         q->scratch_stride = (lz4amd_hip_hc_scratch_bytes(q->max_src) + 255) & ~(uint64_t)255;
         /* ~18 bytes of scratch per source byte of the largest block and workgroup (include/lz4amd.h): a table of large blocks is
          * compressed by as many workgroups as fit a budget (16 GiB, or LZ4AMD_HC_SCRATCH_MB) - the blocks queue on them - and never by
@@ -278,6 +278,7 @@ int lz4amd_plan_attach_hints(lz4amd_plan* p, void* d_hints, size_t stride)
 {
     if (!p || ((size_t)d_hints & 15u) || (stride & 15u) || (d_hints && stride < 32)) return LZ4AMD_E_ARG;
     if (p->op == LZ4AMD_OP_COMPRESS) { p->comp.hints = (uint8_t*)d_hints; p->comp.hint_stride = stride; }
+    else if (p->op == LZ4AMD_OP_COMPRESS_HC) { p->hc.hints = (uint8_t*)d_hints; p->hc.hint_stride = stride; }
     else if (p->op == LZ4AMD_OP_DECOMPRESS && !p->dec.chain) {
         if (d_hints && !p->dec.hint_stats) {
             int k, err = 0;

@@ -77,6 +77,8 @@ typedef struct lz4amd_hc_params {
     int32_t level;                  /* LZ4_compress_HC compressionLevel (lz4hc.h:66) */
     const int32_t* prefix;          /* [n_blocks] or NULL: bytes of history right before src (<= 64 KB used, rounded down to 64) */
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase cycle counts */
+    uint8_t* hints;                 /* optional: block i's entry-point table is written at hints + i * hint_stride (as by lz4amd_comp_params) */
+    uint64_t hint_stride;
 } lz4amd_hc_params;
 
 typedef struct lz4amd_xxh_params {

@@ -129,6 +129,23 @@ extern "C" int emu_compress_hc_batch_prefix(const uint8_t* const* src, const int
     return 0;
 }
 
+extern "C" int emu_compress_hc_batch_hints(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
+                                           int32_t* result, uint32_t n, uint32_t grid, int level, const int32_t* prefix, uint8_t* hints, uint64_t hstride) {
+    using namespace lz4amd;
+    if (grid == 0) grid = n < 8 ? (n ? n : 1) : 8;
+    uint32_t ticket = 0, max_src = 0;
+    for (uint32_t i = 0; i < n; i++) if (src_size[i] > 0 && (uint32_t)src_size[i] > max_src) max_src = src_size[i];
+    max_src += 65536;
+    const uint64_t stride = (hc_scratch_bytes(max_src) + 255) & ~255ull;
+    std::vector<uint8_t> scratch((size_t)(stride * grid + 512));
+    HcBatch P = {};
+    P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
+    P.n_blocks = n; P.ticket = &ticket; P.prof = nullptr; P.level = level; P.max_src = max_src; P.prefix = prefix; P.hints = hints; P.hint_stride = hstride;
+    P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 255) & ~(uintptr_t)255); P.scratch_stride = stride;
+    if (n) simt::launch(grid, kHcThreads, kHcLdsBytes, [&] { hc_batch_body(P); });
+    return 0;
+}
+
 // ---- entry-point tables: the compressor writes one per block (hints + i * stride), the decoder parses from it
 extern "C" int emu_compress_batch_hints(const uint8_t* const* src, const int32_t* src_size, uint8_t* const* dst, const int32_t* dst_cap,
                                         int32_t* result, uint32_t n, uint32_t grid, const int32_t* prefix, uint8_t* hints, uint64_t stride, int32_t accel) {

@@ -30,7 +30,7 @@ def _dev(b, pad=0, fill=0xEE):
     return t
 
 
-def gpu_compress_tables(ctx, datas, acceleration=1):
+def gpu_compress_tables(ctx, datas, acceleration=1, hc_level=None):
     import lz4_amd
     s = torch.cuda.current_stream().cuda_stream
     caps = [lz4_amd.compress_bound(len(d)) for d in datas]
@@ -38,7 +38,8 @@ def gpu_compress_tables(ctx, datas, acceleration=1):
     dsts = [torch.full((c + 64,), 0xEE, dtype=torch.uint8, device="cuda") for c in caps]
     stride = max(lz4_amd.hint_bytes(len(d)) for d in datas)
     hints = torch.full((len(datas), stride), 0xEE, dtype=torch.uint8, device="cuda")
-    plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, lz4_amd.BlockTable([x.data_ptr() for x in srcs], [len(d) for d in datas], [x.data_ptr() for x in dsts], caps))
+    tab = lz4_amd.BlockTable([x.data_ptr() for x in srcs], [len(d) for d in datas], [x.data_ptr() for x in dsts], caps)
+    plan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS, tab) if hc_level is None else lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS_HC, tab, level=hc_level)
     plan.attach_hints(hints.data_ptr(), stride)
     if acceleration != 1:
         plan.set_acceleration(acceleration)
@@ -213,3 +214,20 @@ def test_tables_made_while_decoding_foreign_blocks(ctx, ocodec, reflib, datagen)
     for d, (r, o) in zip(wants, outs):
         assert r == len(d) and o == d, len(d)
     assert used == good and rejected == 0, (used, rejected, good)
+
+
+@pytest.mark.parametrize("level", [9, 2, 12])
+def test_hc_compressor_tables_name_real_sequences_and_are_used(ctx, ocodec, datagen, level):
+    """lz4amd_k_compress_hc writes the tables as well (its emit lanes; one row distance per block): rows are real sequences, and
+    the decoder parses every block from its table - configs[3]'s blocks then decode like the fast compressor's."""
+    datas = [datagen(262144, 60, 3), datagen(200000, 60, 2), datagen(300000, 90, 4), datagen(50000, 0, 5), datagen(100, 50, 1), datagen(13, 50, 0), b"z" * 11,
+             datagen(5000, 20, 1), datagen(131073, 60, 1), datagen(1 << 20, 60, 7), b"\x00" * 300000, b"abcd" * 70000, os.urandom(70000), b"a" * 40000 + os.urandom(3000) + b"a" * 40000]
+    comps, tables = gpu_compress_tables(ctx, datas, hc_level=level)
+    for d, c, t in zip(datas, comps, tables):
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        th.check_table(c, t, len(d))
+    outs, used, rejected = gpu_decompress_tables(ctx, comps, [len(d) for d in datas], tables, salign=3)
+    for d, (r, o) in zip(datas, outs):
+        assert r == len(d) and o == d
+    assert used == len(datas) and rejected == 0

@@ -378,3 +378,41 @@ def test_small_blocks_of_compressible_data_get_their_tables(emu, ocodec, datagen
     assert used == len(datas) and rejected == 0
     for d, (r, o) in zip(datas, outs):
         assert r == len(d) and o == d
+
+
+def emu_compress_hc_tables(emu, datas, level):
+    n = len(datas)
+    caps = [len(d) + len(d) // 255 + 16 for d in datas]
+    srcs = [ctypes.create_string_buffer(d, len(d)) if d else ctypes.create_string_buffer(1) for d in datas]
+    dsts = [ctypes.create_string_buffer(c + 64) for c in caps]
+    stride = max(hint_bytes(len(d)) for d in datas)
+    hraw = ctypes.create_string_buffer(stride * n + 16)
+    hbase = (ctypes.addressof(hraw) + 15) & ~15
+    sp = (ctypes.c_void_p * n)(*[ctypes.addressof(s) for s in srcs])
+    dp = (ctypes.c_void_p * n)(*[ctypes.addressof(d) for d in dsts])
+    ss = (ctypes.c_int32 * n)(*[len(d) for d in datas]); dc = (ctypes.c_int32 * n)(*caps); res = (ctypes.c_int32 * n)()
+    emu.emu_compress_hc_batch_hints(sp, ss, dp, dc, res, n, 0, level, None, ctypes.c_void_p(hbase), ctypes.c_uint64(stride))
+    off = hbase - ctypes.addressof(hraw)
+    return [dsts[i].raw[:res[i]] for i in range(n)], [hraw.raw[off + i * stride: off + (i + 1) * stride] for i in range(n)]
+
+
+@pytest.mark.parametrize("level", [9, 2, 12])
+def test_hc_compressor_tables_name_real_sequences_and_are_used(emu, ocodec, datagen, level):
+    """lz4amd_k_compress_hc writes the same entry-point tables as the fast compressor (its emit lanes, one row per 2^k sequences, k
+    per block): every row is a sequence of the block's real token chain, the blocks are byte for byte what they are without the
+    table, and the decoder parses all of them from their tables."""
+    datas = [datagen(200000, 60, 2), datagen(262144, 60, 3), datagen(300000, 90, 4), datagen(50000, 0, 5), datagen(100, 50, 1), datagen(13, 50, 0), b"z" * 11,
+             datagen(5000, 20, 1), datagen(131073, 60, 1), b"\x00" * 300000, b"abcd" * 70000, os.urandom(70000), b"a" * 40000 + os.urandom(3000) + b"a" * 40000]
+    if level != 9:
+        datas = datas[:6] + datas[9:11]
+    comps, tables = emu_compress_hc_tables(emu, datas, level)
+    plain = tk.emu_compress_hc(emu, datas, level)
+    for d, c, t, (pr, pc) in zip(datas, comps, tables, plain):
+        assert c == pc and pr == len(c)
+        ro, o = ocodec.decompress(c, len(d))
+        assert ro == len(d) and o == d
+        check_table(c, t, len(d))
+    outs, used, rejected = emu_decompress_tables(emu, comps, [len(d) for d in datas], tables, salign=5)
+    for d, (r, o) in zip(datas, outs):
+        assert r == len(d) and o == d
+    assert used == len(datas) and rejected == 0

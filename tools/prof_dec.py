@@ -12,7 +12,7 @@ pct = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 hc = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = lz4_amd.Context(0)
 data = torch.from_numpy(gen_data(nb * bs, pct, 0)).cuda()
-use_hints = not hc and not os.environ.get("NOHINTS")
+use_hints = not os.environ.get("NOHINTS")
 hints = torch.zeros((nb, lz4_amd.hint_bytes(bs)), dtype=torch.uint8, device="cuda") if use_hints else None
 comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs, hc_level=(hc or None), hints=hints)
 out, res, plan = lz4_amd.decompress_blocks(ctx, comp, csizes, bs, nb * bs, hints=hints)
