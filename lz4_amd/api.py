@@ -139,6 +139,21 @@ class Plan:
                                                            flags, int(initial_prefix)), "lz4amd_plan_create_decompress_chained")
         return self
 
+    @classmethod
+    def compress_with_history(cls, ctx, table, prefix_sizes):
+        """LZ4AMD_OP_COMPRESS where block i may reference the prefix_sizes[i] bytes of source right before it (linked blocks:
+        lz4amd_plan_create_compress_prefix)."""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.ctx, self.op, self.table = ctx, OP_COMPRESS, table
+        pre = (ctypes.c_int * table.n)(*[int(x) for x in prefix_sizes])
+        L = lib()
+        L.lz4amd_plan_create_compress_prefix.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        _check(L.lz4amd_plan_create_compress_prefix(ctx._h, ctypes.byref(self._h), table.n, table.src_ptrs, table.src_sizes,
+                                                    table.dst_ptrs, table.dst_caps, pre), "lz4amd_plan_create_compress_prefix")
+        return self
+
     def attach_hints(self, d_hints, stride):
         """Entry-point tables: block i's at d_hints + i * stride (written by a compress plan, read by a decompress plan)."""
         _check(lib().lz4amd_plan_attach_hints(self._h, ctypes.c_void_p(int(d_hints) if d_hints else None), int(stride)), "lz4amd_plan_attach_hints")

@@ -59,6 +59,12 @@
 #define DTRACE(...) do {} while (0)
 #endif
 
+#ifndef LZ4AMD_DEC_NEAR_POLL
+#define LZ4AMD_DEC_NEAR_POLL 0       // developer knob: a piece whose source lies at most this many regions below its own waits on the source's chunk flags, not on the source region's completion
+#endif
+#ifndef LZ4AMD_DEC_HEAD_PRIO
+#define LZ4AMD_DEC_HEAD_PRIO 0       // developer knob: regions this close to the lowest open one are composed at raised issue priority
+#endif
 namespace lz4amd {
 
 using DecBatch = ::lz4amd_dec_params;     // argument block (lz4amd_params.h)
@@ -958,6 +964,22 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
                             if (sa_ && !rdyA) { const uint32_t r = (keyA + an - 1) >> kRegionShift; wr = r < C.R ? r + 1 : 0u; }
                             if (sb_ && !rdyB) { const uint32_t r = (keyB0 + ((packB0 >> 4) & 31u) - 1) >> kRegionShift; if (r < C.R && r + 1 > wr) wr = r + 1; }
                             wr = wave_readlane(wave_incl_max_u32(wr), 63);
+#if LZ4AMD_DEC_NEAR_POLL
+                            if (wr && C.R + 1 - wr <= LZ4AMD_DEC_NEAR_POLL) {
+                                // the source is in a region just below this one: a chain of near matches (a stream that copies from what it has just
+                                // written: LZ4_compress_HC's output, the reference's nearest-occurrence matches).  Waiting for that whole region makes
+                                // the chain advance a region at a time; the waiting lanes look at their own sources' flags instead - a chunk is
+                                // flagged as soon as it is final -, the wave goes on when one of them is in
+                                for (;;) {
+                                    bool in = false;
+                                    if (sa_ && !rdyA) in = range_is_final(C, keyA, keyA + an - 1);
+                                    if (sb_ && !rdyB && !in) in = range_is_final(C, keyB0, keyB0 + ((packB0 >> 4) & 31u) - 1);
+                                    if (__any(in)) break;
+                                    if (uload(&misc[M_ABORT])) return;
+                                    spin_pause();
+                                }
+                            } else
+#endif
                             if (wr) {
                                 const uint32_t* mark = (const uint32_t*)(smem + kOffRegDone) + (wr - 1) % kSlots;
                                 while (uload(mark) != wr) { if (uload(&misc[M_ABORT])) return; spin_pause(); }
@@ -1074,7 +1096,15 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
             ts = t; n_lead = n_cov = 0; }
         uint64_t tr = 0; uint32_t ni = 0;
         DTRACE("region R=%u x0=%u x1=%u j0=%u nrec=%u g=%u\n", R, C.x0, C.x1, C.j0, C.nrec, C.g);
+#if LZ4AMD_DEC_HEAD_PRIO
+        // the lowest open regions are what every other region in flight may be waiting for: their waves go first on their SIMDs
+        const bool head = R <= C.g + LZ4AMD_DEC_HEAD_PRIO - 1;
+        if (head) wave_priority(2);
+#endif
         copy_region(C, dst, w, prof != nullptr, tr, ni);
+#if LZ4AMD_DEC_HEAD_PRIO
+        if (head) wave_priority(0);
+#endif
         n_iters += ni; n_retried += ni ? 1u : 0u;
         DTRACE("region R=%u done\n", R);
         k++;

@@ -24,7 +24,12 @@ def main():
     files = {"kernel_stats": f"{tag}_prof/{tag}_results.txt", "pmc_fetch": f"{tag}_pmc_fetch/{tag}f_results.txt",
              "pmc_write": f"{tag}_pmc_write/{tag}w_results.txt", "pmc_sq1": f"{tag}_pmc_sq1/{tag}s1_results.txt",
              "pmc_sq2": f"{tag}_pmc_sq2/{tag}s2_results.txt", "hc_kernel_stats": f"{tag}_prof_hc/{tag}hc_results.txt",
-             "hc_pmc_fetch": f"{tag}_pmc_fetch_hc/{tag}hf_results.txt", "hc_pmc_write": f"{tag}_pmc_write_hc/{tag}hw_results.txt"}
+             "hc_pmc_fetch": f"{tag}_pmc_fetch_hc/{tag}hf_results.txt", "hc_pmc_write": f"{tag}_pmc_write_hc/{tag}hw_results.txt",
+             "hc_pmc_sq1": f"{tag}_pmc_sq1_hc/{tag}hs_results.txt",
+             "nohints_kernel_stats": f"{tag}_prof_nohints/{tag}nh_results.txt", "nohints_pmc_fetch": f"{tag}_pmc_fetch_nohints/{tag}nhf_results.txt",
+             "nohints_pmc_write": f"{tag}_pmc_write_nohints/{tag}nhw_results.txt", "nohints_pmc_sq1": f"{tag}_pmc_sq1_nohints/{tag}nhs_results.txt",
+             "refdec_kernel_stats": f"{tag}_prof_refdec/{tag}rd_results.txt", "refdec_pmc_fetch": f"{tag}_pmc_fetch_refdec/{tag}rdf_results.txt",
+             "refdec_pmc_write": f"{tag}_pmc_write_refdec/{tag}rdw_results.txt", "refdec_pmc_sq1": f"{tag}_pmc_sq1_refdec/{tag}rds_results.txt"}
     for k, f in files.items():
         if os.path.exists(os.path.join(g, f)):
             shutil.copy(os.path.join(g, f), os.path.join(ROOT, "profiles", f"{name}_rocprof_{k}.txt"))
@@ -50,10 +55,19 @@ def main():
         a, b = counters(hf).get("lz4amd_k_compress_hc"), counters(hw).get("lz4amd_k_compress_hc")
         if a and b:
             doc["compress_hc"] = {"FETCH_SIZE_KiB": a, "WRITE_SIZE_KiB": b, "hbm_bytes_per_launch": int((a * fcorr + b * wcorr) * 1024)}
+    # the decoder on plain LZ4 blocks (no tables): the step's own blocks (bench.py --no-hints) and blocks the reference compressed (tools/prof_refdec.py)
+    for key, fk, wk in (("decompress_without_tables", "nohints_pmc_fetch", "nohints_pmc_write"), ("decompress_reference_input", "refdec_pmc_fetch", "refdec_pmc_write")):
+        a, b = os.path.join(g, files[fk]), os.path.join(g, files[wk])
+        if os.path.exists(a) and os.path.exists(b):
+            x, y = counters(a).get("lz4amd_k_decompress"), counters(b).get("lz4amd_k_decompress")
+            if x and y:
+                doc[key] = {"FETCH_SIZE_KiB": x, "WRITE_SIZE_KiB": y, "hbm_bytes_per_launch": int((x * fcorr + y * wcorr) * 1024),
+                            "source": f"profiles/{name}_rocprof_{fk}.txt, _{wk.split('_', 1)[1]}.txt"}
+    doc["canonical_set"] = f"profiles/{name}_* (one tools/gpu_round.sh visit on the kernel sources named above); older r0N_* files are earlier rounds' records"
     # VALU issue: SQ_INSTS_VALU wave-instructions per dispatch and the kernel's average duration in the same pass.  A SIMD's
-    # VALU pipe takes one wave64 instruction per 4 cycles (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles in every pass),
-    # so instructions x 4 / (CUs x 4 SIMDs) are the pipe-cycles each SIMD spends; against duration x 2.4 GHz (the engine's
-    # top clock: the fraction is a lower bound) that is how full the pipes are.
+    # VALU pipe takes one wave64 instruction per ~4.2 cycles in mixed code (measured: profiles/r05_valu_issue.txt; 2.4 only for runs
+    # of plain add / logic / shift), so instructions x 4.2 / (CUs x 4 SIMDs) are the pipe-cycles each SIMD spends; against duration x 2.4 GHz
+    # (the engine's top clock: the fraction is a lower bound) that is how full the pipes are.
     sq = os.path.join(g, files["pmc_sq1"])
     if os.path.exists(sq):
         dur, valu = {}, {}
@@ -66,7 +80,7 @@ def main():
                 valu[m.group(1)] = float(m.group(2))
         for key, kern in (("compress", "lz4amd_k_compress"), ("decompress", "lz4amd_k_decompress")):
             if key in doc and kern in dur and kern in valu:
-                pipe = valu[kern] * 4.0 / (256 * 4)
+                pipe = valu[kern] * 4.2 / (256 * 4)
                 doc[key]["valu"] = {"SQ_INSTS_VALU": valu[kern], "kernel_us_in_that_pass": dur[kern],
                                     "pipe_cycles_per_simd": int(pipe), "frac_of_kernel_cycles_at_2.4GHz": round(pipe / (dur[kern] * 2400.0), 3),
                                     "source": f"profiles/{name}_rocprof_pmc_sq1.txt"}
