@@ -16,6 +16,9 @@ def counters(path):
         m = re.match(r"\s+(lz4amd_k_\w+)\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)\s+\(n=(\d+)\)", line)
         if m:
             out[m.group(1)] = float(m.group(3))
+        m = re.match(r"\s+(?:void )?(lz4amd_k_stream_copy)<.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)\s+\(n=(\d+)\)", line)      # (the calibration kernel's shapes all move 1 GiB)
+        if m and m.group(1) not in out:
+            out[m.group(1)] = float(m.group(3))
     return out
 
 def main():

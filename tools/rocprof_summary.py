@@ -29,7 +29,7 @@ def main(path):
     if rows:
         print("# PMC counters (average per dispatch)")
         for name, ctr, v, n in rows:
-            if name.startswith("lz4amd"):
+            if "lz4amd" in name:
                 print("  %-45s %-24s %18.1f  (n=%d)" % (name[:45], ctr, v, n))
 
 
