@@ -330,6 +330,27 @@ def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, copy_gbps, level
             if n_s <= len(cs):
                 res["ratio_vs_reference"] = round(cb["ref_comp_bytes"] / sum(cs[:n_s]), 4)
     if level == 9:
+        # highly repetitive data (copies of copies: datagen -P99): where this search is NOT within the reference's +-3 % (no look-back through later
+        # positions' chains, lz4hc.c:906-960) - the gap is part of the line
+        try:
+            nrep = 1024
+            rhost = gen_data(nrep * bs, 99, seed)
+            rdata = torch.from_numpy(rhost).to(data.device)
+            rtab = lz4_amd.BlockTable([rdata.data_ptr() + i * bs for i in range(nrep)], [bs] * nrep, [comp.data_ptr() + i * stride for i in range(nrep)], [stride] * nrep)
+            rplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS_HC, rtab, level=9)
+            rplan.launch(stream)
+            rcs = rplan.results(stream)
+            rms = min(rplan.launch_timed(stream)[0][0] for _ in range(2))
+            rep = {"workload": "%d x %d-byte blocks of datagen -P99, level 9" % (nrep, bs), "ratio": round(nrep * bs / sum(rcs), 4),
+                   "compress_GBps": round(nrep * bs / (rms * 1e-3) / 1e9, 2)}
+            if with_cpu:
+                cbr = cpu_baseline_hc(bs, 99, seed, 9)
+                if cbr and "ref_comp_bytes" in cbr and cbr["sample_blocks"] <= nrep:
+                    rep["ratio_vs_reference"] = round(cbr["ref_comp_bytes"] / sum(rcs[:cbr["sample_blocks"]]), 4)
+                    rep["reference_GBps"] = cbr["value"]
+            res["repetitive"] = rep
+        except Exception as e:
+            res["repetitive"] = {"error": str(e)}
         # levels 10-12 (the optimal parse over the same search), same blocks: one timed launch, bit-exact round trip
         try:
             oplan = lz4_amd.Plan(ctx, lz4_amd.OP_COMPRESS_HC, tab, level=12)

@@ -50,6 +50,9 @@
 #ifndef LZ4AMD_CMP_FLUSH_IN_A
 #define LZ4AMD_CMP_FLUSH_IN_A 1    // developer knob: 0: the tile before leaves after the barrier, one chunk per thread
 #endif
+#ifndef LZ4AMD_CMP_IDLE_SETTLE
+#define LZ4AMD_CMP_IDLE_SETTLE 1
+#endif
 #ifndef LZ4AMD_CMP_LDS_BARRIER
 #define LZ4AMD_CMP_LDS_BARRIER 0      // developer knob: 1: the tile barrier waits for LDS operations only (measured: no difference)
 #endif
@@ -1189,7 +1192,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             }
         } else {
             // -- A0: one wave settles tile k-1 first
-            if (w == kSettleWave && prev_nstrips) {
+            // (a tile of eight strips or fewer - a small block's, a block's first ones - leaves the upper waves without a strip: one of
+            //  them settles, and they write out tile k-1 while the lower ones match)
+            if (w == (LZ4AMD_CMP_IDLE_SETTLE && nstrips <= 8 ? 8u : (uint32_t)kSettleWave) && prev_nstrips) {
                 settle_tile(smem, par ^ 1, prev_nstrips, prev_g0, prev_t0, prev_strip_len, prev_t1, n, cap, a0);
                 if (lane_id() == 0) lds_store_release_local(&misc[CM_READY], tiles_parsed);
             }

@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, lz4_amd
 from bench import gen_data
-nb, bs = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 4 << 20
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+bs = int(os.environ.get("BS", 4 << 20))
 pct = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 accel = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = lz4_amd.Context(0)
@@ -22,7 +23,7 @@ if "match" in os.environ.get("LZ4AMD_LIB", ""):
     names = ["records", "(emit, wave 0 >> 4)", "probe + runs + list", "-", "-", "list fence", "measure", "select"]
 else:
     names = ["loop top (prefetch issue, barrier)", "settle + match (wave 0)", "barrier wait after emit", "insert + flush", "emit (wave 0)", "match+emit: slowest wave", "match+emit: fastest wave", "match+emit: mean wave"]
-tiles = bs // 8192
+tiles = max(1, bs // int(os.environ.get("TILE", 8192)))
 for k, name in enumerate(names):
     d = [w[i * 8 + k] for i in range(n // 8)]
     print("  %-40s cycles per block: median %10d  max %10d   per tile %7d" % (name, statistics.median(d), max(d), statistics.median(d) // tiles))
