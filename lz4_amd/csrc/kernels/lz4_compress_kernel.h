@@ -50,6 +50,15 @@
 #ifndef LZ4AMD_CMP_FLUSH_IN_A
 #define LZ4AMD_CMP_FLUSH_IN_A 1    // developer knob: 0: the tile before leaves after the barrier, one chunk per thread
 #endif
+#ifndef LZ4AMD_CMP_ONE_BARRIER
+#define LZ4AMD_CMP_ONE_BARRIER 1
+#endif
+#ifndef LZ4AMD_CMP_EARLY_COMMIT
+#define LZ4AMD_CMP_EARLY_COMMIT 1
+#endif
+#ifndef LZ4AMD_CMP_RING
+#define LZ4AMD_CMP_RING 82000
+#endif
 #ifndef LZ4AMD_CMP_IDLE_SETTLE
 #define LZ4AMD_CMP_IDLE_SETTLE 1
 #endif
@@ -75,7 +84,7 @@ enum : uint32_t {
     kTileMaxSmall = 2048,              // smaller blocks (4-byte hash, like the reference: lz4.c:1389)
     kTileMin = 1024,
     kStripMin = 256,
-    kSrcRing = 76u << 10,              // the 64 KB window + the tile that is parsed + 16 bytes, and 4 KB to spare (the next tile waits in registers until the parse is over)
+    kSrcRing = LZ4AMD_CMP_RING,                  // the 64 KB window + the tile that is parsed + the next tile (its granules go in while this one is parsed) + 16 bytes + 48 to spare (a match is extended 8 bytes back below the window)
     kSrcPad = 32,                      // mirror of the ring's first bytes: unaligned reads never wrap
     kHashBits = 13,
     kStrips = 16,                      // strips of a tile, one wave each
@@ -99,8 +108,7 @@ enum : uint32_t {
     kCOffTab = kCOffStrip + 2 * kStripFields * kCmpWaves * 4,   // u32[1 << kHashBits]
     kCOffRecs = kCOffTab + (4u << kHashBits),             // MatchRec[2][kRecsPerTile]: a tile's strips behind one another (kRecsPerPair or kRecsPerStrip slots each)
     kCOffEnds = kCOffRecs + 2 * kRecsPerTile * 8,                   // u16[2][kRecsPerTile] where a record's match ends (from the strip's start)
-    kCOffEncp = kCOffEnds + 2 * kRecsPerTile * 2,                   // u16[2][kRecsPerTile] encoded bytes of the strip's records before it
-    kCOffCandS = kCOffEncp + 2 * kRecsPerTile * 2,                  // u32[kCmpWaves][kCandCap] a candidate's first probe slot | distance << 8
+    kCOffCandS = kCOffEnds + 2 * kRecsPerTile * 2,                  // u32[kCmpWaves][kCandCap] a candidate's first probe slot | distance << 8
     kCOffCandE = kCOffCandS + kCmpWaves * kCandCap * 4,             // u8[kCmpWaves][kCandCap] its last probe slot
     kCOffScr = kCOffCandE + kCmpWaves * kCandCap,                   // u32[kCmpWaves][64] the emit's scatter space
     kCOffCarry = kCOffScr + kCmpWaves * 64 * 4,                   // u8[2][16]: encoded bytes of the 16-byte chunk a tile's output ends in (they leave with the next tile)
@@ -110,12 +118,13 @@ enum : uint32_t {
 };
 static_assert(kCmpLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert(kCOffRing % 16 == 0 && kCOffStage % 16 == 0 && kCOffCarry % 16 == 0 && kSrcRing % 16 == 0 && kCOffRecs % 8 == 0 && kCOffCandS % 4 == 0 && kCOffScr % 4 == 0, "LDS alignment");
-static_assert(kSrcRing >= 65536 + kTileMax + 16 + 1024, "the ring holds the window of the tile that is parsed");
+static_assert(kSrcRing >= 65536 + (LZ4AMD_CMP_EARLY_COMMIT ? 2 : 1) * kTileMax + 16 + 48, "the ring holds the window of the tile that is parsed and the tile after it");
 enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY = 4,     // CM_READY: tiles whose output offsets are fixed
-                  CM_EMITQ = 5,        // next strip of the settled tile to write out (handed to whichever wave is free)
-                  CM_INSQ = 48,        // next piece of a full tile to insert into the table (likewise)
-                  CM_EMITDONE = 49,    // strips of the settled tile that are written out (a bit each)
-                  CM_FLUSHQ = 50,      // next 64 chunks of the staging buffer to store (full tiles: whichever wave is free)
+                  // work queues and counts of a tile, two sets by tile parity (a full tile has one barrier: a set is reset during the tile after):
+                  CM_EMITQ = 48,       // + parity: next strip of the settled tile to write out (handed to whichever wave is free)
+                  CM_INSQ = 50,        // next piece of a full tile to insert into the table (likewise)
+                  CM_EMITDONE = 52,    // strips of the settled tile that are written out (a bit each)
+                  CM_FLUSHQ = 54,      // next 64 chunks of the staging buffer to store (full tiles: whichever wave is free)
                   CM_SEQS = 6,         // sequences of the tiles settled so far
                   CM_HOVER = 7,        // entry-point table: a row did not fit the table's room (the table is then left invalid)
                   CM_ROWS = 32,        // ... rows of the tiles settled so far
@@ -352,7 +361,7 @@ __device__ __forceinline__ uint32_t probe_list(const uint8_t* ring, const uint32
 struct ParseState { uint32_t nseq, enc, ll0, cur; };      // records so far, their encoded bytes, the first one's literals, end of the last match taken (first byte not yet covered)
 // One pass of measure / select / records, lane = run: the run's first probe position qs, its distance d, a = the first byte
 // its probes did not compare (last probe + 4).  Runs come in position order; st.cur carries the end of what was taken before.
-__device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap, uint32_t cs, uint32_t cs_off,
+__device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, uint16_t* ends, uint32_t rec_cap, uint32_t cs, uint32_t cs_off,
                                            uint32_t mlimit, uint32_t last_q, bool have, uint32_t qs, uint32_t d, uint32_t a, ParseState& st) {
     const uint32_t lane = lane_id();
     // ---- measure
@@ -438,18 +447,24 @@ __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, 
     // ---- records
     const uint32_t ri = st.nseq + lanes_below(taken);
     uint32_t my_enc = 0, my_ll = 0;
+    uint32_t my_mo = 0;
     if (mine) {
         uint32_t start = prev_end;
         if (qs > prev_end) { uint32_t bk = back; if (bk > qs - prev_end) bk = qs - prev_end; start = qs - bk; }
         my_ll = start - prev_end;
         const uint32_t mlen = e - start;
-        MatchRec r; r.ll = my_ll; r.mo = d | ((mlen - kMinMatch) << 16);
-        recs[ri] = r;
+        my_mo = d | ((mlen - kMinMatch) << 16);
         my_enc = enc_size(my_ll, mlen - kMinMatch);
     }
     if (st.nseq == 0) st.ll0 = wave_readlane(my_ll, (uint32_t)__ffsll((long long)taken) - 1);
     const uint32_t enc_incl = wave_incl_sum(my_enc);
-    if (mine) { ends[ri] = (uint16_t)(e - cs); encp[ri] = (uint16_t)(st.enc + enc_incl - my_enc); }
+    if (mine) {
+        // (ll's upper half: the encoded bytes of the strip's records before this one - what the settle subtracts when an earlier strip's
+        //  match covers the strip's first records; a tile's literal runs and a strip's encoded bytes are far below 64 K)
+        MatchRec r; r.ll = my_ll | ((st.enc + enc_incl - my_enc) << 16); r.mo = my_mo;
+        recs[ri] = r;
+        ends[ri] = (uint16_t)(e - cs);
+    }
     st.enc += wave_readlane(enc_incl, 63);
     st.nseq += ntaken;
     if (last_e > st.cur) st.cur = last_e;
@@ -468,7 +483,7 @@ __device__ __forceinline__ void strip_summary(uint32_t* strip, uint32_t si, cons
 // One wave parses the piece [pcs, pce) of the strip that starts at cs, all by itself: probe, list, and passes over the list; more
 // runs than the list holds are rare: the piece is simply probed again for the next ones (the table is frozen: same answers).
 template <bool SMALL>
-__device__ __forceinline__ void parse_piece(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap,
+__device__ __forceinline__ void parse_piece(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint32_t rec_cap,
                                             uint32_t* candS, uint8_t* candE, uint32_t cs, uint32_t pcs, uint32_t pce, uint32_t mlimit, uint32_t last_q,
                                             uint32_t (&probe_h)[2], uint32_t SH, ParseState& st) {
     const uint32_t lane = lane_id();
@@ -485,7 +500,7 @@ __device__ __forceinline__ void parse_piece(const uint8_t* ring, const uint32_t*
             const bool have = pl + lane < nlist;
             uint32_t S = 0, E = 0;
             if (have) { S = candS[pl + lane]; E = candE[pl + lane]; }
-            parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, pcs + ((S & 255u) << SH), have ? S >> 8 : 1u, pcs + (E << SH) + kMinMatch, st);
+            parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, pcs + ((S & 255u) << SH), have ? S >> 8 : 1u, pcs + (E << SH) + kMinMatch, st);
         }
         if (lo + kCandCap >= total) break;
         wave_lds_fence_local();                                            // (the list is rewritten by the next probe)
@@ -493,21 +508,21 @@ __device__ __forceinline__ void parse_piece(const uint8_t* ring, const uint32_t*
 }
 // ... a whole strip [cs, ce) of at most 256 << SH bytes: strip `w` of its tile (records, summary)
 template <bool SMALL>
-__device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap, uint32_t* strip,
+__device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint32_t rec_cap, uint32_t* strip,
                                             uint32_t* candS, uint8_t* candE, uint32_t w, uint32_t n, uint32_t cs, uint32_t ce, uint32_t tend, uint32_t (&probe_h)[2], uint32_t SH) {
     ParseState st; st.nseq = 0; st.enc = 0; st.ll0 = 0; st.cur = cs;
     // positions that may start a match: q <= n - 12; matches end <= n - 5 and <= tend
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         // a match may run past the strip up to the tile's end: the strips it covers give way (resolve_overruns)
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
-        parse_piece<SMALL>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, ce, mlimit, n - kMfLimit, probe_h, SH, st);
+        parse_piece<SMALL>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs, ce, mlimit, n - kMfLimit, probe_h, SH, st);
     }
     strip_summary(strip, w, st, ce);
 }
 // The measuring wave of a pair: the pair's 1 KB [cs, cs + 1024) as one strip (number `si` of its tile).  Its two pieces were probed and
 // listed by the pair's two waves (nA / nB runs, lists LA / LB: the first piece's wave is the even one); the lists are walked
 // behind one another, 64 runs a pass.  A piece with more runs than its list holds is parsed the single-wave way (probed again).
-__device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint16_t* encp, uint32_t rec_cap, uint32_t* strip,
+__device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint32_t rec_cap, uint32_t* strip,
                                                  const uint32_t* LAs, const uint8_t* LAe, uint32_t nA, const uint32_t* LBs, const uint8_t* LBe, uint32_t nB,
                                                  uint32_t* candS, uint8_t* candE, uint32_t si, uint32_t n, uint32_t cs, uint32_t tend,
                                                  uint32_t* table_free, uint32_t gen, const uint32_t* late_b = nullptr) {      // late_b: the second piece's list comes late (its wave settled the tile before first): the first piece does not wait for it; table_free: told (gen) when this wave probes no more
@@ -525,9 +540,9 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
                     const bool have = pl + lane < nA;
                     uint32_t S = 0, E = 0;
                     if (have) { S = LAs[pl + lane]; E = LAe[pl + lane]; }
-                    parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, cs + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + (E << 1) + kMinMatch, st);
+                    parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, cs + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + (E << 1) + kMinMatch, st);
                 }
-            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st); wave_lds_fence_local(); }
+            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st); wave_lds_fence_local(); }
             uint32_t pv;
             while (((pv = __builtin_amdgcn_readfirstlane(lds_load_acquire_local(late_b))) >> 16) != gen) spin_pause();
             nB = pv & 0xFFFFu;
@@ -537,9 +552,9 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
                     const bool have = pl + lane < nB;
                     uint32_t S = 0, E = 0;
                     if (have) { S = LBs[pl + lane]; E = LBe[pl + lane]; }
-                    parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, cs + 512 + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + 512 + (E << 1) + kMinMatch, st);
+                    parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, cs + 512 + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + 512 + (E << 1) + kMinMatch, st);
                 }
-            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st); }
+            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st); }
         } else if (nA <= kCandCap && nB <= kCandCap) {
             if (lane == 0) lds_store_release_local(table_free, gen);
             const uint32_t cs_off = src_ring_off(cs), total = nA + nB;
@@ -549,13 +564,13 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
                 uint32_t S = 0, E = 0;
                 if (have) { S = inB ? LBs[i - nA] : LAs[i]; E = inB ? LBe[i - nA] : LAe[i]; }
                 const uint32_t base = cs + (inB ? 512u : 0u);
-                parse_pass(ring, recs, ends, encp, rec_cap, cs, cs_off, mlimit, last_q, have, base + ((S & 255u) << 1), have ? S >> 8 : 1u, base + (E << 1) + kMinMatch, st);
+                parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, base + ((S & 255u) << 1), have ? S >> 8 : 1u, base + (E << 1) + kMinMatch, st);
             }
         } else {
             uint32_t ph[2];
-            parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st);
+            parse_piece<false>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st);
             wave_lds_fence_local();
-            parse_piece<false>(ring, tab, recs, ends, encp, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st);
+            parse_piece<false>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st);
         }
     }
     strip_summary(strip, si, st, ce);
@@ -670,7 +685,7 @@ __device__ __forceinline__ void emit_strip_plain(const MatchRec* recs, const uin
     for (uint32_t i = 0; i < nk; i++) {
         const MatchRec r = recs[i];
         const uint32_t mlm4 = r.mo >> 16, off = r.mo & 0xFFFFu;
-        const uint32_t tl = i == 0 ? cs + r.ll - ipos : r.ll;
+        const uint32_t tl = i == 0 ? cs + (r.ll & 0xFFFFu) - ipos : (r.ll & 0xFFFFu);
         const uint32_t lit_d = opos + 1 + lit_hdr_ext(tl);
         if (H.table) hint_row(H, lane == 0, strip[S_ORD * kCmpWaves + w] + i, opos, ipos);
         if (lane == 0) {
@@ -705,7 +720,7 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
         const uint32_t i = base + lane;
         const bool have = i < nk;
         uint32_t ll = 0, mlm4 = 0, off = 0, extra = 0;
-        if (have) { const MatchRec r = recs[i]; ll = r.ll; off = r.mo & 0xFFFFu; mlm4 = r.mo >> 16; }
+        if (have) { const MatchRec r = recs[i]; ll = r.ll & 0xFFFFu; off = r.mo & 0xFFFFu; mlm4 = r.mo >> 16; }      // (ll's upper half: parse_pass)
         if (i == 0) extra = carry;                       // literals inherited from earlier strips
         const uint32_t tl = ll + extra;
         const uint32_t lhdr = 1 + lit_hdr_ext(tl);       // token + the literal length's extension bytes
@@ -828,7 +843,7 @@ __device__ __forceinline__ void flush_end(char* smem, const FlushCtx& f, lz4amd_
 // (same offset, the bytes are the same), or goes as well when less than a minimal match is left - and its summary is
 // brought up to date.  One wave: a short serial walk over the strips settles where each one starts (a strip's own
 // overrun counts only if its last match survives), then lane k puts strip k right (binary search in the record ends).
-__device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs_tile, const uint16_t* ends_tile, const uint16_t* encp_tile, uint32_t rps,
+__device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs_tile, const uint16_t* ends_tile, uint32_t rps,
                                                  uint32_t nstrips, uint32_t g0, uint32_t t0, uint32_t strip_len, uint32_t t1, uint32_t n) {      // rps: record slots per strip
     const uint32_t lane = lane_id();
     const bool mine = lane < nstrips;
@@ -837,7 +852,6 @@ __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs
     const uint32_t nk = mine ? strip[S_N * kCmpWaves + lane] : 0, own_end = mine ? strip[S_END * kCmpWaves + lane] : 0;
     MatchRec* rk = recs_tile + lane * rps;
     const uint16_t* ek = ends_tile + lane * rps;
-    const uint16_t* pk = encp_tile + lane * rps;
     uint32_t q_last = 0;                                  // where my last match starts (strips whose last match runs over)
     if (own_end) q_last = own_end - ((rk[nk - 1].mo >> 16) + kMinMatch);
     if (!__any(own_end != 0)) {                           // nothing ran over in this tile
@@ -880,6 +894,8 @@ __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs
             first = nk; nk2 = 0; enc = 0; ll0 = 0; tail = ce > P ? ce - P : 0;
             if (f < nk) {
                 MatchRec r = rk[f];
+                const uint32_t enc_before = r.ll >> 16;              // encoded bytes of the records that go
+                r.ll &= 0xFFFFu;
                 const uint32_t ef = cs + ek[f], qf = ef - ((r.mo >> 16) + kMinMatch);
                 const uint32_t old_enc = enc_size(r.ll, r.mo >> 16), enc_total = strip[S_ENC * kCmpWaves + lane];
                 bool dropped = false;
@@ -891,15 +907,16 @@ __device__ __forceinline__ void resolve_overruns(uint32_t* strip, MatchRec* recs
                 if (!dropped) {
                     rk[f] = r;
                     first = f; nk2 = nk - f; ll0 = r.ll;
-                    enc = enc_total - pk[f] - old_enc + enc_size(r.ll, r.mo >> 16);
+                    enc = enc_total - enc_before - old_enc + enc_size(r.ll, r.mo >> 16);
                 } else if (f + 1 < nk) {
                     // its bytes [P, ef) are literals of the next record
                     MatchRec r2 = rk[f + 1];
+                    r2.ll &= 0xFFFFu;
                     const uint32_t old2 = enc_size(r2.ll, r2.mo >> 16);
                     r2.ll += ef - P;
                     rk[f + 1] = r2;
                     first = f + 1; nk2 = nk - f - 1; ll0 = r2.ll;
-                    enc = enc_total - pk[f + 1] - old2 + enc_size(r2.ll, r2.mo >> 16);
+                    enc = enc_total - (enc_before + old_enc) - old2 + enc_size(r2.ll, r2.mo >> 16);
                 }
                 if (nk2) { const uint32_t e_last = cs + ek[nk - 1]; tail = e_last < ce ? ce - e_last : 0; }
             }
@@ -953,8 +970,7 @@ __device__ __forceinline__ void settle_tile(char* smem, uint32_t pp, uint32_t ns
 #ifdef LZ4AMD_PROF_TILE
     const uint64_t ts0 = clock_ticks();
 #endif
-    resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kRecsPerTile, (const uint16_t*)(smem + kCOffEnds) + pp * kRecsPerTile,
-                     (const uint16_t*)(smem + kCOffEncp) + pp * kRecsPerTile, rps, nstrips, g0, t0, strip_len, t1, n);
+    resolve_overruns(strip_p, (MatchRec*)(smem + kCOffRecs) + pp * kRecsPerTile, (const uint16_t*)(smem + kCOffEnds) + pp * kRecsPerTile, rps, nstrips, g0, t0, strip_len, t1, n);
     wave_lds_fence_local();
 #ifdef LZ4AMD_PROF_TILE
     const uint64_t ts1 = clock_ticks();
@@ -1042,7 +1058,6 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const uint32_t sw = w;
     MatchRec* recs = (MatchRec*)(smem + kCOffRecs);                            // + parity * kRecsPerTile + strip * its slots
     uint16_t* ends = (uint16_t*)(smem + kCOffEnds);
-    uint16_t* encp = (uint16_t*)(smem + kCOffEncp);
     uint32_t* candS = (uint32_t*)(smem + kCOffCandS) + sw * kCandCap;
     uint8_t* candE = (uint8_t*)(smem + kCOffCandE) + sw * kCandCap;
     uint32_t* pairw = (uint32_t*)(smem + kCOffPair);
@@ -1073,7 +1088,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
-        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_EMITQ] = 0; misc[CM_INSQ] = 0; misc[CM_EMITDONE] = 0; misc[CM_FLUSHQ] = 0; misc[CM_SEQS] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0;
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_SEQS] = 0;
+        for (uint32_t i = CM_EMITQ; i < CM_FLUSHQ + 2; i++) misc[i] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0;
         for (uint32_t i = 0; i < 2 * kCmpWaves; i++) pairw[i] = 0;
 #ifdef LZ4AMD_PROF_TILE
         for (uint32_t i = 24; i < 30; i++) misc[i] = 0;
@@ -1110,7 +1126,6 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         uint32_t* strip_k = strip + par * kStripFields * kCmpWaves;
         MatchRec* recs_k = recs + par * kRecsPerTile;
         uint16_t* ends_k = ends + par * kRecsPerTile;
-        uint16_t* encp_k = encp + par * kRecsPerTile;
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
         tile_geometry(t1 >= pre ? t1 - pre : kTileMax * 4, small, nt_len, nt_strip);
@@ -1125,6 +1140,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #else
         __syncthreads();                                       // ring, table and tile k-1's records ready
 #endif
+        if (tid == 0) { misc[CM_EMITQ + (par ^ 1)] = 0; misc[CM_INSQ + (par ^ 1)] = 0; misc[CM_EMITDONE + (par ^ 1)] = 0; misc[CM_FLUSHQ + (par ^ 1)] = 0; }      // (the tile before's set: nobody looks at it any more)
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
         const bool parse = t0 >= pre;
         const uint32_t g0 = strip_origin(t0, tile_len, strip_len);
@@ -1161,6 +1177,11 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             if (pcs <= last_q) { nw = probe_list<false>(ring, tab, candS, candE, pcs, src_ring_off(pcs), q_hi, 0u, 1u, probe_h); probe_h_valid = true; }
             wave_lds_fence_local();
             if (lane_id() == 0) lds_store_release_local(&pairw[w], (gen << 16) | nw);
+#if LZ4AMD_CMP_EARLY_COMMIT
+            // the next tile's granules (fetched at the tile's top by the upper waves: they have arrived) go into the ring now: its slots hold
+            // bytes more than a window below this tile - nobody reads them any more
+            if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
+#endif
             RSTAMP(0);
             // roles: of the two waves of a pair one measures, one writes out; they swap every tile, and a SIMD (waves w, w + 4, w + 8, w + 12) has two of each
             const uint32_t role = (w ^ (w >> 2) ^ tiles_parsed) & 1u;
@@ -1181,9 +1202,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 const uint32_t* pS = (const uint32_t*)(smem + kCOffCandS) + pw * kCandCap;
                 const uint8_t* pE = (const uint8_t*)(smem + kCOffCandE) + pw * kCandCap;
                 const uint32_t si = w >> 1;
-                if (w & 1u) match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, encp_k + si * kRecsPerPair, kRecsPerPair, strip_k,
+                if (w & 1u) match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, kRecsPerPair, strip_k,
                                              pS, pE, np, candS, candE, nw, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen);
-                else match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, encp_k + si * kRecsPerPair, kRecsPerPair, strip_k,
+                else match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, kRecsPerPair, strip_k,
                                       candS, candE, nw, pS, pE, np, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen, late ? &pairw[pw] : nullptr);
 #if LZ4AMD_CMP_PRIO & 2
                 wave_priority(0);
@@ -1202,8 +1223,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             if (w < nstrips) {
                 const uint32_t cs = strip_lo(g0, t0, w, strip_len);
                 uint32_t ce = g0 + (w + 1) * strip_len; if (ce > t1) ce = t1;
-                if (small) match_strip<true>(ring, tab, recs_k + w * kRecsPerStrip, ends_k + w * kRecsPerStrip, encp_k + w * kRecsPerStrip, kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, 0u);
-                else match_strip<false>(ring, tab, recs_k + w * kRecsPerStrip, ends_k + w * kRecsPerStrip, encp_k + w * kRecsPerStrip, kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, stride4 ? 2u : 1u);
+                if (small) match_strip<true>(ring, tab, recs_k + w * kRecsPerStrip, ends_k + w * kRecsPerStrip, kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, 0u);
+                else match_strip<false>(ring, tab, recs_k + w * kRecsPerStrip, ends_k + w * kRecsPerStrip, kRecsPerStrip, strip_k, candS, candE, w, n, cs, ce, t1, probe_h, stride4 ? 2u : 1u);
                 // the lane probed positions cs + 8 * lane + {0, 2, 4, 6}: with 512-byte strips those are this thread's insert positions
                 probe_h_valid = !small && !stride4 && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
             }
@@ -1220,12 +1241,12 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #endif
             for (;;) {
                 uint32_t sx = 0;
-                if (lane_id() == 0) sx = atomicAdd(&misc[CM_EMITQ], 1u);
+                if (lane_id() == 0) sx = atomicAdd(&misc[CM_EMITQ + par], 1u);
                 sx = __builtin_amdgcn_readfirstlane(sx);
                 if (sx >= prev_nstrips) break;
                 emit_tile_strip(smem, par ^ 1, sx, w, prev_rps, src, dst, a0, ring_lo, H);
                 wave_lds_fence_local();
-                lds_or_release_local(&misc[CM_EMITDONE], 1u << sx);          // (every lane the same bit: a store by lane 0 alone, in this loop, hung the kernel on the device)
+                lds_or_release_local(&misc[CM_EMITDONE + par], 1u << sx);          // (every lane the same bit: a store by lane 0 alone, in this loop, hung the kernel on the device)
             }
         }
 #ifdef LZ4AMD_PROF_ROLES
@@ -1244,17 +1265,17 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             }
             for (;;) {
                 uint32_t px = 0;
-                if (lane_id() == 0) px = atomicAdd(&misc[CM_INSQ], 1u);
+                if (lane_id() == 0) px = atomicAdd(&misc[CM_INSQ + par], 1u);
                 px = __builtin_amdgcn_readfirstlane(px);
                 if (px >= kCmpWaves) break;
                 insert_unit(ring, tab, t0 + 512 * px + 8 * lane_id(), t1, n - kMfLimit, false, px == w && probe_h_valid, probe_h);
             }
             // -- A4: tile k-1's bytes leave, 64 chunks a time, once all its strips are written out
             if (LZ4AMD_CMP_FLUSH_IN_A && prev_nstrips && !misc[CM_FAIL]) {
-                while (uload_cm(&misc[CM_EMITDONE]) != (1u << prev_nstrips) - 1u) CMP_WAIT_PAUSE();
+                while (uload_cm(&misc[CM_EMITDONE + par]) != (1u << prev_nstrips) - 1u) CMP_WAIT_PAUSE();
                 for (;;) {
                     uint32_t fx = 0;
-                    if (lane_id() == 0) fx = atomicAdd(&misc[CM_FLUSHQ], 1u);
+                    if (lane_id() == 0) fx = atomicAdd(&misc[CM_FLUSHQ + par], 1u);
                     fx = __builtin_amdgcn_readfirstlane(fx);
                     if (fx >= kStageBytes / 1024) break;
                     const FlushCtx fj = flush_begin(smem, par ^ 1, a0, 64 * fx + lane_id());
@@ -1267,21 +1288,26 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #endif
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
+        // A full tile is done here - its pieces are in the table, the tile before has left, the next one's granules are in the ring - and has
+        // no second barrier: the one at the next tile's top is the only one.  A small tile:
+        const bool one_barrier = LZ4AMD_CMP_ONE_BARRIER && LZ4AMD_CMP_EARLY_COMMIT && LZ4AMD_CMP_FLUSH_IN_A && paired;
+        bool do_flush = false;
+        FlushCtx fc;
+        if (!one_barrier) {
         __syncthreads();
         if (prof) { const uint64_t t = clock_ticks(); tp[2] += t - tq; tq = t; }
         // -- B: tile k-1's bytes leave; everybody inserts tile k into the table (positions that may start a match) - unless it was a full
         //    tile, which its writing waves inserted while the measuring ones were still at it
-        const bool do_flush = prev_nstrips && !misc[CM_FAIL] && !(LZ4AMD_CMP_FLUSH_IN_A && paired);      // (a full tile's waves stored the tile before already)
-        if (tid == 0) { misc[CM_EMITQ] = 0; misc[CM_INSQ] = 0; misc[CM_EMITDONE] = 0; misc[CM_FLUSHQ] = 0; }      // (nobody looks at them between the two barriers)
-        FlushCtx fc;
+        do_flush = prev_nstrips && !misc[CM_FAIL] && !(LZ4AMD_CMP_FLUSH_IN_A && paired);      // (a full tile's waves stored the tile before already)
         if (do_flush) fc = flush_begin(smem, par ^ 1, a0, tid);
         if (!paired && n >= kMfLimit + 1) insert_unit(ring, tab, t0 + 8 * tid, t1, n - kMfLimit, small, probe_h_valid, probe_h);      // (t0 is a multiple of 16; tiles are at most 8 * kCmpThreads long; a full tile was inserted by its writing waves)
+        }
 #ifdef LZ4AMD_PROF_TILE
         if (prof) { const uint64_t t = clock_ticks(); if (tid == 0) ((uint64_t*)(smem + kCOffMisc))[14] += t - tq; }
 #endif
         // the prefetched granules go into ring slots that hold bytes more than a window + a tile old (before the flush's store:
         // the wait for the load would wait for the store's acknowledgement as well - the counter is in order)
-        if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
+        if (Pp < pf_hi && !(LZ4AMD_CMP_EARLY_COMMIT && paired)) ring_commit16(ring, Pp, pf);
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
         if (do_flush) flush_end(smem, fc, dst, a0, tid);
         if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
