@@ -1103,7 +1103,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
 #ifdef LZ4AMD_PROF_ROLES
-    uint64_t rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // developer build: one wave's cycles by role: probe + list | measuring: partner wait, measure, wait for the settle, write out | writing: wait for the settle, write out
+    uint64_t rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // developer build: one wave's cycles by role: probe + list | measuring: partner wait, measure, wait for the settle, write out | writing: wait for the settle, write out | insert + flush (with LZ4AMD_PROF_ROLES_BARRIER: that goes to "write out", and this is the wait at the barrier)
+    uint64_t rq = 0; uint32_t rlast = 2;
 #endif
     if (prof) tq = clock_ticks();
     {
@@ -1150,7 +1151,12 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         const bool paired = parse && !small && !stride4 && strip_len == 512 && t1 - t0 == 8192;
         uint32_t probe_h[2] = {0, 0}; bool probe_h_valid = false;
 #ifdef LZ4AMD_PROF_ROLES
-        uint64_t rq = clock_ticks(); uint32_t rrole = 2;
+        uint32_t rrole = 2;
+#ifdef LZ4AMD_PROF_ROLES_BARRIER
+        { const uint64_t t_ = clock_ticks(); if (rlast < 2) rt[7] += t_ - rq; rq = t_; }
+#else
+        rq = clock_ticks();
+#endif
 #define RSTAMP(k) do { const uint64_t t_ = clock_ticks(); rt[k] += t_ - rq; rq = t_; } while (0)
 #else
 #define RSTAMP(k) do {} while (0)
@@ -1284,9 +1290,16 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 }
             }
 #ifdef LZ4AMD_PROF_ROLES
+#ifdef LZ4AMD_PROF_ROLES_BARRIER
+            RSTAMP(rrole ? 6 : 4);
+#else
             RSTAMP(7);
 #endif
+#endif
         }
+#ifdef LZ4AMD_PROF_ROLES
+        rlast = rrole;
+#endif
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         // A full tile is done here - its pieces are in the table, the tile before has left, the next one's granules are in the ring - and has
         // no second barrier: the one at the next tile's top is the only one.  A small tile:

@@ -16,7 +16,7 @@ print("%s P%d: compress kernel ms %.3f" % (os.environ.get("LZ4AMD_LIB", "product
 L = lz4_amd.lib()
 w = (ctypes.c_ulonglong * (256 * 8))()
 n = L.lz4amd_plan_profile(plan._h, w, len(w))
-names = ["probe + list (both roles)", "measuring: wait for the partner's list", "measuring: measure / select / records", "measuring: wait for the settle", "measuring: write out", "writing: (settle,) wait for the settle", "writing: write out", "-"]
+names = ["probe + list (both roles)", "measuring: wait for the partner's list", "measuring: measure / select / records", "measuring: wait for the settle", "measuring: write out", "writing: (settle,) wait for the settle", "writing: write out", "insert + flush, both roles (PROF_ROLES_BARRIER build: the wait at the barrier; insert + flush are in 'write out')"]
 tiles = bs // 8192
 for k, name in enumerate(names):
     d = [w[i * 8 + k] for i in range(n // 8)]
