@@ -68,10 +68,21 @@
 #ifndef LZ4AMD_CMP_PRIO
 #define LZ4AMD_CMP_PRIO 2          // developer knob: 1: the settling wave runs at high issue priority, 2: the measuring waves at raised priority
 #endif
+#ifndef LZ4AMD_CMP_MERGE_RUNS
+#define LZ4AMD_CMP_MERGE_RUNS 1
+#endif
 #ifndef LZ4AMD_STRIDE4_FROM
 #define LZ4AMD_STRIDE4_FROM 2
 #endif
 namespace lz4amd {
+
+// developer counters of the CPU interpreter's build (tools/exp/cmp_emu_stats.py): trips of the parse and emit loops
+#ifdef LZ4AMD_EMU_STATS
+extern "C" unsigned long long lz4amd_emu_stats[16];
+#define CMP_STAT(i, v) do { if (lane_id() == 0) __atomic_fetch_add(&lz4amd_emu_stats[i], (unsigned long long)(v), __ATOMIC_RELAXED); } while (0)
+#else
+#define CMP_STAT(i, v) ((void)0)
+#endif
 
 using CompBatch = ::lz4amd_comp_params;   // argument block (lz4amd_params.h)
 
@@ -312,6 +323,22 @@ __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t
         R.dd[j] = (ok && x == f0) ? d : 0u;
     }
     // runs: first / last probe of every stretch of hits with one distance
+#if LZ4AMD_CMP_MERGE_RUNS
+    if (SMALL || SH <= 1) {
+        // ... and a run goes on over ONE probe that missed (the table's slot was taken by something else) when the probe behind it hits with
+        // the run's distance again: the four bytes either probe compared lie next to each other (every second position) or overlap
+        // (every position) - the bytes in between are known to match.  Inside a long match most runs are such fragments.
+        const uint32_t D0 = R.dd[0], D1 = R.dd[1], D2 = R.dd[2], D3 = R.dd[3];
+        const uint32_t m1 = wave_prev_u32(D3), m2 = wave_prev_u32(D2), p4 = wave_next_u32(D0), p5 = wave_next_u32(D1);
+#define LZ4AMD_GOES_ON(x, y, z) ((x) == (y) || ((y) == 0u && (x) == (z)))      // slot x's run continues into the neighbour y, or over the missed neighbour into z
+        R.sb = ((D0 && !LZ4AMD_GOES_ON(D0, m1, m2)) ? 1u : 0u) | ((D1 && !LZ4AMD_GOES_ON(D1, D0, m1)) ? 2u : 0u) |
+               ((D2 && !LZ4AMD_GOES_ON(D2, D1, D0)) ? 4u : 0u) | ((D3 && !LZ4AMD_GOES_ON(D3, D2, D1)) ? 8u : 0u);
+        R.eb = ((D0 && !LZ4AMD_GOES_ON(D0, D1, D2)) ? 1u : 0u) | ((D1 && !LZ4AMD_GOES_ON(D1, D2, D3)) ? 2u : 0u) |
+               ((D2 && !LZ4AMD_GOES_ON(D2, D3, p4)) ? 4u : 0u) | ((D3 && !LZ4AMD_GOES_ON(D3, p4, p5)) ? 8u : 0u);
+#undef LZ4AMD_GOES_ON
+        return R;
+    }
+#endif
     const uint32_t pv = wave_prev_u32(R.dd[3]), nx = wave_next_u32(R.dd[0]);
     R.sb = ((R.dd[0] && R.dd[0] != pv) ? 1u : 0u) | ((R.dd[1] && R.dd[1] != R.dd[0]) ? 2u : 0u) |
            ((R.dd[2] && R.dd[2] != R.dd[1]) ? 4u : 0u) | ((R.dd[3] && R.dd[3] != R.dd[2]) ? 8u : 0u);
@@ -336,6 +363,7 @@ __device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t
         s ^= ls; e2 ^= le;
     }
     while (__any((s | e2) != 0)) {
+        CMP_STAT(5, 1);
         const uint32_t ls = s & (0u - s), le = e2 & (0u - e2);
         if (s && iS < kCandCap) candS[iS] = (slot0 + slot_of(ls)) | (dist_of(R, ls) << 8);
         if (e2 && iE < kCandCap) candE[iE] = (uint8_t)(slot0 + slot_of(le));
@@ -349,6 +377,7 @@ template <bool SMALL>
 __device__ __forceinline__ uint32_t probe_list(const uint8_t* ring, const uint32_t* tab, uint32_t* candS, uint8_t* candE, uint32_t cs, uint32_t cs_off,
                                                uint32_t q_hi, uint32_t lo, uint32_t SH, uint32_t (&probe_h)[2]) {
     const uint32_t lane = lane_id();
+    CMP_STAT(6, 1);
     const Round A = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, lane * (4u << SH)), cs + lane * (4u << SH), q_hi, SH);
     probe_h[0] = A.hh[0]; probe_h[1] = A.hh[1];
     const uint32_t cntA = (uint32_t)__popc(A.sb) | ((uint32_t)__popc(A.eb) << 16);
@@ -364,6 +393,7 @@ struct ParseState { uint32_t nseq, enc, ll0, cur; };      // records so far, the
 __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, uint16_t* ends, uint32_t rec_cap, uint32_t cs, uint32_t cs_off,
                                            uint32_t mlimit, uint32_t last_q, bool have, uint32_t qs, uint32_t d, uint32_t a, ParseState& st) {
     const uint32_t lane = lane_id();
+    CMP_STAT(0, 1); { const unsigned long long hv = __ballot(have); CMP_STAT(1, __popcll(hv)); }
     // ---- measure
     uint32_t e = 0, back = 0, more = 0;
     if (have) {
@@ -412,6 +442,7 @@ __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, 
         if ((uint32_t)__popcll(taken) > room) taken = __ballot(tk && lanes_below(taken) < room);
         const unsigned long long mm = taken & __ballot(more != 0);
         if (!mm) break;
+        CMP_STAT(2, 1);
         // long match: wave-wide compare, 8 bytes per lane per trip (lz4.c:680-703 LZ4_count)
         const uint32_t l = (uint32_t)__ffsll((long long)mm) - 1;
         uint32_t el = wave_readlane(e, l);
@@ -431,7 +462,7 @@ __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, 
                 ext += 8 * fl + wave_readlane(same, fl);
                 break;
             }
-            ext += 512;
+            ext += 512; CMP_STAT(3, 1);
         }
         el += ext;
         e = lane == l ? el : e;
@@ -439,6 +470,7 @@ __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, 
     }
     if (!taken) return;
     const uint32_t ntaken = (uint32_t)__popcll(taken);
+    CMP_STAT(4, ntaken);
     const bool mine = (taken >> lane) & 1;
     const uint32_t pt = wave_incl_max(mine ? e : 0u);
     uint32_t prev_end = wave_prev_u32(pt);                   // end of the match taken before mine (taken lanes)
@@ -533,6 +565,7 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t last_q = n - kMfLimit;
         if (late_b) {
+            CMP_STAT(13, 1);
             // the first piece's runs on their own, then - when its list is there - the second piece's (always in this order for this pair: the bytes do not depend on who was late)
             const uint32_t cs_off = src_ring_off(cs);
             if (nA <= kCandCap) {
@@ -556,6 +589,7 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
                 }
             } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st); }
         } else if (nA <= kCandCap && nB <= kCandCap) {
+            CMP_STAT(10, 1); CMP_STAT(11, nA + nB); CMP_STAT(12, (nA + nB + 63) / 64);
             if (lane == 0) lds_store_release_local(table_free, gen);
             const uint32_t cs_off = src_ring_off(cs), total = nA + nB;
             for (uint32_t pl = 0; pl < total && st.nseq < rec_cap; pl += kCandPerPass) {
@@ -716,7 +750,9 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
     const uint32_t cs_off = src_ring_off(cs);
     uint32_t ipos = 0;             // source position of the next sequence's own literals, from cs
     uint32_t opos = strip[S_OUT * kCmpWaves + w] - dbase;      // staging offset of the next sequence's token
+    CMP_STAT(7, 1);
     for (uint32_t base = 0; base < nk; base += 64) {
+        CMP_STAT(8, 1);
         const uint32_t i = base + lane;
         const bool have = i < nk;
         uint32_t ll = 0, mlm4 = 0, off = 0, extra = 0;
@@ -737,6 +773,7 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
         const uint32_t cnt = have ? (tl + 7) >> 3 : 0u;
         const uint32_t p_incl = wave_incl_sum(cnt), pbase = p_incl - cnt, npieces = wave_readlane(p_incl, 63);
         for (uint32_t W = 0; W < npieces; W += 64) {
+            CMP_STAT(9, 1);
             scr[lane] = 0;
             wave_lds_fence_local();
             if (cnt && pbase < W + 64 && pbase + cnt > W) scr[pbase > W ? pbase - W : 0u] = lane + 1;
@@ -1103,8 +1140,13 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
     uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
 #ifdef LZ4AMD_PROF_ROLES
-    uint64_t rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // developer build: one wave's cycles by role: probe + list | measuring: partner wait, measure, wait for the settle, write out | writing: wait for the settle, write out | insert + flush (with LZ4AMD_PROF_ROLES_BARRIER: that goes to "write out", and this is the wait at the barrier)
-    uint64_t rq = 0; uint32_t rlast = 2;
+    // developer build (tools/prof_roles.py): cycles of wave LZ4AMD_PROF_ROLES in the full tiles where its role is LZ4AMD_PROF_ROLES_SEL (0 measuring, 1 writing, 2 either):
+    // (settle,) probe + list | partner wait, measure | settle wait, emit | wait for the insert gate | insert | wait for the flush gate | flush | wait at the barrier
+#ifndef LZ4AMD_PROF_ROLES_SEL
+#define LZ4AMD_PROF_ROLES_SEL 2
+#endif
+    uint64_t rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t rq = 0; bool ron = false;
 #endif
     if (prof) tq = clock_ticks();
     {
@@ -1118,6 +1160,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     // one wave of every pair measures and selects - and, once CM_READY covers tile k-1, compose its strips in the staging
     // buffer, whoever is free.  Interval B: everybody inserts tile k into the table and stores one 16-byte chunk of tile k-1's
     // bytes.  Records and strip summaries are double buffered for that.
+    U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;            // the granule a thread fetches a tile ahead (declared out here: cleared at the loop's top, the compiler would wait for the
+                                                            //  memory counter there, not knowing whether the load of the trip before was waited for - and with it for the
+                                                            //  acknowledgements of the stores of the tile before: ~3 K cycles, the whole workgroup behind it at the barrier)
     uint32_t par = 0;                                       // buffer parity of tile k
     uint32_t prev_t0 = 0, prev_g0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0, prev_rps = kRecsPerStrip;      // tile k-1, still to be emitted (rps: record slots per strip)
     uint32_t tiles_parsed = 0;                              // tiles whose strips were matched so far (CM_READY counts up to it)
@@ -1134,7 +1179,6 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         // (a tile is at most 512 granules: the upper eight waves fetch them - not the wave that settles the tile before: wherever the
         //  compiler waits for the granule, that wave would wait at the head of the chain everybody else waits for)
         const uint32_t Pp = loaded + 16 * (tid ^ 512u);
-        U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;
         if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 8 * kCmpThreads
 #if LZ4AMD_CMP_LDS_BARRIER
         lds_barrier();                                         // ring, table and tile k-1's records ready (all of it LDS: the fetch just issued, and the stores of the tile before, may still be on their way)
@@ -1151,13 +1195,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         const bool paired = parse && !small && !stride4 && strip_len == 512 && t1 - t0 == 8192;
         uint32_t probe_h[2] = {0, 0}; bool probe_h_valid = false;
 #ifdef LZ4AMD_PROF_ROLES
-        uint32_t rrole = 2;
-#ifdef LZ4AMD_PROF_ROLES_BARRIER
-        { const uint64_t t_ = clock_ticks(); if (rlast < 2) rt[7] += t_ - rq; rq = t_; }
-#else
-        rq = clock_ticks();
-#endif
-#define RSTAMP(k) do { const uint64_t t_ = clock_ticks(); rt[k] += t_ - rq; rq = t_; } while (0)
+        { const uint64_t t_ = clock_ticks(); if (ron) rt[7] += t_ - rq; rq = t_; }
+        ron = paired && (LZ4AMD_PROF_ROLES_SEL == 2 || ((w ^ (w >> 2) ^ tiles_parsed) & 1u) == LZ4AMD_PROF_ROLES_SEL);
+#define RSTAMP(k) do { const uint64_t t_ = clock_ticks(); if (ron) rt[k] += t_ - rq; rq = t_; } while (0)
 #else
 #define RSTAMP(k) do {} while (0)
 #endif
@@ -1186,14 +1226,14 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #if LZ4AMD_CMP_EARLY_COMMIT
             // the next tile's granules (fetched at the tile's top by the upper waves: they have arrived) go into the ring now: its slots hold
             // bytes more than a window below this tile - nobody reads them any more
+            touch_load16(pf);       // (every wave, fetching or not: or the compiler, which does not know at the loop's top whether the granule's load was waited for,
+                                    //  waits there before it clears these registers - for the memory counter, i.e. for the acknowledgements of the stores of the tile
+                                    //  before as well, ~3 K cycles with the whole workgroup behind it at the barrier)
             if (Pp < pf_hi) ring_commit16(ring, Pp, pf);
 #endif
             RSTAMP(0);
             // roles: of the two waves of a pair one measures, one writes out; they swap every tile, and a SIMD (waves w, w + 4, w + 8, w + 12) has two of each
             const uint32_t role = (w ^ (w >> 2) ^ tiles_parsed) & 1u;
-#ifdef LZ4AMD_PROF_ROLES
-            rrole = role;
-#endif
             if (role == 0) {
 #if LZ4AMD_CMP_PRIO & 2
                 wave_priority(2);
@@ -1203,7 +1243,6 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 const bool late = pw == settle_w;                  // (always measured in two steps, whether or not a tile was there to settle)
                 uint32_t pv = 0;
                 if (!late) while (((pv = uload_cm(&pairw[pw])) >> 16) != gen) spin_pause();
-                RSTAMP(1);
                 const uint32_t np = pv & 0xFFFFu;
                 const uint32_t* pS = (const uint32_t*)(smem + kCOffCandS) + pw * kCandCap;
                 const uint8_t* pE = (const uint8_t*)(smem + kCOffCandE) + pw * kCandCap;
@@ -1215,7 +1254,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #if LZ4AMD_CMP_PRIO & 2
                 wave_priority(0);
 #endif
-                RSTAMP(2);
+                RSTAMP(1);
             }
         } else {
             // -- A0: one wave settles tile k-1 first
@@ -1234,6 +1273,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 // the lane probed positions cs + 8 * lane + {0, 2, 4, 6}: with 512-byte strips those are this thread's insert positions
                 probe_h_valid = !small && !stride4 && strip_len == 512 && n >= kMfLimit + 1 && cs <= n - kMfLimit;
             }
+            touch_load16(pf);       // (see above: the code from here on is shared with the full tiles)
         }
         if (prof) { const uint64_t t = clock_ticks(); tp[1] += t - tq; tq = t; }
         // -- A2: write out tile k-1 (into the staging buffer)
@@ -1242,9 +1282,6 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         //    below waits for the last one.
         if (prev_nstrips) {
             while (uload_cm(&misc[CM_READY]) < tiles_parsed) CMP_WAIT_PAUSE();
-#ifdef LZ4AMD_PROF_ROLES
-            if (rrole < 2) RSTAMP(rrole ? 5 : 3);
-#endif
             for (;;) {
                 uint32_t sx = 0;
                 if (lane_id() == 0) sx = atomicAdd(&misc[CM_EMITQ + par], 1u);
@@ -1255,9 +1292,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 lds_or_release_local(&misc[CM_EMITDONE + par], 1u << sx);          // (every lane the same bit: a store by lane 0 alone, in this loop, hung the kernel on the device)
             }
         }
-#ifdef LZ4AMD_PROF_ROLES
-        if (rrole < 2) RSTAMP(rrole ? 6 : 4);
-#endif
+        RSTAMP(2);
         if (paired) {
             // -- A3: the tile goes into the table, piece by piece, by whichever wave is free (the writing waves mostly: the measuring ones have the
             //    longer way to the barrier) - once all sixteen pieces were probed and no measuring wave has to probe one again: the table is
@@ -1269,6 +1304,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 if (__all(f == gen)) break;
                 CMP_WAIT_PAUSE();
             }
+            RSTAMP(3);
             for (;;) {
                 uint32_t px = 0;
                 if (lane_id() == 0) px = atomicAdd(&misc[CM_INSQ + par], 1u);
@@ -1276,9 +1312,11 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 if (px >= kCmpWaves) break;
                 insert_unit(ring, tab, t0 + 512 * px + 8 * lane_id(), t1, n - kMfLimit, false, px == w && probe_h_valid, probe_h);
             }
+            RSTAMP(4);
             // -- A4: tile k-1's bytes leave, 64 chunks a time, once all its strips are written out
             if (LZ4AMD_CMP_FLUSH_IN_A && prev_nstrips && !misc[CM_FAIL]) {
                 while (uload_cm(&misc[CM_EMITDONE + par]) != (1u << prev_nstrips) - 1u) CMP_WAIT_PAUSE();
+                RSTAMP(5);
                 for (;;) {
                     uint32_t fx = 0;
                     if (lane_id() == 0) fx = atomicAdd(&misc[CM_FLUSHQ + par], 1u);
@@ -1289,17 +1327,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                     flush_end(smem, fj, dst, a0, 64 * fx + lane_id());
                 }
             }
-#ifdef LZ4AMD_PROF_ROLES
-#ifdef LZ4AMD_PROF_ROLES_BARRIER
-            RSTAMP(rrole ? 6 : 4);
-#else
-            RSTAMP(7);
-#endif
-#endif
+            RSTAMP(6);
         }
-#ifdef LZ4AMD_PROF_ROLES
-        rlast = rrole;
-#endif
         if (prof) { const uint64_t t = clock_ticks(); tp[4] += t - tq; tq = t; }
         // A full tile is done here - its pieces are in the table, the tile before has left, the next one's granules are in the ring - and has
         // no second barrier: the one at the next tile's top is the only one.  A small tile:
@@ -1320,7 +1349,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #endif
         // the prefetched granules go into ring slots that hold bytes more than a window + a tile old (before the flush's store:
         // the wait for the load would wait for the store's acknowledgement as well - the counter is in order)
-        if (Pp < pf_hi && !(LZ4AMD_CMP_EARLY_COMMIT && paired)) ring_commit16(ring, Pp, pf);
+        if (!(LZ4AMD_CMP_EARLY_COMMIT && paired)) { if (Pp < pf_hi) ring_commit16(ring, Pp, pf); }
         if (pf_hi > loaded) loaded = (pf_hi + 15) & ~15u;
         if (do_flush) flush_end(smem, fc, dst, a0, tid);
         if (prof) { const uint64_t t = clock_ticks(); tp[3] += t - tq; tq = t; }
@@ -1352,19 +1381,17 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #ifdef LZ4AMD_PROF_TILE
             { const uint64_t* m64 = (const uint64_t*)(smem + kCOffMisc); mx = m64[12]; mn = m64[13]; sm = m64[14] * kCmpWaves; }
 #endif
+#ifndef LZ4AMD_PROF_ROLES
             prof[0] = tp[0]; prof[1] = tp[1]; prof[2] = tp[2]; prof[3] = tp[3]; prof[4] = (uint64_t)misc[CM_EMITQ] << 4; prof[5] = mx; prof[6] = mn; prof[7] = sm / kCmpWaves;
-#ifdef LZ4AMD_PROF_ROLES
-        }
-        if (w == LZ4AMD_PROF_ROLES && lane_id() == 0) {
-            for (uint32_t i = 0; i < 8; i++) prof[i] = rt[i];
-        }
-        if (tid == 0) {
 #endif
 #ifdef LZ4AMD_PROF_WAVES
             for (uint32_t i = 0; i < 8; i++) prof[i] = (uint64_t)misc[16 + 2 * i] | ((uint64_t)misc[17 + 2 * i] << 32);      // developer build: match + emit time of each wave (>> 4)
 #endif
         }
     }
+#ifdef LZ4AMD_PROF_ROLES
+    if (prof && w == LZ4AMD_PROF_ROLES && lane_id() == 0) for (uint32_t i = 0; i < 8; i++) prof[i] = rt[i];
+#endif
     // -- the pending bytes of the last chunk, then the final literal run (lz4.c:1302-1329)
     const uint32_t out = misc[CM_OUT], run = misc[CM_CARRY];
     const uint64_t total = (uint64_t)out + 1 + lit_hdr_ext(run) + run;

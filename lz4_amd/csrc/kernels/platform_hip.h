@@ -119,6 +119,8 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(a) : "memory");
 }
+// all of the wave's global loads and stores complete - as an instruction the compiler's wait-count pass sees (vmcnt(0), the other counters open)
+__device__ __forceinline__ void vmem_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 template <int N> __device__ __forceinline__ void vmem_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8); }
@@ -209,6 +211,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // the registers of a global load, complete from here on (the compiler waits for the load at this point, not at a later use behind
 // stores whose number it cannot know: the memory counter is in order)
 __device__ __forceinline__ void settle_load16(lz4amd_u32x4& v) { asm volatile("" : "+v"(v)); }
+// ... the same as a mere use of the registers (no new value: the compiler keeps them where they are)
+__device__ __forceinline__ void touch_load16(const lz4amd_u32x4& v) { asm volatile("" :: "v"(v)); }
 
 // lanes of a wave run in lockstep on the hardware; this only pins the compiler's schedule
 // (and gives the CPU interpreter used by the unit tests a rendezvous point).

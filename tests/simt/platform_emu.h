@@ -25,6 +25,7 @@ static inline uint32_t lanes_below(unsigned long long m) { return (uint32_t)__bu
 static inline uint32_t opaque_u32(uint32_t x) { return x; }
 static inline void lds_dma16(const void* gsrc, void* lds_dst) { memcpy((char*)lds_dst + 16 * (threadIdx.x & 63u), gsrc, 16); }
 template <int N> static inline void vmem_wait() {}
+static inline void vmem_wait_all() {}
 static inline void wave_priority(uint32_t) {}
 static inline void spin_pause() { simt::yield_to_sched(); }
 static inline long long chain_load_acquire(const long long* w) { return __atomic_load_n(w, __ATOMIC_ACQUIRE); }
@@ -75,3 +76,4 @@ static inline void lds_store_release_local(uint32_t* w, uint32_t v) { *(volatile
 static inline void lds_or_release_local(uint32_t* w, uint32_t bits) { *w |= bits; }
 static inline uint32_t lds_load_acquire_local(const uint32_t* w) { return *(volatile const uint32_t*)w; }
 static inline void settle_load16(lz4amd_u32x4&) {}
+static inline void touch_load16(const lz4amd_u32x4&) {}

@@ -1,4 +1,4 @@
-"""Developer aid: one wave's cycles per tile by role in the paired compress kernel (library built with -DLZ4AMD_PROF_ROLES=<wave>). GPU only."""
+"""Developer aid: one wave's cycles per tile by phase in the paired compress kernel (library built with -DLZ4AMD_PROF_ROLES=<wave> [-DLZ4AMD_PROF_ROLES_SEL=0 measuring tiles | 1 writing tiles]). GPU only."""
 import ctypes, os, sys, statistics
 os.environ["LZ4AMD_PROF"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +16,12 @@ print("%s P%d: compress kernel ms %.3f" % (os.environ.get("LZ4AMD_LIB", "product
 L = lz4_amd.lib()
 w = (ctypes.c_ulonglong * (256 * 8))()
 n = L.lz4amd_plan_profile(plan._h, w, len(w))
-names = ["probe + list (both roles)", "measuring: wait for the partner's list", "measuring: measure / select / records", "measuring: wait for the settle", "measuring: write out", "writing: (settle,) wait for the settle", "writing: write out", "insert + flush, both roles (PROF_ROLES_BARRIER build: the wait at the barrier; insert + flush are in 'write out')"]
+names = ["(settle,) probe + list", "wait for the partner's list, measure / select / records", "wait for the settle, write out strips", "wait until the tile may be inserted",
+         "insert", "wait until the tile before may leave", "store the tile before", "wait at the barrier"]
 tiles = bs // 8192
+tot = 0
 for k, name in enumerate(names):
     d = [w[i * 8 + k] for i in range(n // 8)]
-    print("  %-44s cycles per block: median %9d   per tile (role tiles: half) %6d" % (name, statistics.median(d), statistics.median(d) // tiles))
+    tot += statistics.median(d)
+    print("  %-58s cycles per block: median %9d   per full tile of the block %6d" % (name, statistics.median(d), statistics.median(d) // tiles))
+print("  sum per tile %d (a role's tiles are half of them)" % (tot // tiles))
