@@ -557,38 +557,14 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
 __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint32_t rec_cap, uint32_t* strip,
                                                  const uint32_t* LAs, const uint8_t* LAe, uint32_t nA, const uint32_t* LBs, const uint8_t* LBe, uint32_t nB,
                                                  uint32_t* candS, uint8_t* candE, uint32_t si, uint32_t n, uint32_t cs, uint32_t tend,
-                                                 uint32_t* table_free, uint32_t gen, const uint32_t* late_b = nullptr) {      // late_b: the second piece's list comes late (its wave settled the tile before first): the first piece does not wait for it; table_free: told (gen) when this wave probes no more
+                                                 uint32_t* table_free, uint32_t gen) {      // table_free: told (gen) when this wave probes no more
     const uint32_t lane = lane_id();
     const uint32_t ce = cs + 1024;                                   // (full tiles only: the strip lies inside the block)
     ParseState st; st.nseq = 0; st.enc = 0; st.ll0 = 0; st.cur = cs;
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t last_q = n - kMfLimit;
-        if (late_b) {
-            CMP_STAT(13, 1);
-            // the first piece's runs on their own, then - when its list is there - the second piece's (always in this order for this pair: the bytes do not depend on who was late)
-            const uint32_t cs_off = src_ring_off(cs);
-            if (nA <= kCandCap) {
-                for (uint32_t pl = 0; pl < nA && st.nseq < rec_cap; pl += kCandPerPass) {
-                    const bool have = pl + lane < nA;
-                    uint32_t S = 0, E = 0;
-                    if (have) { S = LAs[pl + lane]; E = LAe[pl + lane]; }
-                    parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, cs + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + (E << 1) + kMinMatch, st);
-                }
-            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs, cs + 512, mlimit, last_q, ph, 1u, st); wave_lds_fence_local(); }
-            uint32_t pv;
-            while (((pv = __builtin_amdgcn_readfirstlane(lds_load_acquire_local(late_b))) >> 16) != gen) spin_pause();
-            nB = pv & 0xFFFFu;
-            if (nB <= kCandCap) {
-                if (lane == 0) lds_store_release_local(table_free, gen);
-                for (uint32_t pl = 0; pl < nB && st.nseq < rec_cap; pl += kCandPerPass) {
-                    const bool have = pl + lane < nB;
-                    uint32_t S = 0, E = 0;
-                    if (have) { S = LBs[pl + lane]; E = LBe[pl + lane]; }
-                    parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, cs + 512 + ((S & 255u) << 1), have ? S >> 8 : 1u, cs + 512 + (E << 1) + kMinMatch, st);
-                }
-            } else { uint32_t ph[2]; parse_piece<false>(ring, tab, recs, ends, rec_cap, candS, candE, cs, cs + 512, ce, mlimit, last_q, ph, 1u, st); }
-        } else if (nA <= kCandCap && nB <= kCandCap) {
+        if (nA <= kCandCap && nB <= kCandCap) {
             CMP_STAT(10, 1); CMP_STAT(11, nA + nB); CMP_STAT(12, (nA + nB + 63) / 64);
             if (lane == 0) lds_store_release_local(table_free, gen);
             const uint32_t cs_off = src_ring_off(cs), total = nA + nB;
@@ -1154,15 +1130,15 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         for (uint32_t Pp = 16 * tid; Pp < hi; Pp += 16 * kCmpThreads) ring_commit16(ring, Pp, load_src16(src, n, Pp));
         loaded = (hi + 15) & ~15u;
     }
-    // Two barriers per tile.  Interval A: one wave settles tile k-1 (overrunning matches, then the strips' sizes
-    // into output offsets: ~3.5 K cycles of one wave's dependent work, which used to sit between the barriers with
-    // fifteen waves waiting) and says so in CM_READY; the waves parse tile k - in a full tile all sixteen probe and list, then
-    // one wave of every pair measures and selects - and, once CM_READY covers tile k-1, compose its strips in the staging
-    // buffer, whoever is free.  Interval B: everybody inserts tile k into the table and stores one 16-byte chunk of tile k-1's
-    // bytes.  Records and strip summaries are double buffered for that.
+    // One barrier per full tile (at its top), two per small one.  A full tile k: one writing wave settles tile k-1 (overrunning matches, then the
+    // strips' sizes into output offsets: ~4 K cycles of one wave's dependent work) and says so in CM_READY; fifteen waves probe and list the
+    // tile's sixteen pieces; one wave of every pair measures and selects; whoever is free composes tile k-1's strips in the staging buffer once
+    // CM_READY covers it, inserts tile k's pieces into the table once all are probed, and stores tile k-1's bytes once all its strips are
+    // composed - all handed out from queues in LDS (two sets, by tile parity).  A small tile has a second barrier, behind which everybody
+    // inserts its own positions and stores one 16-byte chunk.  Records and strip summaries are double buffered.
     U32x4 pf; pf[0] = pf[1] = pf[2] = pf[3] = 0;            // the granule a thread fetches a tile ahead (declared out here: cleared at the loop's top, the compiler would wait for the
-                                                            //  memory counter there, not knowing whether the load of the trip before was waited for - and with it for the
-                                                            //  acknowledgements of the stores of the tile before: ~3 K cycles, the whole workgroup behind it at the barrier)
+                                                            //  memory counter there - it does not know whether the load of the trip before was waited for -, i.e. for the
+                                                            //  acknowledgements of the stores of the tile before as well)
     uint32_t par = 0;                                       // buffer parity of tile k
     uint32_t prev_t0 = 0, prev_g0 = 0, prev_t1 = 0, prev_strip_len = 0, prev_nstrips = 0, prev_rps = kRecsPerStrip;      // tile k-1, still to be emitted (rps: record slots per strip)
     uint32_t tiles_parsed = 0;                              // tiles whose strips were matched so far (CM_READY counts up to it)
@@ -1202,8 +1178,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #define RSTAMP(k) do {} while (0)
 #endif
         if (paired) {
-            // -- A0: one writing wave settles tile k-1, before anything else: the other writing waves wait for it, and so does its
-            //    partner, for its list - which therefore measures its own piece (the pair's first) in the meantime
+            // -- A0: one writing wave settles tile k-1, before anything else: the other writing waves wait for it.  It does not probe: its
+            //    partner - which measures the pair's strip anyway - probes both pieces (no list comes late, and the settling wave is free to
+            //    write out as soon as it has settled: eight strips, eight writing waves)
             const uint32_t settle_w = (tiles_parsed & 1u) ? 5u : 1u;      // (an odd wave - its piece is its pair's second - whose role this tile is to write)
             if (w == settle_w && prev_nstrips) {
 #if LZ4AMD_CMP_PRIO & 1
@@ -1219,10 +1196,20 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             const uint32_t last_q = n - kMfLimit;
             const uint32_t pcs = t0 + 512 * w, gen = (tiles_parsed & 0x7FFFu) + 1u;
             const uint32_t q_hi = pcs + 511 < last_q ? pcs + 511 : last_q;
-            uint32_t nw = 0;
-            if (pcs <= last_q) { nw = probe_list<false>(ring, tab, candS, candE, pcs, src_ring_off(pcs), q_hi, 0u, 1u, probe_h); probe_h_valid = true; }
-            wave_lds_fence_local();
-            if (lane_id() == 0) lds_store_release_local(&pairw[w], (gen << 16) | nw);
+            uint32_t nw = 0, nw2 = 0;
+            if (w != settle_w) {
+                if (pcs <= last_q) { nw = probe_list<false>(ring, tab, candS, candE, pcs, src_ring_off(pcs), q_hi, 0u, 1u, probe_h); probe_h_valid = true; }
+                wave_lds_fence_local();
+                if (lane_id() == 0) lds_store_release_local(&pairw[w], (gen << 16) | nw);
+                if (w == (settle_w ^ 1u)) {                        // (the settling wave's piece, into its list)
+                    const uint32_t pcs2 = pcs + 512, q_hi2 = pcs2 + 511 < last_q ? pcs2 + 511 : last_q;
+                    uint32_t ph2[2];
+                    if (pcs2 <= last_q) nw2 = probe_list<false>(ring, tab, (uint32_t*)(smem + kCOffCandS) + settle_w * kCandCap, (uint8_t*)(smem + kCOffCandE) + settle_w * kCandCap,
+                                                                pcs2, src_ring_off(pcs2), q_hi2, 0u, 1u, ph2);
+                    wave_lds_fence_local();
+                    if (lane_id() == 0) lds_store_release_local(&pairw[settle_w], (gen << 16) | nw2);
+                }
+            }
 #if LZ4AMD_CMP_EARLY_COMMIT
             // the next tile's granules (fetched at the tile's top by the upper waves: they have arrived) go into the ring now: its slots hold
             // bytes more than a window below this tile - nobody reads them any more
@@ -1240,9 +1227,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
 #endif
                 // -- A1': the pair's 1 KB, from both lists (the even wave's piece comes first)
                 const uint32_t pw = w ^ 1u;
-                const bool late = pw == settle_w;                  // (always measured in two steps, whether or not a tile was there to settle)
-                uint32_t pv = 0;
-                if (!late) while (((pv = uload_cm(&pairw[pw])) >> 16) != gen) spin_pause();
+                uint32_t pv = nw2;
+                if (pw != settle_w) while (((pv = uload_cm(&pairw[pw])) >> 16) != gen) spin_pause();
                 const uint32_t np = pv & 0xFFFFu;
                 const uint32_t* pS = (const uint32_t*)(smem + kCOffCandS) + pw * kCandCap;
                 const uint8_t* pE = (const uint8_t*)(smem + kCOffCandE) + pw * kCandCap;
@@ -1250,7 +1236,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 if (w & 1u) match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, kRecsPerPair, strip_k,
                                              pS, pE, np, candS, candE, nw, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen);
                 else match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, kRecsPerPair, strip_k,
-                                      candS, candE, nw, pS, pE, np, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen, late ? &pairw[pw] : nullptr);
+                                      candS, candE, nw, pS, pE, np, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen);
 #if LZ4AMD_CMP_PRIO & 2
                 wave_priority(0);
 #endif

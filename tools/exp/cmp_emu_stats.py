@@ -16,6 +16,6 @@ res = emu_compress(emu, [buf.raw[:n]])
 st = list((ctypes.c_ulonglong * 16).in_dll(emu, "lz4amd_emu_stats"))
 tiles = n / 8192
 names = ["parse passes", "runs measured", "select repeats (long match)", "long-match extra trips", "records", "list_round extra trips", "probe_list calls",
-         "emit strips", "emit record passes", "emit literal passes", "pair strips (both lists)", "  their runs", "  their passes (ceil runs/64)", "pair strips (late split)"]
+         "emit strips", "emit record passes", "emit literal passes", "pair strips (both lists)", "  their runs", "  their passes (ceil runs/64)"]
 print("P%d %d MiB: %d bytes; per 8 KB tile:" % (pct, mib, res[0][0]))
 for k, nm in enumerate(names): print("  %-34s %8.2f" % (nm, st[k] / tiles))
