@@ -68,6 +68,9 @@
 #ifndef LZ4AMD_CMP_PRIO
 #define LZ4AMD_CMP_PRIO 2          // developer knob: 1: the settling wave runs at high issue priority, 2: the measuring waves at raised priority
 #endif
+#ifndef LZ4AMD_CMP_HASH32
+#define LZ4AMD_CMP_HASH32 1
+#endif
 #ifndef LZ4AMD_CMP_MERGE_RUNS
 #define LZ4AMD_CMP_MERGE_RUNS 1
 #endif
@@ -171,9 +174,17 @@ template <class Ptr> __device__ __forceinline__ Ptr put_len_ext(Ptr p, uint32_t 
 // full-rate 24-bit multiply-adds over the overlapping byte triples of the same bytes; any well mixed function of the
 // bytes gives the same matches up to table collisions.
 __device__ __forceinline__ uint32_t hash_pos32(uint32_t lo, uint32_t hi, bool small) {
+#if LZ4AMD_CMP_HASH32
+    // the reference's own 4-byte hash (lz4.c:777-783: one 32-bit multiply - measured on gfx950 it issues like a 24-bit one, tools/exp/valu_issue.hip),
+    // the fifth byte added in with a 24-bit multiply-add: 4 instructions instead of 6
+    uint32_t h = lo * 2654435761u;
+    if (!small) h += __umul24(hi & 0xFFu, 0xC2B2AFu);
+    return h >> (32 - kHashBits);
+#else
     uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(lo >> 8, 0x85EBCBu);
     if (!small) h += __umul24(hi & 0xFFu, 0xC2B2AFu);
     return h >> (32 - kHashBits);
+#endif
 }
 __device__ __forceinline__ uint32_t hash_pos(uint64_t v8, bool small) { return hash_pos32((uint32_t)v8, (uint32_t)(v8 >> 32), small); }
 
