@@ -327,7 +327,7 @@ __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t
         if (j & 1) R.hh[j >> 1] |= hj << 16; else R.hh[j >> 1] = hj;
         const uint32_t c = tab[hj];
         const uint32_t d = q - c;
-        const bool ok = q <= q_hi && d - 1u < kMaxDistance;             // c < q, q - c <= 65535 (d - 1 wraps for c >= q)
+        const bool ok = q <= q_hi && d <= kMaxDistance;                 // q - c <= 65535 (c < q: the table is frozen while a tile is probed - it holds positions of earlier tiles, or 0)
         const uint32_t co = ok ? ring_back(o0 + (j << SH), d) : 0u;
         const uint32_t* a = (const uint32_t*)(ring + (co & ~3u));
         const uint32_t x = align_bytes(a[1], a[0], co & 3u);
@@ -417,12 +417,14 @@ __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, 
             uint32_t xd[7], yd[7];
 #pragma unroll
             for (uint32_t i = 0; i < 7; i++) { xd[i] = xa[i]; yd[i] = ya[i]; }
-            uint32_t same = 24;
+            // (the first dword that differs is picked by a chain of selects, its first differing byte found once)
+            uint32_t zf = 0, base = 24;
 #pragma unroll
             for (int i = 5; i >= 0; i--) {
                 const uint32_t z = align_bytes(xd[i + 1], xd[i], ao & 3u) ^ align_bytes(yd[i + 1], yd[i], ko & 3u);
-                same = z ? 4 * (uint32_t)i + ((uint32_t)(__ffs((int)z) - 1) >> 3) : same;
+                zf = z ? z : zf; base = z ? 4 * (uint32_t)i : base;
             }
+            uint32_t same = zf ? base + ((uint32_t)(__ffs((int)zf) - 1) >> 3) : 24u;
             more = (same == 24 && a + 24 < mlimit) ? 1u : 0u;
             if (same > mlimit - a) same = mlimit - a;
             e = a + same;
@@ -1049,20 +1051,15 @@ __device__ __forceinline__ void insert_unit(const uint8_t* ring, uint32_t* tab, 
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) dw[i] = a[i];
         uint32_t h[8];
-#pragma unroll
-        for (uint32_t i = 1; i < 8; i += 2) {
-            const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
-            h[i] = hash_pos32(lo, hi, small);
-        }
+        // (the position's first four bytes by one byte alignment - none for the aligned ones -, its fifth byte by one bit-field extract)
+#define LZ4AMD_INS_HASH(i) hash_pos32((i) & 3 ? align_bytes(dw[(i) / 4 + 1], dw[(i) / 4], (i) & 3) : dw[(i) / 4], dw[((i) + 4) / 4] >> (8 * (((i) + 4) & 3)), small)
+        h[1] = LZ4AMD_INS_HASH(1); h[3] = LZ4AMD_INS_HASH(3); h[5] = LZ4AMD_INS_HASH(5); h[7] = LZ4AMD_INS_HASH(7);
         if (have_h) {                                           // computed when the strip was probed (wave-uniform)
             h[0] = probe_h[0] & 0xFFFFu; h[2] = probe_h[0] >> 16; h[4] = probe_h[1] & 0xFFFFu; h[6] = probe_h[1] >> 16;
         } else {
-#pragma unroll
-            for (uint32_t i = 0; i < 8; i += 2) {
-                const uint32_t lo = align_bytes(dw[i / 4 + 1], dw[i / 4], i & 3), hi = align_bytes(dw[i / 4 + 2], dw[i / 4 + 1], i & 3);
-                h[i] = hash_pos32(lo, hi, small);
-            }
+            h[0] = LZ4AMD_INS_HASH(0); h[2] = LZ4AMD_INS_HASH(2); h[4] = LZ4AMD_INS_HASH(4); h[6] = LZ4AMD_INS_HASH(6);
         }
+#undef LZ4AMD_INS_HASH
         if (q0 + 7 < t1 && q0 + 7 <= last_q) {                  // every thread but the ones at a block's very end: no per-position test
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) atomicMax(&tab[h[i]], q0 + i);
