@@ -751,7 +751,8 @@ __device__ __forceinline__ void emit_strip_lds(const uint8_t* ring, const MatchR
         const uint32_t lhdr = 1 + lit_hdr_ext(tl);       // token + the literal length's extension bytes
         const uint32_t e = have ? lhdr + tl + 2 + (mlm4 >= 15 ? len_ext_bytes(mlm4 - 15) : 0u) : 0u;
         const uint32_t adv = have ? ll + mlm4 + kMinMatch : 0;
-        const uint32_t e_incl = wave_incl_sum(e), a_incl = wave_incl_sum(adv);
+        const uint32_t ea_incl = wave_incl_sum(e | (adv << 16));       // (one scan for both: a tile's encoded bytes and a strip's advance stay far below 64 K)
+        const uint32_t e_incl = ea_incl & 0xFFFFu, a_incl = ea_incl >> 16;
         const uint32_t rel = ipos + a_incl - adv;        // my own literals start here (from cs); the carried ones lie before
         const uint32_t so = rel >= extra ? ring_fwd(cs_off, rel - extra) : ring_back(cs_off, extra - rel);
         const uint32_t my_o = opos + e_incl - e, lit_d = my_o + lhdr;
