@@ -181,8 +181,10 @@ __device__ __forceinline__ uint32_t hash_pos32(uint32_t lo, uint32_t hi, bool sm
     // the reference's own 4-byte hash (lz4.c:777-783: one 32-bit multiply - measured on gfx950 it issues like a 24-bit one, tools/exp/valu_issue.hip),
     // the fifth byte added in with a 24-bit multiply-add: 4 instructions instead of 6
     // (blocks under 64 KB + 11 keep the 24-bit form over their four bytes: with it datagen -P90 in 64 KiB blocks comes out 1.5 % smaller)
-    if (small) return (__umul24(lo, 0x9E3779u) + __umul24(lo >> 8, 0x85EBCBu)) >> (32 - kHashBits);
-    return (lo * 2654435761u + __umul24(hi & 0xFFu, 0xC2B2AFu)) >> (32 - kHashBits);
+    uint32_t h;
+    if (small) h = __umul24(lo, 0x9E3779u) + __umul24(lo >> 8, 0x85EBCBu);
+    else h = lo * 2654435761u + __umul24(hi & 0xFFu, 0xC2B2AFu);
+    return h >> (32 - kHashBits);
 #else
     uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(lo >> 8, 0x85EBCBu);
     if (!small) h += __umul24(hi & 0xFFu, 0xC2B2AFu);
