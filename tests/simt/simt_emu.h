@@ -211,7 +211,7 @@ static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
-static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+static inline int __umul24(unsigned a, unsigned b) { return (int)((a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }      // (HIP declares it returning int - amd_device_functions.h: an expression of such products shifts arithmetically unless it goes through an unsigned first)
 
 // atomics: fibers of one block never run concurrently; blocks on different OS threads may,
 // so global atomics use real atomics (harmless for LDS).
