@@ -767,13 +767,18 @@ def launch_ranks(n, argv):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:                                                   # a rank died: do not leave the others at a rendezvous
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    live = list(procs)
+    while live:                                              # all ranks are polled together: the first one that dies ends the others at once
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code and not rc:
+                rc = code
+                for q in live:                               # (do not leave them at a rendezvous until its timeout)
+                    q.kill()
     return rc
 
 

@@ -1165,7 +1165,10 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         // -- prefetch: the next tile's bytes (one 16-byte granule per thread, committed after the parse)
         uint32_t nt_len, nt_strip;
         tile_geometry(t1 >= pre ? t1 - pre : kTileMax * 4, small, nt_len, nt_strip);
-        uint32_t pf_hi = loaded + nt_len; if (pf_hi > n || pf_hi < loaded) pf_hi = n;     // stays 16 bytes ahead of the tile
+        // (the ring's commit points assume that `loaded` is never more than 16 bytes ahead of the next tile's end: the history's last tile is cut
+        //  at `pre`, which need not be a multiple of the tile - what was fetched beyond the cut counts, nothing is fetched twice)
+        uint32_t pf_hi = t1 + nt_len + 16; if (pf_hi > n || pf_hi < t1) pf_hi = n;     // stays 16 bytes ahead of the tile
+        if (pf_hi < loaded) pf_hi = loaded;
         // (a tile is at most 512 granules: the upper eight waves fetch them - not the wave that settles the tile before: wherever the
         //  compiler waits for the granule, that wave would wait at the head of the chain everybody else waits for)
         const uint32_t Pp = loaded + 16 * (tid ^ 512u);

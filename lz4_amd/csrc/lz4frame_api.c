@@ -323,7 +323,9 @@ struct LZ4F_dctx_s {
     int hashing; pthread_t hthread; size_t hash_n; const uint8_t* hash_p;
     /* a stored block that arrives in pieces goes straight from the caller's input to the caller's output (lz4frame.c:1790-1830) */
     int raw_on; size_t raw_left, raw_b0, raw_b1; xxh32_state raw_xxh;      /* raw_b0 .. raw_b1: bytes of the block that were buffered before (they go first) */
+    int test_no_bthread;                          /* fault injection for the tests, read from the environment once, when the context is made (batch_thread_start) */
 };
+static void dctx_read_test_hooks(LZ4F_dctx* d) { const char* e = getenv("LZ4AMD_TEST_NO_BATCH_THREAD"); d->test_no_bthread = e && e[0] == '1'; }
 static void* dctx_hash_thread(void* arg) { LZ4F_dctx* d = (LZ4F_dctx*)arg; xxh32_update(&d->xxh, d->hash_p, d->hash_n); return NULL; }
 static void dctx_hash_join(LZ4F_dctx* d) { if (d->hashing) { pthread_join(d->hthread, NULL); d->hashing = 0; } }
 static void dctx_batch_drop(LZ4F_dctx* d) { if (d->busy > 0) pthread_join(d->bthread, NULL); d->busy = 0; }      /* (a batch nobody waits for any more) */
@@ -364,6 +366,7 @@ LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned v
     if (!dctxPtr) return ERR(parameter_null);
     (void)version;
     *dctxPtr = (LZ4F_dctx*)calloc(1, sizeof **dctxPtr);
+    if (*dctxPtr) dctx_read_test_hooks(*dctxPtr);
     return *dctxPtr ? 0 : ERR(allocation_failed);
 }
 void LZ4F_resetDecompressionContext(LZ4F_dctx* d)
@@ -394,7 +397,7 @@ LZ4F_dctx* LZ4F_createDecompressionContext_advanced(LZ4F_CustomMem customMem, un
     if (customMem.customCalloc) d = (LZ4F_dctx*)customMem.customCalloc(customMem.opaqueState, sizeof *d);
     else if (customMem.customAlloc) { d = (LZ4F_dctx*)customMem.customAlloc(customMem.opaqueState, sizeof *d); if (d) memset(d, 0, sizeof *d); }
     else d = (LZ4F_dctx*)calloc(1, sizeof *d);
-    if (d) { d->cmem = customMem; d->has_cmem = customMem.customFree != NULL; }
+    if (d) { d->cmem = customMem; d->has_cmem = customMem.customFree != NULL; dctx_read_test_hooks(d); }
     return d;
 }
 
@@ -707,12 +710,11 @@ static size_t size_hint(const LZ4F_dctx* d)
     }
 }
 
-/* (test hook: LZ4AMD_TEST_NO_BATCH_THREAD=1 makes the helper thread of a large batch fail to start, the way pthread_create does
- *  when the process is out of threads) */
+/* (test hook: LZ4AMD_TEST_NO_BATCH_THREAD=1 in the environment WHEN THE CONTEXT IS CREATED makes the helper thread of a large batch
+ *  fail to start, the way pthread_create does when the process is out of threads; the environment is not looked at again) */
 static int batch_thread_start(LZ4F_dctx* d, void* (*fn)(void*))
 {
-    const char* e = getenv("LZ4AMD_TEST_NO_BATCH_THREAD");
-    if (e && e[0] == '1') return -1;
+    if (d->test_no_bthread) return -1;
     return pthread_create(&d->bthread, NULL, fn, d);
 }
 static void* batch_thread(void* arg)

@@ -287,3 +287,44 @@ def test_small_messages_with_a_small_dictionary_keep_the_reference_ratio(L, ref,
         pos += n
     ref.LZ4_freeStreamDecode(sd)
     assert outb.raw[:pos] == data[:pos]
+
+
+@pytest.mark.parametrize("pre", [16, 4096 + 16, 49168, 60000, 65520])
+def test_plan_compress_with_history_that_is_not_a_multiple_of_the_tile(oracle, datagen, pre):
+    """Round-5 advisor finding (high; the interpreter twin is in test_kernels_emulated.py): a history length that is not a
+    multiple of the compressor's 8 KB tile, blocks that reach the paired tiles, matches at the far edge of the window."""
+    import random
+    import torch
+    import lz4_amd
+    ctx = lz4_amd.Context()
+    n = 300000
+    per = datagen(65500, 20, pre)
+    far = (per * 7)[:pre + n]
+    blk = bytearray(pre + n)
+    S = random.Random(pre).randbytes(40)
+    p0 = pre + 70000
+    blk[p0:p0 + 40] = S; blk[p0 + 16500:p0 + 16540] = S
+    blk[p0 - 65500:p0 - 65494] = S[:6]; blk[p0 - 65494:p0 - 65488] = bytes(6 * [0x99])
+    datas = [far, bytes(blk), datagen(pre + n, 60, pre + 1)]
+    stride = (pre + n + 255) & ~255
+    src = torch.zeros((len(datas), stride), dtype=torch.uint8, device="cuda")
+    for i, d in enumerate(datas):
+        src[i, :len(d)] = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cap = lz4_amd.compress_bound(n)
+    cstride = (cap + 255) & ~255
+    comp = torch.zeros((len(datas), cstride), dtype=torch.uint8, device="cuda")
+    tab = lz4_amd.BlockTable([src.data_ptr() + i * stride + pre for i in range(len(datas))], [n] * len(datas),
+                             [comp.data_ptr() + i * cstride for i in range(len(datas))], [cap] * len(datas))
+    plan = lz4_amd.Plan.compress_with_history(ctx, tab, [pre] * len(datas))
+    s = torch.cuda.current_stream().cuda_stream
+    plan.launch(s)
+    sizes = plan.results(s)
+    oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, vp, ci, ci, ctypes.c_size_t]
+    host = comp.cpu().numpy()
+    for i, d in enumerate(datas):
+        assert sizes[i] > 0
+        out = ctypes.create_string_buffer(d[:pre], pre + n)
+        r = oracle.lz4o_decompress_safe_prefix(host[i, :sizes[i]].tobytes(), _addr(out, pre), sizes[i], n, pre)
+        assert r == n and out.raw[pre:pre + n] == d[pre:pre + n], (pre, i)
+    assert sizes[1] < 3000
+    plan.close()

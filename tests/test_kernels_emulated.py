@@ -415,6 +415,46 @@ def test_compress_with_history_decodes_with_prefix_oracle(emu, oracle, datagen):
     assert r == n and out.raw[pre:pre + n] == data[pre:pre + n]
 
 
+def _emu_compress_prefix(emu, oracle, data, pre, n):
+    """compress data[pre:pre+n] with data[:pre] as history on the interpreter; decode with the oracle's prefix decoder"""
+    buf = ctypes.create_string_buffer(data, len(data))
+    cap = n + n // 255 + 16
+    dst = ctypes.create_string_buffer(cap + 32)
+    sp = (ctypes.c_void_p * 1)(ctypes.addressof(buf) + pre); dp = (ctypes.c_void_p * 1)(ctypes.addressof(dst))
+    ss = (ctypes.c_int32 * 1)(n); dc = (ctypes.c_int32 * 1)(cap); res = (ctypes.c_int32 * 1)(); pr = (ctypes.c_int32 * 1)(pre)
+    emu.emu_compress_batch_prefix.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emu.emu_compress_batch_prefix(sp, ss, dp, dc, res, 1, 1, pr)
+    assert res[0] > 0
+    out = ctypes.create_string_buffer(data[:pre], pre + n)
+    oracle.lz4o_decompress_safe_prefix.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+    r = oracle.lz4o_decompress_safe_prefix(dst.raw[:res[0]], ctypes.addressof(out) + pre, res[0], n, pre)
+    return res[0], r == n and out.raw[pre:pre + n] == data[pre:pre + n]
+
+
+@pytest.mark.parametrize("pre", [16, 4096 + 16, 49168, 60000, 65520])
+def test_compress_with_history_that_is_not_a_multiple_of_the_tile(emu, oracle, datagen, pre):
+    """Round-5 advisor finding (high): the history's last tile is cut at `pre`; with pre % 8192 != 0 the prefetch ran up to 8176
+    bytes ahead of the tiles for the rest of the block and the early ring commit overwrote window bytes that were still probed
+    (wrong bytes out on a directed input).  Blocks large enough to reach the paired 8 KB tiles, far-distance data."""
+    n = 300000
+    rnd = random.Random(pre)
+    # (a) window-distance repeats: datagen noise with period ~65500 (every match lives at the far edge of the window)
+    per = datagen(65500, 20, pre)
+    data = (per * 7)[:pre + n]
+    size, ok = _emu_compress_prefix(emu, oracle, data, pre, n)
+    assert ok
+    size_al, ok_al = _emu_compress_prefix(emu, oracle, (per * 7)[:65536 + n], 65536, n)
+    assert ok_al and size <= 1.5 * size_al + (65536 - pre)            # (less history: its bytes as literals on top; far-edge candidates survive in the table by luck - the overwritten ring gave 1.8 x)
+    # (b) the directed input: a 40-byte string S at q and q + 16500, S[:6] followed by other bytes at q - 65500
+    blk = bytearray(pre + n)
+    S = rnd.randbytes(40)
+    p0 = pre + 70000
+    blk[p0:p0 + 40] = S; blk[p0 + 16500:p0 + 16540] = S
+    blk[p0 - 65500:p0 - 65500 + 6] = S[:6]; blk[p0 - 65494:p0 - 65488] = bytes(6 * [0x99])
+    size, ok = _emu_compress_prefix(emu, oracle, bytes(blk), pre, n)
+    assert ok and size < 3000
+
+
 # ------------------------------------------------------------------ LZ4_compress_HC kernel (lz4_hc_kernel.h)
 def emu_compress_hc(emu, datas, level=9, caps=None, grid=0):
     n = len(datas)
