@@ -62,6 +62,52 @@
 #ifndef LZ4AMD_DEC_NEAR_POLL
 #define LZ4AMD_DEC_NEAR_POLL 0       // developer knob: a piece whose source lies at most this many regions below its own waits on the source's chunk flags, not on the source region's completion
 #endif
+// developer build (-DLZ4AMD_DEC_TRACE, LZ4AMD_PROF=1 in the environment; tools/prof_trace.py): workgroup 0 logs what its copy waves do, when
+#ifdef LZ4AMD_DEC_TRACE
+// (stamps are kept in registers and written once, when the region is complete: a log write is a round trip to memory)
+#define DSTAMP_DECL uint64_t rst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rsn_ = 0
+#define DSTAMP(k_) do { if (!rst_[k_]) rst_[k_] = clock_ticks(); } while (0)
+#define DSTAMP_LAST(k_) do { rst_[k_] = clock_ticks(); } while (0)
+#define DCOUNT() do { rsn_++; } while (0)
+#define DFLUSH(prof_, R_, np_) do { if ((prof_) && blockIdx.x == 0 && lane_here() == 0) { uint64_t* tr_ = (prof_) + (uint64_t)gridDim.x * 8; \
+    const unsigned long long i_ = atomicAdd((unsigned long long*)tr_, 1ull); \
+    if (i_ < (4u << 20) / 80 - 2) { uint64_t* q_ = tr_ + 1 + 10 * i_; q_[0] = (R_) | ((uint64_t)wave_id() << 32) | ((uint64_t)(np_) << 40) | ((uint64_t)rsn_ << 48); for (int j_ = 0; j_ < 8; j_++) q_[1 + j_] = rst_[j_]; } } } while (0)
+#else
+#define DSTAMP_DECL
+#define DSTAMP(k_) do {} while (0)
+#define DSTAMP_LAST(k_) do {} while (0)
+#define DCOUNT() do {} while (0)
+#define DFLUSH(prof_, R_, np_) do {} while (0)
+#endif
+#ifndef LZ4AMD_DEC_PROF
+#ifdef LZ4AMD_DEC_TRACE
+#define LZ4AMD_DEC_PROF 1
+#else
+#define LZ4AMD_DEC_PROF 0            // 1: the role profile of tools/prof_dec.py (LZ4AMD_PROF=1 in the environment) - a developer build, tools/build_variant.sh prof -DLZ4AMD_DEC_PROF=1
+#endif
+#endif
+#ifndef LZ4AMD_DEC_CHUNK
+#define LZ4AMD_DEC_CHUNK 16          // output bytes a lane composes at a time: 16 (regions of 1 KB) or 32 (regions of 2 KB; measured: DESIGN section 6)
+#endif
+#ifndef LZ4AMD_DEC_PARSE_GLOBAL
+#define LZ4AMD_DEC_PARSE_GLOBAL 2    // 1: the parser waves read the stream from memory (L2), not from the compressed ring: how far they run ahead of the copy is then
+                                     // not set by what the 32 KB ring holds beyond the regions in flight; 2: for large blocks that are mostly stream; 0: never
+#endif
+#ifndef LZ4AMD_DEC_COPYWAVES
+#define LZ4AMD_DEC_COPYWAVES (LZ4AMD_DEC_MAXLEAD + 1 < 15 ? LZ4AMD_DEC_MAXLEAD + 1 : 15)      // no more than there can be regions in flight
+#endif
+#ifndef LZ4AMD_DEC_DMADEPTH
+#define LZ4AMD_DEC_DMADEPTH 16
+#endif
+#ifndef LZ4AMD_DEC_CRKB
+#define LZ4AMD_DEC_CRKB 32u           // compressed ring, KB (a power of two)
+#endif
+#ifndef LZ4AMD_DEC_MAXLEAD
+#define LZ4AMD_DEC_MAXLEAD (LZ4AMD_DEC_CHUNK == 32 ? 10 : 15)        // regions in flight - 1 (what the LDS has room for: every region in flight is a slot of the output ring on top of the 64 KB window)
+#endif
+#ifndef LZ4AMD_DEC_LAND_PRIO
+#define LZ4AMD_DEC_LAND_PRIO 0       // developer knob: issue priority of a copy wave while it lands pending pieces
+#endif
 #ifndef LZ4AMD_DEC_HEAD_PRIO
 #define LZ4AMD_DEC_HEAD_PRIO 0       // developer knob: regions this close to the lowest open one are composed at raised issue priority
 #endif
@@ -75,42 +121,49 @@ enum : uint32_t {
     kDecThreads = 1024,
     kDecWaves = kDecThreads / 64,
     kMoveWave = kDecWaves - 1,                  // compressed stream, sequence records, region index -> LDS
-    kCopyWaves = kDecWaves - 1,                 // waves 0 .. kCopyWaves-1 (one fewer when the block comes with an entry-point table:
-                                                //   kParsers waves below the mover then parse the stream from the table's entries, PARSER below)
-    kChunk = 16,                                // output bytes composed at a time
-    kRegionShift = 10,
+    kCopyWaves = kDecWaves - 1,                 // waves 0 .. kCopyWaves-1 may copy (fewer when the block comes with an entry-point table:
+                                                //   kParsers waves below the mover then parse the stream from the table's entries, PARSER below);
+                                                //   kActiveCopy of them do: no more than there can be regions in flight
+    kChunk = LZ4AMD_DEC_CHUNK,                  // output bytes composed at a time by one lane (a region's fixed costs and a piece's address work are paid per
+                                                //   lane-pass, not per byte: 16-byte chunks take 2 passes per KB of datagen -P60, 32-byte chunks ~1.25 - but with 2 KB
+                                                //   regions more of the window is in flight, and more pieces find their source not final yet)
+    kRegionShift = kChunk == 32 ? 11 : 10,
     kRegion = 1u << kRegionShift,               // 64 chunks
-    kSlots = 80,                                // output ring slots (regions): 64 KB window + regions in flight (96 before: the 16 KB went to the record ring)
+    kWindowSlots = 65536u >> kRegionShift,      // slots the 64 KB LZ4 window takes
+    kMaxLead = LZ4AMD_DEC_MAXLEAD,              // a wave may lead the first unfinished region by this many
+    kActiveCopy = LZ4AMD_DEC_COPYWAVES,         // copy waves that take regions (the others have nothing to do in stage B)
+    kSlots = kWindowSlots + kMaxLead + 1,       // output ring slots (regions): the window + the regions in flight
     kRingBytes = kSlots * kRegion,
-    kRingPad = 32,                              // mirror of the first bytes: reads never wrap
-    kMaxLead = kSlots - 64 - 1,                 // a wave may lead the first unfinished region by this many
-    kCrBytes = 32u << 10,                       // compressed ring (direct mapped: position mod 32 K)
-    kCrPad = 32,
+    kRingPad = 2 * kChunk,                      // mirror of the first bytes: reads (kChunk + 4 bytes from a dword boundary) never wrap
+    kCrBytes = LZ4AMD_DEC_CRKB << 10,           // compressed ring (direct mapped: position mod 32 K)
+    kCrPad = kChunk + 16,
     kRecCap = 2048,                             // sequence-record ring (1024 rows filled up on many-sequence data: HC-compressed 256 KiB blocks waited for room)
     kRecMask = kRecCap - 1,
-    kIdxRing = 512,                             // first record of a region, per region (ring)
+    kIdxRing = kChunk == 32 ? 128 : 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
-    kEntRing = 256,                             // rows of the block's entry-point table (16 B each), ring
+    kEntRing = kChunk == 32 ? 128 : 256,                             // rows of the block's entry-point table (16 B each), ring
     kEntMask = kEntRing - 1,
     kLaneSeqMax = 1024,                         // sequences between two rows of a table (lz4amd_k_compress writes a row every 2 to 16)
-    kDmaDepth = 16,                             // LDS-DMA instructions (1 KB each) the mover keeps in flight
-    kMaxTrips = 10,                             // round-B trips per region (32 records each)
+    kDmaDepth = LZ4AMD_DEC_DMADEPTH,            // LDS-DMA instructions (1 KB each) the mover keeps in flight
+    kMaxTrips = kChunk == 32 ? 17 : 9,          // round-B trips per region (32 records each: a region of 2 KB starts at most 512 sequences + 2, one of 1 KB 258)
     kBias = pre::kBias,                         // output positions are biased: [kBias - prefix, kBias) is the history before dst
     kFirstRegion = kBias >> kRegionShift,
     kNone = 0xFFFFFFFFu,
 };
-static_assert(kMaxLead + 1 >= kCopyWaves, "every copy wave must be able to work at once");
+static_assert(kChunk == 16 || kChunk == 32, "chunk");
+static_assert((uint32_t)kRegionShift == (uint32_t)pre::kRegionShiftPre, "stage A's region index is per region of the copy stage");
 
 // LDS carve-up of stage B (bytes); stage A uses the same memory before (lz4_preparse_kernel.h)
 enum : uint32_t {
     kOffMisc = 0,                                            // u32[64] control words
-    kOffMaskTab = kOffMisc + 64 * 4,                         // U32x4[17]: byte masks, entry n selects bytes [0, n) of a chunk
-    kOffFin = kOffMaskTab + 17 * 16 + 16,                    // u32[16] regions completed per copy wave
-    kOffBits = kOffFin + 16 * 4,                             // u8[kSlots * 64] per chunk of the output ring: the lap tag of the region whose bytes are final there
+    kOffMaskTab = kOffMisc + 64 * 4,                         // U32x8[33]: byte masks, entry n selects bytes [0, n) of a chunk
+    kOffBits = kOffMaskTab + (kChunk + 1) * 32,                        // u8[kSlots * 64] per chunk of the output ring: the lap tag of the region whose bytes are final there
     kOffRegDone = kOffBits + kSlots * 64,                    // u32[kSlots] region + 1 that is complete in the slot
-    kOffIdx = kOffRegDone + kSlots * 4,                      // u32[kIdxRing]
-    kOffPend = kOffIdx + kIdxRing * 4,                       // u64[kCopyWaves][kMaxTrips + 2] pending masks of round B
-    kOffEnt = (kOffPend + kCopyWaves * (kMaxTrips + 2) * 8 + 15) & ~15u,    // lz4amd_hint_entry[kEntRing]
+    kOffProg = kOffRegDone + kSlots * 4,                     // u32[kSlots] the slot's bell: counts up whenever the region in the slot has landed pieces
+    kOffIdx = kOffProg + kSlots * 4,                         // u32[kIdxRing]
+    kOffPend = (kOffIdx + kIdxRing * 4 + 7) & ~7u,           // per copy wave: u64[kMaxTrips] pending masks of round B, u32[16] pending pieces per chunk (a byte each)
+    kPendStride = kMaxTrips * 8 + 64,
+    kOffEnt = (kOffPend + kActiveCopy * kPendStride + 15) & ~15u,    // lz4amd_hint_entry[kEntRing]
     kOffRecs = kOffEnt + kEntRing * 16,                      // SeqRec[kRecCap]
     kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
     kOffRing = kOffCr + kCrBytes + kCrPad,                   // output ring + pad
@@ -118,7 +171,7 @@ enum : uint32_t {
     kDecLdsBytes = kStreamLdsBytes > pre::kPreLdsBytes ? kStreamLdsBytes : pre::kPreLdsBytes,
 };
 static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
-static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0, "LDS alignment");
+static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0 && (kOffMaskTab % 32) == 0, "LDS alignment");
 
 enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_SPARE, M_CHI, M_CLO, M_HEAD, M_IHEAD, M_NEXT, M_OPEN,
                   M_EHEAD,       // rows of the entry-point table resident (mover -> parser)
@@ -143,45 +196,50 @@ __device__ __forceinline__ uint32_t uload(const uint32_t* w) { return __builtin_
 using pre::chunk_byte;
 using pre::chunk_set_byte;
 using pre::load_granule;
-// dword k of the 16-byte mask that selects bytes [0, n), n in 0..16
+// A chunk in registers: two register quads (the second one only with 32-byte chunks)
+struct U32x8 { U32x4 a, b; };
+constexpr bool kWide = kChunk == 32;
+__device__ __forceinline__ U32x8 zero8() { U32x8 z; z.a[0] = z.a[1] = z.a[2] = z.a[3] = 0; z.b = z.a; return z; }
+// dword k (0..7) of the mask that selects bytes [0, n) of a chunk, n in 0..kChunk
 __device__ __forceinline__ uint32_t low_bytes_mask(uint32_t n, uint32_t k) {
     const int32_t r = (int32_t)n - 4 * (int32_t)k;
     return r >= 4 ? 0xFFFFFFFFu : (r <= 0 ? 0u : ((1u << (8 * r)) - 1u));
 }
-// v restricted to bytes [lo, hi): two rows of the LDS mask table (computing the eight dword masks took ~60 instructions
-// per call, three calls per region - a fifth of the copy stage's instruction count)
-__device__ __forceinline__ U32x4 keep_bytes(const char* smem, const U32x4& v, uint32_t lo, uint32_t hi) {
-    const U32x4 mh = *(const U32x4*)(smem + kOffMaskTab + 16 * hi), ml = *(const U32x4*)(smem + kOffMaskTab + 16 * lo);
-    U32x4 r;
-    r[0] = v[0] & mh[0] & ~ml[0]; r[1] = v[1] & mh[1] & ~ml[1]; r[2] = v[2] & mh[2] & ~ml[2]; r[3] = v[3] & mh[3] & ~ml[3];
+// row n of the LDS mask table (32 bytes a row): bytes [0, n) of a chunk (computing the dword masks took ~60 instructions per call, three
+// calls per region - a fifth of the copy stage's instruction count; the rows are read before the piece's source, so that both travel together)
+__device__ __forceinline__ U32x8 mask_row(const char* smem, uint32_t n) {
+    const U32x4* p = (const U32x4*)(smem + kOffMaskTab + 32 * n);
+    U32x8 r; r.a = p[0]; if constexpr (kWide) r.b = p[1]; else r.b = r.a; return r;
+}
+// v restricted to bytes [lo, hi): mh = row hi, ml = row lo
+__device__ __forceinline__ U32x8 and_rows(const U32x8& v, const U32x8& mh, const U32x8& ml) {
+    U32x8 r;
+    r.a[0] = v.a[0] & mh.a[0] & ~ml.a[0]; r.a[1] = v.a[1] & mh.a[1] & ~ml.a[1]; r.a[2] = v.a[2] & mh.a[2] & ~ml.a[2]; r.a[3] = v.a[3] & mh.a[3] & ~ml.a[3];
+    if constexpr (kWide) { r.b[0] = v.b[0] & mh.b[0] & ~ml.b[0]; r.b[1] = v.b[1] & mh.b[1] & ~ml.b[1]; r.b[2] = v.b[2] & mh.b[2] & ~ml.b[2]; r.b[3] = v.b[3] & mh.b[3] & ~ml.b[3]; }
+    else r.b = r.a;
     return r;
 }
-// (the same with the table rows read by the caller - before the piece's source read, so that both travel together)
-__device__ __forceinline__ U32x4 mask_row(const char* smem, uint32_t n) { return *(const U32x4*)(smem + kOffMaskTab + 16 * n); }
-__device__ __forceinline__ U32x4 and_rows(const U32x4& v, const U32x4& mh, const U32x4& ml) {
-    U32x4 r;
-    r[0] = v[0] & mh[0] & ~ml[0]; r[1] = v[1] & mh[1] & ~ml[1]; r[2] = v[2] & mh[2] & ~ml[2]; r[3] = v[3] & mh[3] & ~ml[3];
+__device__ __forceinline__ U32x8 and_row(const U32x8& v, const U32x8& mh) {
+    U32x8 r;
+    r.a[0] = v.a[0] & mh.a[0]; r.a[1] = v.a[1] & mh.a[1]; r.a[2] = v.a[2] & mh.a[2]; r.a[3] = v.a[3] & mh.a[3];
+    if constexpr (kWide) { r.b[0] = v.b[0] & mh.b[0]; r.b[1] = v.b[1] & mh.b[1]; r.b[2] = v.b[2] & mh.b[2]; r.b[3] = v.b[3] & mh.b[3]; }
+    else r.b = r.a;
     return r;
 }
-__device__ __forceinline__ U32x4 and_row(const U32x4& v, const U32x4& mh) {
-    U32x4 r;
-    r[0] = v[0] & mh[0]; r[1] = v[1] & mh[1]; r[2] = v[2] & mh[2]; r[3] = v[3] & mh[3];
-    return r;
-}
-__device__ __forceinline__ U32x4 keep_low_bytes(const char* smem, const U32x4& v, uint32_t hi) {
-    const U32x4 mh = *(const U32x4*)(smem + kOffMaskTab + 16 * hi);
-    U32x4 r;
-    r[0] = v[0] & mh[0]; r[1] = v[1] & mh[1]; r[2] = v[2] & mh[2]; r[3] = v[3] & mh[3];
-    return r;
-}
-// 16 bytes starting at ANY byte a of an LDS array of dwords (the arrays are padded: a + 20 is in range)
-__device__ __forceinline__ U32x4 lds_read16_at(const uint8_t* base, uint32_t a) {
+__device__ __forceinline__ U32x8 keep_bytes(const char* smem, const U32x8& v, uint32_t lo, uint32_t hi) { return and_rows(v, mask_row(smem, hi), mask_row(smem, lo)); }
+__device__ __forceinline__ U32x8 keep_low_bytes(const char* smem, const U32x8& v, uint32_t hi) { return and_row(v, mask_row(smem, hi)); }
+// kChunk bytes starting at ANY byte a of an LDS array of dwords (the arrays are padded: a + kChunk + 4 is in range): aligned dwords
+// and byte alignments - an LDS access that is not aligned to its own width is served lane by lane on gfx950
+__device__ __forceinline__ U32x8 lds_read_chunk_at(const uint8_t* base, uint32_t a) {
     const uint32_t* r32 = (const uint32_t*)(base + (a & ~3u));
     const uint32_t sh = a & 3u;
     const uint32_t d0 = r32[0], d1 = r32[1], d2 = r32[2], d3 = r32[3], d4 = r32[4];
-    U32x4 v;
-    v[0] = align_bytes(d1, d0, sh); v[1] = align_bytes(d2, d1, sh);
-    v[2] = align_bytes(d3, d2, sh); v[3] = align_bytes(d4, d3, sh);
+    U32x8 v;
+    v.a[0] = align_bytes(d1, d0, sh); v.a[1] = align_bytes(d2, d1, sh); v.a[2] = align_bytes(d3, d2, sh); v.a[3] = align_bytes(d4, d3, sh);
+    if constexpr (kWide) {
+        const uint32_t d5 = r32[5], d6 = r32[6], d7 = r32[7], d8 = r32[8];
+        v.b[0] = align_bytes(d5, d4, sh); v.b[1] = align_bytes(d6, d5, sh); v.b[2] = align_bytes(d7, d6, sh); v.b[3] = align_bytes(d8, d7, sh);
+    } else v.b = v.a;
     return v;
 }
 
@@ -384,6 +442,16 @@ __device__ __forceinline__ uint64_t cr_fetch8(const char* cr, uint32_t x, uint32
     const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
     return (uint64_t)align_bytes(d1, d0, a & 3u) | ((uint64_t)align_bytes(d2, d1, a & 3u) << 32);
 }
+// ... the same from memory (LZ4AMD_DEC_PARSE_GLOBAL): never a byte outside src[0, csize) - a look that would run over the block's end is
+// moved back to end there (its value is then not the stream at x: every caller that can get there takes the careful form, which does not use it)
+__device__ __forceinline__ uint32_t g_fetch4(lz4amd_gsrc src, uint32_t x, uint32_t csize) {
+    if (csize < 4) return 0;
+    uint32_t v; __builtin_memcpy(&v, src + (x + 4 <= csize ? x : csize - 4), 4); return v;
+}
+__device__ __forceinline__ uint64_t g_fetch8(lz4amd_gsrc src, uint32_t x, uint32_t csize) {
+    if (csize < 8) return 0;
+    uint64_t v; __builtin_memcpy(&v, src + (x + 8 <= csize ? x : csize - 8), 8); return v;
+}
 // one stream byte at position x (x < csize): out of the compressed ring when it is resident, else from memory
 __device__ __forceinline__ uint32_t pbyte(const char* cr, lz4amd_gsrc src, uint32_t x, uint32_t mis, uint32_t chi) {
     if (x < chi) return (uint32_t)*(const uint8_t*)(cr + mod_cr(x + mis));
@@ -432,7 +500,7 @@ __device__ __forceinline__ void ext_field(bool need, uint32_t& pos, uint32_t& ac
 // rules, any field length, bytes from memory when they are not resident, the block's last sequence.
 struct Walk { uint32_t p, o, i, end, oend, iend; uint64_t W; bool act, res, bad; };      // res: every byte of the lane's row is in the ring; W: the eight stream bytes at p (asked for as soon as p is known: the walk is a chain of dependent LDS round trips)
 struct StepOut { SeqRec r; uint32_t oe; bool ok; };
-struct PCtx { const char* cr; lz4amd_gsrc src; uint32_t csize, mis, chi, capB, low; };
+struct PCtx { const char* cr; lz4amd_gsrc src; uint32_t csize, mis, chi, capB, low; bool pg; };      // pg: the walk reads the stream from memory, not from the compressed ring
 __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t& n_careful) {
     StepOut S; S.r.outpos = w.o; S.r.litpos = 0; S.r.ll = 0; S.r.off = 0; S.oe = w.o; S.ok = false;
     uint32_t pn = w.p;
@@ -456,7 +524,7 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
         const uint32_t m = q + ll;
         // (m + 24 <= csize: not the last sequence, lz4.c:2279, and every length byte looked at may be read, lz4.c:1986-2006)
         careful = careful || (w.act && (lmore || m + 24 > X.csize || X.capB - w.o < ll + kMfLimit));
-        const uint32_t V = cr_fetch4(X.cr, m, X.mis);
+        const uint32_t V = X.pg ? g_fetch4(X.src, m, X.csize) : cr_fetch4(X.cr, m, X.mis);
         const uint32_t off = V & 0xFFFFu, f1 = (V >> 16) & 0xFFu, f2 = V >> 24;
         const bool mx = (b & 15u) == 15, mx2 = mx && f1 == 255;
         const uint32_t ml = (b & 15u) + (mx ? f1 : 0u) + (mx2 ? f2 : 0u) + kMinMatch;
@@ -469,7 +537,7 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
         S.r.litpos = q; S.r.ll = ll; S.r.off = off;
         S.oe = S.ok ? ms + ml : S.oe;
         pn = S.ok ? m + 2 + (mx ? 1u : 0u) + (mx2 ? 1u : 0u) : pn;
-        w.W = cr_fetch8(X.cr, pn, X.mis);                  // the next token, on its way while this sequence's record is written
+        w.W = X.pg ? g_fetch8(X.src, pn, X.csize) : cr_fetch8(X.cr, pn, X.mis);                  // the next token, on its way while this sequence's record is written
     }
     if (__any(careful)) {
         n_careful++;
@@ -497,7 +565,7 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
         go = on && !cbad;
         w.bad = w.bad || (on && cbad);
         if (go) { S.r.litpos = q; S.r.ll = ll; S.r.off = last ? 0u : off; S.oe = last ? ms : ms + ml; pn = last ? X.csize : nx; S.ok = true; }
-        if (on) w.W = cr_fetch8(X.cr, pn, X.mis);
+        if (on) w.W = X.pg ? g_fetch8(X.src, pn, X.csize) : cr_fetch8(X.cr, pn, X.mis);
     }
     w.p = pn;
     return S;
@@ -526,6 +594,9 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
     const HintEnt* ent = (const HintEnt*)(smem + kOffEnt);
     const uint32_t lane = lane_here();
     PCtx X; X.cr = smem + kOffCr; X.src = src; X.csize = csize; X.mis = stream_misalign(src); X.chi = 0; X.capB = cap + kBias; X.low = kBias - prefix;
+    // (a block that is mostly stream - datagen -P60 and less compressible - and large: how far the walk may run ahead of the copy is else set by what
+    //  the 32 KB ring holds beyond the regions in flight; blocks of long matches walk faster out of the LDS)
+    X.pg = LZ4AMD_DEC_PARSE_GLOBAL == 2 ? (total >= (1u << 20) && csize > (total >> 1) - (total >> 4)) : LZ4AMD_DEC_PARSE_GLOBAL != 0;
     wave_priority_high();                              // the copy waves wait for what these waves produce
     uint32_t tail = 0, stall = 0;
     bool fail = false;
@@ -559,7 +630,7 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         const uint32_t ticket = __builtin_amdgcn_readfirstlane(qd[2]), turn = __builtin_amdgcn_readfirstlane(qd[3]);
         const uint32_t ehead = __builtin_amdgcn_readfirstlane(qc[0]);
         const uint32_t g = c.open;
-        X.chi = c.chi;
+        X.chi = X.pg ? 0u : c.chi;            // (0: every byte the careful form looks at comes from memory)
         // how many lanes?  Rows [r0, r0 + nl] must be resident; the lanes' records must fit the record ring behind the first
         // record an open region still needs, their regions the index ring; and the lanes' stream bytes should be resident.
         uint32_t nlmax = nreg - r0 < 64 ? nreg - r0 : 64;
@@ -578,7 +649,7 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         const uint32_t Rb = (B.out + kBias + kRegion - 1) >> kRegionShift;              // regions below Rb have their first byte before my lane's end
         const bool okrec = B.ord + 1 - tail <= kRecCap;
         const bool okidx = Rb + 1 <= g + kIdxRing;
-        const unsigned long long mh = __ballot(lane < nlmax && okrec && okidx), mr = __ballot(lane < nlmax && okrec && okidx && B.tok <= X.chi);
+        const unsigned long long mh = __ballot(lane < nlmax && okrec && okidx), mr = __ballot(lane < nlmax && okrec && okidx && (X.pg || B.tok <= X.chi));
         const uint32_t nl_hard = ~mh ? (uint32_t)__ffsll((long long)~mh) - 1 : 64u, nl_res = ~mr ? (uint32_t)__ffsll((long long)~mr) - 1 : 64u;      // leading lanes that may go
         const bool drained = turn == ticket;                                            // every claimed batch is published
         uint32_t nl = nl_res;
@@ -611,7 +682,7 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         // ---- walk
         Walk w; w.p = A.tok; w.o = A.out + kBias; w.i = A.ord; w.end = B.tok; w.oend = B.out + kBias; w.iend = B.ord;
         w.act = lane < nl && w.p < w.end; w.res = allres; w.bad = false;
-        w.W = cr_fetch8(X.cr, w.p, X.mis);
+        w.W = X.pg ? g_fetch8(X.src, w.p, X.csize) : cr_fetch8(X.cr, w.p, X.mis);
         uint32_t head = 0, sRa = Ra, scarry = 0;
         while (__any(w.act)) {
             n_steps++;
@@ -716,37 +787,44 @@ struct RegionCtx {
     uint32_t tagLo, tagHi;          // lap tags of the ring's two laps the region can read: the one below its own, its own
 };
 
-// Finality of output bytes is kept per 16-byte chunk of the output ring as ONE BYTE: the lap tag of the region whose
+// Finality of output bytes is kept per 32-byte chunk of the output ring as ONE BYTE: the lap tag of the region whose
 // bytes are final there (a region's lap = region / kSlots; tag = lap + 1 mod 256, 0 = nothing yet).  A slot is recycled
 // only once nobody can read its old region (kMaxLead), so "the byte holds the tag of the lap I mean" is the whole test -
 // no region numbers, no 64-bit masks, no first-open-region compare.
-__device__ __forceinline__ uint32_t lap_tag(uint32_t lap) { return (lap + 1u) & 0xFFu; }
-// output bytes [sa, sb] final?  (sb - sa < 16; both within the 64 KB below the region's end)
-__device__ __forceinline__ bool range_is_final(const RegionCtx& C, uint32_t sa, uint32_t sb) {
+// (tags are 16 .. 255: a chunk with k pending pieces holds tag - k, see copy_region, and that must neither wrap nor be 0)
+__device__ __forceinline__ uint32_t lap_tag(uint32_t lap) { return 16u + lap % 240u; }
+// output bytes [sa, sb] final?  (sb - sa < 32; both within the 64 KB below the region's end)  oka / okb: the chunk of sa / of sb is
+__device__ __forceinline__ void range_flags(const RegionCtx& C, uint32_t sa, uint32_t sb, bool& oka, bool& okb) {
     const uint8_t* done = (const uint8_t*)(C.smem + kOffBits);
     const uint32_t oa = sa - C.ringB, ob = sb - C.ringB;                 // [0, 2 * ring): the lap below the region's, then its own
     const bool ha = oa >= kRingBytes, hb = ob >= kRingBytes;
     uint32_t fa, fb;
-    lds_load_flags2(done + ((ha ? oa - kRingBytes : oa) >> 4), done + ((hb ? ob - kRingBytes : ob) >> 4), fa, fb);
-    return fa == (ha ? C.tagHi : C.tagLo) && fb == (hb ? C.tagHi : C.tagLo);
+    lds_load_flags2(done + ((ha ? oa - kRingBytes : oa) / kChunk), done + ((hb ? ob - kRingBytes : ob) / kChunk), fa, fb);
+    oka = fa == (ha ? C.tagHi : C.tagLo); okb = fb == (hb ? C.tagHi : C.tagLo);
 }
-__device__ __forceinline__ U32x4 ring_read16(const RegionCtx& C, uint32_t pos) {
-    return lds_read16_at((const uint8_t*)(C.smem + kOffRing), ring_fold(pos - C.ringB));
+__device__ __forceinline__ bool range_is_final(const RegionCtx& C, uint32_t sa, uint32_t sb) {
+    bool a, b; range_flags(C, sa, sb, a, b); return a && b;
+}
+__device__ __forceinline__ U32x8 ring_read32(const RegionCtx& C, uint32_t pos) {
+    return lds_read_chunk_at((const uint8_t*)(C.smem + kOffRing), ring_fold(pos - C.ringB));
 }
 
-// Bytes [lo, lo + n) of v := output bytes [d, d + n) of the piece (literal run or match of rec; ms = where
-// the match starts).  false: a source is not final yet.  own_ok: every lower piece of d's own chunk is done
-// (only a match with a period < 16 that starts inside a chunk reads its own chunk).
-// key: a piece that is not ready for the most common reason - a plain match whose source bytes [key, key + n) lie in
-// other chunks that are still in flight - reports where its source starts: it can be finished later with one poll of
-// those chunks' lap tags and one ring read.  kKeyAlways: only a full attempt can tell.
+// What a piece's fetch found out.  ready: its bytes can be put now.  plain: they are v's bytes [lo, lo + n) (v holds the 32 bytes from the
+// chunk's first byte on as the source has them); else the piece is a match whose period is shorter than the piece: it is copied
+// byte by byte inside the ring, from dist bytes back (copy_short_period).
+// key: a piece that is not ready for the most common reason - a plain match whose source bytes [key, key + n) lie in other chunks that
+// are still in flight - reports where its source starts: it can be finished later with one poll of those chunks' lap tags and one ring
+// read.  kKeyAlways: only a full attempt can tell.
 enum : uint32_t { kKeyAlways = 0xFFFFFFFFu };
-__device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint32_t d, uint32_t lo, uint32_t n,
-                                           const SeqRec& rec, uint32_t ms, bool own_ok, U32x4& v, uint32_t& key) {
+struct Fetch { U32x8 v; uint32_t key, dist; bool ready, plain; };
+// Bytes [lo, lo + n) of a chunk := output bytes [d, d + n) of the piece (literal run or match of rec; ms = where the match starts).
+// own_ok: every lower piece of d's own chunk is done (only a match with a period < 32 that starts inside a chunk reads its own chunk).
+__device__ __forceinline__ Fetch item_fetch(const RegionCtx& C, bool is_lit, uint32_t d, uint32_t lo, uint32_t n,
+                                            const SeqRec& rec, uint32_t ms, bool own_ok) {
     // Literal pieces and match pieces sit side by side in a wave, so both address computations run for every lane anyway:
-    // they are written straight-line and end in ONE 16-byte LDS read at the selected address (compressed ring or output
+    // they are written straight-line and end in ONE 32-byte LDS read at the selected address (compressed ring or output
     // ring) instead of one predicated read per kind.
-    key = kKeyAlways;
+    Fetch F; F.key = kKeyAlways;
     // -- a literal piece: stream bytes [A, A + n)
     const uint32_t A = rec.litpos + (d - rec.outpos);
     const uint32_t a = mod_cr(A + C.mis - lo);                               // (the ring is direct mapped on memory address: position + the block's misalignment; below position 0 only masked-off bytes)
@@ -755,7 +833,7 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     uint32_t dist = rec.off;
     const uint32_t into = d - ms;
 #ifdef LZ4AMD_TRACE
-    if (!is_lit && dist == 0) { fprintf(stderr, "ZERO OFFSET item: R=%u d=%u lo=%u n=%u rec{%u,%u,%u,%u} ms=%u j0=%u nrec=%u\n", C.R, d, lo, n, rec.outpos, rec.litpos, rec.ll, rec.off, ms, C.j0, C.nrec); return false; }
+    if (!is_lit && dist == 0) { fprintf(stderr, "ZERO OFFSET item: R=%u d=%u lo=%u n=%u rec{%u,%u,%u,%u} ms=%u j0=%u nrec=%u\n", C.R, d, lo, n, rec.outpos, rec.litpos, rec.ll, rec.off, ms, C.j0, C.nrec); }
 #endif
     if (!is_lit && into >= dist) {
         // the source lies inside this very match (it overlaps itself): every earlier period holds the same bytes; read one
@@ -769,47 +847,59 @@ __device__ __forceinline__ bool item_fetch(const RegionCtx& C, bool is_lit, uint
     }
     const uint32_t s = d - dist;
     // sources below my chunk must be final; sources inside my own chunk (a match that starts inside a chunk,
-    // offset < 16 + lo) are in once every lower piece of the chunk is
+    // offset < 32 + lo) are in once every lower piece of the chunk is
     const uint32_t cstart = d - lo;
     const uint32_t se = n <= dist ? s + n - 1 : d - 1;                       // last source byte
     const bool below = s < cstart;
     bool src_final = true;
     if (!is_lit && below) src_final = range_is_final(C, s, se < cstart ? se : cstart - 1);
     const bool wait_own = src_final && se >= cstart && !own_ok;
-    if (!is_lit && !src_final && n <= dist && se < cstart) key = s;
-    const bool ready = is_lit ? lit_ok : (src_final && !wait_own);
-    const bool plain = is_lit || n <= dist;
+    if (!is_lit && !src_final && n <= dist && se < cstart) F.key = s;
+    F.ready = is_lit ? lit_ok : (src_final && !wait_own);
+    F.plain = is_lit || n <= dist;
+    F.dist = dist;
     {   // (read whether or not the piece is ready: the address is always inside its ring, and the read then does not wait
         //  for the lap tags' own trip to LDS)
         const uint32_t addr = is_lit ? kOffCr + a : kOffRing + ring_fold(s - lo - C.ringB);
-        v = lds_read16_at((const uint8_t*)C.smem, addr);
+        F.v = lds_read_chunk_at((const uint8_t*)C.smem, addr);
     }
-    if (ready && !plain) {
-        // period < n <= 16: bytes [s, d) are the pattern
-        const U32x4 pat = ring_read16(C, s);
-        v[0] = v[1] = v[2] = v[3] = 0;
-        uint32_t k = 0;
-#pragma nounroll
-        for (uint32_t i = 0; i < n; i++) { chunk_set_byte(v, lo + i, chunk_byte(pat, k)); if (++k == dist) k = 0; }
-    }
-    return ready;
+    return F;
 }
 
-__device__ __forceinline__ void lds_or16(char* smem, uint32_t off, const U32x4& v) {
+__device__ __forceinline__ void lds_or32(char* smem, uint32_t off, const U32x8& v) {
     unsigned long long* q = (unsigned long long*)(smem + off);
-    atomicOr(&q[0], (unsigned long long)v[0] | ((unsigned long long)v[1] << 32));
-    atomicOr(&q[1], (unsigned long long)v[2] | ((unsigned long long)v[3] << 32));
+    atomicOr(&q[0], (unsigned long long)v.a[0] | ((unsigned long long)v.a[1] << 32));
+    atomicOr(&q[1], (unsigned long long)v.a[2] | ((unsigned long long)v.a[3] << 32));
+    if constexpr (kWide) {
+        atomicOr(&q[2], (unsigned long long)v.b[0] | ((unsigned long long)v.b[1] << 32));
+        atomicOr(&q[3], (unsigned long long)v.b[2] | ((unsigned long long)v.b[3] << 32));
+    }
 }
 
-// chunk c of the region's slot |= v (the ring's pad mirrors chunks 0-1 of slot 0 at all times, so that a 16-byte
+// chunk c of the region's slot |= v (the ring's pad mirrors chunks 0-1 of slot 0 at all times, so that a chunk-sized
 // read that starts in the ring's last bytes runs on into valid data)
-__device__ __forceinline__ void slot_or16(const RegionCtx& C, uint32_t c, const U32x4& v) {
-    lds_or16(C.smem, kOffRing + (C.slot << kRegionShift) + (c << 4), v);
-    if (C.slot == 0 && c < kRingPad / kChunk) lds_or16(C.smem, kOffRing + kRingBytes + (c << 4), v);
+__device__ __forceinline__ void slot_or32(const RegionCtx& C, uint32_t c, const U32x8& v) {
+    lds_or32(C.smem, kOffRing + (C.slot << kRegionShift) + c * kChunk, v);
+    if (C.slot == 0 && c < kRingPad / kChunk) lds_or32(C.smem, opaque_u32(kOffRing + kRingBytes) + c * kChunk, v);      // (opaque: or the compiler keeps the four addresses in registers through every loop around)
 }
-__device__ __forceinline__ void slot_write16(const RegionCtx& C, uint32_t c, const U32x4& v) {
-    *(U32x4*)(C.smem + kOffRing + (C.slot << kRegionShift) + (c << 4)) = v;
-    if (C.slot == 0 && c < kRingPad / kChunk) *(U32x4*)(C.smem + kOffRing + kRingBytes + (c << 4)) = v;
+__device__ __forceinline__ void slot_write32(const RegionCtx& C, uint32_t c, const U32x8& v) {
+    U32x4* q = (U32x4*)(C.smem + kOffRing + (C.slot << kRegionShift) + c * kChunk);
+    q[0] = v.a; if constexpr (kWide) q[1] = v.b;
+    if (C.slot == 0 && c < kRingPad / kChunk) { U32x4* m = (U32x4*)(C.smem + opaque_u32(kOffRing + kRingBytes) + c * kChunk); m[0] = v.a; if constexpr (kWide) m[1] = v.b; }
+}
+// A match whose period is shorter than the piece (dist < n <= 32; only the first chunk or two of a match with a short period: deeper
+// into it an earlier, farther period is read): output bytes [d, d + n) := the bytes dist before them, one after the other, inside the
+// ring - the serial copy of the format, by one lane (the DS unit serves a wave's LDS operations in order).  The bytes are the piece's
+// own: nobody else writes them, what the other pieces of the chunk OR in there is zero.
+__device__ __forceinline__ void copy_short_period(const RegionCtx& C, uint32_t d, uint32_t dist, uint32_t n) {
+    uint8_t* ring = (uint8_t*)(C.smem + kOffRing);
+    const uint32_t od = (C.slot << kRegionShift) + (d - C.x0);             // ring address of d (inside the region's slot)
+#pragma nounroll
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t b = lds_load_byte(ring + ring_fold(d + i - dist - C.ringB));
+        lds_store_byte(ring + od + i, b);
+        if (od + i < kRingPad) lds_store_byte(ring + kRingBytes + od + i, b);      // (slot 0's first bytes: the mirror behind the ring's end)
+    }
 }
 
 // chunks that still have a pending piece: OR of 1 << chunk over the lanes of pm (few lanes: a scalar loop)
@@ -835,29 +925,70 @@ __device__ __forceinline__ BItem b_item(const RegionCtx& C, uint32_t t) {
         it.ms = it.rec.outpos + it.rec.ll;
         it.d = it.is_lit ? it.rec.outpos : it.ms;
         const uint32_t pe = it.is_lit ? it.ms : nout;
-        it.lo = it.d & 15u;
+        it.lo = it.d & (kChunk - 1);
         it.valid = it.d >= C.x0 && it.d < C.x1 && it.lo != 0 && pe > it.d;
         const uint32_t n = pe - it.d;
-        it.n = n < 16 - it.lo ? n : 16 - it.lo;
-        it.chunk = (it.d - C.x0) >> 4;
+        it.n = n < kChunk - it.lo ? n : kChunk - it.lo;
+        it.chunk = (it.d - C.x0) / kChunk;
     }
     return it;
 }
+// what the retry loop keeps of a pending round-B item of the first trip: lo (5 bits), n (6), chunk (6)
+__device__ __forceinline__ uint32_t pack_b(uint32_t lo, uint32_t n, uint32_t chunk) { return lo | (n << 5) | (chunk << 11); }
+__device__ __forceinline__ uint32_t pack_lo(uint32_t p) { return p & 31u; }
+__device__ __forceinline__ uint32_t pack_n(uint32_t p) { return (p >> 5) & 63u; }
+__device__ __forceinline__ uint32_t pack_chunk(uint32_t p) { return p >> 11; }
+
+// Pending pieces per chunk: a byte per chunk, four to a word (a 32-byte chunk starts at most 13 pieces).
+__device__ __forceinline__ uint32_t cnt_one(uint32_t c) { return 1u << (8u * (c & 3u)); }
+__device__ __forceinline__ uint32_t cnt_of(uint32_t word, uint32_t c) { return (word >> (8u * (c & 3u))) & 0xFFu; }
+// A chunk's flag byte holds the region's lap tag when the chunk is final, and tag - k while k of its pieces are pending (anything but the
+// tag is "not final" to a reader).  A pending piece that is in - its bytes were written BEFORE: the DS unit serves a wave's operations in
+// order - adds one to the byte: the chunk's last piece makes it final, no lane has to know that it was the last, nothing is read back.
+__device__ __forceinline__ void piece_landed(uint8_t* done, uint32_t c) { c = opaque_u32(c); atomicAdd((uint32_t*)done + (c >> 2), cnt_one(c)); }      // (opaque: the address is made here, not kept in a register - or in scratch - through the loops around)
+
+// What a waiting piece looks at: the flag bytes of its source's first and last chunk (LDS offsets) and the tags they must hold.
+struct Watch { uint32_t f0, f1, tags; };
+__device__ __forceinline__ Watch watch_of(const RegionCtx& C, uint32_t sa, uint32_t sb) {
+    const uint32_t oa = sa - C.ringB, ob = sb - C.ringB;                 // [0, 2 * ring): the lap below the region's, then its own
+    const bool ha = oa >= kRingBytes, hb = ob >= kRingBytes;
+    Watch W;
+    W.f0 = kOffBits + (ha ? oa - kRingBytes : oa) / kChunk; W.f1 = kOffBits + (hb ? ob - kRingBytes : ob) / kChunk;
+    W.tags = (ha ? C.tagHi : C.tagLo) | ((hb ? C.tagHi : C.tagLo) << 8);
+    return W;
+}
 
 // Compose region C.R in its ring slot and store it.
-__device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint32_t w, bool timed, uint64_t& t_retry, uint32_t& n_iter) {
+//   first pass   round A (lane = chunk: the piece that covers the chunk's first byte) and round B (lane = piece head: every piece that starts
+//                inside a chunk, 32 records a trip).  A piece whose source is not final yet (it lies in a region another wave is composing) is
+//                PENDING: counted on its chunk.  Right behind the pass every chunk's flag byte is set: the tag, less its pending pieces.
+//   landing      every waiting lane looks at the flag bytes of its own source chunks; a piece that is in is ORed into its chunk and counted
+//                on the chunk's flag byte, and the slot's BELL (kOffProg) moves.  Nothing came in: the wave sleeps on the bell of the region
+//                that holds the highest chunk it waits for.  From one region's piece to the piece of the next region that waited for it
+//                that is: add to the flag byte -> bell -> wake: bell and flags in one trip -> ring read -> OR, add -> bell.
+//                (round 5: the waiting wave slept until the WHOLE source region was complete and went round a loop of ~10 dependent trips
+//                to the LDS and ~300 instructions before its own chunks were flagged: with most regions waiting for a piece of a region just
+//                below, that chain set the decoder's pace.)
+enum : uint32_t { kKeyed = 3 };
+static_assert(kKeyed == 3, "lds_load_word_then6");                 // waits a lane keeps in registers: its round-A piece, its pieces of round B's first two trips
+__device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint32_t w, uint64_t* prof, uint64_t& t_retry, uint32_t& n_iter) {
     char* smem = C.smem;
+    const bool timed = prof != nullptr;
+    DSTAMP_DECL; DSTAMP(0);                             // first pass begins
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     const SeqRec* recs = (const SeqRec*)(smem + kOffRecs);
     uint8_t* done = (uint8_t*)(smem + kOffBits) + C.slot * 64;        // my chunks' bytes (they hold the tag of the lap below: not final)
-    unsigned long long* pend = (unsigned long long*)(smem + kOffPend) + w * (kMaxTrips + 2);     // [0] scratch, [1..] trips
+    unsigned long long* pend = (unsigned long long*)(smem + kOffPend + w * kPendStride);     // pending lanes of round B, per trip
+    uint32_t* cnt = (uint32_t*)(pend + kMaxTrips);                    // pending pieces per chunk
+    uint32_t* bells = (uint32_t*)(smem + kOffProg);
+    uint32_t mybell = C.R << 8;                                       // the slot's bell: every lane stores the same next value (values no earlier region left in this slot)
     const uint32_t lane = lane_here();
     const uint32_t slot_off = kOffRing + (C.slot << kRegionShift);
     {   const uint32_t lap = (C.R - C.slot) / kSlots; C.tagHi = lap_tag(lap); C.tagLo = lap_tag(lap - 1); }
     C.ringB = (C.R - C.slot - kSlots) << kRegionShift;
     // ---- round A: which record covers the first byte of each chunk?  (scratch: the slot itself)
     uint32_t* fs = (uint32_t*)(smem + slot_off);
-    fs[lane] = 0;
+    fs[lane] = 0;                                      // (cnt[] is all zero here: a region that counted pending pieces clears it behind its first pass)
     wave_lds_fence();
     for (uint32_t base = 1; base < C.nrec; base += 64) {
         const uint32_t r = base + lane;
@@ -880,174 +1011,240 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
         ams = arec.outpos + arec.ll;
         alit = c0 < ams;
         const uint32_t pe = alit ? ams : nout;
-        an = pe - c0 < 16 ? pe - c0 : 16;
+        an = pe - c0 < kChunk ? pe - c0 : kChunk;
     }
+    // what my pending pieces wait for: [0] round A, [1] round B's first trip.  key: where the source starts (kKeyAlways: not a
+    // plain wait for source chunks - only a full attempt can tell); pack: lo / n / chunk
+    uint32_t key[kKeyed] = {kKeyAlways, kKeyAlways}, pack[kKeyed] = {0, 0};
+    uint64_t pm[kKeyed] = {0, 0};                    // pending lanes of the three
+    uint32_t npend;                                     // pending pieces of the region
+    bool later = false;                                 // ... some of them in round B's trips behind the first
     {
-        U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
-        bool ready = false;
-        uint32_t keyA = kKeyAlways, keyB0 = kKeyAlways, packB0 = 0;    // what my pending pieces wait for (round A; round B, first trip: + lo / n / chunk)
         const BItem it0 = b_item(C, 0);                // round B's first trip reads its records while round A's reads are in flight
+        bool readyA = false;
         if (actA) {
-            const U32x4 mA = mask_row(smem, an);                   // (read before the piece's source: one trip to the LDS for both)
-            ready = item_fetch(C, alit, c0, 0, an, arec, ams, true, v, keyA);
-            v = ready ? and_row(v, mA) : U32x4{0, 0, 0, 0};
-            slot_write16(C, lane, v);
+            const U32x8 mA = mask_row(smem, an);                   // (read before the piece's source: one trip to the LDS for both)
+            const Fetch F = item_fetch(C, alit, c0, 0, an, arec, ams, true);
+            readyA = F.ready; key[0] = F.key; pack[0] = pack_b(0, an, lane);
+            slot_write32(C, lane, F.ready && F.plain ? and_row(F.v, mA) : zero8());
+            if (F.ready && !F.plain) copy_short_period(C, c0, F.dist, an);
+            if (F.ready && an == kChunk) lds_store_flag(done + lane, C.tagHi);      // (the chunk is this one piece: final here and now)
+            if (!F.ready) atomicAdd(&cnt[lane >> 2], cnt_one(lane));
         }
-        uint64_t pendA = __ballot(actA && !ready);
+        pm[0] = __ballot(actA && !readyA);
+        npend = (uint32_t)__popcll(pm[0]);
         // ---- round B: heads of the pieces that start inside a chunk, 32 records per trip
         const uint32_t trips = (C.nrec + 31) / 32;
-        uint64_t pendBc = 0;                           // chunks with a pending round-B piece
         for (uint32_t t = 0; t < trips; t++) {
             const BItem it = t == 0 ? it0 : b_item(C, t);
             bool rdy = false;
             if (it.valid) {
-                U32x4 bv;
-                uint32_t kb;
-                const U32x4 mh = mask_row(smem, it.lo + it.n), ml = mask_row(smem, it.lo);
-                rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, false, bv, kb);
-                if (rdy) slot_or16(C, it.chunk, and_rows(bv, mh, ml));
-                else if (t == 0) { keyB0 = kb; packB0 = it.lo | (it.n << 4) | (it.chunk << 9); }
+                const U32x8 mh = mask_row(smem, it.lo + it.n), ml = mask_row(smem, it.lo);
+                const Fetch F = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, false);
+                rdy = F.ready;
+                if (rdy) { if (F.plain) slot_or32(C, it.chunk, and_rows(F.v, mh, ml)); else copy_short_period(C, it.d, F.dist, it.n); }
+                else {
+                    atomicAdd(&cnt[it.chunk >> 2], cnt_one(it.chunk));
+                    if (t == 0) { key[1] = F.key; pack[1] = pack_b(it.lo, it.n, it.chunk); }
+                }
             }
-            const unsigned long long pm = __ballot(it.valid && !rdy);
-            if (lane == 0) pend[1 + t] = pm;
-            if (pm) pendBc |= chunks_of(pm, it.chunk);
+            const unsigned long long m = __ballot(it.valid && !rdy);
+            if (lane == 0) pend[t] = m;
+            npend += (uint32_t)__popcll(m);
+            if (t == 0) pm[1] = m; else later = later || m != 0;
         }
-        // ---- pieces whose sources were still in flight: try again until they are all in
-        if (pendA || pendBc) {
-            const uint64_t tr0 = timed ? clock_ticks() : 0;
-            uint64_t published = 0;
-            uint32_t idle_polls = 0;
-            const uint64_t actm = __ballot(actA);
-            for (;;) {
-                // chunks without a pending piece are final: tell the other waves
-                const uint64_t pendchunks = pendA | pendBc;
-                const uint64_t pub = ~pendchunks & actm;
-                if (pub != published) {
-                    wave_lds_fence();                  // (their bytes first)
-                    if (((pub & ~published) >> lane) & 1ull) lds_store_flag(done + lane, C.tagHi);
-                    published = pub;
-                }
-                if (!pendchunks) break;
-                n_iter++;
-                wave_lds_fence();                      // (pend[] of the last pass)
-                {
-                    // the cheap way first: plain matches that only waited for their source chunks (one poll, one ring read)
-                    const unsigned long long pb0 = pend[1];
-                    const bool sa_ = ((pendA >> lane) & 1ull) && keyA != kKeyAlways;
-                    bool rdyA = false;
-                    if (sa_ && range_is_final(C, keyA, keyA + an - 1)) { slot_or16(C, lane, keep_low_bytes(smem, ring_read16(C, keyA), an)); rdyA = true; }
-                    const unsigned long long doneA = __ballot(rdyA);
-                    const bool sb_ = ((pb0 >> lane) & 1ull) && keyB0 != kKeyAlways;
-                    bool rdyB = false;
-                    if (sb_) {
-                        const uint32_t blo = packB0 & 15u, bn = (packB0 >> 4) & 31u, bch = packB0 >> 9;
-                        if (range_is_final(C, keyB0, keyB0 + bn - 1)) { slot_or16(C, bch, keep_bytes(smem, ring_read16(C, keyB0 - blo), blo, blo + bn)); rdyB = true; }
-                    }
-                    const unsigned long long doneB = __ballot(rdyB);
-                    pendA &= ~doneA;
-                    const unsigned long long left0 = pb0 & ~doneB;
-                    if (doneB) { if (lane == 0) pend[1] = left0; wave_lds_fence(); }
-                    // is anything left that needs the full attempt?  (other waits, later trips)
-                    bool later = false;
-                    for (uint32_t t = 1; t < trips; t++) later = later || pend[1 + t] != 0;
-                    const bool hard = __any((((pendA >> lane) & 1ull) && keyA == kKeyAlways) || (((left0 >> lane) & 1ull) && keyB0 == kKeyAlways));
-                    if (!hard && !later) {
-                        pendBc = left0 ? chunks_of(left0, packB0 >> 9) : 0;
-                        if (!(doneA | doneB)) {
-                            // Nothing came in: the sources belong to regions other waves are still composing.  A poll of the chunk
-                            // flags costs ~80 instructions of a SIMD the other waves need; instead the wave sleeps on ONE word - the
-                            // complete mark of the highest region below its own that a waiting piece reads from (a region's chunks
-                            // are flagged before its mark is set; its slot is not recycled while this region is open) - and looks at
-                            // the flags again when that region is done.  Pieces that read from this region's own chunks follow
-                            // from the ones they wait for.
-                            uint32_t wr = 0;                                  // (region + 1)
-                            if (sa_ && !rdyA) { const uint32_t r = (keyA + an - 1) >> kRegionShift; wr = r < C.R ? r + 1 : 0u; }
-                            if (sb_ && !rdyB) { const uint32_t r = (keyB0 + ((packB0 >> 4) & 31u) - 1) >> kRegionShift; if (r < C.R && r + 1 > wr) wr = r + 1; }
-                            wr = wave_readlane(wave_incl_max_u32(wr), 63);
-#if LZ4AMD_DEC_NEAR_POLL
-                            if (wr && C.R + 1 - wr <= LZ4AMD_DEC_NEAR_POLL) {
-                                // the source is in a region just below this one: a chain of near matches (a stream that copies from what it has just
-                                // written: LZ4_compress_HC's output, the reference's nearest-occurrence matches).  Waiting for that whole region makes
-                                // the chain advance a region at a time; the waiting lanes look at their own sources' flags instead - a chunk is
-                                // flagged as soon as it is final -, the wave goes on when one of them is in
-                                for (;;) {
-                                    bool in = false;
-                                    if (sa_ && !rdyA) in = range_is_final(C, keyA, keyA + an - 1);
-                                    if (sb_ && !rdyB && !in) in = range_is_final(C, keyB0, keyB0 + ((packB0 >> 4) & 31u) - 1);
-                                    if (__any(in)) break;
-                                    if (uload(&misc[M_ABORT])) return;
-                                    spin_pause();
-                                }
-                            } else
-#endif
-                            if (wr) {
-                                const uint32_t* mark = (const uint32_t*)(smem + kOffRegDone) + (wr - 1) % kSlots;
-                                while (uload(mark) != wr) { if (uload(&misc[M_ABORT])) return; spin_pause(); }
-                            } else { if (++idle_polls > 2) spin_pause_long(); else spin_pause(); }
-                            if (uload(&misc[M_ABORT])) return;
-                        } else idle_polls = 0;
-                        continue;
-                    }
-                }
-                {   // the full attempt: literal pieces wait for stream bytes - how many are resident now?  (plain matches, the cheap way
-                    // above, need none of the control words)
-                    const Ctl c = ctl_snapshot(smem);
-                    if (c.abort_) return;
-                    C.chi = c.chi; C.g = c.open;
-                }
-                pendBc = 0;
-                if (pendA) {
-                    const bool mine = (pendA >> lane) & 1ull;
-                    bool rdy = false;
-                    if (mine) {
-                        U32x4 av;
-                        rdy = item_fetch(C, alit, c0, 0, an, arec, ams, true, av, keyA);
-                        if (rdy) slot_or16(C, lane, keep_low_bytes(smem, av, an));
-                    }
-                    pendA &= ~__ballot(rdy);
-                }
-                bool earlier_clear = true;
-                for (uint32_t t = 0; t < trips; t++) {
-                    const unsigned long long pm = pend[1 + t];
-                    if (!pm) continue;
-                    const BItem it = b_item(C, t);
-                    const bool mine = (pm >> lane) & 1ull;
-                    // is every lower piece of my own chunk in? (chunk A, the earlier trips, the lower lanes of this trip)
-                    const unsigned long long lower = pm & ((1ull << lane) - 1ull);
-                    const uint32_t h = lower ? 63u - (uint32_t)__clzll((long long)lower) : 0u;
-                    const uint32_t hc = (uint32_t)__shfl((int)it.chunk, (int)h);
-                    const bool own_ok = earlier_clear && !((pendA >> it.chunk) & 1ull) && (!lower || hc != it.chunk);
-                    bool rdy = false;
-                    if (mine) {
-                        U32x4 bv;
-                        uint32_t kb;
-                        rdy = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, own_ok, bv, kb);
-                        if (!rdy && t == 0) { keyB0 = kb; packB0 = it.lo | (it.n << 4) | (it.chunk << 9); }
-                        if (rdy) slot_or16(C, it.chunk, keep_bytes(smem, bv, it.lo, it.lo + it.n));
-                    }
-                    const unsigned long long left = pm & ~__ballot(rdy);
-                    if (lane == 0) pend[1 + t] = left;
-                    if (left) { earlier_clear = false; pendBc |= chunks_of(left, it.chunk); }
-                }
-            }
-            if (timed) t_retry += clock_ticks() - tr0;
+        // ---- every chunk's flag byte: the tag less the chunk's pending pieces (none: final) - tell the other waves
+        wave_lds_fence();                              // (the pieces' bytes and the counts first)
+        if (npend == 0) lds_store_flag(done + lane, C.tagHi);
+        else {
+            lds_store_flag(done + lane, C.tagHi - cnt_of(cnt[lane >> 2], lane));
+            wave_lds_fence();
+            if (lane < 16) cnt[lane] = 0;              // (for the wave's next region)
         }
     }
-    // ---- the region is complete: its bytes into registers, tell the other waves (they read the ring, not HBM: a region
-    //      that waits for this one need not wait for the store as well), then to HBM
-    wave_lds_fence();
-    U32x4 v; v[0] = v[1] = v[2] = v[3] = 0;
-    if (actA) v = *(const U32x4*)(smem + slot_off + kChunk * lane);
-    wave_lds_fence();                                   // (the slot is not read again: whoever recycles it may)
-    lds_store_flag(done + lane, C.tagHi);
-    wave_lds_fence();
-    if (lane == 0) lds_store_release((uint32_t*)(smem + kOffRegDone) + C.slot, C.R + 1);
-    if (actA) {
-        const uint32_t c1 = c0 + kChunk < C.x1 ? c0 + kChunk : C.x1;
-        if (c1 - c0 == kChunk) st_global16(dst + (c0 - kBias), v);
-        else {
+    DSTAMP(1);                                          // first pass done
+    const uint32_t npend0 = npend; (void)npend0;
+    // ---- pieces whose sources were still in flight: land them as their sources come in
+    bool aborted = false;                               // the block was given up (M_ABORT) while this region waited
+    if (npend) {
+        const uint64_t tr0 = timed ? clock_ticks() : 0;
+        const uint32_t trips = (C.nrec + 31) / 32;
+        uint32_t idle_polls = 0;
+        wave_lds_order();
+        { lds_store_relaxed(&bells[C.slot], ++mybell); wake_workgroup(); }
+#if LZ4AMD_DEC_LAND_PRIO
+        wave_priority(LZ4AMD_DEC_LAND_PRIO);           // (a region that lands pieces is what other regions wait for: its few instructions go first on its SIMD)
+#endif
+        const uint32_t* const still = &misc[M_SPARE];  // (a word that does not move: the bell of a lane that watches none)
+        const uint32_t* bp[kKeyed] = {still, still};   // the bells my two waits watch: those of the regions that hold the chunks they wait for
+        bool dirty = true;                             // the waits changed: look again at what the lanes watch
+        Watch W[kKeyed];
+        bool on[kKeyed] = {false, false};
+        bool hard = false;
+        for (;;) {                                     // (left by break only: a return out of the nest of loops is a construct that has miscompiled on the device before)
+            n_iter++;
+            if (dirty) {
+                hard = later;
+#pragma unroll
+                for (uint32_t k = 0; k < kKeyed; k++) {
+                    const bool mine = (pm[k] >> lane) & 1ull;
+                    on[k] = mine && key[k] != kKeyAlways;
+                    hard = hard || __any(mine && key[k] == kKeyAlways);
+                    W[k] = watch_of(C, key[k], key[k] + pack_n(pack[k]) - 1);
+                    if (!on[k]) { W[k].f0 = W[k].f1 = kOffBits; bp[k] = still; }
+                }
+                dirty = false;
+            }
+            // -- one trip to the LDS: my bells, THEN the flag bytes my pieces wait for (a flag that is set behind this look moves its
+            //    region's bell behind the value read here)
+            uint32_t seen[kKeyed], fl[2 * kKeyed];
+            {
+                const uint8_t* sm8 = (const uint8_t*)smem;
+                const uint8_t* const fp[4] = {sm8 + W[0].f0, sm8 + W[0].f1, sm8 + W[1].f0, sm8 + W[1].f1};
+                lds_load_words_then4(bp[0], bp[1], fp, seen[0], seen[1], fl);
+                wave_converge();
+            }
+            bool in[kKeyed], ok0[kKeyed];
+            bool any_in = false;
+#pragma unroll
+            for (uint32_t k = 0; k < kKeyed; k++) {
+                ok0[k] = fl[2 * k] == (W[k].tags & 0xFFu);
+                in[k] = on[k] && ok0[k] && fl[2 * k + 1] == (W[k].tags >> 8);
+                any_in = any_in || in[k];
+            }
+            bool progress = false;
+            if (__any(any_in)) {
+                uint32_t landed = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kKeyed; k++) {
+                    if (in[k]) {
+                        const uint32_t lo = pack_lo(pack[k]), n = pack_n(pack[k]), ch = pack_chunk(pack[k]);
+                        slot_or32(C, ch, keep_bytes(smem, ring_read32(C, key[k] - lo), lo, lo + n));
+                        piece_landed(done, ch);
+                    }
+                    const unsigned long long dn = __ballot(in[k]);
+                    if (dn) { pm[k] &= ~dn; landed += (uint32_t)__popcll(dn); if (k && lane == 0) pend[k - 1] = pm[k]; }
+                }
+                npend -= landed;
+                wave_lds_order();
+                { lds_store_relaxed(&bells[C.slot], ++mybell); wake_workgroup(); }
+                DSTAMP(3); DSTAMP_LAST(4);     // first / last landing the cheap way
+                if (!npend) break;
+                progress = true; dirty = true;
+            }
+            // -- the other waits (literals whose stream bytes are not resident yet, matches that read their own chunk, matches with a period
+            //    shorter than the piece, everything of the later trips): the full attempt, when the cheap way brought nothing
+            if (hard && !progress) {
+                {   const Ctl c = ctl_snapshot(smem);          // literal pieces wait for stream bytes - how many are resident now?
+                    if (c.abort_) { aborted = true; break; }
+                    C.chi = c.chi; C.g = c.open; }
+                wave_lds_fence();                              // (pend[] of the last pass)
+                uint32_t landed = 0;
+                if (pm[0]) {
+                    const bool mine = (pm[0] >> lane) & 1ull;
+                    bool rdy = false;
+                    if (mine) {
+                        const Fetch F = item_fetch(C, alit, c0, 0, an, arec, ams, true);
+                        rdy = F.ready; key[0] = F.key;
+                        if (rdy) { if (F.plain) slot_or32(C, lane, keep_low_bytes(smem, F.v, an)); else copy_short_period(C, c0, F.dist, an);
+                                   piece_landed(done, lane); }
+                    }
+                    const unsigned long long dn = __ballot(rdy);
+                    pm[0] &= ~dn; landed += (uint32_t)__popcll(dn);
+                }
+                bool earlier_clear = true;
+                later = false;
+                for (uint32_t t = 0; t < trips; t++) {
+                    const unsigned long long m = pend[t];
+                    if (!m) continue;
+                    const BItem it = b_item(C, t);
+                    const bool mine = (m >> lane) & 1ull;
+                    // is every lower piece of my own chunk in? (chunk A, the earlier trips, the lower lanes of this trip)
+                    const unsigned long long lower = m & ((1ull << lane) - 1ull);
+                    const uint32_t h = lower ? 63u - (uint32_t)__clzll((long long)lower) : 0u;
+                    const uint32_t hc = (uint32_t)__shfl((int)it.chunk, (int)h);
+                    const bool own_ok = earlier_clear && !((pm[0] >> it.chunk) & 1ull) && (!lower || hc != it.chunk);
+                    bool rdy = false;
+                    if (mine) {
+                        const Fetch F = item_fetch(C, it.is_lit, it.d, it.lo, it.n, it.rec, it.ms, own_ok);
+                        rdy = F.ready;
+                        if (!rdy && t == 0) { key[1] = F.key; pack[1] = pack_b(it.lo, it.n, it.chunk); }
+                        if (rdy) { if (F.plain) slot_or32(C, it.chunk, keep_bytes(smem, F.v, it.lo, it.lo + it.n)); else copy_short_period(C, it.d, F.dist, it.n);
+                                   piece_landed(done, it.chunk); }
+                    }
+                    const unsigned long long dn = __ballot(rdy), left = m & ~dn;
+                    landed += (uint32_t)__popcll(dn);
+                    if (lane == 0) pend[t] = left;
+                    if (t == 0) pm[1] = left; else later = later || left != 0;
+                    if (left) earlier_clear = false;
+                }
+                npend -= landed;
+                DSTAMP(5);                              // first full attempt
+                dirty = true;
+                if (landed) { wave_lds_order(); { lds_store_relaxed(&bells[C.slot], ++mybell); wake_workgroup(); } }
+                if (!npend) break;
+                progress = landed != 0;
+            }
+            if (progress) { idle_polls = 0; continue; }
+            // -- nothing came in.  Every waiting lane watches the bell of the region that holds the chunk it waits for (its source's first
+            //    chunk that is not final; a chunk of my own region: none, it follows from my other pieces) - if that is the bell it read
+            //    before the flags; else the wave looks once more, bells first.  Then it sleeps until somebody's s_wakeup, and goes on when
+            //    one of its lanes' bells has moved.
+            bool moved = false;
+#pragma unroll
+            for (uint32_t k = 0; k < kKeyed; k++) {
+                const uint32_t* nb = still;
+                if (on[k]) { const uint32_t r = (ok0[k] ? key[k] + pack_n(pack[k]) - 1 : key[k]) >> kRegionShift; if (r < C.R) nb = &bells[r % kSlots]; }
+                moved = moved || nb != bp[k];
+                bp[k] = nb;
+            }
+            if (__any(moved)) continue;
+            if (__any(bp[0] != still || bp[1] != still)) {
+                for (uint32_t k = 0; k < 24; k++) {            // (bounded: a lost wake-up, a wait that is not what it seemed)
+                    uint32_t b0, b1;
+                    lds_load_2v(bp[0], bp[1], b0, b1);
+                    if (__any(b0 != seen[0] || b1 != seen[1])) break;
+                    if ((k & 3u) == 3u && uload(&misc[M_ABORT])) { aborted = true; break; }
+                    sleep_until_woken(); DCOUNT();
+                }
+                DSTAMP(2);                                  // first time the sleep ended
+            } else { if (++idle_polls > 2) spin_pause_long(); else spin_pause(); }
+            if (aborted || uload(&misc[M_ABORT])) { aborted = true; break; }
+        }
+#if LZ4AMD_DEC_LAND_PRIO
+        wave_priority(0);
+#endif
+        if (timed) t_retry += clock_ticks() - tr0;
+    }
+    if (!aborted) {
+        // ---- the region is complete (every chunk is flagged): its bytes into registers, tell the other waves (they read the ring, not HBM: a
+        //      region that waits for this one need not wait for the store as well), then to HBM - in rows of 64 aligned 16-byte
+        //      stores (lane l: bytes [16 l, 16 l + 16) of either KB of the region): 1 KB contiguous per store instruction
+        wave_lds_fence();
+        const uint32_t h0 = C.x0 + 16 * lane, h1 = h0 + 1024;
+        U32x4 v0, v1; v0[0] = v0[1] = v0[2] = v0[3] = 0; v1 = v0;
+        if (h0 < C.x1) v0 = *(const U32x4*)(smem + slot_off + 16 * lane);
+        if constexpr (kWide) { if (h1 < C.x1) v1 = *(const U32x4*)(smem + slot_off + 1024 + 16 * lane); }
+        wave_lds_fence();                                   // (the slot is not read again: whoever recycles it may)
+        if (lane == 0) lds_store_release((uint32_t*)(smem + kOffRegDone) + C.slot, C.R + 1);
+        lds_store_relaxed(&bells[C.slot], ++mybell);
+        wake_workgroup();
+        DSTAMP(6); DFLUSH(prof, C.R, npend0 > 255 ? 255u : npend0);      // complete
+        if (h0 < C.x1) {
+            if (h0 + 16 <= C.x1) st_global16(dst + (h0 - kBias), v0);
+            else {
 #pragma nounroll
-            for (uint32_t i = 0; i < c1 - c0; i++) dst[c0 - kBias + i] = (uint8_t)chunk_byte(v, i);
+                for (uint32_t i = 0; i < C.x1 - h0; i++) dst[h0 - kBias + i] = (uint8_t)chunk_byte(v0, i);
+            }
+        }
+        if constexpr (kWide) {
+            if (h1 < C.x1) {
+                if (h1 + 16 <= C.x1) st_global16(dst + (h1 - kBias), v1);
+                else {
+#pragma nounroll
+                    for (uint32_t i = 0; i < C.x1 - h1; i++) dst[h1 - kBias + i] = (uint8_t)chunk_byte(v1, i);
+                }
+            }
         }
     }
 }
@@ -1101,7 +1298,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
         const bool head = R <= C.g + LZ4AMD_DEC_HEAD_PRIO - 1;
         if (head) wave_priority(2);
 #endif
-        copy_region(C, dst, w, prof != nullptr, tr, ni);
+        copy_region(C, dst, w, prof, tr, ni);
 #if LZ4AMD_DEC_HEAD_PRIO
         if (head) wave_priority(0);
 #endif
@@ -1129,11 +1326,11 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
     if (tid == 0) { misc[M_ABORT] = 0; misc[M_SPARE] = 0; misc[M_CHI] = 0; misc[M_IHEAD] = kFirstRegion; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion;
                     misc[M_EHEAD] = 0; misc[M_PR0] = 0; misc[M_PBAD] = 0;
                     misc[P_LOCK] = 0; misc[P_NEXT] = 0; misc[P_RZ] = kFirstRegion; misc[P_TICKET] = 0; misc[P_TURN] = 0; misc[P_ICARRY] = 0; }
-    if (tid < 16) ((uint32_t*)(smem + kOffFin))[tid] = 0;
-    if (tid < 17) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid, k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
+    if (tid < 2 * (kChunk + 1)) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid >> 1, 4 * (tid & 1) + k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
     // chunk flags: the history before dst (positions below kBias = regions 0..63, lap 0) is final, nothing else is
     for (uint32_t i = tid; i < kSlots * 16; i += kDecThreads) ((uint32_t*)(smem + kOffBits))[i] = i < kFirstRegion * 16 ? 0x01010101u * lap_tag(0) : 0u;
-    if (tid < kSlots) ((uint32_t*)(smem + kOffRegDone))[tid] = 0;
+    if (tid < kSlots) { ((uint32_t*)(smem + kOffRegDone))[tid] = 0; ((uint32_t*)(smem + kOffProg))[tid] = 0; }
+    for (uint32_t i = tid; i < kActiveCopy * kPendStride / 4; i += kDecThreads) ((uint32_t*)(smem + kOffPend))[i] = 0;      // (the copy waves' pending counts start at zero)
     if (prefix) {
         uint8_t* ring = (uint8_t*)(smem + kOffRing);
         const uint32_t lo = kBias - prefix;
@@ -1152,7 +1349,7 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
     // (nreg: rows of the table; nreg + 1 entries behind its 16-byte header)
     if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem, hinted ? hint + 16 : hint, nreg + 1);
     else if (hinted && w >= kFirstParseWave) parser_role(src, csize, cap, prefix, total, nseq, nreg, rend, smem, prof);
-    else copy_role(w, src, dst, nseq, total, rend, smem, prof, hinted);
+    else if (w < kActiveCopy) copy_role(w, src, dst, nseq, total, rend, smem, prof, hinted);
     __syncthreads();
     return misc[M_PBAD] == 0;
 }
@@ -1197,7 +1394,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     uint32_t prefix = chained ? kBias : (P.prefix ? (uint32_t)P.prefix[b] : 0u); if (prefix > kBias) prefix = kBias;
 
     SeqRec* rectab = (SeqRec*)(P.scratch + (uint64_t)blockIdx.x * P.scratch_stride);
-    uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
+    uint64_t* prof = (LZ4AMD_DEC_PROF && P.prof) ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;      // (a developer build's stamps: the product kernel carries none of that code)
     uint64_t tstart = 0;
     if (prof && tid == 0) tstart = clock_ticks();
 

@@ -64,9 +64,12 @@ __host__ __device__ inline uint64_t toks_bytes(uint32_t csize) {
     const uint32_t span = csize < kSpanMax ? csize : kSpanMax;
     return (((uint64_t)span / 3 + 8) * 4 + 15) & ~15ull;
 }
-// ... and behind the token list the REGION INDEX: for every 1 KB region of the block's output the record that holds the region's
+// ... and behind the token list the REGION INDEX: for every 2 KB region of the block's output the record that holds the region's
 // first byte (u32 per region): the copy stage of the decoder finds a region's records through it, straight from the table
-enum : uint32_t { kRegionShiftPre = 10 };
+#ifndef LZ4AMD_DEC_CHUNK
+#define LZ4AMD_DEC_CHUNK 16
+#endif
+enum : uint32_t { kRegionShiftPre = LZ4AMD_DEC_CHUNK == 32 ? 11 : 10 };      // (lz4_decompress_kernel.h: a region is 64 chunks)
 __host__ __device__ inline uint64_t max_regions(uint32_t max_csize, uint32_t max_out) {
     const uint64_t most = (uint64_t)max_csize * 255 + 64;                // the format's largest expansion
     const uint64_t out = max_out < most ? max_out : most;

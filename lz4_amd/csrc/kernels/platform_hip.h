@@ -57,6 +57,23 @@ __device__ __forceinline__ void lds_load_flags2(const uint8_t* p0, const uint8_t
     v1 = *(const volatile __attribute__((address_space(3))) uint8_t*)p1;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// one byte of LDS another lane's store may just have written / may read next (the serial copy of a short-period match)
+__device__ __forceinline__ uint32_t lds_load_byte(const uint8_t* p) { return *(const volatile __attribute__((address_space(3))) uint8_t*)p; }
+__device__ __forceinline__ void lds_store_byte(uint8_t* p, uint32_t v) { *(volatile __attribute__((address_space(3))) uint8_t*)p = (uint8_t)v; }
+// two control words, THEN four flag bytes, read now, all in one trip to the LDS (the DS unit serves a wave's reads in issue order: what the
+// bytes hold was published before whatever moves the word behind the value read here)
+// two words (a lane's own two: the bells it watches), read now, one trip
+__device__ __forceinline__ void lds_load_2v(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) {
+    v0 = *(const volatile __attribute__((address_space(3))) uint32_t*)p0;
+    v1 = *(const volatile __attribute__((address_space(3))) uint32_t*)p1;
+}
+__device__ __forceinline__ void lds_load_words_then4(const uint32_t* w0, const uint32_t* w1, const uint8_t* const p[4], uint32_t& wv0, uint32_t& wv1, uint32_t f[4]) {
+    wv0 = *(const volatile __attribute__((address_space(3))) uint32_t*)w0;
+    wv1 = *(const volatile __attribute__((address_space(3))) uint32_t*)w1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] = *(const volatile __attribute__((address_space(3))) uint8_t*)p[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ void lds_store_flag(uint8_t* p, uint32_t v) { *(volatile __attribute__((address_space(3))) uint8_t*)p = (uint8_t)v; }
 // two consecutive 16-byte LDS reads issued back to back (one wait for both)
 __device__ __forceinline__ void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b) {
@@ -122,6 +139,13 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
 // all of the wave's global loads and stores complete - as an instruction the compiler's wait-count pass sees (vmcnt(0), the other counters open)
 __device__ __forceinline__ void vmem_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 template <int N> __device__ __forceinline__ void vmem_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+// s_wakeup: every wave of the workgroup that sits in an s_sleep goes on at once (a wave that is not sleeping ignores it).  A wave that
+// waits for another one's LDS word sleeps LONG and is woken by the writer: no polling traffic, no poll period on the hand-off's path.
+__device__ __forceinline__ void wake_workgroup() { asm volatile("s_wakeup" ::: "memory"); }
+#ifndef LZ4AMD_DEC_SLEEP
+#define LZ4AMD_DEC_SLEEP 24
+#endif
+__device__ __forceinline__ void sleep_until_woken() { __builtin_amdgcn_s_sleep(LZ4AMD_DEC_SLEEP); }      // (at most ~1.5 K cycles: a wake-up that came a moment before the sleep is lost)
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void spin_pause_long() { __builtin_amdgcn_s_sleep(8); }
 template <int N> __device__ __forceinline__ void spin_pause_n() { __builtin_amdgcn_s_sleep(N); }      // (64 * N cycles)

@@ -10,6 +10,7 @@
 #include "../../include/lz4amd.h"
 #include "lz4amd_ffi.h"
 #include "lz4amd_internal.h"
+#define LZ4AMD_TRACE_BYTES (4u << 20)
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -133,8 +134,9 @@ int lz4amd_plan_create(lz4amd_ctx* ctx, lz4amd_plan** out, lz4amd_op op, int n,
         q->scratch_stride = (lz4amd_hip_dec_scratch_bytes(max_c, max_cap) + 255) & ~(uint64_t)255;
         q->prof = NULL;
         if (getenv("LZ4AMD_PROF")) {            /* developer aid: per-workgroup phase timestamps */
-            q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64, &err));
-            if (q->prof && lz4amd_hip_memset(q->prof, 0, (size_t)(grid ? grid : 1) * 64, NULL)) err = LZ4AMD_E_RUNTIME;
+            /* (behind the workgroups' words: room for the event trace of a developer build, -DLZ4AMD_DEC_TRACE) */
+            q->prof = (uint64_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)(grid ? grid : 1) * 64 + LZ4AMD_TRACE_BYTES, &err));
+            if (q->prof && lz4amd_hip_memset(q->prof, 0, (size_t)(grid ? grid : 1) * 64 + LZ4AMD_TRACE_BYTES, NULL)) err = LZ4AMD_E_RUNTIME;
         }
         q->ticket = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
         q->scratch = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, (size_t)q->scratch_stride * (grid ? grid : 1), &err));
@@ -383,6 +385,7 @@ int lz4amd_plan_profile(lz4amd_plan* p, unsigned long long* words, int max_words
     if (!src) return 0;
     (void)lz4amd_hip_use_device(p->ctx->device);
     n = (int)p->grid * 8;
+    if (p->op == LZ4AMD_OP_DECOMPRESS && max_words > n) n += LZ4AMD_TRACE_BYTES / 8;      /* (the developer build's event trace behind the workgroups' words) */
     if (n > max_words) n = max_words;
     if (lz4amd_hip_d2h(words, src, (size_t)n * 8, NULL) || lz4amd_hip_sync(NULL)) return 0;
     return n;

@@ -40,6 +40,8 @@ extern "C" int emu_decompress_batch_prefix(const uint8_t* const* src, const int3
     P.src = src; P.src_size = src_size; P.dst = dst; P.dst_cap = dst_cap; P.result = result;
     P.n_blocks = n; P.ticket = &ticket; P.prefix = prefix; P.chain = nullptr; P.stored = nullptr;
     P.scratch = (uint8_t*)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15); P.scratch_stride = stride; P.prof = nullptr;
+    std::vector<uint64_t> profbuf((size_t)grid * 8 + 8);
+    if (getenv("EMU_PROF")) P.prof = profbuf.data();       // (the developer profile's stamps: their code paths run on the interpreter too)
     simt::launch(grid, kDecThreads, kDecLdsBytes, [&] { decompress_batch_body(P); });
     return 0;
 }

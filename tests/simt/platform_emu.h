@@ -39,6 +39,15 @@ static inline uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
 }
 typedef uint32_t lz4amd_u32x4 __attribute__((vector_size(16)));
 static inline void lds_load_flags2(const uint8_t* p0, const uint8_t* p1, uint32_t& v0, uint32_t& v1) { v0 = *(const volatile uint8_t*)p0; v1 = *(const volatile uint8_t*)p1; }
+static inline uint32_t lds_load_byte(const uint8_t* p) { return *(const volatile uint8_t*)p; }
+static inline void lds_store_byte(uint8_t* p, uint32_t v) { *(volatile uint8_t*)p = (uint8_t)v; }
+static inline void wake_workgroup() {}
+static inline void sleep_until_woken() { simt::yield_to_sched(); }
+static inline void lds_load_2v(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) { v0 = *(const volatile uint32_t*)p0; v1 = *(const volatile uint32_t*)p1; }
+static inline void lds_load_words_then4(const uint32_t* w0, const uint32_t* w1, const uint8_t* const p[4], uint32_t& wv0, uint32_t& wv1, uint32_t f[4]) {
+    wv0 = *(const volatile uint32_t*)w0; wv1 = *(const volatile uint32_t*)w1;
+    for (int k = 0; k < 4; k++) f[k] = *(const volatile uint8_t*)p[k];
+}
 static inline void lds_store_flag(uint8_t* p, uint32_t v) { *(volatile uint8_t*)p = (uint8_t)v; }
 static inline void lds_load_pair16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b) { memcpy(&a, (const void*)p, 16); memcpy(&b, (const void*)(p + 1), 16); }
 static inline void lds_load_quad16(const lz4amd_u32x4* p, lz4amd_u32x4& a, lz4amd_u32x4& b, lz4amd_u32x4& c, lz4amd_u32x4& d) {

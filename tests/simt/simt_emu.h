@@ -216,6 +216,7 @@ static inline int __umul24(unsigned a, unsigned b) { return (int)((a & 0xFFFFFFu
 // atomics: fibers of one block never run concurrently; blocks on different OS threads may,
 // so global atomics use real atomics (harmless for LDS).
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class T> static inline T atomicSub(T* p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
 template <class T> static inline T atomicOr(T* p, T v)  { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 template <class T> static inline T atomicAnd(T* p, T v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
