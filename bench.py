@@ -269,13 +269,18 @@ def stream_copy_gbps(ctx, lz4_amd, torch, nbytes, stream):
     return 2.0 * nbytes / (ms.value * 1e-3) / 1e9
 
 
-def roofline_obj(kernel, ms, alg_bytes, copy_gbps, traffic):
+def roofline_obj(kernel, ms, alg_bytes, copy_gbps, traffic, table_bytes=0):
+    """alg_bytes: SURVEY 8(d)'s algorithmic bytes (U + C per launch).  table_bytes: the entry-point tables' rows written / read on top of
+    them - real traffic, but not in 8(d)'s figure: `frac` is on U + C alone, `frac_with_table_rows` beside it."""
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     r = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBPS, 5),
          "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
          "frac_of_measured_copy": round(ach / copy_gbps, 5) if copy_gbps else None,
          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": round(ms, 4)}
+    if table_bytes:
+        r["table_row_bytes_per_launch"] = table_bytes
+        r["frac_with_table_rows"] = round((alg_bytes + table_bytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if ms > 0 else 0.0
     # what holds the kernel below that roofline today: VALU issue (committed SQ counters of the same kernel sources)
     v = measured_traffic().get(kernel, {}).get("valu")
     if v:
@@ -427,12 +432,12 @@ def bench_shape_2048(ctx, lz4_amd, torch, data, stream, bs, copy_gbps, use_hints
 
 def table_bytes_written(torch, hints):
     """Bytes of the entry-point tables the compressor actually wrote (header + rows + end row of every valid table), from the
-    tables themselves: word 7 of a table (row 0's last word) is its number of rows."""
+    tables themselves (csrc/lz4amd_params.h: 32 bytes of header, word 4 = the number of rows, then rows + 1 entries of 8 bytes)."""
     if hints is None:
         return 0
     w = hints.view(torch.int32).view(hints.shape[0], -1)[:, :8].cpu()
-    valid = w[:, 0] == 0x48345A4C
-    return int(((w[:, 7][valid].to(torch.int64) + 2) * 16).sum().item())
+    valid = w[:, 0] == 0x32485A4C
+    return int((32 + (w[:, 4][valid].to(torch.int64) + 1) * 8).sum().item())
 
 
 def bench_shape_small(ctx, lz4_amd, torch, data, stream, bs=64 << 10):
@@ -471,7 +476,7 @@ def bench_shape_small(ctx, lz4_amd, torch, data, stream, bs=64 << 10):
             "note": "one 1024-thread workgroup per block whatever its size: a 64 KiB block's matches reach into the block itself only, its regions wait for the ones just before them"}
 
 
-def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(20, 90), nblk=256, nref=16):
+def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(0, 20, 90), nblk=256, nref=16):
     """The step's two kernels on other compressibilities (the ratio window is two-sided, and the rates depend on the
     data): nblk blocks of `datagen -P<pct> -s1`, compressed and decoded like the step's; ratio_vs_reference = reference bytes / our
     bytes on the first nref blocks (> 1: ours is smaller)."""
@@ -753,6 +758,15 @@ def data_path(dist, torch, dev, rank, world, data, comp, csizes, pack=None, shar
             "scatter_bytes": U * (world - 1), "gather_bytes": sum(totals) - totals[0], "blocks": blocks, "sizes": [t.tolist() for t in allsz]}
 
 
+def rccl_version(torch):
+    """The RCCL (torch's "nccl") version this process is linked with, as a string; None when torch has none."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
+
+
 def launch_ranks(n, argv):
     """`bench.py --gpus N` without a launcher: start the N ranks (this file again, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
     environment), wait for them; rank 0 prints the JSON line on the stdout it inherits.  Returns the worst exit code."""
@@ -831,6 +845,10 @@ def main():
     ap.add_argument("--no-hc", action="store_true", help="skip the LZ4_compress_HC (configs[3]) side measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the 2048-block shape and the configs[2] frame object")
     ap.add_argument("--no-data-path", action="store_true", help="N>1: skip the RCCL scatter / gather measurement")
+    ap.add_argument("--shards", choices=("root", "local"), default="root",
+                    help="N>1: root = configs[4]'s movement (rank 0 holds the corpus: scatter of the shards, gather of the payloads, all of it through "
+                         "rank 0's xGMI links); local = every rank keeps the shard it generated, only the compressed sizes are all-gathered: the codec's "
+                         "scaling without the funnel through rank 0")
     ap.add_argument("--no-foreign", action="store_true", help="skip the decode of the same blocks without tables and of reference-compressed blocks (profiling runs: the decompress kernel's average then is the step's)")
     ap.add_argument("--no-hints", action="store_true",
                     help="do not pass the compressor's entry-point tables to the decoder (include/lz4amd.h): every block is decoded the way a foreign block is")
@@ -1008,7 +1026,7 @@ def main():
     if rank == 0:
         copy_gbps = stream_copy_gbps(ctx, lz4_amd, torch, 1 << 30, stream)
         tbytes = table_bytes_written(torch, hints)
-        alg = {"compress": U + C + tbytes, "decompress": U + C + tbytes}        # U read + C written / C read + U written; the tables' rows are bytes written / read as well
+        alg = {"compress": U + C, "decompress": U + C}        # U read + C written / C read + U written (the tables' rows, written / read as well, are reported beside: frac_with_table_rows)
         pmc = measured_traffic() if (nb == 256 and bs == 4 << 20 and args.pct == 60) else {}
         traffic = {k: pmc.get(k, {}).get("hbm_bytes_per_launch") for k in ("compress", "decompress")}
         kernels = []
@@ -1022,6 +1040,7 @@ def main():
             "metric": "GB/s compress + decompress, 4 MB independent blocks (uncompressed bytes through one compress+decompress pass per second)",
             "value": round(bytes_all / t_max / 1e9, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "world_size": (dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1), "rccl_version": rccl_version(torch),
             "ms_per_step": round(t_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (datagen -P%d restated in tools/datagen.c, md5-pinned to the reference tool)" % args.pct,
@@ -1045,8 +1064,8 @@ def main():
             "decompress_GBps_without_tables": foreign.get("own_blocks_without_table", {}).get("decompress_GBps"),
             "decompress_GBps_reference_input": foreign.get("reference_compressed_blocks", {}).get("decompress_GBps"),
             "ratio_with_tables": round(U / (C + tbytes), 4) if hints is not None else None,
-            "roofline": roofline_obj(dom["kernel"], dom["avg_ms"], dom["algorithmic_bytes"], copy_gbps, traffic.get(dom["kernel"])),
-            "roofline_decompress": roofline_obj("decompress", k_ms["decompress"], alg["decompress"], copy_gbps, traffic.get("decompress")),
+            "roofline": roofline_obj(dom["kernel"], dom["avg_ms"], dom["algorithmic_bytes"], copy_gbps, traffic.get(dom["kernel"]), tbytes),
+            "roofline_decompress": roofline_obj("decompress", k_ms["decompress"], alg["decompress"], copy_gbps, traffic.get("decompress"), tbytes),
             "kernels": kernels,
             "entry_point_tables": ({"used": True, "room_bytes_per_block": hstride, "room_bytes_per_launch": hstride * nb,
                                     "bytes_written_per_launch": tbytes, "bytes_written_per_block": tbytes // nb, "fraction_of_compressed_bytes": round(tbytes / C, 4),
@@ -1062,7 +1081,27 @@ def main():
         }
     # ---- N > 1: the movement configs[4] names, over RCCL (not part of `value`, which stays the kernel-only rate)
     dp = None
-    if world > 1 and not args.no_data_path:
+    if world > 1 and not args.no_data_path and args.shards == "local":
+        # every rank keeps its own shard: the one exchange is the all_gather of the compressed sizes (what a consumer of the sharded corpus needs
+        # to address the blocks); no byte of payload crosses a link
+        try:
+            mine = torch.tensor(list(csizes), dtype=torch.int32, device=dev)
+            allsz = [torch.empty_like(mine) for _ in range(world)]
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            dist.all_gather(allsz, mine)
+            torch.cuda.synchronize()
+            t_sizes = aggregate(dist, time.perf_counter() - t0, 0, device=dev)[0]
+            if rank == 0:
+                result["data_path"] = {"mode": "--shards local: shards stay where they were generated; all_gather of int32 csize[%d] only" % nb,
+                                       "world_size": dist.get_world_size(), "backend": dist.get_backend(), "sizes_s": round(t_sizes, 6),
+                                       "compressed_bytes_all_ranks": int(sum(int(t.sum().item()) for t in allsz)),
+                                       "kernel_only_GBps": round(bytes_all / t_max / 1e9, 3),
+                                       "note": "unmeasured on multi-GPU hardware until a SCALE record exists"}
+        except Exception as e:
+            if rank == 0:
+                result["data_path"] = {"error": str(e)}
+    elif world > 1 and not args.no_data_path:
         # setup, untimed and outside the watchdog below: rank 0 collects every rank's shard (8 GiB each at the default size: tens of GiB over
         # xGMI); a collective that never returns must still not cost the bench line, so it has a (long) watchdog of its own
         def bail_setup():

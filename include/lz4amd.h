@@ -97,7 +97,8 @@ int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, i
 /* Entry-point tables ("hints") - an optional, out-of-band column of the block table.
  * A compress plan (LZ4AMD_OP_COMPRESS) that has them attached writes, next to every block, a small table that names a
  * sequence of the block's token chain about every 512 bytes of source (every 2nd to 16th sequence): {position of its token in the block, position of its literals in the source,
- * sequences before it} (16 bytes a row, ~2.5 % of a `datagen -P60` block; layout: csrc/lz4amd_params.h).  The block itself is an ordinary
+ * sequences before it, mod 256} (8 bytes a row: 2.4 % of the source, 4.9 % of the compressed bytes of a `datagen -P60` block; blocks whose compressed
+ * size needs more than 24 bits get none; layout: csrc/lz4amd_params.h).  The block itself is an ordinary
  * LZ4 block, byte for byte what it is without the table.  A decompress plan (LZ4AMD_OP_DECOMPRESS, lz4amd_plan_create /
  * _prefix) that has the tables attached parses every block from all its entries at once instead of first discovering the
  * serial token chain (what LZ4_decompress_generic's loop does implicitly, lz4.c:2123-2445) - about a third of the decoder's

@@ -2,6 +2,7 @@
 // Included AFTER a platform header (platform_hip.h in the product build).
 #pragma once
 #include <stdint.h>
+#include "../lz4amd_params.h"
 
 namespace lz4amd {
 
@@ -30,6 +31,20 @@ __device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) { uint64_t v; __bui
 using U32x4 = ::lz4amd_u32x4;             // 16 bytes as four dwords (platform header)
 template <class Ptr> __device__ __forceinline__ U32x4 ld_global16(Ptr p) { return ld_global16_raw(p); }
 template <class Ptr> __device__ __forceinline__ void st_global16(Ptr p, const U32x4& v) { st_global16_raw(p, v); }
+
+// ---- entry-point tables (lz4amd_params.h): what the three writers (lz4amd_k_compress, lz4amd_k_compress_hc, the decoder's stage A) store
+__device__ __forceinline__ void hint_store_row(lz4amd_gdst table, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord) {
+    st_global8_raw(table + LZ4AMD_HINT_HEAD + LZ4AMD_HINT_ROW * (uint64_t)r, (uint64_t)((tok & 0xFFFFFFu) | (ord << 24)) | ((uint64_t)out << 32));
+}
+// the table is valid from here on: its end row, its first row, its header (written last)
+__device__ __forceinline__ void hint_store_head(lz4amd_gdst table, uint32_t out_size, uint32_t csize, uint32_t nseq, uint32_t nrows) {
+    hint_store_row(table, nrows, csize, out_size, nseq);
+    hint_store_row(table, 0, 0, 0, 0);
+    U32x4 h2; h2[0] = nrows; h2[1] = h2[2] = h2[3] = 0;
+    st_global16(table + 16, h2);
+    U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = out_size; h[2] = csize; h[3] = nseq;
+    st_global16(table, h);
+}
 
 // ---- wave-level inclusive scans (64 lanes) ------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) { return wave_incl_sum_u32(v); }

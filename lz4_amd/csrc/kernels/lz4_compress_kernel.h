@@ -80,6 +80,13 @@
 #ifndef LZ4AMD_STRIDE4_FROM
 #define LZ4AMD_STRIDE4_FROM 2
 #endif
+#ifndef LZ4AMD_CMP_PROF
+#if defined(LZ4AMD_PROF_ROLES) || defined(LZ4AMD_PROF_TILE) || defined(LZ4AMD_PROF_WAVES) || defined(LZ4AMD_PROF_HC)
+#define LZ4AMD_CMP_PROF 1
+#else
+#define LZ4AMD_CMP_PROF 0        // 1: the phase stamps of tools/prof_cmp.py / prof_hc.py (LZ4AMD_PROF=1 in the environment): a developer build, tools/build_variant.sh prof -DLZ4AMD_CMP_PROF=1
+#endif
+#endif
 namespace lz4amd {
 
 // developer counters of the CPU interpreter's build (tools/exp/cmp_emu_stats.py): trips of the parse and emit loops
@@ -612,10 +619,7 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
 // chain (lz4_decompress_kernel.h: PARSER); the block itself is an ordinary LZ4 block.  The rows are written where the
 // sequences are written out: a lane of the emit knows its sequence's place in the output and in the source.
 struct HintOut { lz4amd_gdst table; uint32_t cap_rows, pre; uint32_t* over; uint32_t ord0, row0, k; };      // table == null: none wanted; ord0 / row0 / k: the tile's first ordinal, first row, log2 of its row distance
-__device__ __forceinline__ void st_hint(lz4amd_gdst hints, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord, uint32_t w3 = 0) {
-    U32x4 v; v[0] = tok; v[1] = out; v[2] = ord; v[3] = w3;
-    st_global16(hints + 16 * (uint64_t)(r + 1), v);                 // (row 0 of the memory is the header)
-}
+__device__ __forceinline__ void st_hint(lz4amd_gdst hints, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord) { hint_store_row(hints, r, tok, out, ord); }
 __device__ __forceinline__ void hint_row(const HintOut& H, bool on, uint32_t ord, uint32_t tok, uint32_t src_pos) {
     const uint32_t x = ord - H.ord0;
     if (on && (x & ((1u << H.k) - 1u)) == 0) {
@@ -1110,7 +1114,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const bool stride4 = !small && P.acceleration >= LZ4AMD_STRIDE4_FROM;      // LZ4_compress_fast's speed / ratio knob: every fourth position is probed instead of every second
     const uint32_t a0 = (uint32_t)((uintptr_t)P.dst[b] & 15u);        // dst's place on HBM's 16-byte grid
     const lz4amd_gdst hints = P.hints ? LZ4AMD_TO_GDST(P.hints + (uint64_t)b * P.hint_stride) : (lz4amd_gdst)nullptr;      // optional entry-point table
-    HintOut H; H.table = hints; H.cap_rows = P.hint_stride >= 48 ? (uint32_t)(P.hint_stride / 16 - 2) : 0u; H.pre = pre; H.over = &misc[CM_HOVER]; H.ord0 = H.row0 = H.k = 0;
+    HintOut H; H.table = hints; H.cap_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride); H.pre = pre; H.over = &misc[CM_HOVER]; H.ord0 = H.row0 = H.k = 0;
 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
@@ -1127,7 +1131,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     uint32_t t0 = 0, tile_len, strip_len;
     tile_geometry(pre ? kTileMax * 4 : 0, small, tile_len, strip_len);      // (the history goes in in the largest tiles; the block itself starts with small ones)
     uint32_t loaded = 0;                                  // ring holds [.., loaded)
-    uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
+    uint64_t* prof = (LZ4AMD_CMP_PROF && P.prof) ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;      // (a developer build's stamps: the product kernel carries none of that code)
     uint64_t tp[5] = {0, 0, 0, 0, 0}, tq = 0;
 #ifdef LZ4AMD_PROF_ROLES
     // developer build (tools/prof_roles.py): cycles of wave LZ4AMD_PROF_ROLES in the full tiles where its role is LZ4AMD_PROF_ROLES_SEL (0 measuring, 1 writing, 2 either):
@@ -1410,11 +1414,8 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         // block's end; row 0 (the block's first sequence) carries the number of rows; the header makes the table valid
         const uint32_t seqs = misc[CM_SEQS], nseq = seqs + 1, last_row = misc[CM_ROWS], nrows = last_row + 1;      // (the last sequence has a row of its own)
         if (last_row && last_row < H.cap_rows) st_hint(hints, last_row, out, n - run - pre, seqs);
-        if (nrows <= H.cap_rows && !misc[CM_HOVER]) {
-            st_hint(hints, nrows, (uint32_t)total, (uint32_t)n_i, nseq);
-            st_hint(hints, 0, 0, 0, 0, nrows);
-            U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = (uint32_t)n_i; h[2] = (uint32_t)total; h[3] = nseq;
-            st_global16(hints, h);
+        if (nrows <= H.cap_rows && !misc[CM_HOVER] && total < LZ4AMD_HINT_MAX_CSIZE) {
+            hint_store_head(hints, (uint32_t)n_i, (uint32_t)total, nseq, nrows);
         } else *(uint32_t*)hints = 0;                                 // (more sequences than the table has room for: no table)
     }
     {

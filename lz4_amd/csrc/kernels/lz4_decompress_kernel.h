@@ -99,6 +99,9 @@
 #ifndef LZ4AMD_DEC_DMADEPTH
 #define LZ4AMD_DEC_DMADEPTH 16
 #endif
+#ifndef LZ4AMD_DEC_FULL_BATCH
+#define LZ4AMD_DEC_FULL_BATCH 0      // n > 0: a parser wave waits for a fuller batch of rows while the copy waves have records for n regions ahead
+#endif
 #ifndef LZ4AMD_DEC_CRKB
 #define LZ4AMD_DEC_CRKB 32u           // compressed ring, KB (a power of two)
 #endif
@@ -141,7 +144,7 @@ enum : uint32_t {
     kRecMask = kRecCap - 1,
     kIdxRing = kChunk == 32 ? 128 : 512,                             // first record of a region, per region (ring)
     kIdxMask = kIdxRing - 1,
-    kEntRing = kChunk == 32 ? 128 : 256,                             // rows of the block's entry-point table (16 B each), ring
+    kEntRing = 256,                             // rows of the block's entry-point table (8 B each), ring; the mover brings 128 rows an instruction
     kEntMask = kEntRing - 1,
     kLaneSeqMax = 1024,                         // sequences between two rows of a table (lz4amd_k_compress writes a row every 2 to 16)
     kDmaDepth = LZ4AMD_DEC_DMADEPTH,            // LDS-DMA instructions (1 KB each) the mover keeps in flight
@@ -164,7 +167,7 @@ enum : uint32_t {
     kOffPend = (kOffIdx + kIdxRing * 4 + 7) & ~7u,           // per copy wave: u64[kMaxTrips] pending masks of round B, u32[16] pending pieces per chunk (a byte each)
     kPendStride = kMaxTrips * 8 + 64,
     kOffEnt = (kOffPend + kActiveCopy * kPendStride + 15) & ~15u,    // lz4amd_hint_entry[kEntRing]
-    kOffRecs = kOffEnt + kEntRing * 16,                      // SeqRec[kRecCap]
+    kOffRecs = kOffEnt + kEntRing * 8,                       // SeqRec[kRecCap]
     kOffCr = kOffRecs + kRecCap * 16,                        // compressed ring + pad
     kOffRing = kOffCr + kCrBytes + kCrPad,                   // output ring + pad
     kStreamLdsBytes = kOffRing + kRingBytes + kRingPad,
@@ -370,9 +373,11 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
                 lds_dma16(rectab + (hi + lane < nrows ? hi + lane : nrows - 1), (char*)recs + ((hi & kRecMask) << 4));      // (rows behind the table's last: the last again, nobody reads them)
                 fifo |= 1ull << q; q++; hi += 64; did = true;
             }
-            if (hinted && q < kDmaDepth && ei < nent && ei + 64 <= pr0 + kEntRing) {
-                lds_dma16((const void*)(hint + 16 * (uint64_t)(ei + lane < nent ? ei + lane : nent - 1)), ent + ((ei & kEntMask) << 4));
-                fifo |= 1ull << q; q++; ei += 64; did = true;
+            if (hinted && q < kDmaDepth && ei < nent && ei + 128 <= pr0 + kEntRing) {
+                // (a lane brings two rows: 16 bytes; behind the table's last pair of rows the last pair again - the table's memory is a multiple of 16 bytes)
+                const uint32_t pair = (ei >> 1) + lane, lastp = (nent - 1) >> 1;
+                lds_dma16((const void*)(hint + 16 * (uint64_t)(pair < lastp ? pair : lastp)), ent + ((ei & kEntMask) << 3));
+                fifo |= 1ull << q; q++; ei += 128; did = true;
             }
             if (!did) break;
             issued = true;
@@ -390,7 +395,7 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
             if (((sc + (crBytes >> 10) - 1) & ~((crBytes >> 10) - 1)) < s1) {            // (a chunk that starts a lap has landed)
                 if (lane < kCrPad / 16) *(U32x4*)(cr + crBytes + 16 * lane) = *(const U32x4*)(cr + 16 * lane);
             }
-            sc = s1; if (hinted) ec += 64 * nrec; else hc += 64 * nrec;
+            sc = s1; if (hinted) ec += 128 * nrec; else hc += 64 * nrec;
             fifo >>= r; q = keep;
             wave_lds_fence();
             if (lane == 0) {
@@ -426,7 +431,7 @@ __device__ __forceinline__ void mover_role(lz4amd_gsrc src, uint32_t csize, cons
 // that does not fit the stream costs time only: M_PBAD, and the block is decoded again the ordinary way.
 // Bytes that are not in the ring (a row far ahead of what the mover has loaded; length fields of many bytes) are read
 // from memory instead.
-struct HintEnt { uint32_t tok, out, ord, zero; };
+struct HintEnt { uint32_t tok, out, ord; };      // a row as the walk uses it: ord (sequences before it) is counted up from the rows' 8-bit differences
 
 // four stream bytes from position x on, out of the compressed ring (two aligned dwords and a byte alignment; the ring's pad
 // covers the dword behind its end)
@@ -583,7 +588,7 @@ __device__ __forceinline__ StepOut parser_step(const PCtx& X, Walk& w, uint32_t&
 #define LZ4AMD_PARSERS 2
 #endif
 enum : uint32_t { kParsers = LZ4AMD_PARSERS, kFirstParseWave = kDecWaves - 1 - kParsers };
-enum : uint32_t { P_NEXT = 16, P_RZ, P_TICKET, P_TURN, P_LOCK, P_ICARRY };      // shared words of the parser waves (misc[]); the first four are
+enum : uint32_t { P_NEXT = 16, P_RZ, P_TICKET, P_TURN, P_LOCK, P_ICARRY, P_ORD };      // (P_ORD: sequences before row P_NEXT)      // shared words of the parser waves (misc[]); the first four are
 static_assert(M_EHEAD == M_ABORT + 8 && P_NEXT == M_ABORT + 12, "the words a claim looks at are 64 consecutive bytes");      // read with M_ABORT .. M_PBAD in one trip to the LDS
 __device__ __forceinline__ void parser_unlock(uint32_t* misc) { wave_lds_fence(); if (lane_here() == 0) lds_store_release(&misc[P_LOCK], 0u); }
 __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix, uint32_t total, uint32_t nseq,
@@ -591,14 +596,14 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     uint32_t* idx = (uint32_t*)(smem + kOffIdx);
     SeqRec* recs = (SeqRec*)(smem + kOffRecs);
-    const HintEnt* ent = (const HintEnt*)(smem + kOffEnt);
+    const lz4amd_hint_entry* ent = (const lz4amd_hint_entry*)(smem + kOffEnt);
     const uint32_t lane = lane_here();
     PCtx X; X.cr = smem + kOffCr; X.src = src; X.csize = csize; X.mis = stream_misalign(src); X.chi = 0; X.capB = cap + kBias; X.low = kBias - prefix;
     // (a block that is mostly stream - datagen -P60 and less compressible - and large: how far the walk may run ahead of the copy is else set by what
     //  the 32 KB ring holds beyond the regions in flight; blocks of long matches walk faster out of the LDS)
     X.pg = LZ4AMD_DEC_PARSE_GLOBAL == 2 ? (total >= (1u << 20) && csize > (total >> 1) - (total >> 4)) : LZ4AMD_DEC_PARSE_GLOBAL != 0;
     wave_priority_high();                              // the copy waves wait for what these waves produce
-    uint32_t tail = 0, stall = 0;
+    uint32_t tail = 0, stall = 0, thin = 0;
     bool fail = false;
     uint32_t n_batch = 0, n_lanes = 0, n_steps = 0, n_careful = 0; uint64_t t_wait = 0, t_walk = 0, tq = prof ? clock_ticks() : 0;      // developer profile
 #ifdef LZ4AMD_PROF_PARSER
@@ -636,13 +641,24 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
         uint32_t nlmax = nreg - r0 < 64 ? nreg - r0 : 64;
         const uint32_t er = ehead > r0 + 1 ? ehead - r0 - 1 : 0;
         if (er < nlmax) nlmax = er;
-        HintEnt A, B; A.tok = A.out = A.ord = A.zero = 0; B = A;
-        if (lane < nlmax) { A = ent[(r0 + lane) & kEntMask]; B = ent[(r0 + lane + 1) & kEntMask]; }
+        HintEnt A, B; A.tok = A.out = A.ord = 0; B = A;
+        uint32_t dseq = 0;                              // sequences between my row and the next
+        if (lane < nlmax) {
+            const lz4amd_hint_entry a = ent[(r0 + lane) & kEntMask], b = ent[(r0 + lane + 1) & kEntMask];
+            A.tok = a.tok_ord & 0xFFFFFFu; A.out = a.out; B.tok = b.tok_ord & 0xFFFFFFu; B.out = b.out;
+            dseq = ((b.tok_ord >> 24) - (a.tok_ord >> 24)) & 0xFFu;
+            A.ord = a.tok_ord >> 24;                    // (for now: its low 8 bits, checked against the count below)
+        }
+        const uint32_t ord0 = uload(&misc[P_ORD]);      // sequences before row r0 (counted by the batches claimed before; under the lock)
+        const uint32_t incl = wave_incl_sum_u32(dseq);
+        const bool lowbad = lane < nlmax && A.ord != ((ord0 + incl - dseq) & 0xFFu);      // (the row's own 8 bits must be what the count says)
+        A.ord = ord0 + incl - dseq; B.ord = A.ord + dseq;
         const uint32_t tail_now = idx[g & kIdxMask];       // (asked for with the rows: one trip; it counts only if the entry is there)
         // the rows themselves: never decreasing, inside the block, no more sequences between two of them than 512 bytes of output can start
         bool rowbad = lane < nlmax && (A.tok > B.tok || A.out > B.out || A.ord > B.ord || B.tok > csize || B.out > total || B.ord - A.ord > kLaneSeqMax
                                        || (A.tok == B.tok) != (A.ord == B.ord) || (A.tok == B.tok && A.out != B.out));
         if (r0 == 0 && lane == 0 && nlmax && (A.tok | A.out | A.ord)) rowbad = true;
+        rowbad = rowbad || lowbad;
         if (r0 + lane + 1 == nreg && lane < nlmax && (B.tok != csize || B.out != total || B.ord != nseq)) rowbad = true;
         if (__any(rowbad)) { fail = true; parser_unlock(misc); break; }
         if (g < c.ihead) tail = __builtin_amdgcn_readfirstlane(tail_now);               // first record an open region needs (only ever grows)
@@ -661,17 +677,23 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
             nl = 1;
         }
         if (!nl && !nl_hard && drained && nlmax && wave_readlane(okrec ? 1u : 0u, 0) && wave_readlane(Rb, 0) - Ra > kIdxRing / 2) { smode = true; nl = 1; }
+#if LZ4AMD_DEC_FULL_BATCH
+        // A walk costs the wave the same whether 5 of its lanes have a row or all 64: a small batch is taken only when it has to be - the
+        // copy waves are about to run out of records (fewer than LZ4AMD_DEC_FULL_BATCH regions' worth published ahead of the region handed
+        // out last), the rows end, or nothing is claimed at all; else the wave lets the mover and the copy make room for a fuller one.
+        if (nl && !smode && nl < 48 && r0 + nl < nreg && !drained && c.ihead >= c.next + LZ4AMD_DEC_FULL_BATCH && thin < 64) { thin++; nl = 0; }
+#endif
         if (!nl) {
 #ifdef LZ4AMD_PROF_PARSER
             n_nowork++;
 #endif
             parser_unlock(misc); spin_pause_long(); PSTAMP(t_sel); continue; }
-        stall = 0;
-        const uint32_t RbN = wave_readlane(Rb, nl - 1);
+        stall = 0; thin = 0;
+        const uint32_t RbN = wave_readlane(Rb, nl - 1), ordN = wave_readlane(B.ord, nl - 1);
         const bool allres = nl_res != 0;
         wave_lds_fence();
         if (lane == 0) {
-            misc[P_NEXT] = r0 + nl; misc[P_RZ] = RbN > Ra ? RbN : Ra; misc[P_TICKET] = ticket + 1;
+            misc[P_NEXT] = r0 + nl; misc[P_RZ] = RbN > Ra ? RbN : Ra; misc[P_TICKET] = ticket + 1; misc[P_ORD] = ordN;
             lds_store_release(&misc[M_PR0], r0 + nl);       // (the rows of claimed batches are in their waves' registers)
         }
         if (!smode) parser_unlock(misc);                    // (a row that fills the index as it goes keeps the lock: nobody may run ahead of it)
@@ -1310,7 +1332,9 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
     }
 out: ;
 #ifndef LZ4AMD_PROF_PARSER
-    if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[5] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); }
+    // (through LDS, written out by thread 0 behind the roles' barrier: the direct store from here faulted on the device in one build - 16-byte chunks,
+    //  stamps on - and not in the others)
+    if (prof && w == 0 && lane == 0) { uint64_t* q = (uint64_t*)(smem + kOffMisc) + 24; q[0] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); q[1] = t_rec | (t_lead << 32); q[2] = t_work | (t_retry << 32); }
 #endif
 }
 
@@ -1325,7 +1349,7 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
     // ---- stage B: control words, done entries, the history before dst (linked blocks, lz4.c:2719 usingDict prefix mode) -> ring
     if (tid == 0) { misc[M_ABORT] = 0; misc[M_SPARE] = 0; misc[M_CHI] = 0; misc[M_IHEAD] = kFirstRegion; misc[M_HEAD] = 0; misc[M_CLO] = 0; misc[M_NEXT] = kFirstRegion; misc[M_OPEN] = kFirstRegion;
                     misc[M_EHEAD] = 0; misc[M_PR0] = 0; misc[M_PBAD] = 0;
-                    misc[P_LOCK] = 0; misc[P_NEXT] = 0; misc[P_RZ] = kFirstRegion; misc[P_TICKET] = 0; misc[P_TURN] = 0; misc[P_ICARRY] = 0; }
+                    misc[P_LOCK] = 0; misc[P_NEXT] = 0; misc[P_RZ] = kFirstRegion; misc[P_TICKET] = 0; misc[P_TURN] = 0; misc[P_ICARRY] = 0; misc[P_ORD] = 0; }
     if (tid < 2 * (kChunk + 1)) { U32x4 m; for (uint32_t k = 0; k < 4; k++) m[k] = low_bytes_mask(tid >> 1, 4 * (tid & 1) + k); *(U32x4*)(smem + kOffMaskTab + 16 * tid) = m; }
     // chunk flags: the history before dst (positions below kBias = regions 0..63, lap 0) is final, nothing else is
     for (uint32_t i = tid; i < kSlots * 16; i += kDecThreads) ((uint32_t*)(smem + kOffBits))[i] = i < kFirstRegion * 16 ? 0x01010101u * lap_tag(0) : 0u;
@@ -1347,10 +1371,13 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
     const uint32_t rend = (kBias + total + kRegion - 1) >> kRegionShift;          // regions [kFirstRegion, rend)
     const bool hinted = hint != nullptr;
     // (nreg: rows of the table; nreg + 1 entries behind its 16-byte header)
-    if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem, hinted ? hint + 16 : hint, nreg + 1);
+    if (w == kMoveWave) mover_role(src, csize, rectab, ridx, nseq, rend, smem, hinted ? hint + LZ4AMD_HINT_HEAD : hint, nreg + 1);
     else if (hinted && w >= kFirstParseWave) parser_role(src, csize, cap, prefix, total, nseq, nreg, rend, smem, prof);
     else if (w < kActiveCopy) copy_role(w, src, dst, nseq, total, rend, smem, prof, hinted);
     __syncthreads();
+#ifndef LZ4AMD_PROF_PARSER
+    if (prof && tid == 0) { const uint64_t* q = (const uint64_t*)(smem + kOffMisc) + 24; prof[5] = q[0]; prof[6] = q[1]; prof[7] = q[2]; }
+#endif
     return misc[M_PBAD] == 0;
 }
 
@@ -1407,10 +1434,10 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     if (use_hints && !chained && P.hints && P.hint_stride >= 48) {
         const lz4amd_gsrc hp = LZ4AMD_TO_GSRC(P.hints + (uint64_t)b * P.hint_stride);
         const U32x4 h = ld_global16(hp);                     // { magic, output bytes, compressed bytes, sequences }
-        const U32x4 e0 = ld_global16(hp + 16);               // the first row { 0, 0, 0, rows }
-        if (h[0] == LZ4AMD_HINT_MAGIC && h[2] == csize && h[1] != 0 && h[1] <= cap && h[3] != 0 && h[3] <= csize
-            && (e0[0] | e0[1] | e0[2]) == 0 && e0[3] != 0 && ((uint64_t)e0[3] + 2) * 16 <= P.hint_stride) {
-            hint = hp; total = h[1]; nseq = h[3]; nrows = e0[3];
+        const U32x4 e0 = ld_global16(hp + 16);               // { rows, 0, 0, 0 }
+        if (h[0] == LZ4AMD_HINT_MAGIC && h[2] == csize && csize < LZ4AMD_HINT_MAX_CSIZE && h[1] != 0 && h[1] <= cap && h[3] != 0 && h[3] <= csize
+            && e0[0] != 0 && (e0[1] | e0[2] | e0[3]) == 0 && LZ4AMD_HINT_HEAD + ((uint64_t)e0[0] + 1) * LZ4AMD_HINT_ROW <= P.hint_stride) {
+            hint = hp; total = h[1]; nseq = h[3]; nrows = e0[0];
         }
     }
     // ---- stage A: the record table (a malformed block ends here, nothing written).  On request it also writes the block's
@@ -1419,7 +1446,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     uint32_t make_rows = 0;
     if (!hint && ok && !stored && !chained && P.hint_make && P.hints && P.hint_stride >= 48) {
         make = LZ4AMD_TO_GDST((uint8_t*)P.hints + (uint64_t)b * P.hint_stride);
-        make_rows = (uint32_t)(P.hint_stride / 16 - 2);
+        make_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride);
         if (tid == 0) *(uint32_t*)make = 0;                      // (no table until it is whole)
     }
     if (!hint && ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx, make, make_rows)) {

@@ -53,6 +53,13 @@
 #pragma once
 #include "lz4_compress_kernel.h"
 
+#ifndef LZ4AMD_HC_PROF
+#if defined(LZ4AMD_PROF_ROLES) || defined(LZ4AMD_PROF_TILE) || defined(LZ4AMD_PROF_WAVES) || defined(LZ4AMD_PROF_HC)
+#define LZ4AMD_HC_PROF 1
+#else
+#define LZ4AMD_HC_PROF 0        // 1: the phase stamps of tools/prof_cmp.py / prof_hc.py (LZ4AMD_PROF=1 in the environment): a developer build, tools/build_variant.sh prof -DLZ4AMD_HC_PROF=1
+#endif
+#endif
 namespace lz4amd {
 
 // developer counters of the CPU interpreter's build (tools/exp/hc_emu_stats.py): how many trips the walk loop makes, with how many lanes
@@ -1073,7 +1080,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     MatchRec* recs_g = (MatchRec*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src) + hc_st1_bytes(P.max_src));
     HcEnt* list_g = (HcEnt*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src) + hc_st1_bytes(P.max_src) + hc_recs_bytes(P.max_src));
     uint32_t* count_g = (uint32_t*)(scratch + hc_chain_bytes(P.max_src) + hc_st0_bytes(P.max_src) + hc_st1_bytes(P.max_src) + hc_recs_bytes(P.max_src) + hc_list_bytes(P.max_src));
-    uint64_t* prof = P.prof ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;
+    uint64_t* prof = (LZ4AMD_HC_PROF && P.prof) ? P.prof + (uint64_t)blockIdx.x * 8 : nullptr;      // (a developer build's stamps: the product kernel carries none of that code)
     uint64_t tq = prof ? clock_ticks() : 0;
 
     uint32_t nstrips = 0, strip_len = 0;
@@ -1130,7 +1137,7 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
         __syncthreads();
         // -- emit (the emit lanes also write the optional entry-point table's rows: lz4amd_params.h)
         if (w < nstrips && !misc[HM_FAIL] && strip[S_N * kCmpWaves + w]) {
-            HintOut H; H.table = hints; H.cap_rows = P.hint_stride >= 48 ? (uint32_t)(P.hint_stride / 16 - 2) : 0u; H.pre = first; H.over = &misc[HM_HOVER]; H.ord0 = 0; H.row0 = 0; H.k = misc[HM_HK];
+            HintOut H; H.table = hints; H.cap_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride); H.pre = first; H.over = &misc[HM_HOVER]; H.ord0 = 0; H.row0 = 0; H.k = misc[HM_HK];
             emit_strip(nullptr, recs_g + (uint64_t)w * rec_cap + misc[HM_FIRST0 + w], strip, w, src, dst, first + w * strip_len, 0xFFFFFFFFu, hints ? &H : nullptr, strip[6 * kCmpWaves + w]);
         }
         __syncthreads();
@@ -1147,15 +1154,12 @@ __device__ __forceinline__ void hc_one_block(const HcBatch& P, uint32_t b, char*
     if (hints && tid == 0) {
         // as lz4amd_k_compress ends its tables: the block's last sequence (its final literals) has a row of its own, the row behind it is the
         // block's end, row 0 carries the number of rows, the header makes the table valid
-        const uint32_t cap_rows = P.hint_stride >= 48 ? (uint32_t)(P.hint_stride / 16 - 2) : 0u;
+        const uint32_t cap_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride);
         const uint32_t seqs = n > first && n - first >= kMfLimit + 1 ? misc[HM_SEQS] : 0u, k = seqs ? misc[HM_HK] : 0u;
         const uint32_t last_row = (seqs + (1u << k) - 1) >> k, nrows = last_row + 1;
         if (last_row && last_row < cap_rows) st_hint(hints, last_row, out, n - run - first, seqs);
-        if (nrows <= cap_rows && !(seqs && misc[HM_HOVER])) {
-            st_hint(hints, nrows, (uint32_t)total, (uint32_t)n_i, seqs + 1);
-            st_hint(hints, 0, 0, 0, 0, nrows);
-            U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = (uint32_t)n_i; h[2] = (uint32_t)total; h[3] = seqs + 1;
-            st_global16(hints, h);
+        if (nrows <= cap_rows && !(seqs && misc[HM_HOVER]) && total < LZ4AMD_HINT_MAX_CSIZE) {
+            hint_store_head(hints, (uint32_t)n_i, (uint32_t)total, seqs + 1, nrows);
         } else *(uint32_t*)hints = 0;
     }
     const uint32_t lit_dst = out + 1 + lit_hdr_ext(run);

@@ -265,10 +265,6 @@ __device__ __forceinline__ int slow_token(lz4amd_gsrc g, uint32_t csize, uint32_
 // hint_out (optional): the block's entry-point table is written on the way (include/lz4amd.h; layout csrc/lz4amd_params.h) - a row
 // per 2^k tokens, k <= 3 set per trip of P5 so that rows are ~512 bytes of output apart, one row per token of the slow path - so
 // that the next decode of the same block can skip this stage; hint_cap_rows: rows the table has room for.
-__device__ __forceinline__ void st_hint_row(lz4amd_gdst t, uint32_t r, uint32_t tok, uint32_t out, uint32_t ord, uint32_t w3) {
-    U32x4 v; v[0] = tok; v[1] = out; v[2] = ord; v[3] = w3;
-    st_global16(t + 16 * (uint64_t)(r + 1), v);
-}
 __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, uint32_t cap, uint32_t prefix,
                                                SeqRec* rectab, char* smem, uint64_t table_size,
                                                uint32_t& nseq_out, uint32_t& total_out, uint64_t* prof = nullptr, uint32_t** ridx_out = nullptr,
@@ -525,7 +521,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
                         if (hint_out && (x & ((1u << hk) - 1u)) == 0) {
                             const uint32_t row = hrows + (x >> hk);
                             if (row >= hint_cap_rows) misc[M_HOVER] = 1u;
-                            else if (row) st_hint_row(hint_out, row, tp[j], o - kBias, nrec + i0 + 64 * j, 0);      // (row 0 is written at the end: it carries the number of rows)
+                            else if (row) hint_store_row(hint_out, row, tp[j], o - kBias, nrec + i0 + 64 * j);      // (row 0 is written at the end: it carries the number of rows)
                         }
                     }
                 }
@@ -540,7 +536,7 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
         if (stop) {
             if (hint_out && tid == 0) {             // (the slow path's token gets a row of its own)
                 if (hrows >= hint_cap_rows) misc[M_HOVER] = 1u;
-                else if (hrows) st_hint_row(hint_out, hrows, tend, obase - kBias, nrec, 0);
+                else if (hrows) hint_store_row(hint_out, hrows, tend, obase - kBias, nrec);
             }
             hrows++;
             if (tid < 64) {
@@ -563,12 +559,8 @@ __device__ __forceinline__ bool preparse_block(lz4amd_gsrc src, uint32_t csize, 
     if (hint_out) {
         __syncthreads();                                      // (M_HOVER)
         if (tid == 0) {
-            if (!misc[M_HOVER] && hrows && hrows <= hint_cap_rows) {
-                st_hint_row(hint_out, hrows, csize, obase - kBias, nrec, 0);              // the block's end
-                st_hint_row(hint_out, 0, 0, 0, 0, hrows);                                  // the first sequence, and the number of rows
-                U32x4 h; h[0] = LZ4AMD_HINT_MAGIC; h[1] = obase - kBias; h[2] = csize; h[3] = nrec;
-                st_global16(hint_out, h);
-            }
+            if (!misc[M_HOVER] && hrows && hrows <= hint_cap_rows && csize < LZ4AMD_HINT_MAX_CSIZE)
+                hint_store_head(hint_out, obase - kBias, csize, nrec, hrows);      // the block's end, the first sequence, the number of rows: the table is valid
         }
     }
     if (prof && tid == 0) { prof[2] = pt[0] | (pt[1] << 32); prof[3] = pt[2] | (pt[3] << 32); prof[4] = pt[4] | (pt[5] << 32); }

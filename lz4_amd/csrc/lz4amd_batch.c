@@ -10,6 +10,7 @@
 #include "../../include/lz4amd.h"
 #include "lz4amd_ffi.h"
 #include "lz4amd_internal.h"
+#include "lz4amd_params.h"
 #define LZ4AMD_TRACE_BYTES (4u << 20)
 #include <stdlib.h>
 #include <string.h>
@@ -270,10 +271,10 @@ int lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, in
 }
 
 size_t lz4amd_hint_bytes(int src_size)
-{   /* header + room for one row per 128 bytes of source (a row is 8 sequences: blocks that average less than 16 bytes per
-     * sequence get no table) + the end row (lz4amd_params.h) */
+{   /* header + room for one row (8 bytes) per 128 bytes of source (a row is 8 sequences: blocks that average less than 16 bytes per
+     * sequence get no table) + the end row (lz4amd_params.h), a multiple of 16 */
     if (src_size < 0) return 0;
-    return 16u * (((size_t)src_size + 127u) / 128u + 3u);
+    return (LZ4AMD_HINT_HEAD + LZ4AMD_HINT_ROW * (((size_t)src_size + 127u) / 128u + 2u) + 15u) & ~(size_t)15u;
 }
 
 int lz4amd_plan_attach_hints(lz4amd_plan* p, void* d_hints, size_t stride)

@@ -31,10 +31,9 @@ typedef struct lz4amd_dec_params {
                                      * hints memory must then be writable): the next decode of the same block parses from it */
 } lz4amd_dec_params;
 
-/* One block's entry-point table: a 16-byte header { magic, out_size, csize, nseq } followed by rows + 1 entries of 16 bytes.
- * Entry r names a sequence of the block's token chain: where its token sits in the compressed block, where its literals
- * start in the output, how many sequences precede it.  Entry 0 is the block's first sequence { 0, 0, 0 } and carries the number
- * of rows in its fourth word; entry `rows` is the block's end { csize, out_size, nseq }; entries never decrease.  The
+/* One block's entry-point table (layout: below, at LZ4AMD_HINT_MAGIC).  Row r names a sequence of the block's token chain: where its
+ * token sits in the compressed block, where its literals start in the output, how many sequences precede it (mod 256: the decoder counts
+ * them up from row to row).  Row 0 is the block's first sequence, row `nrows` the block's end; rows never decrease.  The
  * compressor writes about one row per 512 bytes of source and never fewer than one per 8 sequences - per 16 on data of fewer
  * than 32 bytes per sequence, whose rows would not fit the table's room otherwise (the distance, a power of two of sequences,
  * is set tile by tile from the tile's own number of sequences): every lane of the decoder's parser walks a row's
@@ -42,11 +41,19 @@ typedef struct lz4amd_dec_params {
  * because the lanes' rows must lie in the 32 KB of the stream that are resident.  (Rows at fixed distances in the output -
  * an earlier layout - left two thirds of the lanes' steps idle: the sequences per KB vary threefold.)  Any table whose rows
  * lie on the chain works; one that does not is found out and costs time only. */
-#define LZ4AMD_HINT_MAGIC 0x48345A4Cu           /* "LZ4H" */
+#define LZ4AMD_HINT_MAGIC 0x32485A4Cu           /* "LZH2": rows of 8 bytes (round 6; "LZ4H" had rows of 16) */
+/* Layout: 32 bytes of header - { magic, out_size, csize, nseq }, { nrows, 0, 0, 0 } - then nrows + 1 rows of 8 bytes:
+ * { token position (24 bits) | sequences before the row mod 256 (8 bits), output position }.  Row 0 is the block's first sequence { 0, 0 }, row nrows
+ * the block's end { csize | nseq mod 256 << 24, out_size }.  Two neighbouring rows are at most 255 sequences apart (the decoder counts the sequences
+ * before a row up from the differences), and a block whose compressed size does not fit 24 bits has no table. */
+#define LZ4AMD_HINT_HEAD 32u
+#define LZ4AMD_HINT_ROW 8u
+#define LZ4AMD_HINT_MAX_CSIZE (1u << 24)
+#define LZ4AMD_HINT_CAP_ROWS(stride) ((stride) >= 48 ? (uint32_t)(((stride) - LZ4AMD_HINT_HEAD) / LZ4AMD_HINT_ROW - 1) : 0u)      /* rows 0 .. cap - 1, and the end row */
 #define LZ4AMD_HINT_EVERY_MAX 16u            /* sequences between two rows of a table lz4amd_k_compress writes, at most (data of fewer than 32 bytes
                                               * per sequence; 8 and fewer otherwise: about a row per 512 bytes) */
 #define LZ4AMD_HINT_EVERY_LOG2 4u
-typedef struct lz4amd_hint_entry { uint32_t tok, out, ord, zero; } lz4amd_hint_entry;      /* header: { magic, out_size, csize, nseq } */
+typedef struct lz4amd_hint_entry { uint32_t tok_ord, out; } lz4amd_hint_entry;
 
 typedef struct lz4amd_comp_params {
     const uint8_t* const* src;      /* [n_blocks] */

@@ -111,7 +111,9 @@ def test_tables_made_for_foreign_blocks_decode_every_corpus(ctx, ocodec, reflib,
         outs, used, rejected = gpu_decompress_tables(ctx, blocks, [len(d) for d in wants], tables, salign=sal)
         for d, (r, o) in zip(wants, outs):
             assert r == len(d) and o == d, (every, by_bytes, sal, len(d))
-        assert used == len(blocks) and rejected == 0, (every, by_bytes, used, rejected)
+        # (rows every 3000 bytes of a block of 6-byte sequences are more than 255 sequences apart: the rows' 8 bits cannot say that, such a table
+        #  is rejected - not wrong; tests/test_hints_emulated.py has the case with rows 2000 sequences apart as well)
+        assert used + rejected == len(blocks) and (rejected == 0 or by_bytes == 3000) and used >= len(blocks) - 2, (every, by_bytes, used, rejected)
 
 
 def test_tables_that_lie_only_cost_time(ctx, ocodec, datagen):
@@ -119,25 +121,25 @@ def test_tables_that_lie_only_cost_time(ctx, ocodec, datagen):
     d = datagen(300000, 60, 5)
     c = ocodec.compress(d)[1]
     good = th.make_table(c)
-    nrows = len(good) // 16
+    nrows = th.header(good)[4]
     blocks, tables = [], []
     for t in range(48):
         bad = bytearray(good)
         kind = t % 4
         if kind == 0:
             for _ in range(rnd.randint(1, 4)):
-                struct.pack_into("<I", bad, 16 + 4 * rnd.randrange(4 * (nrows - 1)), rnd.randrange(1 << 22))
+                struct.pack_into("<I", bad, 32 + 4 * rnd.randrange(2 * (nrows - 1)), rnd.randrange(1 << 22))
         elif kind == 1:
             r = rnd.randrange(1, nrows - 1)
-            tok, out, ordn, z = struct.unpack_from("<4I", bad, 16 * r)
-            struct.pack_into("<4I", bad, 16 * r, tok + rnd.choice((1, 2, 3)), out + rnd.choice((0, 1)), ordn, z)
+            tok, out, olo = th.unpack_row(bad, r)
+            th.set_row(bad, r, tok + rnd.choice((1, 2, 3)), out + rnd.choice((0, 1)), olo)
         elif kind == 2:
             r = rnd.randrange(1, nrows - 1)
-            tok, out, ordn, z = struct.unpack_from("<4I", bad, 16 * r)
-            struct.pack_into("<4I", bad, 16 * r, tok, out + (1 if t % 8 < 4 else 0), ordn + (0 if t % 8 < 4 else 1), z)
+            tok, out, olo = th.unpack_row(bad, r)
+            th.set_row(bad, r, tok, out + (1 if t % 8 < 4 else 0), olo + (0 if t % 8 < 4 else 1))
         else:
             bad = bytearray(rnd.randbytes(len(good)))
-            struct.pack_into("<4I", bad, 0, *struct.unpack_from("<4I", good, 0))
+            struct.pack_into("<8I", bad, 0, *struct.unpack_from("<8I", good, 0))
         blocks.append(c); tables.append(bytes(bad))
     outs, used, rejected = gpu_decompress_tables(ctx, blocks, [len(d)] * len(blocks), tables)
     for r, o in outs:
@@ -207,7 +209,7 @@ def test_tables_made_while_decoding_foreign_blocks(ctx, ocodec, reflib, datagen)
     assert used == 0 and rejected == 0 and made[1] >= len(blocks) - 4, (used, rejected, made[1])
     good = 0
     for d, c, t in zip(wants, blocks, made[0]):
-        if struct.unpack_from("<I", t, 0)[0] == th.MAGIC:
+        if th.is_valid(t):
             th.check_table(c, t, len(d)); good += 1
     assert good >= len(blocks) - 6, good
     outs, used, rejected = gpu_decompress_tables(ctx, blocks, [len(d) for d in wants], made[0], salign=3)

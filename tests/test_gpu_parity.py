@@ -487,6 +487,36 @@ def test_many_small_blocks(ctx, datagen, ocodec):
     assert o == host[3 * 65536:4 * 65536]
 
 
+def test_device_only_failures_of_round_5_stay_fixed(ctx, datagen, ocodec):
+    """Two failures that only the gfx950 build showed (the CPU interpreter runs the same source and saw neither; tests/simt/README.md):
+    (a) commit 1b375b1 - the hash of blocks under 64 KB + 11 returned `(__umul24(a, k) + __umul24(b, l)) >> 19` directly; HIP's __umul24
+        returns int, the shift was arithmetic, the table index negative: a memory fault on 64 KiB blocks of datagen -P90 (many blocks per
+        workgroup, every position probed);
+    (b) `if (lane == 0) atomicAdd(word)` behind an inlined function with an early return, inside the emit queue's loop, hung the kernel: the
+        queue's tail (fewer strips left than waves) is what ran into it - blocks whose last tile has one to fifteen strips.
+    4096 x 64 KiB of -P90, and blocks of every tail length, round trip on the device and through the oracle decoder."""
+    import lz4_amd
+    nblk, bs = 4096, 65536
+    host = datagen(nblk * bs, 90, 11)
+    data = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
+    comp, csizes, _ = lz4_amd.compress_blocks(ctx, data, bs)
+    assert all(0 < c <= lz4_amd.compress_bound(bs) for c in csizes)
+    out, res, _ = lz4_amd.decompress_blocks(ctx, comp, csizes, bs, data.numel())
+    assert res == [bs] * nblk and torch.equal(out, data)
+    hc = comp.cpu().numpy()
+    for i in range(0, nblk, 257):
+        ro, o = ocodec.decompress(hc[i, :csizes[i]].tobytes(), bs)
+        assert ro == bs and o == host[i * bs:(i + 1) * bs], i
+    # (b) every number of strips in the last tile: 64 KB + 11 (the first size on the big-block path) up, in steps of half a strip
+    for k in range(0, 40):
+        n = 65536 + 11 + 8192 * 3 + 512 * k + (k * 37) % 512
+        h = datagen(n, 60, 100 + k)
+        d = torch.frombuffer(bytearray(h), dtype=torch.uint8).cuda()
+        c, cs, _ = lz4_amd.compress_blocks(ctx, d, n)
+        o, r, _ = lz4_amd.decompress_blocks(ctx, c, cs, n, n)
+        assert r == [n] and torch.equal(o, d), n
+
+
 def test_acceleration_trades_size_for_speed(ctx, ocodec, reflib, datagen):
     """LZ4_compress_fast's acceleration (lz4.c:1382-1400): through the batch plan (lz4amd_plan_set_acceleration) and through the
     classic name.  Every setting decodes, sizes never shrink as the value grows, acceleration 1 is LZ4_compress_default,

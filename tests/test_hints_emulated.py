@@ -11,15 +11,11 @@ import pytest
 
 import test_kernels_emulated as tk
 
-MAGIC = 0x48345A4C
+from hint_format import MAGIC, hint_bytes, pack_table, unpack_row, set_row, header, is_valid, row_offset, table_bytes
 CANARY = 0xEE
 
 
 EVERY = 16                     # lz4amd_k_compress's rows are at most 16 sequences apart (LZ4AMD_HINT_EVERY_MAX; 8 and fewer on data of 32 bytes per sequence and more)
-
-
-def hint_bytes(n):
-    return 16 * ((n + 127) // 128 + 3)
 
 
 def token_chain(comp):
@@ -68,30 +64,26 @@ def make_table(comp, every=EVERY, by_bytes=0):
         rows = [(ch[k][0], ch[k][1], k) for k in range(0, len(ch), every)]
     if not rows:
         rows = [(0, 0, 0)]
-    t = struct.pack("<4I", MAGIC, n, len(comp), len(ch))
-    for r, (tok, out, ordn) in enumerate(rows):
-        t += struct.pack("<4I", tok, out, ordn, len(rows) if r == 0 else 0)
-    t += struct.pack("<4I", len(comp), n, len(ch), 0)
-    return t
+    return pack_table(n, len(comp), len(ch), rows)
 
 
 def check_table(comp, table, n):
     """a table lz4amd_k_compress wrote: every row is a sequence of the block's real token chain, rows are at most 8 sequences
     apart, the block's last sequence has a row, the first row carries the number of rows"""
-    magic, osz, csz, nseq = struct.unpack_from("<4I", table, 0)
+    magic, osz, csz, nseq, nrows = header(table)
     assert (magic, osz, csz) == (MAGIC, n, len(comp))
     ch, total = token_chain(comp)
     assert total == n and nseq == len(ch)
-    z0 = struct.unpack_from("<4I", table, 16)
-    nrows = z0[3]
-    assert z0[:3] == (0, 0, 0) and 1 <= nrows <= nseq and 16 * (nrows + 2) <= len(table)
+    assert struct.unpack_from("<3I", table, 20) == (0, 0, 0) and 1 <= nrows <= nseq and table_bytes(nrows) <= len(table)
+    assert unpack_row(table, 0) == (0, 0, 0)
     prev = 0
     for r in range(1, nrows):
-        tok, out, ordn, z = struct.unpack_from("<4I", table, 16 * (r + 1))
-        assert z == 0 and prev < ordn <= prev + EVERY and ordn < nseq and (tok, out) == ch[ordn], (r, tok, out, ordn)
+        tok, out, olo = unpack_row(table, r)
+        ordn = prev + ((olo - prev) & 0xFF)                          # (the rows carry the count's low 8 bits: neighbours are at most 255 apart)
+        assert prev < ordn <= prev + EVERY and ordn < nseq and (tok, out) == ch[ordn], (r, tok, out, ordn)
         prev = ordn
     assert prev == nseq - 1 or nrows == 1 and nseq <= EVERY + 1, (prev, nseq)
-    assert struct.unpack_from("<4I", table, 16 * (nrows + 1)) == (len(comp), n, nseq, 0)
+    assert unpack_row(table, nrows) == (len(comp), n, nseq & 0xFF)
     return nrows
 
 
@@ -184,8 +176,9 @@ def test_tables_made_for_foreign_blocks_decode_every_corpus(emu, foreign):
         outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], tables, salign=sal)
         for d, (r, o) in zip(wants, outs):
             assert r == len(d) and o == d, (every, by_bytes, sal, len(d))
-        # (rows 2000 sequences apart: a lane of the parser then owns more sequences than it accepts - such a table is rejected, not wrong)
-        assert used + rejected == len(blocks) and (rejected == 0 or every == 2000) and used >= 40, (every, by_bytes, used, rejected)
+        # (rows more than 255 sequences apart - every 2000 sequences; every 3000 bytes of a block of 6-byte sequences - cannot be said in the rows' 8 bits:
+        #  the count the parser keeps then does not match what the lanes walk, and such a table is rejected, not wrong)
+        assert used + rejected == len(blocks) and (rejected == 0 or every == 2000 or by_bytes == 3000) and used >= 40, (every, by_bytes, used, rejected)
 
 
 def test_compressor_tables_name_real_sequences_and_are_used(emu, ocodec, datagen):
@@ -212,7 +205,7 @@ def test_compressor_tables_name_real_sequences_and_are_used(emu, ocodec, datagen
     assert all(r < 0 for r, _ in outs) and used == 0
     # a failed or empty compression leaves no valid table
     comps2, tables2 = emu_compress_tables(emu, [b"", datas[0]])
-    assert struct.unpack_from("<I", tables2[0], 0)[0] != MAGIC and struct.unpack_from("<I", tables2[1], 0)[0] == MAGIC
+    assert not is_valid(tables2[0]) and is_valid(tables2[1])
 
 
 def test_tables_that_lie_only_cost_time(emu, ocodec, datagen):
@@ -221,22 +214,22 @@ def test_tables_that_lie_only_cost_time(emu, ocodec, datagen):
     c = ocodec.compress(d)[1]
     good = make_table(c)
     other = make_table(ocodec.compress(datagen(300000, 60, 6))[1])
-    nrows = len(good) // 16
+    nrows = header(good)[4]
     blocks, tables = [], []
     for t in range(60):
         bad = bytearray(good)
         kind = t % 6
         if kind == 0:                                              # random words anywhere behind the header
             for _ in range(rnd.randint(1, 4)):
-                struct.pack_into("<I", bad, 16 + 4 * rnd.randrange(4 * (nrows - 1)), rnd.randrange(1 << 22))
+                struct.pack_into("<I", bad, 32 + 4 * rnd.randrange(2 * (nrows - 1)), rnd.randrange(1 << 22))
         elif kind == 1:                                            # a row moved a little: still inside the block, not on the chain
             r = rnd.randrange(1, nrows - 1)
-            tok, out, ordn, z = struct.unpack_from("<4I", bad, 16 * r)
-            struct.pack_into("<4I", bad, 16 * r, tok + rnd.choice((1, 2, 3)), out + rnd.choice((0, 1)), ordn, z)
+            tok, out, olo = unpack_row(bad, r)
+            set_row(bad, r, tok + rnd.choice((1, 2, 3)), out + rnd.choice((0, 1)), olo)
         elif kind == 2:                                            # a true token with the wrong output position / count
             r = rnd.randrange(1, nrows - 1)
-            tok, out, ordn, z = struct.unpack_from("<4I", bad, 16 * r)
-            struct.pack_into("<4I", bad, 16 * r, tok, out + (1 if t % 2 else 0), ordn + (0 if t % 2 else 1), z)
+            tok, out, olo = unpack_row(bad, r)
+            set_row(bad, r, tok, out + (1 if t % 2 else 0), olo + (0 if t % 2 else 1))
         elif kind == 3:                                            # header says something else
             struct.pack_into("<I", bad, 4 * rnd.randrange(1, 4), rnd.randrange(1 << 20))
         elif kind == 4:                                            # another block's table
@@ -244,7 +237,7 @@ def test_tables_that_lie_only_cost_time(emu, ocodec, datagen):
         else:                                                      # noise
             bad = bytearray(rnd.randbytes(len(good)))
             if t % 2:
-                struct.pack_into("<4I", bad, 0, *struct.unpack_from("<4I", good, 0))
+                struct.pack_into("<8I", bad, 0, *struct.unpack_from("<8I", good, 0))
         blocks.append(c); tables.append(bytes(bad))
     outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d)] * len(blocks), tables)
     for r, o in outs:
@@ -315,10 +308,10 @@ def test_a_table_without_room_for_its_rows_is_left_invalid(emu, ocodec, datagen)
     ro, o = ocodec.decompress(comp, len(d))
     assert ro == len(d) and o == d
     ch, _ = token_chain(comp)
-    assert (len(ch) + EVERY - 1) // EVERY + 2 > stride // 16            # (the premise: more rows than room, even at 8 sequences a row)
+    assert table_bytes((len(ch) + EVERY - 1) // EVERY) > stride            # (the premise: more rows than room, even at 16 sequences a row)
     off = hbase - ctypes.addressof(hraw)
     table = hraw.raw[off:off + stride]
-    assert struct.unpack_from("<I", table, 0)[0] != MAGIC
+    assert not is_valid(table)
     assert hraw.raw[off + stride:off + stride + 4096] == b"\xEE" * 4096   # nothing behind the table's end
     outs, used, rejected = emu_decompress_tables(emu, [comp], [len(d)], [table])
     assert outs[0] == (len(d), d) and (used, rejected) == (0, 0)
@@ -337,7 +330,7 @@ def test_tables_made_while_decoding_foreign_blocks(emu, foreign):
     assert used == 0 and rejected == 0 and made[1] >= len(blocks) - 4, (used, rejected, made[1])
     good = 0
     for d, c, t in zip(wants, blocks, made[0]):
-        if struct.unpack_from("<I", t, 0)[0] == MAGIC:
+        if is_valid(t):
             check_table(c, t, len(d)); good += 1
         else:
             assert t == bytes(len(t)) or struct.unpack_from("<I", t, 0)[0] == 0        # (left invalid: more rows than room)
@@ -350,8 +343,9 @@ def test_tables_made_while_decoding_foreign_blocks(emu, foreign):
     liars = []
     for t in made[0]:
         b = bytearray(t)
-        if struct.unpack_from("<I", t, 0)[0] == MAGIC and struct.unpack_from("<4I", t, 16)[3] > 2:
-            struct.pack_into("<I", b, 32 + 4, struct.unpack_from("<I", t, 32 + 4)[0] + 1)     # row 1: output position off by one
+        if is_valid(t) and header(t)[4] > 2:
+            tok1, out1, olo1 = unpack_row(t, 1)
+            set_row(b, 1, tok1, out1 + 1, olo1)                                          # row 1: output position off by one
         liars.append(bytes(b))
     made2 = []
     outs, used, rejected = emu_decompress_tables(emu, blocks, [len(d) for d in wants], liars, make=made2)
