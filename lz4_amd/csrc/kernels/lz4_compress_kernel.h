@@ -77,6 +77,14 @@
 #ifndef LZ4AMD_CMP_MERGE_RUNS
 #define LZ4AMD_CMP_MERGE_RUNS 1
 #endif
+#ifndef LZ4AMD_CMP_HASH_MUL
+#define LZ4AMD_CMP_HASH_MUL 0x85EBCA6Bu      // (not the reference's 2654435761, lz4.c:777: tests/datagen.c draws its bytes with a generator that multiplies by the very same
+                                             //  constant, and the literals of `datagen -P0` then hash into a few table slots - same-address LDS atomics, 9.2 ms per 4 MiB block
+                                             //  against 2.4 ms on uniform random bytes; with any other odd multiplier both take 2.4.  Compressible datagen output: unchanged)
+#endif
+#ifndef LZ4AMD_CMP_CLAMP_RUNS
+#define LZ4AMD_CMP_CLAMP_RUNS 0      // developer knob (measured: no gain on datagen -P0 - its trouble was the hash, see LZ4AMD_CMP_HASH_MUL - and bytes lost on -P90)
+#endif
 #ifndef LZ4AMD_STRIDE4_FROM
 #define LZ4AMD_STRIDE4_FROM 2
 #endif
@@ -185,12 +193,12 @@ template <class Ptr> __device__ __forceinline__ Ptr put_len_ext(Ptr p, uint32_t 
 // bytes gives the same matches up to table collisions.
 __device__ __forceinline__ uint32_t hash_pos32(uint32_t lo, uint32_t hi, bool small) {
 #if LZ4AMD_CMP_HASH32
-    // the reference's own 4-byte hash (lz4.c:777-783: one 32-bit multiply - measured on gfx950 it issues like a 24-bit one, tools/exp/valu_issue.hip),
+    // the form of the reference's 4-byte hash (lz4.c:777-783: one 32-bit multiply - measured on gfx950 it issues like a 24-bit one, tools/exp/valu_issue.hip),
     // the fifth byte added in with a 24-bit multiply-add: 4 instructions instead of 6
     // (blocks under 64 KB + 11 keep the 24-bit form over their four bytes: with it datagen -P90 in 64 KiB blocks comes out 1.5 % smaller)
     uint32_t h;
     if (small) h = __umul24(lo, 0x9E3779u) + __umul24(lo >> 8, 0x85EBCBu);
-    else h = lo * 2654435761u + __umul24(hi & 0xFFu, 0xC2B2AFu);
+    else h = lo * LZ4AMD_CMP_HASH_MUL + __umul24(hi & 0xFFu, 0xC2B2AFu);
     return h >> (32 - kHashBits);
 #else
     uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(lo >> 8, 0x85EBCBu);
@@ -589,6 +597,14 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t last_q = n - kMfLimit;
+#if LZ4AMD_CMP_CLAMP_RUNS
+        // A piece that listed more runs than its list holds - every fourth byte starts one: literals of a skewed alphabet (datagen -P0), a
+        // block of 4-byte matches - keeps the first kCandCap of them, in position order; its last bytes find no match of their own (one that
+        // reaches them from before still covers them).  Parsing such a piece the single-wave way (probed again, list after list) made
+        // incompressible text three times slower than compressible data, for no byte saved.
+        if (nA > kCandCap) nA = kCandCap;
+        if (nB > kCandCap) nB = kCandCap;
+#endif
         if (nA <= kCandCap && nB <= kCandCap) {
             CMP_STAT(10, 1); CMP_STAT(11, nA + nB); CMP_STAT(12, (nA + nB + 63) / 64);
             if (lane == 0) lds_store_release_local(table_free, gen);

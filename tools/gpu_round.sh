@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-tag=${1:-r05}
+tag=${1:-r06}
 what=${2:-all}
 if [ "$what" != "prof" ]; then
 timeout 900 python -m pytest tests -m gpu -x -q --timeout 300 > gpurun_out/${tag}_gputests.log 2>&1; tail -2 gpurun_out/${tag}_gputests.log
@@ -35,6 +35,8 @@ NH="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-hc --no-extra
 ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/${tag}_pmc_fetch_hc -o ${tag}hf -- python $R/tools/prof_hc.py 4096 262144 60 9 > /dev/null 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/${tag}_pmc_write_hc -o ${tag}hw -- python $R/tools/prof_hc.py 4096 262144 60 9 > /dev/null 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --kernel-trace -d $R/gpurun_out/${tag}_pmc_sq1_hc -o ${tag}hs -- python $R/tools/prof_hc.py 4096 262144 60 9 > /dev/null 2>&1 )
+# configs[2] device resident: the chained decode of linked blocks, the gather into frame layout, the batched XXH32 (so that every frac of the line has a profiles/ counterpart)
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_frame -o ${tag}fr -- python $R/tools/prof_frame.py > $R/gpurun_out/${tag}_prof_frame.log 2>&1 )
 ( timeout 120 python tools/stress_gpu.py 30 5 2>&1 | tail -1 ) > gpurun_out/${tag}_stress.log; cat gpurun_out/${tag}_stress.log
 for db in $(find gpurun_out -name "${tag}*results.db"); do python tools/rocprof_summary.py $db > ${db%.db}.txt 2>&1; tail -n 6 ${db%.db}.txt; rm -f $db; done      # (the databases are tens of MB: gpurun copies back 64 MiB at most)
 find gpurun_out -type f \( -name "*.db" -o -name "*.pftrace" -o -name "*.rocpd" \) -delete

@@ -32,7 +32,8 @@ def main():
              "nohints_kernel_stats": f"{tag}_prof_nohints/{tag}nh_results.txt", "nohints_pmc_fetch": f"{tag}_pmc_fetch_nohints/{tag}nhf_results.txt",
              "nohints_pmc_write": f"{tag}_pmc_write_nohints/{tag}nhw_results.txt", "nohints_pmc_sq1": f"{tag}_pmc_sq1_nohints/{tag}nhs_results.txt",
              "refdec_kernel_stats": f"{tag}_prof_refdec/{tag}rd_results.txt", "refdec_pmc_fetch": f"{tag}_pmc_fetch_refdec/{tag}rdf_results.txt",
-             "refdec_pmc_write": f"{tag}_pmc_write_refdec/{tag}rdw_results.txt", "refdec_pmc_sq1": f"{tag}_pmc_sq1_refdec/{tag}rds_results.txt"}
+             "refdec_pmc_write": f"{tag}_pmc_write_refdec/{tag}rdw_results.txt", "refdec_pmc_sq1": f"{tag}_pmc_sq1_refdec/{tag}rds_results.txt",
+             "frame_kernel_stats": f"{tag}_prof_frame/{tag}fr_results.txt"}
     for k, f in files.items():
         if os.path.exists(os.path.join(g, f)):
             shutil.copy(os.path.join(g, f), os.path.join(ROOT, "profiles", f"{name}_rocprof_{k}.txt"))
