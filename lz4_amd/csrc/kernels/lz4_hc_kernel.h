@@ -160,7 +160,10 @@ __device__ __forceinline__ uint32_t hc_attempts(int level) {
 // A walk that is parked between two bands keeps its attempts in 8 bits: in units of 1 up to 256, of 2 up to 512, of 8 beyond
 // (what is lost to the rounding is at most one unit per band).
 __device__ __forceinline__ uint32_t hc_att_shift(uint32_t attempts) { return attempts <= 256u ? 0u : attempts <= 512u ? 1u : 3u; }
-__device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHcHashLog); }
+#ifndef LZ4AMD_HC_HASH_MUL
+#define LZ4AMD_HC_HASH_MUL 2654435761u      // lz4hc.c:121 LZ4HC_hashPtr
+#endif
+__device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * LZ4AMD_HC_HASH_MUL) >> (32 - kHcHashLog); }
 
 // Per-position search result: st0 = best length | offset << 8.  A walk that goes on in the next band is a list entry (hc_search_band).
 struct HcEnt { uint32_t x, y; };
