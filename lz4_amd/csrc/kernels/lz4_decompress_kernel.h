@@ -1332,9 +1332,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
     }
 out: ;
 #ifndef LZ4AMD_PROF_PARSER
-    // (through LDS, written out by thread 0 behind the roles' barrier: the direct store from here faulted on the device in one build - 16-byte chunks,
-    //  stamps on - and not in the others)
-    if (prof && w == 0 && lane == 0) { uint64_t* q = (uint64_t*)(smem + kOffMisc) + 24; q[0] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); q[1] = t_rec | (t_lead << 32); q[2] = t_work | (t_retry << 32); }
+    if (prof && w == 0 && lane == 0) { prof[6] = t_rec | (t_lead << 32); prof[7] = t_work | (t_retry << 32); prof[5] = n_iters | ((uint64_t)n_retried << 32) | ((uint64_t)k << 48); }
 #endif
 }
 
@@ -1375,9 +1373,6 @@ __device__ __forceinline__ bool stream_block(lz4amd_gsrc src, uint32_t csize, lz
     else if (hinted && w >= kFirstParseWave) parser_role(src, csize, cap, prefix, total, nseq, nreg, rend, smem, prof);
     else if (w < kActiveCopy) copy_role(w, src, dst, nseq, total, rend, smem, prof, hinted);
     __syncthreads();
-#ifndef LZ4AMD_PROF_PARSER
-    if (prof && tid == 0) { const uint64_t* q = (const uint64_t*)(smem + kOffMisc) + 24; prof[5] = q[0]; prof[6] = q[1]; prof[7] = q[2]; }
-#endif
     return misc[M_PBAD] == 0;
 }
 

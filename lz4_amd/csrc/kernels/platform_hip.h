@@ -165,9 +165,7 @@ __device__ __forceinline__ void st_global16_raw(uint8_t* p, const lz4amd_u32x4& 
 __device__ __forceinline__ lz4amd_u32x4 ld_global16_raw(lz4amd_gsrc p) { lz4amd_u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st_global16_raw(lz4amd_gdst p, const lz4amd_u32x4& v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ void st_global8_raw(lz4amd_gdst p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
-// (s_memtime returns its value to an SGPR pair asynchronously; the wait is made explicit here, on the value itself: one developer build - the
-//  decoder with 16-byte chunks and its stamps on - faulted on the device until it was)
-__device__ __forceinline__ uint64_t clock_ticks() { uint64_t t = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t) :: "memory"); return t; }
+__device__ __forceinline__ uint64_t clock_ticks() { return __builtin_readcyclecounter(); }
 
 // value of v in lane l (l wave-uniform): v_readlane_b32, no LDS round trip
 __device__ __forceinline__ uint32_t wave_readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
