@@ -78,9 +78,11 @@
 #define LZ4AMD_CMP_MERGE_RUNS 1
 #endif
 #ifndef LZ4AMD_CMP_HASH_MUL
-#define LZ4AMD_CMP_HASH_MUL 0xCC9E2D51u      // (not the reference's 2654435761, lz4.c:777: tests/datagen.c draws its bytes with a generator that multiplies by the very same
-                                             //  constant, and the literals of `datagen -P0` then hash into a few table slots - same-address LDS atomics, 9.2 ms per 4 MiB block
-                                             //  against 2.4 ms on uniform random bytes; with any other odd multiplier both take 2.4.  Compressible datagen output: unchanged)
+#define LZ4AMD_CMP_HASH_MUL 0x9E3779B9u      // (not the reference's 2654435761 = 0x9E3779B1, lz4.c:777: tests/datagen.c draws its bytes with a generator that multiplies by the very
+                                             //  same constant, and the literals of `datagen -P0` then hash into a few table slots - same-address LDS atomics, 9.2 ms per 4 MiB block
+                                             //  against 2.4 ms on uniform random bytes.  Measured on the GPU: 0x9E3779B9 and 0xCC9E2D51 2.4 ms, 0x27D4EB2F 3.8, 0x85EBCA6B / 0xC2B2AE35
+                                             //  9.1, 0x165667B1 12.1; blocks made with 0xCC9E2D51 decode 9 % slower WITHOUT their tables (2.10 against 1.94 ms per GiB, by any build of
+                                             //  the decoder; sequence statistics identical - not understood), with this one as with the reference's.  Compressible datagen: unchanged)
 #endif
 #ifndef LZ4AMD_CMP_CLAMP_RUNS
 #define LZ4AMD_CMP_CLAMP_RUNS 0      // developer knob (measured: no gain on datagen -P0 - its trouble was the hash, see LZ4AMD_CMP_HASH_MUL - and bytes lost on -P90)

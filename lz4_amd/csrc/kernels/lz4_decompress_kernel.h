@@ -99,6 +99,9 @@
 #ifndef LZ4AMD_DEC_DMADEPTH
 #define LZ4AMD_DEC_DMADEPTH 16
 #endif
+#ifndef LZ4AMD_DEC_FULL_START
+#define LZ4AMD_DEC_FULL_START 0      // n > 0: the first n batches of a block wait for all their rows' stream bytes
+#endif
 #ifndef LZ4AMD_DEC_FULL_BATCH
 #define LZ4AMD_DEC_FULL_BATCH 0      // n > 0: a parser wave waits for a fuller batch of rows while the copy waves have records for n regions ahead
 #endif
@@ -677,6 +680,11 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
             nl = 1;
         }
         if (!nl && !nl_hard && drained && nlmax && wave_readlane(okrec ? 1u : 0u, 0) && wave_readlane(Rb, 0) - Ra > kIdxRing / 2) { smode = true; nl = 1; }
+#if LZ4AMD_DEC_FULL_START
+        // At a block's start the stream and the rows are still on their way: a batch claimed now has a handful of lanes and costs the wave as many
+        // steps as a full one (a 64 KiB block: 128 rows, six batches of 18).  The first batches wait until their rows' bytes are there.
+        if (nl && !smode && r0 < 64u * LZ4AMD_DEC_FULL_START && nl < (nreg - r0 < 64u ? nreg - r0 : 64u) && X.chi < csize && !X.pg && thin < 512) { thin++; parser_unlock(misc); spin_pause(); continue; }
+#endif
 #if LZ4AMD_DEC_FULL_BATCH
         // A walk costs the wave the same whether 5 of its lanes have a row or all 64: a small batch is taken only when it has to be - the
         // copy waves are about to run out of records (fewer than LZ4AMD_DEC_FULL_BATCH regions' worth published ahead of the region handed
