@@ -511,7 +511,9 @@ def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(0
         if rb is not None:
             o["ratio_vs_reference"] = round(sum(rb[1]) / sum(cs[:len(rb[1])]), 4)
         out["P%d" % pct] = o
-    out["note"] = "%d blocks per row, like the step's table; the step's own compressibility is in the top-level fields" % nblk
+    out["note"] = ("%d blocks per row, like the step's table; the step's own compressibility is in the top-level fields.  P0 (incompressible): the compress "
+                   "rate of blocks without a single match depends on where their buffers lie - 2.4 ms or 12-17 ms per 64 blocks of 4 MiB, same bytes (DESIGN.md "
+                   "section 6, open); from -P2 on it does not" % nblk)
     return out
 
 

@@ -84,6 +84,12 @@
                                              //  9.1, 0x165667B1 12.1; blocks made with 0xCC9E2D51 decode 9 % slower WITHOUT their tables (2.10 against 1.94 ms per GiB, by any build of
                                              //  the decoder; sequence statistics identical - not understood), with this one as with the reference's.  Compressible datagen: unchanged)
 #endif
+#ifndef LZ4AMD_CMP_STAGGER
+#define LZ4AMD_CMP_STAGGER 0
+#endif
+#ifndef LZ4AMD_CMP_TAIL_ROTATE
+#define LZ4AMD_CMP_TAIL_ROTATE 0      // developer knob (measured: no effect)
+#endif
 #ifndef LZ4AMD_CMP_CLAMP_RUNS
 #define LZ4AMD_CMP_CLAMP_RUNS 0      // developer knob (measured: no gain on datagen -P0 - its trouble was the hash, see LZ4AMD_CMP_HASH_MUL - and bytes lost on -P90)
 #endif
@@ -1134,6 +1140,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const lz4amd_gdst hints = P.hints ? LZ4AMD_TO_GDST(P.hints + (uint64_t)b * P.hint_stride) : (lz4amd_gdst)nullptr;      // optional entry-point table
     HintOut H; H.table = hints; H.cap_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride); H.pre = pre; H.over = &misc[CM_HOVER]; H.ord0 = H.row0 = H.k = 0;
 
+#if LZ4AMD_CMP_STAGGER
+    for (uint32_t k = 0; k < (blockIdx.x & 7u) * LZ4AMD_CMP_STAGGER; k++) __builtin_amdgcn_s_sleep(127);      // developer knob: workgroups out of step
+#endif
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
@@ -1451,7 +1460,21 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     {
         const uint32_t sp = n - run;
         const uint32_t full = run & ~15u;
+#ifdef LZ4AMD_CMP_DBG_NOTAIL
+        if (false)
+#endif
+        {
+#if LZ4AMD_CMP_TAIL_ROTATE
+        // (a long final run - an incompressible block is ONE literal run - is copied from a block-dependent place on, around: blocks of one size
+        //  are whole multiples of the memory's channel interleave apart, and workgroups that reach this copy together, at the same place in their
+        //  blocks, all ask the same channels)
+        const uint32_t rot = full >= (1u << 16) ? (((b * 2654435761u) >> 8) % (full >> 14)) << 14 : 0u;        // a multiple of 16 KB (one trip of the workgroup)
+        for (uint32_t i = rot + 16 * tid; i < full; i += 16 * kCmpThreads) st_global16(dst + lit_dst + i, ld_global16(src + sp + i));
+        for (uint32_t i = 16 * tid; i < rot; i += 16 * kCmpThreads) st_global16(dst + lit_dst + i, ld_global16(src + sp + i));
+#else
         for (uint32_t i = 16 * tid; i < full; i += 16 * kCmpThreads) st_global16(dst + lit_dst + i, ld_global16(src + sp + i));
+#endif
+        }
         for (uint32_t i = full + tid; i < run; i += kCmpThreads) dst[lit_dst + i] = src[sp + i];
     }
 }

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, lz4_amd, numpy as np
 from bench import gen_data
-nb, bs = 64, 4 << 20
+nb, bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 4 << 20
 ctx = lz4_amd.Context(0)
 s = torch.cuda.current_stream().cuda_stream
 for name, host in (("datagen -P0", gen_data(nb * bs, 0, 1)), ("uniform random", np.random.default_rng(1).integers(0, 256, nb * bs, dtype=np.uint8)), ("datagen -P90", gen_data(nb * bs, 90, 1)), ("datagen -P20", gen_data(nb * bs, 20, 1)),
