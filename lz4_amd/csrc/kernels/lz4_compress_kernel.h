@@ -658,11 +658,16 @@ __device__ __forceinline__ void hint_row(const HintOut& H, bool on, uint32_t ord
 __device__ __forceinline__ void copy_literals(lz4amd_gdst dst, uint32_t d, lz4amd_gsrc src, const uint8_t* ring,
                                               uint32_t sp, uint32_t len, uint32_t ring_lo) {
     const uint32_t lane = lane_id();
+    // (8 bytes a lane: a tile that does not fit the staging buffer - it ends a literal run of many KB, the rule on data that hardly compresses - comes
+    //  through here whole; byte stores made `datagen -P2` 1.8 times slower than -P60)
+    const uint32_t n8 = len >> 3;
     if (sp >= ring_lo) {
         const uint32_t o = src_ring_off(sp);
-        for (uint32_t i = lane; i < len; i += 64) dst[d + i] = ring[ring_fwd(o, i)];
+        for (uint32_t k = lane; k < n8; k += 64) st_global8_raw(dst + d + 8 * k, ring_ld8(ring, ring_fwd(o, 8 * k)));
+        for (uint32_t i = 8 * n8 + lane; i < len; i += 64) dst[d + i] = ring[ring_fwd(o, i)];
     } else {
-        for (uint32_t i = lane; i < len; i += 64) dst[d + i] = src[sp + i];
+        for (uint32_t k = lane; k < n8; k += 64) st_global8_raw(dst + d + 8 * k, ld_u64_g(src + sp + 8 * k));
+        for (uint32_t i = 8 * n8 + lane; i < len; i += 64) dst[d + i] = src[sp + i];
     }
 }
 

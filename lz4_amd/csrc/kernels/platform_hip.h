@@ -167,6 +167,7 @@ __device__ __forceinline__ lz4amd_u32x4 ld_global16_raw(const uint8_t* p) { lz4a
 __device__ __forceinline__ void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ lz4amd_u32x4 ld_global16_raw(lz4amd_gsrc p) { lz4amd_u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st_global16_raw(lz4amd_gdst p, const lz4amd_u32x4& v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ uint64_t ld_u64_g(lz4amd_gsrc p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ void st_global8_raw(lz4amd_gdst p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 __device__ __forceinline__ uint64_t clock_ticks() { return __builtin_readcyclecounter(); }
 

@@ -59,6 +59,7 @@ static inline void lds_load_pair16_then2(const lz4amd_u32x4* p, lz4amd_u32x4& a,
 }
 static inline lz4amd_u32x4 ld_global16_raw(const uint8_t* p) { lz4amd_u32x4 v; memcpy(&v, p, 16); return v; }
 static inline void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { memcpy(p, &v, 16); }
+static inline uint64_t ld_u64_g(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 static inline void st_global8_raw(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
 static inline uint64_t clock_ticks() { return 0; }
 static inline uint32_t take_ticket(uint32_t* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED); }
