@@ -62,9 +62,6 @@
 #ifndef LZ4AMD_CMP_IDLE_SETTLE
 #define LZ4AMD_CMP_IDLE_SETTLE 1
 #endif
-#ifndef LZ4AMD_CMP_LDS_BARRIER
-#define LZ4AMD_CMP_LDS_BARRIER 0      // developer knob: 1: the tile barrier waits for LDS operations only (measured: no difference)
-#endif
 #ifndef LZ4AMD_CMP_PRIO
 #define LZ4AMD_CMP_PRIO 2          // developer knob: 1: the settling wave runs at high issue priority, 2: the measuring waves at raised priority
 #endif
@@ -83,15 +80,6 @@
                                              //  against 2.4 ms on uniform random bytes.  Measured on the GPU: 0x9E3779B9 and 0xCC9E2D51 2.4 ms, 0x27D4EB2F 3.8, 0x85EBCA6B / 0xC2B2AE35
                                              //  9.1, 0x165667B1 12.1; blocks made with 0xCC9E2D51 decode 9 % slower WITHOUT their tables (2.10 against 1.94 ms per GiB, by any build of
                                              //  the decoder; sequence statistics identical - not understood), with this one as with the reference's.  Compressible datagen: unchanged)
-#endif
-#ifndef LZ4AMD_CMP_STAGGER
-#define LZ4AMD_CMP_STAGGER 0
-#endif
-#ifndef LZ4AMD_CMP_TAIL_ROTATE
-#define LZ4AMD_CMP_TAIL_ROTATE 0      // developer knob (measured: no effect)
-#endif
-#ifndef LZ4AMD_CMP_CLAMP_RUNS
-#define LZ4AMD_CMP_CLAMP_RUNS 0      // developer knob (measured: no gain on datagen -P0 - its trouble was the hash, see LZ4AMD_CMP_HASH_MUL - and bytes lost on -P90)
 #endif
 #ifndef LZ4AMD_STRIDE4_FROM
 #define LZ4AMD_STRIDE4_FROM 2
@@ -605,14 +593,6 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
     if (n >= kMfLimit + 1 && cs <= n - kMfLimit) {
         uint32_t mlimit = n - kLastLiterals; if (mlimit > tend) mlimit = tend;
         const uint32_t last_q = n - kMfLimit;
-#if LZ4AMD_CMP_CLAMP_RUNS
-        // A piece that listed more runs than its list holds - every fourth byte starts one: literals of a skewed alphabet (datagen -P0), a
-        // block of 4-byte matches - keeps the first kCandCap of them, in position order; its last bytes find no match of their own (one that
-        // reaches them from before still covers them).  Parsing such a piece the single-wave way (probed again, list after list) made
-        // incompressible text three times slower than compressible data, for no byte saved.
-        if (nA > kCandCap) nA = kCandCap;
-        if (nB > kCandCap) nB = kCandCap;
-#endif
         if (nA <= kCandCap && nB <= kCandCap) {
             CMP_STAT(10, 1); CMP_STAT(11, nA + nB); CMP_STAT(12, (nA + nB + 63) / 64);
             if (lane == 0) lds_store_release_local(table_free, gen);
@@ -1145,9 +1125,6 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     const lz4amd_gdst hints = P.hints ? LZ4AMD_TO_GDST(P.hints + (uint64_t)b * P.hint_stride) : (lz4amd_gdst)nullptr;      // optional entry-point table
     HintOut H; H.table = hints; H.cap_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride); H.pre = pre; H.over = &misc[CM_HOVER]; H.ord0 = H.row0 = H.k = 0;
 
-#if LZ4AMD_CMP_STAGGER
-    for (uint32_t k = 0; k < (blockIdx.x & 7u) * LZ4AMD_CMP_STAGGER; k++) __builtin_amdgcn_s_sleep(127);      // developer knob: workgroups out of step
-#endif
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
@@ -1209,11 +1186,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
         //  compiler waits for the granule, that wave would wait at the head of the chain everybody else waits for)
         const uint32_t Pp = loaded + 16 * (tid ^ 512u);
         if (Pp < pf_hi) pf = load_src16(src, n, Pp);           // nt_len <= 8 * kCmpThreads
-#if LZ4AMD_CMP_LDS_BARRIER
-        lds_barrier();                                         // ring, table and tile k-1's records ready (all of it LDS: the fetch just issued, and the stores of the tile before, may still be on their way)
-#else
         __syncthreads();                                       // ring, table and tile k-1's records ready
-#endif
         if (tid == 0) { misc[CM_EMITQ + (par ^ 1)] = 0; misc[CM_INSQ + (par ^ 1)] = 0; misc[CM_EMITDONE + (par ^ 1)] = 0; misc[CM_FLUSHQ + (par ^ 1)] = 0; }      // (the tile before's set: nobody looks at it any more)
         if (prof) { const uint64_t t = clock_ticks(); tp[0] += t - tq; tq = t; }
         const bool parse = t0 >= pre;
@@ -1465,21 +1438,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     {
         const uint32_t sp = n - run;
         const uint32_t full = run & ~15u;
-#ifdef LZ4AMD_CMP_DBG_NOTAIL
-        if (false)
-#endif
-        {
-#if LZ4AMD_CMP_TAIL_ROTATE
-        // (a long final run - an incompressible block is ONE literal run - is copied from a block-dependent place on, around: blocks of one size
-        //  are whole multiples of the memory's channel interleave apart, and workgroups that reach this copy together, at the same place in their
-        //  blocks, all ask the same channels)
-        const uint32_t rot = full >= (1u << 16) ? (((b * 2654435761u) >> 8) % (full >> 14)) << 14 : 0u;        // a multiple of 16 KB (one trip of the workgroup)
-        for (uint32_t i = rot + 16 * tid; i < full; i += 16 * kCmpThreads) st_global16(dst + lit_dst + i, ld_global16(src + sp + i));
-        for (uint32_t i = 16 * tid; i < rot; i += 16 * kCmpThreads) st_global16(dst + lit_dst + i, ld_global16(src + sp + i));
-#else
         for (uint32_t i = 16 * tid; i < full; i += 16 * kCmpThreads) st_global16(dst + lit_dst + i, ld_global16(src + sp + i));
-#endif
-        }
         for (uint32_t i = full + tid; i < run; i += kCmpThreads) dst[lit_dst + i] = src[sp + i];
     }
 }

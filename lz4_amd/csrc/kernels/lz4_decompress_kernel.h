@@ -59,9 +59,6 @@
 #define DTRACE(...) do {} while (0)
 #endif
 
-#ifndef LZ4AMD_DEC_NEAR_POLL
-#define LZ4AMD_DEC_NEAR_POLL 0       // developer knob: a piece whose source lies at most this many regions below its own waits on the source's chunk flags, not on the source region's completion
-#endif
 // developer build (-DLZ4AMD_DEC_TRACE, LZ4AMD_PROF=1 in the environment; tools/prof_trace.py): workgroup 0 logs what its copy waves do, when
 #ifdef LZ4AMD_DEC_TRACE
 // (stamps are kept in registers and written once, when the region is complete: a log write is a round trip to memory)
@@ -99,23 +96,11 @@
 #ifndef LZ4AMD_DEC_DMADEPTH
 #define LZ4AMD_DEC_DMADEPTH 16
 #endif
-#ifndef LZ4AMD_DEC_FULL_START
-#define LZ4AMD_DEC_FULL_START 0      // n > 0: the first n batches of a block wait for all their rows' stream bytes
-#endif
-#ifndef LZ4AMD_DEC_FULL_BATCH
-#define LZ4AMD_DEC_FULL_BATCH 0      // n > 0: a parser wave waits for a fuller batch of rows while the copy waves have records for n regions ahead
-#endif
 #ifndef LZ4AMD_DEC_CRKB
 #define LZ4AMD_DEC_CRKB 32u           // compressed ring, KB (a power of two)
 #endif
 #ifndef LZ4AMD_DEC_MAXLEAD
 #define LZ4AMD_DEC_MAXLEAD (LZ4AMD_DEC_CHUNK == 32 ? 10 : 15)        // regions in flight - 1 (what the LDS has room for: every region in flight is a slot of the output ring on top of the 64 KB window)
-#endif
-#ifndef LZ4AMD_DEC_LAND_PRIO
-#define LZ4AMD_DEC_LAND_PRIO 0       // developer knob: issue priority of a copy wave while it lands pending pieces
-#endif
-#ifndef LZ4AMD_DEC_HEAD_PRIO
-#define LZ4AMD_DEC_HEAD_PRIO 0       // developer knob: regions this close to the lowest open one are composed at raised issue priority
 #endif
 namespace lz4amd {
 
@@ -606,7 +591,7 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
     //  the 32 KB ring holds beyond the regions in flight; blocks of long matches walk faster out of the LDS)
     X.pg = LZ4AMD_DEC_PARSE_GLOBAL == 2 ? (total >= (1u << 20) && csize > (total >> 1) - (total >> 4)) : LZ4AMD_DEC_PARSE_GLOBAL != 0;
     wave_priority_high();                              // the copy waves wait for what these waves produce
-    uint32_t tail = 0, stall = 0, thin = 0;
+    uint32_t tail = 0, stall = 0;
     bool fail = false;
     uint32_t n_batch = 0, n_lanes = 0, n_steps = 0, n_careful = 0; uint64_t t_wait = 0, t_walk = 0, tq = prof ? clock_ticks() : 0;      // developer profile
 #ifdef LZ4AMD_PROF_PARSER
@@ -680,23 +665,12 @@ __device__ __forceinline__ void parser_role(lz4amd_gsrc src, uint32_t csize, uin
             nl = 1;
         }
         if (!nl && !nl_hard && drained && nlmax && wave_readlane(okrec ? 1u : 0u, 0) && wave_readlane(Rb, 0) - Ra > kIdxRing / 2) { smode = true; nl = 1; }
-#if LZ4AMD_DEC_FULL_START
-        // At a block's start the stream and the rows are still on their way: a batch claimed now has a handful of lanes and costs the wave as many
-        // steps as a full one (a 64 KiB block: 128 rows, six batches of 18).  The first batches wait until their rows' bytes are there.
-        if (nl && !smode && r0 < 64u * LZ4AMD_DEC_FULL_START && nl < (nreg - r0 < 64u ? nreg - r0 : 64u) && X.chi < csize && !X.pg && thin < 512) { thin++; parser_unlock(misc); spin_pause(); continue; }
-#endif
-#if LZ4AMD_DEC_FULL_BATCH
-        // A walk costs the wave the same whether 5 of its lanes have a row or all 64: a small batch is taken only when it has to be - the
-        // copy waves are about to run out of records (fewer than LZ4AMD_DEC_FULL_BATCH regions' worth published ahead of the region handed
-        // out last), the rows end, or nothing is claimed at all; else the wave lets the mover and the copy make room for a fuller one.
-        if (nl && !smode && nl < 48 && r0 + nl < nreg && !drained && c.ihead >= c.next + LZ4AMD_DEC_FULL_BATCH && thin < 64) { thin++; nl = 0; }
-#endif
         if (!nl) {
 #ifdef LZ4AMD_PROF_PARSER
             n_nowork++;
 #endif
             parser_unlock(misc); spin_pause_long(); PSTAMP(t_sel); continue; }
-        stall = 0; thin = 0;
+        stall = 0;
         const uint32_t RbN = wave_readlane(Rb, nl - 1), ordN = wave_readlane(B.ord, nl - 1);
         const bool allres = nl_res != 0;
         wave_lds_fence();
@@ -1102,9 +1076,6 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
         uint32_t idle_polls = 0;
         wave_lds_order();
         { lds_store_relaxed(&bells[C.slot], ++mybell); wake_workgroup(); }
-#if LZ4AMD_DEC_LAND_PRIO
-        wave_priority(LZ4AMD_DEC_LAND_PRIO);           // (a region that lands pieces is what other regions wait for: its few instructions go first on its SIMD)
-#endif
         const uint32_t* const still = &misc[M_SPARE];  // (a word that does not move: the bell of a lane that watches none)
         const uint32_t* bp[kKeyed] = {still, still};   // the bells my two waits watch: those of the regions that hold the chunks they wait for
         bool dirty = true;                             // the waits changed: look again at what the lanes watch
@@ -1241,9 +1212,6 @@ __device__ __forceinline__ void copy_region(RegionCtx& C, lz4amd_gdst dst, uint3
             } else { if (++idle_polls > 2) spin_pause_long(); else spin_pause(); }
             if (aborted || uload(&misc[M_ABORT])) { aborted = true; break; }
         }
-#if LZ4AMD_DEC_LAND_PRIO
-        wave_priority(0);
-#endif
         if (timed) t_retry += clock_ticks() - tr0;
     }
     if (!aborted) {
@@ -1323,15 +1291,7 @@ __device__ __forceinline__ void copy_role(uint32_t w, lz4amd_gsrc src, lz4amd_gd
             ts = t; n_lead = n_cov = 0; }
         uint64_t tr = 0; uint32_t ni = 0;
         DTRACE("region R=%u x0=%u x1=%u j0=%u nrec=%u g=%u\n", R, C.x0, C.x1, C.j0, C.nrec, C.g);
-#if LZ4AMD_DEC_HEAD_PRIO
-        // the lowest open regions are what every other region in flight may be waiting for: their waves go first on their SIMDs
-        const bool head = R <= C.g + LZ4AMD_DEC_HEAD_PRIO - 1;
-        if (head) wave_priority(2);
-#endif
         copy_region(C, dst, w, prof, tr, ni);
-#if LZ4AMD_DEC_HEAD_PRIO
-        if (head) wave_priority(0);
-#endif
         n_iters += ni; n_retried += ni ? 1u : 0u;
         DTRACE("region R=%u done\n", R);
         k++;

@@ -141,10 +141,7 @@ __device__ __forceinline__ void vmem_wait_all() { __builtin_amdgcn_s_waitcnt(0x0
 template <int N> __device__ __forceinline__ void vmem_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 // s_wakeup: every wave of the workgroup that sits in an s_sleep goes on at once (a wave that is not sleeping ignores it).  A wave that
 // waits for another one's LDS word sleeps LONG and is woken by the writer: no polling traffic, no poll period on the hand-off's path.
-#ifndef LZ4AMD_DEC_NOWAKE
-#define LZ4AMD_DEC_NOWAKE 0
-#endif
-__device__ __forceinline__ void wake_workgroup() { if (!LZ4AMD_DEC_NOWAKE) asm volatile("s_wakeup" ::: "memory"); }
+__device__ __forceinline__ void wake_workgroup() { asm volatile("s_wakeup" ::: "memory"); }
 #ifndef LZ4AMD_DEC_SLEEP
 #define LZ4AMD_DEC_SLEEP 24
 #endif
