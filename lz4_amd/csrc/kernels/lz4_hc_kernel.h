@@ -101,6 +101,11 @@ enum : uint32_t {
 #define LZ4AMD_HC_RUN 8
 #endif
     kHcBatch = LZ4AMD_HC_BATCH,                       // links a lane chases before it verifies the candidates found (nearest band)
+#ifndef LZ4AMD_HC_STALE
+#define LZ4AMD_HC_STALE 32       // a walk of the nearest band ends after this many links in a row that did not lengthen its match (levels 3-9; 0: never).  Measured,
+                                 // 1024 x 256 KiB at level 9, time / bytes against 0: 16 -10 % / 0 (-P60), -18 % / +0.27 % (-P90), -31 % / +1.6 % (-P99); 24 -8 / -13 / -26 %, 0 / +0.13 / +0.9 %;
+                                 // 32 -6 / -7 / -19 %, 0 / +0.05 / +0.4 %; 64 -3 / -1 / -9 %; 128 0 / 0 / -3 %
+#endif
 #ifndef LZ4AMD_HC_BATCH_FAR
 #define LZ4AMD_HC_BATCH_FAR 4
 #endif
@@ -111,6 +116,15 @@ enum : uint32_t {
     // for -14 % walk trips in the nearest band, tools/exp/hc_emu_stats.py); the optimal parse prices every cell and keeps 32.
     kHcSkipLenLazy = 8, kHcSkipLenOpt = 32,
     kHcRunsPerTile = kHcTile / kHcRun,
+#ifndef LZ4AMD_HC_TAIL_POS
+#define LZ4AMD_HC_TAIL_POS 2048
+#endif
+#ifndef LZ4AMD_HC_TAIL_RUN
+#define LZ4AMD_HC_TAIL_RUN 2
+#endif
+    kHcTailPos = LZ4AMD_HC_TAIL_POS, kHcTailRun = LZ4AMD_HC_TAIL_RUN,      // the tile's last positions go out in short runs
+    kHcLongRuns = (kHcTile - kHcTailPos) / kHcRun,
+    kHcUnitsPerTile = kHcLongRuns + kHcTailPos / kHcTailRun,
 };
 // LDS carve-up (bytes); the chain phase, the search phase and the parse phase reuse the same region
 enum : uint32_t {
@@ -363,7 +377,9 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
             }
             if (tid == 0) misc[HM_POOL] = 0;
             __syncthreads();
-            const uint32_t nunits = NEAR ? kHcRunsPerTile : cn;          // work units of the round: entries, or runs
+            // (the nearest band's last kHcTailPos positions of a tile are handed out in runs of kHcTailRun: what a tile waits for at its barrier is the run that
+            //  was taken last, walked by one lane position after position)
+            const uint32_t nunits = NEAR ? (uint32_t)kHcUnitsPerTile : cn;          // work units of the round: entries, or runs
             // -- the walks.  The nearest band's tile is a pool of runs of kHcRun consecutive positions; idle lanes of any wave take
             //    the next runs (which lane walks a run does not change its result).  The loop is wave-synchronous
             //    and predicated: every trip CHASES up to kB links of each lane's chain (dependent LDS reads,
@@ -378,6 +394,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                 bool active = false;
                 int32_t p = 0;
                 uint32_t dist = 0, best = 3, boff = 0, att = 0, lim = 0, mt = 0, pp = 0, best_in = 3;
+                uint32_t stale = 0;                                          // (LZ4AMD_HC_STALE) links since the match last grew
                 Q16 mw; mw.a = mw.b = mw.c = mw.d = 0;                        // sixteen of my own bytes: the window the candidates are compared in
 #ifdef LZ4AMD_PROF_HC
                 hp_t0x = clock_ticks();
@@ -395,7 +412,9 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                         const uint32_t mine_i = base + lanes_below(idle);
                         if (base + nidle >= nunits) pool_dry = true;
                         if (want && mine_i < nunits) {
-                            if (!NEAR) { eidx = mine_i; run_left = 1; } else { pp = mine_i * kHcRun - 1; run_left = kHcRun; }
+                            if (!NEAR) { eidx = mine_i; run_left = 1; }
+                            else if (mine_i < kHcLongRuns) { pp = mine_i * kHcRun - 1; run_left = kHcRun; }
+                            else { pp = kHcLongRuns * kHcRun + (mine_i - kHcLongRuns) * kHcTailRun - 1; run_left = kHcTailRun; }
                             inh_len = 0;
                         }
                     }
@@ -446,7 +465,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                                 }
                             }
                         }
-                        if (walk) { if (NEAR) mw = lds_ld16(mine, pp + (best > 15 ? best - 15 : 0)); else mt = lds_ld4(mine, pp + best - 3); active = true; HC_STAT(NEAR ? 0 : 5, 1); }
+                        if (walk) { if (NEAR) mw = lds_ld16(mine, pp + (best > 15 ? best - 15 : 0)); else mt = lds_ld4(mine, pp + best - 3); active = true; stale = 0; HC_STAT(NEAR ? 0 : 5, 1); }
                         else if (!kept) inh_len = 0;                        // nothing to hand to the next position
                         if (kept) HC_STAT(NEAR ? 1 : 6, 1);
                     }
@@ -460,6 +479,7 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                     //      the window AND the band: one compare against the higher of the two bounds; which of them ended the walk is
                     //      looked at once, behind the links
                     uint32_t cd[kB];
+                    const uint32_t att_trip0 = att, best_trip0 = best;
                     const int32_t qmin = p - (int32_t)kMaxDistance > low ? p - (int32_t)kMaxDistance : low;
                     bool alive = active && dist != 0 && att != 0;
 #pragma unroll
@@ -561,6 +581,16 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                         }
                     }
                     if (full) { over = true; next = 0; }
+#if LZ4AMD_HC_STALE
+                    // A chain inside a stretch of copies of copies holds candidate after candidate with the same bytes: none of them lengthens the
+                    // match, and a walk through all of them (256 links at level 9) is what a tile waits for at its barrier - one position in a
+                    // thousand.  The nearest band gives such a walk up after LZ4AMD_HC_STALE links in a row without gain (a rule of the position
+                    // alone: the output does not depend on which lane walks it).
+                    if (NEAR && attempts <= 256) {                     // (the optimal parse of levels 10-12 asks for deeper searches on purpose)
+                        stale = best > best_trip0 ? 0u : stale + (att_trip0 - att);
+                        if (active && stale >= LZ4AMD_HC_STALE) { over = true; next = 0; }
+                    }
+#endif
                     const bool park = active && over && next != 0;           // the walk goes on in the next band
                     if (active && over) {
                         if (NEAR) res0[pp] = best | (boff << 8);
