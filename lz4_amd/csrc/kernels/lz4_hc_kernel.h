@@ -117,7 +117,7 @@ enum : uint32_t {
     kHcSkipLenLazy = 8, kHcSkipLenOpt = 32,
     kHcRunsPerTile = kHcTile / kHcRun,
 #ifndef LZ4AMD_HC_TAIL_POS
-#define LZ4AMD_HC_TAIL_POS 2048
+#define LZ4AMD_HC_TAIL_POS 4096
 #endif
 #ifndef LZ4AMD_HC_TAIL_RUN
 #define LZ4AMD_HC_TAIL_RUN 2
@@ -418,20 +418,10 @@ template <bool NEAR> __device__ __forceinline__ void hc_search_band(lz4amd_gsrc 
                             inh_len = 0;
                         }
                     }
-                    // ---- once the pool is dry, what is still queued is what the lanes hold in their runs (a tile is one run of kHcRun
-                    //      positions per lane on average: without this the tile ends when its slowest lane has walked its run alone).
-                    //      Idle lanes take over the last queued position of lanes that have any, one each per trip.
-                    if (pool_dry && NEAR) {
-                        const uint32_t queued = active ? run_left : (run_left ? run_left - 1 : 0);      // positions behind the one in progress / about to start
-                        unsigned long long donors = __ballot(queued != 0), takers = __ballot(!active && run_left == 0);
-                        while (donors && takers) {
-                            const uint32_t dl = (uint32_t)__ffsll((long long)donors) - 1, tl = (uint32_t)__ffsll((long long)takers) - 1;
-                            donors &= donors - 1; takers &= takers - 1;
-                            const uint32_t last = wave_readlane(pp + run_left, dl);          // the donor's last position (in the tile)
-                            if (lane == dl) run_left--;
-                            if (lane == tl) { pp = last - 1; run_left = 1; inh_len = 0; }
-                        }
-                    }
+                    // (Round 5 let idle lanes take over the last queued position of busy ones once the pool was dry.  A position taken over starts without
+                    //  what its predecessor found, so its result depended on which lanes happened to be idle - harmless while every walk was exhaustive,
+                    //  visible in the bytes once walks end early (LZ4AMD_HC_STALE) - and with the tile's last positions in short runs the kernel is 3 %
+                    //  faster without it.)
                     // ---- next position of my run.  In the nearest band it starts from what its predecessor found:
                     //      a match of length L at p is a match of length L - 1 at p + 1 (same offset), so inside a long
                     //      match only the first position pays for measuring it
