@@ -55,6 +55,19 @@ def test_hc_capacity_semantics(ctx, datagen):
     assert r3 == 0 and r4 == 0                                         # one byte less fails (limitedOutput, lz4hc.c:297-300)
 
 
+def test_hc_output_does_not_depend_on_scheduling(ctx, datagen):
+    """The same block in many slots of one launch, next to blocks of other sizes: every copy must come out byte for byte the same (which lanes
+    and waves walk which positions differs from workgroup to workgroup; round 6 found a take-over of queued positions that showed in the bytes)."""
+    a, b = datagen(262144, 60, 5), datagen(200000, 99, 6)
+    for level in (3, 9):
+        datas = []
+        for k in range(24):
+            datas += [a, b, datagen(1000 + 3001 * k, 40, k)]
+        outs = gpu_compress_hc(ctx, datas, level=level)
+        for k in range(24):
+            assert outs[3 * k] == outs[0] and outs[3 * k + 1] == outs[1], (level, k)
+
+
 def test_hc_ratio_window_level9(ctx, golden, datagen):
     for key, pct in (("p60_4m_256k_blocks_hc9", 60), ("p90_4m_256k_blocks_hc9", 90), ("p20_2m_256k_blocks_hc9", 20),
                      ("p50_1m_64k_blocks_hc9", 50), ("p60_8m_4m_blocks_hc9", 60)):
