@@ -1367,7 +1367,12 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     const int32_t csize_i = P.src_size[b];
     const int32_t cap_i = P.dst_cap[b];
     const bool chained = P.chain != nullptr;
-    const bool stored = chained && P.stored && P.stored[b];
+    const bool stored = chained && P.stored && (P.stored[b] & 1);
+    // a launch may hold several chains ("runs": kernels/chain_spec_kernel.h decodes stretches of a linked frame side by side): bit 1 of a block's
+    // flag marks the first block of a run - it starts at its own dst[b] with prefix[b] bytes of history and waits for nobody; the blocks
+    // behind it have the same dst[] and prefix[] and count their positions from there
+    const bool run_head = chained && (b == 0 || (P.stored && (P.stored[b] & 2)));
+    const bool run_tail = chained && (b + 1 >= P.n_blocks || (P.stored && (P.stored[b + 1] & 2)));
 
     // -- degenerate inputs (lz4.c:2036, 2062-2069); in a chain they are failures like any other
     bool ok = true;
@@ -1424,22 +1429,22 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     if (chained) {
         // -- where does my output start?  (published by the workgroup that owns block b-1)
         if (tid == 0) {
-            long long s;
-            while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
+            long long s = 0;
+            if (!run_head) while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
             misc[M_CHI] = (uint32_t)(unsigned long long)s; misc[M_SPARE] = (uint32_t)((unsigned long long)s >> 32);
         }
         __syncthreads();
         start = (long long)((unsigned long long)misc[M_CHI] | ((unsigned long long)misc[M_SPARE] << 32));
         __syncthreads();                                       // (stage B re-initialises those words)
-        const unsigned long long before = (unsigned long long)(start < 0 ? 0 : start) + (P.prefix ? (unsigned long long)(uint32_t)P.prefix[0] : 0ull);
+        const unsigned long long before = (unsigned long long)(start < 0 ? 0 : start) + (P.prefix ? (unsigned long long)(uint32_t)P.prefix[b] : 0ull);
         prefix = before < kBias ? (uint32_t)before : kBias;
         // a predecessor failed, this block is malformed, or a match reaches before the start of the history (lz4.c:2356)
         if (start < 0 || !ok || (!stored && minref < kBias - prefix)) {
             if (tid == 0) P.result[b] = -1;
-            chain_publish(P, b, -2);                            // the chain ends here
+            if (!run_tail) chain_publish(P, b, -2);             // the chain ends here
             return true;
         }
-        dst = LZ4AMD_TO_GDST(P.dst[0]) + start;
+        dst = LZ4AMD_TO_GDST(P.dst[b]) + start;
         if (stored) for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
     }
 
@@ -1455,7 +1460,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         P.result[b] = (int32_t)total;
         if (prof) prof[0] = clock_ticks() - tstart;
     }
-    if (chained) chain_publish(P, b, start + (long long)total);
+    if (chained && !run_tail) chain_publish(P, b, start + (long long)total);
     return true;
 }
 
@@ -1465,7 +1470,10 @@ __device__ __forceinline__ void decompress_batch_body(const DecBatch& P) {
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) misc[M_BLOCK] = take_ticket(P.ticket);
+        if (threadIdx.x == 0) {
+            const uint32_t t = take_ticket(P.ticket);
+            misc[M_BLOCK] = (P.order && t < P.n_blocks) ? P.order[t] : t;
+        }
         __syncthreads();
         const uint32_t b = misc[M_BLOCK];
         if (b >= P.n_blocks) break;

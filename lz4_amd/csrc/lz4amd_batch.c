@@ -89,6 +89,7 @@ void lz4amd_plan_destroy(lz4amd_plan* p)
     int i;
     if (!p) return;
     if (p->ctx) (void)lz4amd_hip_use_device(p->ctx->device);
+    lz4amd_plan_destroy(p->inner);
     for (i = 0; i < LZ4AMD_PLAN_MAX_BUFS; i++) lz4amd_hip_free(p->bufs[i]);
     for (i = 0; i < 5; i++) lz4amd_hip_event_destroy(p->ev[i]);
     free(p);
@@ -246,28 +247,146 @@ int lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, in
                                           void* const* d_dst, const int* dst_caps, const int* prefix_sizes, int level)
 { return plan_create_with_prefix(ctx, out, LZ4AMD_OP_COMPRESS_HC, n, d_src, src_sizes, d_dst, dst_caps, prefix_sizes, level); }
 
-int lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
-                                          const void* const* d_src, const int* src_sizes,
-                                          void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix)
+/* Dependent blocks in one launch, general form: block i writes behind the blocks of its run at dsts[i] (the same for all blocks of a run) with
+ * prefixes[i] bytes of history in front of the run; flags[i]: bit 0 stored block, bit 1 first block of a run (lz4amd_dec_params.chain). */
+static int chained_runs_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n, const void* const* d_src, const int* src_sizes,
+                               void* const* dsts, const int* dst_caps, const unsigned char* flags, const int* prefixes)
 {
-    void** dsts; int* pre; int rc, err = 0, i, k;
+    int rc, err = 0, k;
     lz4amd_plan* p;
-    if (!out || n <= 0 || !d_dst0 || initial_prefix < 0) return LZ4AMD_E_ARG;
-    dsts = (void**)malloc((size_t)n * sizeof *dsts); pre = (int*)calloc((size_t)n, sizeof *pre);
-    if (!dsts || !pre) { free(dsts); free(pre); return LZ4AMD_E_MEMORY; }
-    for (i = 0; i < n; i++) dsts[i] = d_dst0;
-    pre[0] = initial_prefix;
-    rc = plan_create_with_prefix(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, dsts, dst_caps, pre, 0);
-    free(dsts); free(pre);
+    rc = plan_create_with_prefix(ctx, out, LZ4AMD_OP_DECOMPRESS, n, d_src, src_sizes, dsts, dst_caps, prefixes, 0);
     if (rc) return rc;
     p = *out;
     for (k = 0; k < LZ4AMD_PLAN_MAX_BUFS && p->bufs[k]; k++) {}
     if (k + 2 > LZ4AMD_PLAN_MAX_BUFS) { lz4amd_plan_destroy(p); *out = NULL; return LZ4AMD_E_MEMORY; }
     p->dec.chain = (long long*)(p->bufs[k] = dev_array(NULL, ((size_t)n + 1) * sizeof(long long), &err));
-    if (stored) p->dec.stored = (const uint8_t*)(p->bufs[k + 1] = dev_array(stored, (size_t)n, &err));
+    if (flags) p->dec.stored = (const uint8_t*)(p->bufs[k + 1] = dev_array(flags, (size_t)n, &err));
     if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
     if (err) { lz4amd_plan_destroy(p); *out = NULL; return err; }
     return LZ4AMD_OK;
+}
+
+/* Linked blocks side by side (kernels/chain_spec_kernel.h): the chain is cut in units of `group` blocks; the plan owns ONE launch of dependent
+ * blocks in runs - unit 0 in place, every other unit three times against made-up histories, in slots of its own - and the tables of the passes
+ * that put the output together.  Costs 3 x (64 KB + a unit) of device memory per unit; a plan that cannot have it, or whose chain is one unit,
+ * decodes one block after the other. */
+static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                               const void* const* d_src, const int* src_sizes,
+                               void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix)
+{
+    size_t un = (size_t)n, ne, nu, G, len0, e, stride;
+    lz4amd_plan* p;
+    const void** esrc = NULL; void** edst = NULL; int *esz = NULL, *ecap = NULL, *epre = NULL; unsigned char* efl = NULL;
+    unsigned max_cap = 0;
+    int err = 0, nb = 0, i, rc;
+    lz4amd_spec_params* q;
+    for (i = 0; i < n; i++) {
+        if (dst_caps[i] <= 0) return LZ4AMD_E_ARG;
+        if ((unsigned)dst_caps[i] > max_cap) max_cap = (unsigned)dst_caps[i];
+    }
+    {   /* blocks per unit: as many as make 1 MiB (a unit's blocks are decoded one after the other, units side by side: the dependent stretch at
+         * a unit's start - ~100 KB on datagen -P60 - should be a small part of it) */
+        const char* g = getenv("LZ4AMD_CHAIN_GROUP");
+        G = g && atoi(g) > 0 ? (size_t)atoi(g) : ((size_t)1 << 20) / max_cap;
+        if (G < 1) G = 1;
+        if (G * (size_t)max_cap > ((size_t)1 << 30)) G = ((size_t)1 << 30) / max_cap;     /* (positions inside a unit are 31-bit numbers) */
+        if (G < 1) return LZ4AMD_E_ARG;
+    }
+    nu = (un + G - 1) / G;
+    if (nu < 2) return LZ4AMD_E_ARG;
+    len0 = G < un ? G : un;
+    ne = len0 + 3 * (un - len0);
+    stride = (65536u + G * (size_t)max_cap + 64u + 255u) & ~(size_t)255u;
+    {   const char* lim = getenv("LZ4AMD_CHAIN_SLOTS_MB");                     /* (the slots' budget: 64 GiB of the 288) */
+        const unsigned long long budget = lim && atoll(lim) > 0 ? (unsigned long long)atoll(lim) << 20 : (unsigned long long)64 << 30;
+        if ((unsigned long long)stride * 3ull * (nu - 1) > budget) return LZ4AMD_E_MEMORY;
+    }
+    if (lz4amd_hip_use_device(ctx->device)) { lz4amd_set_error(lz4amd_hip_errstr()); return LZ4AMD_E_RUNTIME; }
+    p = (lz4amd_plan*)calloc(1, sizeof *p);
+    if (!p) return LZ4AMD_E_MEMORY;
+    p->ctx = ctx; p->op = LZ4AMD_OP_DECOMPRESS; p->n = n; p->spec_max_cap = (unsigned)(G * max_cap);
+    q = &p->spec;
+    q->n = (uint32_t)n; q->prefix0 = (uint32_t)initial_prefix; q->group = (uint32_t)G; q->n_units = (uint32_t)nu;
+    q->out = (uint8_t*)d_dst0; q->slot_stride = stride;
+    q->result = (int32_t*)(p->bufs[nb++] = dev_array(NULL, un * sizeof(int), &err));
+    p->d_results = (int*)q->result;
+    q->start = (long long*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(long long), &err));
+    q->done = (long long*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(long long), &err));
+    q->size = (int32_t*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(int), &err));
+    q->lastdep = (int32_t*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(int), &err));
+    q->badpos = (int32_t*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(int), &err));
+    q->info = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
+    if (!err) q->slots = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, stride * 3 * (nu - 1), &err));
+    esrc = (const void**)malloc(ne * sizeof *esrc); edst = (void**)malloc(ne * sizeof *edst);
+    esz = (int*)malloc(ne * sizeof *esz); ecap = (int*)malloc(ne * sizeof *ecap); epre = (int*)malloc(ne * sizeof *epre); efl = (unsigned char*)malloc(ne);
+    if (!esrc || !edst || !esz || !ecap || !epre || !efl) err = LZ4AMD_E_MEMORY;
+    if (!err) {
+        /* entries 0 .. len0 - 1: unit 0 where it belongs; then unit u, variant v, block j at len0 + (u - 1) * 3 * G + v * len(u) + j */
+        size_t u, v, j;
+        for (j = 0; j < len0; j++) {
+            esrc[j] = d_src[j]; edst[j] = d_dst0; esz[j] = src_sizes[j]; ecap[j] = dst_caps[j]; epre[j] = initial_prefix;
+            efl[j] = (unsigned char)((stored && stored[j] ? 1 : 0) | (j == 0 ? 2 : 0));
+        }
+        e = len0;
+        for (u = 1; u < nu; u++) {
+            const size_t lenu = un - u * G < G ? un - u * G : G;
+            for (v = 0; v < 3; v++)
+                for (j = 0; j < lenu; j++, e++) {
+                    const size_t b = u * G + j;
+                    esrc[e] = d_src[b]; edst[e] = q->slots + ((u - 1) * 3 + v) * stride + 65536; esz[e] = src_sizes[b]; ecap[e] = dst_caps[b]; epre[e] = 65536;
+                    efl[e] = (unsigned char)((stored && stored[b] ? 1 : 0) | (j == 0 ? 2 : 0));
+                }
+        }
+        rc = chained_runs_create(ctx, &p->inner, (int)ne, esrc, esz, edst, ecap, efl, epre);
+        if (rc) err = rc;
+    }
+    if (!err && G > 1) {
+        /* tickets: the first blocks of all runs, then the second ones, ... (lz4amd_dec_params.order) */
+        unsigned* ord = (unsigned*)malloc(ne * sizeof *ord);
+        size_t j, u, v, t = 0;
+        int k;
+        if (!ord) err = LZ4AMD_E_MEMORY;
+        for (j = 0; ord && j < G; j++) {
+            if (j < len0) ord[t++] = (unsigned)j;
+            for (u = 1; u < nu; u++) {
+                const size_t lenu = un - u * G < G ? un - u * G : G;
+                for (v = 0; v < 3 && j < lenu; v++) ord[t++] = (unsigned)(len0 + (u - 1) * 3 * G + v * lenu + j);
+            }
+        }
+        for (k = 0; k < LZ4AMD_PLAN_MAX_BUFS && p->inner->bufs[k]; k++) {}
+        if (ord && k < LZ4AMD_PLAN_MAX_BUFS && t == ne) p->inner->dec.order = (const uint32_t*)(p->inner->bufs[k] = dev_array(ord, ne * sizeof *ord, &err));
+        else if (!err) err = LZ4AMD_E_MEMORY;
+        if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
+        free(ord);
+    }
+    free(esrc); free(edst); free(esz); free(ecap); free(epre); free(efl);
+    if (!err) {
+        q->spec_result = (const int32_t*)p->inner->d_results;
+        p->dec.chain = q->start;                                        /* (marks the plan as one of dependent blocks: no tables, lz4amd_plan_attach_hints) */
+        p->grid = p->inner->grid;
+        if (lz4amd_hip_launch_spec_fill(q, NULL) || lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
+    }
+    if (err) { lz4amd_plan_destroy(p); return err; }
+    *out = p;
+    return LZ4AMD_OK;
+}
+
+int lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
+                                          const void* const* d_src, const int* src_sizes,
+                                          void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix)
+{
+    void** dsts; int* pre; unsigned char* fl; int rc, i;
+    if (!ctx || !out || n <= 0 || !d_src || !src_sizes || !dst_caps || !d_dst0 || initial_prefix < 0) return LZ4AMD_E_ARG;
+    *out = NULL;
+    /* two units and more: side by side; LZ4AMD_CHAIN_SERIAL=1 keeps the chain of copy stages (also what a plan falls back to) */
+    if (n >= 2 && !getenv("LZ4AMD_CHAIN_SERIAL") && chained_spec_create(ctx, out, n, d_src, src_sizes, d_dst0, dst_caps, stored, initial_prefix) == LZ4AMD_OK)
+        return LZ4AMD_OK;
+    dsts = (void**)malloc((size_t)n * sizeof *dsts); pre = (int*)calloc((size_t)n, sizeof *pre); fl = (unsigned char*)calloc((size_t)n, 1);
+    if (!dsts || !pre || !fl) { free(dsts); free(pre); free(fl); return LZ4AMD_E_MEMORY; }
+    for (i = 0; i < n; i++) { dsts[i] = d_dst0; pre[i] = initial_prefix; fl[i] = stored && stored[i] ? 1 : 0; }
+    rc = chained_runs_create(ctx, out, n, d_src, src_sizes, dsts, dst_caps, stored ? fl : NULL, pre);
+    free(dsts); free(pre); free(fl);
+    return rc;
 }
 
 size_t lz4amd_hint_bytes(int src_size)
@@ -337,6 +456,7 @@ int lz4amd_plan_set_acceleration(lz4amd_plan* p, int acceleration)
 
 static int launch_stage(lz4amd_plan* p, int stage, void* stream)
 {
+    if (p->inner) return stage == 0 ? lz4amd_hip_launch_spec(&p->spec, &p->inner->dec, p->inner->grid, p->spec_max_cap, stream) : 0;
     if (p->op == LZ4AMD_OP_DECOMPRESS)
         return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
     if (p->op == LZ4AMD_OP_XXH32) return stage == 0 ? lz4amd_hip_launch_xxh32(&p->xxh, stream) : 0;
@@ -382,6 +502,7 @@ int lz4amd_plan_profile(lz4amd_plan* p, unsigned long long* words, int max_words
     int n;
     const uint64_t* src;
     if (!p) return 0;
+    if (p->inner) return lz4amd_plan_profile(p->inner, words, max_words);
     src = p->op == LZ4AMD_OP_DECOMPRESS ? p->dec.prof : p->op == LZ4AMD_OP_COMPRESS_HC ? p->hc.prof : p->comp.prof;
     if (!src) return 0;
     (void)lz4amd_hip_use_device(p->ctx->device);

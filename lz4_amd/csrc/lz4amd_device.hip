@@ -6,6 +6,7 @@
 #include "kernels/lz4_hc_kernel.h"
 #include "kernels/xxh32_kernel.h"
 #include "kernels/gather_kernel.h"
+#include "kernels/chain_spec_kernel.h"
 #include "lz4amd_ffi.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +20,12 @@ __global__ void __launch_bounds__(kCmpThreads) lz4amd_k_compress(lz4amd_comp_par
 __global__ void __launch_bounds__(kHcThreads) lz4amd_k_compress_hc(lz4amd_hc_params p) { hc_batch_body(p); }
 __global__ void __launch_bounds__(64) lz4amd_k_xxh32(lz4amd_xxh_params p) { xxh32_block_body(p); }
 __global__ void __launch_bounds__(256) lz4amd_k_gather(lz4amd_gather_params p) { gather_block_body(p); }
+
+__global__ void __launch_bounds__(kSpecThreads) lz4amd_k_spec_fill(lz4amd_spec_params p) { spec_fill_body(p); }
+__global__ void __launch_bounds__(kSpecScanThreads) lz4amd_k_spec_scan(lz4amd_spec_params p) { spec_scan_body(p); }
+__global__ void __launch_bounds__(kSpecThreads) lz4amd_k_spec_merge(lz4amd_spec_params p) { spec_merge_body(p); }
+__global__ void __launch_bounds__(kSpecPatchThreads) lz4amd_k_spec_patch(lz4amd_spec_params p) { spec_patch_body(p); }
+__global__ void __launch_bounds__(kSpecScanThreads) lz4amd_k_spec_results(lz4amd_spec_params p) { spec_results_body(p); }
 
 // calibration: a plain 16-bytes-per-lane stream copy, the bandwidth this box's HBM actually delivers to a read+write stream.
 // U granules per thread and trip, all loads issued before the first store (U * 16 bytes in flight per lane); NT: non-temporal stores.
@@ -146,6 +153,25 @@ extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned
         HIPCHK(hipMemsetAsync(p->chain, 0, sizeof(long long), (hipStream_t)s));
     }
     hipLaunchKernelGGL(lz4amd_k_decompress, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// linked blocks side by side (kernels/chain_spec_kernel.h): the made-up histories once, when the plan is made ...
+extern "C" int lz4amd_hip_launch_spec_fill(const lz4amd_spec_params* p, void* s) {
+    if (p->n_units < 2) return 0;
+    hipLaunchKernelGGL(lz4amd_k_spec_fill, dim3(3 * (p->n_units - 1) * kSpecFillParts), dim3(kSpecThreads), 0, (hipStream_t)s, *p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// ... and per launch: the decoder over block 0 and the three variants of every other block, positions, merge, patch, results
+extern "C" int lz4amd_hip_launch_spec(const lz4amd_spec_params* p, const lz4amd_dec_params* dec, unsigned dec_grid, unsigned max_cap, void* s) {
+    if (!p->n) return 0;
+    if (lz4amd_hip_launch_decompress(dec, dec_grid, s)) return -1;
+    const unsigned slices = (max_cap + kSpecSlice - 1) / kSpecSlice;
+    hipLaunchKernelGGL(lz4amd_k_spec_scan, dim3(1), dim3(kSpecScanThreads), 0, (hipStream_t)s, *p);
+    hipLaunchKernelGGL(lz4amd_k_spec_merge, dim3(p->n_units, slices ? slices : 1), dim3(kSpecThreads), 0, (hipStream_t)s, *p);
+    hipLaunchKernelGGL(lz4amd_k_spec_patch, dim3(p->n_units < 512 ? p->n_units : 512), dim3(kSpecPatchThreads), 0, (hipStream_t)s, *p);
+    hipLaunchKernelGGL(lz4amd_k_spec_results, dim3(1), dim3(kSpecScanThreads), 0, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());
     return 0;
 }

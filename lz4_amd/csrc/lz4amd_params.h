@@ -18,10 +18,14 @@ typedef struct lz4amd_dec_params {
     uint64_t* prof;                 /* optional: 8 words per workgroup of phase timestamps */
     /* dependent blocks (lz4frame linked blocks): chain != NULL.  chain[i] = output bytes before block i (chain[0] = 0,
      * the others -1 before the launch, written by the workgroup that finishes block i-1; < -1: a predecessor failed).
-     * Block i then writes at dst[0] + chain[i], sees min(64 KB, prefix[0] + chain[i]) bytes of history there, and
-     * stored[i] != 0 marks a block that is copied as is (lz4frame.c:1758-1830). */
+     * Block i then writes at dst[i] + chain[i], sees min(64 KB, prefix[i] + chain[i]) bytes of history there, and
+     * bit 0 of stored[i] marks a block that is copied as is (lz4frame.c:1758-1830).  Bit 1 marks the first block of a RUN: a launch may hold
+     * several chains behind one another; a run's blocks share dst[] and prefix[], its first block starts at dst[i] and waits for nobody,
+     * its last block publishes nothing (block 0 is a first block by itself). */
     long long* chain;               /* [n + 1] or NULL */
     const uint8_t* stored;          /* [n] or NULL */
+    const uint32_t* order;          /* [n] or NULL: the block the k-th ticket stands for (runs: first blocks of all runs, then second blocks, ... -
+                                     * a workgroup per RUN is at work, and a block's predecessor still has the lower ticket) */
     /* entry-point tables ("hints", include/lz4amd.h): block i's table starts at hints + i * hint_stride; NULL = none.
      * Read only, never trusted: every entry is checked against the stream before a byte that depends on it is final. */
     const uint8_t* hints;
@@ -54,6 +58,26 @@ typedef struct lz4amd_dec_params {
                                               * per sequence; 8 and fewer otherwise: about a row per 512 bytes) */
 #define LZ4AMD_HINT_EVERY_LOG2 4u
 typedef struct lz4amd_hint_entry { uint32_t tok_ord, out; } lz4amd_hint_entry;
+
+/* Linked blocks decoded side by side (kernels/chain_spec_kernel.h).  The chain is cut in UNITS of `group` consecutive blocks (the last one may be
+ * shorter).  Unit 0 is decoded in place; unit u >= 1 three times, against three made-up 64 KB histories, into
+ * slots[(3 * (u - 1) + v) * slot_stride + 65536] - each copy a run of dependent blocks of ONE launch of lz4amd_k_decompress (lz4amd_dec_params.chain).
+ * spec_result: the results of that launch - entries 0 .. len(0) - 1: unit 0's blocks; len(0) + (u - 1) * 3 * group + v * len(u) + j: block j of
+ * unit u, variant v. */
+typedef struct lz4amd_spec_params {
+    uint32_t n, prefix0;            /* blocks of the chain; bytes of data right before out (<= 64 KB used) */
+    uint32_t group, n_units;
+    uint8_t* out;                   /* where block 0 starts; unit u at out + start[u] */
+    uint8_t* slots; uint64_t slot_stride;
+    const int32_t* spec_result;
+    long long* start;               /* [n_units] output bytes before unit u */
+    int32_t* size;                  /* [n_units] decoded bytes of the unit's blocks up to its first bad one */
+    int32_t* lastdep;               /* [n_units] last byte of the unit that is a copy of a history byte, -1: none */
+    int32_t* badpos;                /* [n_units] first byte of the unit that refers to data before the start (lz4.c:2356), INT32_MAX: none */
+    long long* done;                /* [n_units] != 0: the unit's bytes are final */
+    uint32_t* info;                 /* [0] units to put together (the first one with a bad block is the last), [1] ticket counter */
+    int32_t* result;                /* [n] decoded size per block, -1 from the first failure on */
+} lz4amd_spec_params;
 
 typedef struct lz4amd_comp_params {
     const uint8_t* const* src;      /* [n_blocks] */

@@ -59,7 +59,7 @@ extern "C" int emu_decompress_chained(const uint8_t* const* src, const int32_t* 
     std::vector<uint8_t> scratch((size_t)(stride * grid + 64));
     std::vector<uint8_t*> dsts(n ? n : 1, dst0);
     std::vector<long long> chain(n + 1, -1); chain[0] = 0;
-    std::vector<int32_t> pre(n ? n : 1, 0); pre[0] = initial_prefix;
+    std::vector<int32_t> pre(n ? n : 1, initial_prefix);
     uint32_t ticket = 0;
     DecBatch P = {};
     P.src = src; P.src_size = src_size; P.dst = dsts.data(); P.dst_cap = dst_cap; P.result = result;

@@ -1,0 +1,130 @@
+"""Linked blocks decoded side by side (lz4_amd/csrc/kernels/chain_spec_kernel.h) against the chain of copy stages they replace
+(LZ4AMD_CHAIN_SERIAL=1) and against the source: lz4frame.c:1901-1915 - a block's matches reach 64 KB back into the output before it.
+The frames are written by this library's LZ4F_compressFrame (linked blocks, the format's default) and by the reference's CLI
+(tests/golden); the blocks are taken out of the frames and handed to lz4amd_plan_create_decompress_chained as device pointers."""
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from test_gpu_parity import ctx  # noqa: E402,F401
+from test_gpu_frame import L, compress_frame  # noqa: E402,F401
+from test_kernels_emulated import _frame_blocks  # noqa: E402
+
+
+def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False):
+    """-> (results, output bytes).  blocks: [(stored?, payload)]"""
+    import lz4_amd
+    payloads = [p for _, p in blocks]
+    blob = torch.frombuffer(bytearray(b"".join(payloads) + b"\0" * 64), dtype=torch.uint8).cuda()
+    offs = [sum(len(p) for p in payloads[:i]) for i in range(len(payloads))]
+    out = torch.full((len(history) + total + cap + 128,), 0xEE, dtype=torch.uint8, device="cuda")
+    if history:
+        out[16:16 + len(history)] = torch.frombuffer(bytearray(history), dtype=torch.uint8).cuda()
+    at = 16 + len(history)
+    old = os.environ.pop("LZ4AMD_CHAIN_SERIAL", None)
+    if serial:
+        os.environ["LZ4AMD_CHAIN_SERIAL"] = "1"
+    try:
+        plan = lz4_amd.Plan.chained(ctx, [blob.data_ptr() + o for o in offs], [len(p) for p in payloads], out.data_ptr() + at,
+                                    [cap] * len(payloads), stored=None if drop_stored else [r for r, _ in blocks], initial_prefix=len(history))
+    finally:
+        os.environ.pop("LZ4AMD_CHAIN_SERIAL", None)
+        if old is not None:
+            os.environ["LZ4AMD_CHAIN_SERIAL"] = old
+    res = None
+    for _ in range(2):                                                       # a plan is launched again and again
+        plan.launch(torch.cuda.current_stream().cuda_stream)
+        r = plan.results(torch.cuda.current_stream().cuda_stream)
+        assert res is None or r == res
+        res = r
+    plan.close()
+    good = sum(r for r in res if r > 0) if all(r >= 0 for r in res) else sum(res[:[i for i, r in enumerate(res) if r < 0][0]])
+    host = out.cpu().numpy().tobytes()
+    assert host[:16] == b"\xEE" * 16
+    return res, host[at:at + good]
+
+
+def both(ctx, blocks, cap, data, history=b""):
+    rs, os_ = run_chain(ctx, blocks, cap, len(data), True, history)
+    rp, op = run_chain(ctx, blocks, cap, len(data), False, history)
+    assert rs == rp
+    assert os_ == data and op == data
+    return rp
+
+
+def linked_blocks(L, data, bsid, level=0):
+    frame = compress_frame(L, data, level=level, blockSizeID=bsid)
+    indep, blocks = _frame_blocks(frame)
+    assert not indep
+    return blocks
+
+
+def test_side_by_side_equals_the_serial_chain(ctx, L, datagen):
+    rng = random.Random(5)
+    cases = [
+        (datagen(3 << 20, 60, 1), 4),                                          # 64 KB blocks: every block's history is the whole block before
+        (datagen(5 << 20, 50, 2), 5),                                          # 256 KB
+        (datagen((9 << 20) + 12345, 60, 3), 7),                                # 4 MB blocks, a short last one
+        (datagen(2 << 20, 95, 4), 6),                                          # long matches
+        (b"a" * (1 << 20) + b"abcdefg" * 100000 + bytes(range(256)) * 4000, 4),      # every byte a copy of a byte of the first block, period 1 / 7 / 256
+        (datagen(200000, 60, 6) + rng.randbytes(150000) + datagen(300000, 60, 7) + rng.randbytes(70000) + datagen(100000, 50, 8), 4),   # stored blocks in the chain
+        (datagen(70000, 60, 9), 4),                                            # two blocks
+    ]
+    for data, bsid in cases:
+        blocks = linked_blocks(L, data, bsid)
+        cap = {4: 65536, 5: 262144, 6: 1 << 20, 7: 4 << 20}[bsid]
+        res = both(ctx, blocks, cap, data)
+        assert all(r > 0 for r in res) and sum(res) == len(data)
+    # HC-compressed linked blocks (matches just behind the write position, and far ones)
+    data = datagen(1 << 20, 70, 11)
+    both(ctx, linked_blocks(L, data, 4, level=9), 65536, data)
+
+
+def test_side_by_side_with_history_in_front_and_batches_that_start_anywhere(ctx, L, datagen):
+    data = datagen(1 << 20, 60, 21)
+    blocks = linked_blocks(L, data, 4)
+    for first, hist in ((3, 65536), (5, 65536), (1, 65536)):
+        lo = first * 65536
+        h = data[lo - hist:lo]
+        res = both(ctx, blocks[first:first + 6], 65536, data[lo:lo + 6 * 65536], history=h)
+        assert res == [65536] * 6
+    # less history than the blocks refer to: the chain fails at its first block, both ways (lz4.c:2356)
+    for serial in (True, False):
+        res, _ = run_chain(ctx, blocks[3:6], 65536, 3 * 65536, serial, history=data[3 * 65536 - 100:3 * 65536])
+        assert all(r < 0 for r in res), (serial, res)
+        res, _ = run_chain(ctx, blocks[3:6], 65536, 3 * 65536, serial)
+        assert all(r < 0 for r in res), (serial, res)
+
+
+def test_side_by_side_small_blocks_and_errors(ctx, L, datagen):
+    # blocks much smaller than the window: a block's history spans many blocks before it
+    import lz4_amd
+    data = datagen(300000, 70, 31)
+    bs = 3000
+    srcs = [data[i:i + bs] for i in range(0, len(data), bs)]
+    # compress every piece with the data before it as history (device compressor, linked: lz4amd_plan_create_compress_prefix)
+    whole = torch.frombuffer(bytearray(data + b"\0" * 64), dtype=torch.uint8).cuda()
+    bound = lz4_amd.compress_bound(bs)
+    dst = torch.zeros(len(srcs) * bound + 64, dtype=torch.uint8, device="cuda")
+    table = lz4_amd.BlockTable([whole.data_ptr() + i * bs for i in range(len(srcs))], [len(s) for s in srcs],
+                               [dst.data_ptr() + i * bound for i in range(len(srcs))], [bound] * len(srcs))
+    plan = lz4_amd.Plan.compress_with_history(ctx, table, [min(i * bs, 65536) for i in range(len(srcs))])
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    cs = plan.results(torch.cuda.current_stream().cuda_stream)
+    plan.close()
+    host = dst.cpu().numpy().tobytes()
+    blocks = [(False, host[i * bound:i * bound + c]) for i, c in enumerate(cs)]
+    assert sum(cs) < len(data) * 0.6                                          # (the history is used)
+    res = both(ctx, blocks, bs, data)
+    assert res == [len(s) for s in srcs]
+    # a damaged block in the middle ends the chain there, the blocks before it stand
+    bad = list(blocks); bad[40] = (False, bad[40][1][:-5])
+    for serial in (True, False):
+        res, out = run_chain(ctx, bad, bs, len(data), serial)
+        assert res[:40] == [bs] * 40 and all(r < 0 for r in res[40:]), serial
+        assert out == data[:40 * bs]
