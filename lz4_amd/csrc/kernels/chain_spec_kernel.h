@@ -25,7 +25,7 @@
 namespace lz4amd {
 
 using SpecBatch = ::lz4amd_spec_params;
-constexpr uint32_t kSpecHist = 65536, kSpecSlice = 65536, kSpecThreads = 256, kSpecScanThreads = 1024, kSpecPatchThreads = 1024, kSpecPre = kSpecHist / (kSpecPatchThreads * 4), kSpecFillParts = kSpecHist / (kSpecThreads * 16);
+constexpr uint32_t kSpecHist = 65536, kSpecSlice = 65536, kSpecThreads = 256, kSpecScanThreads = 1024, kSpecPatchThreads = 1024, kSpecPre = kSpecHist / (kSpecPatchThreads * 8), kSpecFillParts = kSpecHist / (kSpecThreads * 16);
 
 __device__ __forceinline__ uint8_t* spec_slot(const SpecBatch& P, uint32_t u, uint32_t v) {       // unit u >= 1, variant v: its made-up history, then its output
     return P.slots + ((uint64_t)(u - 1) * 3 + v) * P.slot_stride;
@@ -141,7 +141,9 @@ __device__ __forceinline__ void spec_merge_body(const SpecBatch& P) {
 // ---- bytes that do.  Workgroups of kSpecPatchThreads take blocks in order from a ticket counter (a block that has to wait for the one before
 //      finds it taken by a running workgroup; "block" below: a unit).  A thread gathers the history bytes of its 16 (sixteen loads in flight, always from before the
 //      block: no store of the block can alias them) and stores them with A's bytes as one piece.
+constexpr uint32_t kSpecPatchLds = kSpecHist + 32;                        // the unit's history, from the 8-byte boundary below its first byte
 __device__ __forceinline__ void spec_patch_body(const SpecBatch& P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t spec_hist[];
     __shared__ uint32_t s_k, s_bad;
     const uint32_t tid = threadIdx.x, n = P.n_units, nvalid = P.info[0];
     for (;;) {
@@ -156,11 +158,10 @@ __device__ __forceinline__ void spec_patch_body(const SpecBatch& P) {
         const uint8_t* A = live ? spec_slot(P, k, 0) + kSpecHist : nullptr;
         const uint8_t* B = live ? spec_slot(P, k, 1) + kSpecHist : nullptr;
         const uint8_t* C = live ? spec_slot(P, k, 2) + kSpecHist : nullptr;
-        // A thread works on batches of kSpecPre pieces of FOUR bytes (a batch of the workgroup: 64 KB): all of a batch's loads, then all of its
-        // gathers, then all of its stores - the compiler cannot know that the stores never hit what the next piece reads, and piece after piece
-        // every step waited ~2 us for the one before.  The 64 lanes of a load cover 256 neighbouring bytes of output, whose history bytes are
-        // mostly neighbours as well.  What does not depend on the block before - the first batch's loads - is read before waiting for it.
-        uint32_t pa[kSpecPre], pb[kSpecPre], px[kSpecPre], pw[kSpecPre];
+        // A thread works on batches of kSpecPre pieces of FOUR bytes (a batch of the workgroup: 32 KB - sixteen pieces a thread spilled registers): all of a batch's loads from the slots first
+        // (the compiler cannot know that the stores to the output never hit what the next piece reads); the history bytes come out of the LDS.
+        // What does not depend on the block before - the first batch's loads - is read before waiting for it.
+        uint32_t pa[kSpecPre], pb[kSpecPre], px[kSpecPre];
         auto load_batch = [&](uint32_t first) {
 #pragma unroll
             for (uint32_t i = 0; i < kSpecPre; i++) {
@@ -193,6 +194,16 @@ __device__ __forceinline__ void spec_patch_body(const SpecBatch& P) {
             const uint32_t before = start + (long long)P.prefix0 < (long long)kSpecHist ? (uint32_t)(start + (long long)P.prefix0) : kSpecHist;      // bytes of data in front of the block, 64 KB of them count
             const bool aligned = (((uintptr_t)out) & 3u) == 0;
             uint32_t bad = 0x7FFFFFFFu;
+            // the history goes to the LDS in 8-byte pieces (lanes side by side), the gathers read it there: a gather from memory costs a cache
+            // line per lane - ~100 cycles per wave instruction, 40 us per 64 KB of patched bytes on one CU
+            const uint32_t shift = (uint32_t)((uintptr_t)hist & 7u);
+            {
+                const unsigned long long* g = (const unsigned long long*)(hist - shift);
+                const uint32_t first = (kSpecHist - before + shift) / 8;     // (the piece that holds the first byte of data; nothing is read below it)
+                for (uint32_t i = first + tid; i < (kSpecHist + shift + 7) / 8; i += kSpecPatchThreads)
+                    ((unsigned long long*)spec_hist)[i] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
             for (uint32_t first = 0; first * kSpecPatchThreads * 4 <= (uint32_t)last; first += kSpecPre) {
                 if (first) load_batch(first);
 #pragma unroll
@@ -205,22 +216,15 @@ __device__ __forceinline__ void spec_patch_body(const SpecBatch& P) {
                         const uint32_t aj = (a >> (8 * j)) & 0xFFu, idx = (((b >> (8 * j)) & 0xFFu) << 8) | aj;
                         const bool dep = ((x >> (8 * j)) & 0xFFu) != 0 && j < nb;
                         if (dep && kSpecHist - idx > before && p + j < bad) bad = p + j;       // lz4.c:2356: before the start of the data
-                        // (no branch around the load: a byte that does not come from the history is read from A again - a load in a branch of its own
-                        //  waits for its data there, and the 64 loads of a batch went one after the other, ~0.7 us each)
-                        const uint8_t* from = (dep && kSpecHist - idx <= before) ? hist + idx : A + (p <= (uint32_t)last ? p : 0) + j;
-                        w |= (uint32_t)__hip_atomic_load(from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << (8 * j);
+                        const bool take = dep && kSpecHist - idx <= before;
+                        const uint32_t hv = spec_hist[take ? shift + idx : 0u];      // (no branch around the read: a read in a branch of its own is waited for there)
+                        w |= (take ? hv : aj) << (8 * j);
                     }
-                    pw[i] = w;
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < kSpecPre; i++) {
-                    if (px[i] == 0) continue;
-                    const uint32_t p = ((first + i) * kSpecPatchThreads + tid) * 4;
-                    const uint32_t nb = (uint32_t)last + 1 - p < 4 ? (uint32_t)last + 1 - p : 4;
-                    if (aligned && nb == 4) __hip_atomic_store((uint32_t*)(out + p), pw[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (x == 0) continue;
+                    if (aligned && nb == 4) __hip_atomic_store((uint32_t*)(out + p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else
                         for (uint32_t j = 0; j < nb; j++)
-                            if ((px[i] >> (8 * j)) & 0xFFu) __hip_atomic_store(out + p + j, (uint8_t)(pw[i] >> (8 * j)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((x >> (8 * j)) & 0xFFu) __hip_atomic_store(out + p + j, (uint8_t)(w >> (8 * j)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (bad != 0x7FFFFFFFu) atomicMin(&s_bad, bad);

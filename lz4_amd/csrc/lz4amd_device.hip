@@ -69,6 +69,7 @@ extern "C" int lz4amd_hip_init(int device, int* n_cus) {
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCmpLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress_hc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHcLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_spec_patch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSpecPatchLds));
     return 0;
 }
 
@@ -170,7 +171,7 @@ extern "C" int lz4amd_hip_launch_spec(const lz4amd_spec_params* p, const lz4amd_
     const unsigned slices = (max_cap + kSpecSlice - 1) / kSpecSlice;
     hipLaunchKernelGGL(lz4amd_k_spec_scan, dim3(1), dim3(kSpecScanThreads), 0, (hipStream_t)s, *p);
     hipLaunchKernelGGL(lz4amd_k_spec_merge, dim3(p->n_units, slices ? slices : 1), dim3(kSpecThreads), 0, (hipStream_t)s, *p);
-    hipLaunchKernelGGL(lz4amd_k_spec_patch, dim3(p->n_units < 512 ? p->n_units : 512), dim3(kSpecPatchThreads), 0, (hipStream_t)s, *p);
+    hipLaunchKernelGGL(lz4amd_k_spec_patch, dim3(p->n_units < 512 ? p->n_units : 512), dim3(kSpecPatchThreads), kSpecPatchLds, (hipStream_t)s, *p);
     hipLaunchKernelGGL(lz4amd_k_spec_results, dim3(1), dim3(kSpecScanThreads), 0, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());
     return 0;
