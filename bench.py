@@ -555,10 +555,12 @@ def bench_frame_device(ctx, lz4_amd, torch, data, out, stream, bs, copy_gbps):
             "roofline_compress": roofline_obj("compress", cms, U + C, copy_gbps, None),
             "roofline_gather": {"kernel": "gather", "bound": "hbm", "achieved": round(2 * C / (gms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(2 * C / (gms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes_per_launch": 2 * C, "avg_ms": round(gms, 4)},
-            "roofline_decompress": {"kernel": "decompress (chained)", "bound": "hbm", "achieved": round((U + C) / (dms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline_decompress": {"kernel": "decompress + spec_merge + spec_patch (linked blocks side by side)", "bound": "hbm", "achieved": round((U + C) / (dms * 1e-3) / 1e9, 2),
+                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round((U + C) / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "algorithmic_bytes_per_launch": U + C, "avg_ms": round(dms, 3),
-                                    "limited_by": "decompression history is the block before's OUTPUT: the copy stages of a linked frame run one after the other, one CU at a time "
-                                                  "(~1.2 ms per 4 MiB block); the pre-parses overlap"}}
+                                    "limited_by": "every block but the first is decoded three times (against three made-up histories: which bytes depend on the history, and on which "
+                                                  "byte of it), without entry-point tables (a frame has no room for them): 3 x the plain decoder's time on 3 (n - 1) + 1 blocks, then "
+                                                  "two bandwidth passes; round 5's chain of copy stages, one CU at a time: decompress_serial_chain_GBps"}}
 
 
 def bench_frame(lz4_amd, host):
@@ -674,9 +676,9 @@ def bench_frame(lz4_amd, host):
     r["independent_64K"] = d64
     r["note"] = ("PCIe inclusive (host buffers in, host buffers out): a parity path, not the HBM-resident rate; second of two calls. "
                  "The decoder works in batches of up to 32 MiB of input / 1024 blocks: a batch is on the device (a helper thread) while the one before is handed "
-                 "to the caller and the next is taken in, through page-locked buffers.  Linked blocks decode chained inside one launch per batch: only their copy "
-                 "stages run one after the other, ~1.2 ms per 4 MiB block on one CU, which bounds a linked frame at ~3.4 GB/s whatever else overlaps; "
-                 "frames with a content checksum are bound by the one serial XXH32 over the content on the host (~6.3 GB/s on this box)")
+                 "to the caller and the next is taken in, through page-locked buffers.  Linked blocks decode side by side, batch by batch (kernels/chain_spec_kernel.h; round 5's chain of copy "
+                 "stages bound a linked frame at ~3.4 GB/s whatever else overlapped); what bounds a frame now is the host's share: the transfers, and for "
+                 "frames with a content checksum the one serial XXH32 over the content on the host (~6.3 GB/s on this box)")
     return r
 
 
