@@ -1354,6 +1354,8 @@ __device__ __forceinline__ void chain_publish(const DecBatch& P, uint32_t b, lon
     __syncthreads();                                       // every store of the block was issued
     if (threadIdx.x == 0) chain_store_release(&P.chain[b + 1], v);
 }
+__device__ __forceinline__ bool chain_run_head(const DecBatch& P, uint32_t b) { return b == 0 || (P.stored && (P.stored[b] & 2)); }
+__device__ __forceinline__ bool chain_run_tail(const DecBatch& P, uint32_t b) { return b + 1 >= P.n_blocks || (P.stored && (P.stored[b + 1] & 2)); }
 // ------------------------------------------------------------------------------ one block
 // (independent and dependent blocks share ONE copy of stage A and stage B: the kernel is instruction-cache bound enough)
 // use_hints: try the block's entry-point table, if the plan has one.  Returns false when the table did not fit the stream:
@@ -1371,8 +1373,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     // a launch may hold several chains ("runs": kernels/chain_spec_kernel.h decodes stretches of a linked frame side by side): bit 1 of a block's
     // flag marks the first block of a run - it starts at its own dst[b] with prefix[b] bytes of history and waits for nobody; the blocks
     // behind it have the same dst[] and prefix[] and count their positions from there
-    const bool run_head = chained && (b == 0 || (P.stored && (P.stored[b] & 2)));
-    const bool run_tail = chained && (b + 1 >= P.n_blocks || (P.stored && (P.stored[b + 1] & 2)));
+    // (both questions are asked where they are needed, not kept in registers across the block's decode: the kernel spills scalars as it is)
 
     // -- degenerate inputs (lz4.c:2036, 2062-2069); in a chain they are failures like any other
     bool ok = true;
@@ -1430,7 +1431,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         // -- where does my output start?  (published by the workgroup that owns block b-1)
         if (tid == 0) {
             long long s = 0;
-            if (!run_head) while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
+            if (!chain_run_head(P, b)) while ((s = chain_load_acquire(&P.chain[b])) == -1) chain_wait_pause();
             misc[M_CHI] = (uint32_t)(unsigned long long)s; misc[M_SPARE] = (uint32_t)((unsigned long long)s >> 32);
         }
         __syncthreads();
@@ -1441,7 +1442,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         // a predecessor failed, this block is malformed, or a match reaches before the start of the history (lz4.c:2356)
         if (start < 0 || !ok || (!stored && minref < kBias - prefix)) {
             if (tid == 0) P.result[b] = -1;
-            if (!run_tail) chain_publish(P, b, -2);             // the chain ends here
+            if (!chain_run_tail(P, b)) chain_publish(P, b, -2); // the chain ends here
             return true;
         }
         dst = LZ4AMD_TO_GDST(P.dst[b]) + start;
@@ -1460,7 +1461,7 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         P.result[b] = (int32_t)total;
         if (prof) prof[0] = clock_ticks() - tstart;
     }
-    if (chained && !run_tail) chain_publish(P, b, start + (long long)total);
+    if (chained && !chain_run_tail(P, b)) chain_publish(P, b, start + (long long)total);
     return true;
 }
 
