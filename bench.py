@@ -254,6 +254,18 @@ def reference_blocks(host, bs, n):
     return comp, sizes
 
 
+def reference_hc_sizes(host, bs, n, level):
+    """Per-block sizes of the first n blocks of `host` under the reference's LZ4_compress_HC (oracle/_ref, a checker); None when it is not built."""
+    so = os.path.join(ROOT, "oracle", "_ref", "liblz4_ref.so")
+    if not os.path.exists(so):
+        return None
+    R = ctypes.CDLL(so)
+    R.LZ4_compress_HC.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    cap = bs + bs // 255 + 16
+    dst = ctypes.create_string_buffer(cap)
+    return [int(R.LZ4_compress_HC(host.ctypes.data + i * bs, dst, bs, cap, level)) for i in range(n)]
+
+
 def stream_copy_gbps(ctx, lz4_amd, torch, nbytes, stream):
     """This box's own read+write stream rate: a plain 16-bytes-per-lane copy kernel of the library (2 * bytes / time)."""
     L = lz4_amd.lib()
@@ -353,6 +365,14 @@ def bench_hc(ctx, lz4_amd, torch, data, out, stream, pct, seed, copy_gbps, level
                 if cbr and "ref_comp_bytes" in cbr and cbr["sample_blocks"] <= nrep:
                     rep["ratio_vs_reference"] = round(cbr["ref_comp_bytes"] / sum(rcs[:cbr["sample_blocks"]]), 4)
                     rep["reference_GBps"] = cbr["value"]
+                # block by block (the aggregate hides single blocks: the start of a -P99 stream has few distinct bytes yet): the first 128 blocks
+                rs = reference_hc_sizes(rhost, bs, 128, 9)
+                if rs and all(r > 0 for r in rs):
+                    per = [r / c for r, c in zip(rs, rcs)]                                  # reference bytes / our bytes, per block
+                    rep["worst_block_ratio_vs_reference"] = round(min(per), 4)
+                    rep["worst_block"] = int(per.index(min(per)))
+                    rep["blocks_more_than_5pct_larger"] = int(sum(1 for x in per if x < 1 / 1.05))
+                    rep["per_block_sample"] = "the stream's first 128 blocks, reference LZ4_compress_HC level 9 on the host"
             res["repetitive"] = rep
         except Exception as e:
             res["repetitive"] = {"error": str(e)}
@@ -547,6 +567,7 @@ def bench_frame_device(ctx, lz4_amd, torch, data, out, stream, bs, copy_gbps):
     cms = min(cplan.launch_timed(stream)[0][0] for _ in range(3))
     gms = min(gplan.launch_timed(stream)[1] for _ in range(3))
     dms = min(dplan.launch_timed(stream)[1] for _ in range(3))
+    cstats = dplan.chain_stats()
     dplan.close()
     # the chain of copy stages the side-by-side decode replaces (round 5; what a plan without memory for the slots falls back to)
     os.environ["LZ4AMD_CHAIN_SERIAL"] = "1"
@@ -559,11 +580,16 @@ def bench_frame_device(ctx, lz4_amd, torch, data, out, stream, bs, copy_gbps):
     ok = ok and splan.results(stream) == [bs] * nb and bool(torch.equal(out, data))
     splan.close()
     return {"workload": "configs[2], device side only: %d linked %d-byte blocks (%.2f GiB) resident in HBM: compress with 64 KB of history (one launch), gather into frame layout (one launch), "
-                        "decode of the linked blocks side by side (kernels/chain_spec_kernel.h: the ordinary decoder over block 0 and three copies of every other block, merge, patch); "
+                        "decode of the linked blocks side by side (kernels/chain_spec_kernel.h: the ordinary decoder over block 0 and two copies of every other block - a third where the two cannot tell -, merge, patch); "
                         "no transfers, no host checksum" % (nb, bs, U / 2**30),
             "bit_exact": ok, "ratio": round(U / C, 4),
             "compress_GBps": round(U / (cms * 1e-3) / 1e9, 2), "gather_GBps": round(C / (gms * 1e-3) / 1e9, 2), "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 3),
             "decompress_serial_chain_GBps": round(U / (sms * 1e-3) / 1e9, 3),
+            "side_by_side": {"units": int(cstats["units"]), "units_decoded_three_times": int(cstats["units_decoded_three_times"]),
+                             "fraction_walked_by_patch": round(cstats["bytes_walked_by_patch"] / max(1, cstats["bytes_of_units_1_on"]), 4),
+                             "note": "lz4amd_plan_chain_stats: a unit is decoded against two made-up histories; a third decode only where a match in the unit's first 255 bytes "
+                                     "reads one of the first 256 bytes of the 64 KB before it (gated inside the launch); the patch pass walks every unit up to its last "
+                                     "byte that is a copy of a history byte"},
             "compress_plus_gather_GBps": round(U / ((cms + gms) * 1e-3) / 1e9, 2),
             "roofline_compress": roofline_obj("compress", cms, U + C, copy_gbps, None),
             "roofline_gather": {"kernel": "gather", "bound": "hbm", "achieved": round(2 * C / (gms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -571,9 +597,10 @@ def bench_frame_device(ctx, lz4_amd, torch, data, out, stream, bs, copy_gbps):
             "roofline_decompress": {"kernel": "decompress + spec_merge + spec_patch (linked blocks side by side)", "bound": "hbm", "achieved": round((U + C) / (dms * 1e-3) / 1e9, 2),
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round((U + C) / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "algorithmic_bytes_per_launch": U + C, "avg_ms": round(dms, 3),
-                                    "limited_by": "every block but the first is decoded three times (against three made-up histories: which bytes depend on the history, and on which "
-                                                  "byte of it), without entry-point tables (a frame has no room for them): 3 x the plain decoder's time on 3 (n - 1) + 1 blocks, then "
-                                                  "two bandwidth passes; round 5's chain of copy stages, one CU at a time: decompress_serial_chain_GBps"}}
+                                    "limited_by": "every block but the first is decoded twice (against two made-up histories: which bytes depend on the history, and on which "
+                                                  "byte of it; a third time where those two cannot tell), without entry-point tables (a frame has no room for them): 2 x the plain "
+                                                  "decoder's time on 2 (n - 1) + 1 blocks, then two bandwidth passes; round 5's chain of copy stages, one CU at a time: "
+                                                  "decompress_serial_chain_GBps"}}
 
 
 def bench_frame(lz4_amd, host):
@@ -680,6 +707,10 @@ def bench_frame(lz4_amd, host):
         r["cpu_baseline"] = ref_frame(7, 0, 1, min(n, 512 << 20))
     except Exception as e:
         r["cpu_baseline"] = {"error": str(e)}
+    nc = one_frame(7, 0, 0)                                  # the same linked frame without the content checksum: no serial XXH32 on the host
+    r["linked_4M_no_checksum"] = {k: nc[k] for k in ("compress_GBps", "decompress_GBps", "bit_exact", "header_hex") if k in nc} if "error" not in nc else nc
+    l64 = one_frame(4, 0, 0)                                 # the frame format's defaults: linked 64 KiB blocks, no checksums
+    r["linked_64K_no_checksum"] = {k: l64[k] for k in ("compress_GBps", "decompress_GBps", "bit_exact", "header_hex", "ratio") if k in l64} if "error" not in l64 else l64
     d64 = one_frame(4, 1, 0)
     d64["workload"] = "the same GiB as one frame of independent 64 KiB blocks (the frame format's default block size), no checksums"
     try:

@@ -99,6 +99,11 @@ int  lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, i
 int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                            const void* const* d_src, const int* src_sizes,
                                            void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix);
+/* a side-by-side plan of dependent blocks, after a launch: out = { units of the chain, units that were decoded a third time (a match in their
+ * first 255 bytes reads one of the first 256 bytes of the 64 KB before them: two made-up histories cannot name those), bytes of units 1..
+ * up to their unit's last byte that is a copy of a history byte (what the patch pass walks), decoded bytes of units 1.. }.  LZ4AMD_E_ARG for
+ * any other plan; synchronises the device */
+int  lz4amd_plan_chain_stats(lz4amd_plan* plan, unsigned long long out[4]);
 /* Entry-point tables ("hints") - an optional, out-of-band column of the block table.
  * A compress plan (LZ4AMD_OP_COMPRESS) that has them attached writes, next to every block, a small table that names a
  * sequence of the block's token chain about every 512 bytes of source (every 2nd to 16th sequence): {position of its token in the block, position of its literals in the source,

@@ -57,6 +57,7 @@ def lib():
     L.lz4amd_hint_bytes.restype = ctypes.c_size_t
     L.lz4amd_plan_attach_hints.argtypes = [vp, vp, ctypes.c_size_t]
     L.lz4amd_plan_hint_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+    L.lz4amd_plan_chain_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     L.lz4amd_plan_set_acceleration.argtypes = [vp, i]
     L.lz4amd_plan_make_hints.argtypes = [vp, i]
     L.lz4amd_plan_hints_made.argtypes = [vp, ctypes.POINTER(ctypes.c_uint)]
@@ -163,6 +164,12 @@ class Plan:
         u, r = ctypes.c_uint(), ctypes.c_uint()
         _check(lib().lz4amd_plan_hint_stats(self._h, ctypes.byref(u), ctypes.byref(r)), "lz4amd_plan_hint_stats")
         return u.value, r.value
+
+    def chain_stats(self):
+        """Side-by-side plan of dependent blocks, after a launch: dict(units, units_decoded_three_times, bytes_walked_by_patch, bytes_of_units_1_on)."""
+        v = (ctypes.c_ulonglong * 4)()
+        _check(lib().lz4amd_plan_chain_stats(self._h, v), "lz4amd_plan_chain_stats")
+        return {"units": v[0], "units_decoded_three_times": v[1], "bytes_walked_by_patch": v[2], "bytes_of_units_1_on": v[3]}
 
     def make_hints(self, on=True):
         """Decompress plan with tables attached: blocks without a usable table get theirs written while they are decoded."""

@@ -4,14 +4,20 @@
 // A byte of LZ4 output is a copy of exactly ONE earlier byte: a literal of its block, or - through a chain of matches - a byte of the history
 // the block started with.  So a stretch of the chain can be decoded before its history exists: decode it against a made-up history and every
 // byte that does not come from the history is already right; for the others it is enough to know WHICH history byte they copy.  The chain is cut
-// in UNITS (one block of 1 MiB and more; as many smaller blocks as make 1 MiB).  Every unit but the first is decoded three times by the ordinary
+// in UNITS (one block of 1 MiB and more; as many smaller blocks as make 1 MiB).  Every unit but the first is decoded by the ordinary
 // decoder - lz4amd_k_decompress, ONE launch: a unit's blocks are a run of dependent blocks of that launch, the runs do not wait for each other
-// (lz4amd_dec_params.chain) - against histories whose byte i is
-//     A: i & 0xFF        B: i >> 8        C: ~i & 0xFF
-// A and C differ in every byte, so an output byte depends on the history exactly when its A and C values differ, and then {B, A} is the index
-// of the history byte it copies.  What follows is bandwidth work:
-//   spec_scan     sizes -> output positions (the decoded sizes do not depend on the history's content); the first unit with a bad block
-//   spec_merge    all units at once: A's bytes go to their place where A == C; the last byte that depends on the history is noted per unit
+// (lz4amd_dec_params.chain) - against made-up histories whose byte i (lo = i & 0xFF, hi = i >> 8) is
+//     A: lo        B: lo + (255 - hi) + 1 (mod 256)        C: ~lo
+// A and B differ wherever hi != 0, and then {A, B} give the index back: an output byte depends on the history exactly when its A and B values
+// differ - unless it copies one of the FIRST 256 bytes of the 64 KB (hi = 0: B = A).  Only matches in a unit's first 255 bytes with offsets
+// above 65280 read those; every block reports whether it has one (lz4amd_dec_params.lowref), and only such units are decoded a third
+// time, against C, which differs from A in every byte: the run of variant C is GATED on what the first block of variant A reports
+// (lz4amd_dec_params.gate; tickets: A's blocks, then C's, then B's - a run that is not wanted costs a look at a flag).  A unit whose first
+// block is so small that a later one could begin within those 255 bytes is decoded three times without asking.  (Two histories cannot
+// tell all 65 536 positions and "no history" apart: two bytes that differ are 65 280 pairs.)  What follows is bandwidth work:
+//   spec_scan     sizes -> output positions (the decoded sizes do not depend on the history's content); the first unit with a bad block; which
+//                 units were decoded against C
+//   spec_merge    all units at once: A's bytes go to their place where A == B (== C); the last byte that depends on the history is noted per unit
 //   spec_patch    per unit, bytes 0 .. last dependent: out[p] = out[unit start - 65536 + index].  The history is complete by then, except where it
 //                 overlaps a unit's patched stretch - only then a unit waits for the unit before it (always, for units of less than 64 KB).
 //                 A reference before the start of the data (lz4.c:2356) is an error, found here.
@@ -32,15 +38,15 @@ __device__ __forceinline__ uint8_t* spec_slot(const SpecBatch& P, uint32_t u, ui
 }
 __device__ __forceinline__ uint32_t spec_byte(const lz4amd_u32x4& v, uint32_t j) { return (v[j >> 2] >> ((j & 3) * 8)) & 0xFFu; }
 __device__ __forceinline__ uint32_t spec_len(const SpecBatch& P, uint32_t u) { const uint32_t r = P.n - u * P.group; return r < P.group ? r : P.group; }      // blocks of unit u
-__device__ __forceinline__ uint32_t spec_entry(const SpecBatch& P, uint32_t u, uint32_t v, uint32_t j) {      // where lz4amd_k_decompress left the result of block j of unit u, variant v
+__device__ __forceinline__ uint32_t spec_entry(const SpecBatch& P, uint32_t u, uint32_t v, uint32_t j) {      // where lz4amd_k_decompress left the result of block j of unit u, variant v (0: A, 1: B, 2: C)
     return u == 0 ? j : spec_len(P, 0) + (u - 1) * 3 * P.group + v * spec_len(P, u) + j;
 }
-// decoded size of block j of unit u, -1 if any of its decodes failed (they fail alike: what a block refers to does not depend on the history's content)
+// decoded size of block j of unit u, -1 if one of its decodes failed (they fail alike: what a block refers to does not depend on the history's content)
 __device__ __forceinline__ int32_t spec_block_size(const SpecBatch& P, uint32_t u, uint32_t j) {
     const int32_t a = P.spec_result[spec_entry(P, u, 0, j)];
     if (u == 0) return a;
-    const int32_t b = P.spec_result[spec_entry(P, u, 1, j)], c = P.spec_result[spec_entry(P, u, 2, j)];
-    return (a >= 0 && a == b && a == c) ? a : -1;
+    const int32_t b = P.spec_result[spec_entry(P, u, 1, j)];
+    return (a >= 0 && a == b) ? a : -1;
 }
 // ---- the made-up histories.  grid: 3 * (n_units - 1) * kSpecFillParts workgroups of kSpecThreads
 __device__ __forceinline__ void spec_fill_body(const SpecBatch& P) {
@@ -54,7 +60,7 @@ __device__ __forceinline__ void spec_fill_body(const SpecBatch& P) {
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {
             const uint32_t i = i0 + q * 4 + j;
-            const uint32_t b = v == 0 ? (i & 0xFFu) : v == 1 ? (i >> 8) : (~i & 0xFFu);
+            const uint32_t b = v == 0 ? (i & 0xFFu) : v == 1 ? ((i & 0xFFu) + (255u - (i >> 8)) + 1u) & 0xFFu : (~i & 0xFFu);
             x |= b << (j * 8);
         }
         w[q] = x;
@@ -103,6 +109,9 @@ __device__ __forceinline__ void spec_scan_body(const SpecBatch& P) {
         P.start[k] = (long long)at; P.size[k] = (int32_t)s;
         P.lastdep[k] = -1; P.done[k] = 0; P.badpos[k] = 0x7FFFFFFF;
         at += s;
+        bool three = false;                                                // was the unit decoded against C?  (a block reports 1 or 0, whatever becomes of it)
+        if (k >= 1 && k <= bad) for (uint32_t j = 0, m = spec_len(P, k); j < m; j++) three = three || P.lowref[spec_entry(P, k, 0, j)] == 1u;
+        P.three[k] = three ? 1 : 0;
     }
     if (t == 0) { P.info[0] = bad < n ? bad + 1 : n; P.info[1] = 0; }
 }
@@ -119,7 +128,7 @@ __device__ __forceinline__ void spec_merge_body(const SpecBatch& P) {
     if (tid == 0) wg_dep = -1;
     __syncthreads();
     const uint8_t* A = spec_slot(P, k, 0) + kSpecHist;
-    const uint8_t* C = spec_slot(P, k, 2) + kSpecHist;
+    const uint8_t* C = spec_slot(P, k, P.three[k] ? 2 : 1) + kSpecHist;       // what tells the bytes that come from the history: B, or C if B cannot
     const bool aligned = (((uintptr_t)out) & 15u) == 0;
     int32_t dep = -1;
     for (uint32_t p = lo + tid * 16; p < hi; p += kSpecThreads * 16) {
@@ -157,7 +166,7 @@ __device__ __forceinline__ void spec_patch_body(const SpecBatch& P) {
         const long long start = P.start[k];
         const uint8_t* A = live ? spec_slot(P, k, 0) + kSpecHist : nullptr;
         const uint8_t* B = live ? spec_slot(P, k, 1) + kSpecHist : nullptr;
-        const uint8_t* C = live ? spec_slot(P, k, 2) + kSpecHist : nullptr;
+        const uint8_t* C = live ? spec_slot(P, k, P.three[k] ? 2 : 1) + kSpecHist : nullptr;
         // A thread works on batches of kSpecPre pieces of FOUR bytes (a batch of the workgroup: 32 KB - sixteen pieces a thread spilled registers): all of a batch's loads from the slots first
         // (the compiler cannot know that the stores to the output never hit what the next piece reads); the history bytes come out of the LDS.
         // What does not depend on the block before - the first batch's loads - is read before waiting for it.
@@ -213,7 +222,7 @@ __device__ __forceinline__ void spec_patch_body(const SpecBatch& P) {
                     uint32_t w = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) {
-                        const uint32_t aj = (a >> (8 * j)) & 0xFFu, idx = (((b >> (8 * j)) & 0xFFu) << 8) | aj;
+                        const uint32_t aj = (a >> (8 * j)) & 0xFFu, idx = ((255u - ((((b >> (8 * j)) & 0xFFu) - aj - 1u) & 0xFFu)) << 8) | aj;
                         const bool dep = ((x >> (8 * j)) & 0xFFu) != 0 && j < nb;
                         if (dep && kSpecHist - idx > before && p + j < bad) bad = p + j;       // lz4.c:2356: before the start of the data
                         const bool take = dep && kSpecHist - idx <= before;
@@ -244,7 +253,12 @@ __device__ __forceinline__ void spec_results_body(const SpecBatch& P) {
     const uint32_t t = threadIdx.x, n = P.n, G = P.group;
     if (t == 0) first_bad = n;
     __syncthreads();
-    for (uint32_t b = t; b < n; b += kSpecScanThreads) if (spec_block_size(P, b / G, b % G) < 0) atomicMin(&first_bad, b);
+    for (uint32_t b = t; b < n; b += kSpecScanThreads) {
+        const uint32_t u = b / G, j = b % G;
+        const int32_t sz = spec_block_size(P, u, j);
+        // (a unit's third decode answers like the other two)
+        if (sz < 0 || (u >= 1 && u < P.info[0] && P.three[u] && P.spec_result[spec_entry(P, u, 2, j)] != sz)) atomicMin(&first_bad, b);
+    }
     for (uint32_t u = t; u < P.n_units; u += kSpecScanThreads) {
         const int32_t bp = P.badpos[u];
         if (bp == 0x7FFFFFFF) continue;

@@ -164,7 +164,7 @@ enum : uint32_t {
 static_assert(kDecLdsBytes <= 160u * 1024u, "LDS budget");
 static_assert((kOffRecs % 16) == 0 && (kOffCr % 16) == 0 && (kOffRing % 16) == 0 && (kOffBits % 16) == 0 && (kOffPend % 8) == 0 && (kOffMaskTab % 32) == 0, "LDS alignment");
 
-enum : uint32_t { M_BLOCK = 0, M_ABORT = 4, M_SPARE, M_CHI, M_CLO, M_HEAD, M_IHEAD, M_NEXT, M_OPEN,
+enum : uint32_t { M_BLOCK = 0, M_TWIN = 3, M_ABORT = 4, M_SPARE, M_CHI, M_CLO, M_HEAD, M_IHEAD, M_NEXT, M_OPEN,
                   M_EHEAD,       // rows of the entry-point table resident (mover -> parser)
                   M_PR0,         // first row the parser still needs (parser -> mover)
                   M_PBAD };      // the table does not fit the stream: the block is decoded again without it      // (M_HEAD, M_IHEAD: one aligned 64-bit word, published together: table rows resident, region index entries resident)      // (word 1 is the pre-parse's error word)
@@ -1360,7 +1360,13 @@ __device__ __forceinline__ bool chain_run_tail(const DecBatch& P, uint32_t b) { 
 // (independent and dependent blocks share ONE copy of stage A and stage B: the kernel is instruction-cache bound enough)
 // use_hints: try the block's entry-point table, if the plan has one.  Returns false when the table did not fit the stream:
 // the caller decodes the block again without it.
-__device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, char* smem, bool use_hints) {
+// kRuns: the kernel of dependent blocks (lz4amd_k_decompress_runs: gated blocks, lowref).  The general kernel (lz4amd_k_decompress: the step's) is,
+// instruction for instruction, what it was before there were gated blocks.  Both ask P.chain at run time: a build in which kRuns made `chained` a
+// compile-time constant (either way: no chain code in the one, no tables' code in the other; 204 / 147 spilled scalars instead of 232) faulted in
+// its first launch, with or without -amdgpu-spill-sgpr-to-vgpr=false (not understood; this form is the one that is tested).
+constexpr uint32_t kNoTwin = 0xFFFFFFFFu;
+template <bool kRuns>
+__device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, char* smem, bool use_hints, uint32_t twin_of = kNoTwin) {
     const uint32_t tid = threadIdx.x;
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
 
@@ -1418,12 +1424,33 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         make_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride);
         if (tid == 0) *(uint32_t*)make = 0;                      // (no table until it is whole)
     }
-    if (!hint && ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx, make, make_rows)) {
+    // (lz4amd_k_decompress_runs: a block whose twin - the same bytes against another history - was decoded by this workgroup a moment ago takes over
+    //  what stage A found for it: the record table still lies in the workgroup's scratch)
+    bool carried = false;
+    uint32_t carried_minref = 0;
+    if constexpr (kRuns) {
+        if (twin_of != kNoTwin && ok && !stored) {
+            const uint32_t* c = LZ4AMD_CHAIN_CARRY(P.chain, P.n_blocks) + 4u * twin_of;
+            const uint32_t c0 = flag_load_agent(c);
+            if (c0 != 0xFFFFFFFFu) {
+                nseq = c0; total = flag_load_agent(c + 1); ridx = (uint32_t*)((char*)rectab + flag_load_agent(c + 2)); carried_minref = flag_load_agent(c + 3);
+                carried = true;
+                if (tid == 0) flag_store_agent(LZ4AMD_CHAIN_CARRY(P.chain, P.n_blocks) + 4u * b, LZ4AMD_CHAIN_CARRIED);      // (counted by lz4amd_plan_chain_stats)
+            }
+        }
+    }
+    if (!(kRuns && carried) && !hint && ok && !stored && !pre::preparse_block(src, csize, cap, prefix, rectab, smem, pre::table_bytes(csize), nseq, total, prof, &ridx, make, make_rows)) {
         if (!chained) { if (tid == 0) P.result[b] = err_at(((const uint32_t*)(smem + pre::kOffMisc))[pre::M_ERR]); return true; }
         ok = false;
     }
     if (prof && tid == 0) prof[1] = clock_ticks() - tstart;
-    const uint32_t minref = ((const uint32_t*)(smem + pre::kOffMisc))[pre::M_MINREF];
+    const uint32_t minref = (kRuns && carried) ? carried_minref : ((const uint32_t*)(smem + pre::kOffMisc))[pre::M_MINREF];
+    if constexpr (kRuns) {
+        if (!carried && ok && !stored && tid == 0) {                  // for the twin
+            uint32_t* c = LZ4AMD_CHAIN_CARRY(P.chain, P.n_blocks) + 4u * b;
+            flag_store_agent(c + 1, total); flag_store_agent(c + 2, (uint32_t)((const char*)ridx - (const char*)rectab)); flag_store_agent(c + 3, minref); flag_store_agent(c, nseq);
+        }
+    }
     __syncthreads();            // record table visible to the whole workgroup; stage A's LDS is dead
 
     long long start = 0;
@@ -1441,11 +1468,13 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
         prefix = before < kBias ? (uint32_t)before : kBias;
         // a predecessor failed, this block is malformed, or a match reaches before the start of the history (lz4.c:2356)
         if (start < 0 || !ok || (!stored && minref < kBias - prefix)) {
-            if (tid == 0) P.result[b] = -1;
+            if (tid == 0) { P.result[b] = -1; if (kRuns) flag_store_agent(&LZ4AMD_CHAIN_LOWREF(P.chain, P.n_blocks)[b], 0u); }
             if (!chain_run_tail(P, b)) chain_publish(P, b, -2); // the chain ends here
             return true;
         }
         dst = LZ4AMD_TO_GDST(P.dst[b]) + start;
+        // (kernels/chain_spec_kernel.h wants to know: does a match read one of the first 256 bytes of the 64 KB in front of the run?)
+        if (kRuns && tid == 0) flag_store_agent(&LZ4AMD_CHAIN_LOWREF(P.chain, P.n_blocks)[b], (!stored && (unsigned long long)minref + (unsigned long long)start < (unsigned long long)kBias - 65536u + 256u) ? 1u : 0u);
         if (stored) for (uint32_t i = tid; i < total; i += kDecThreads) dst[i] = src[i];
     }
 
@@ -1466,21 +1495,45 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
 }
 
 // Workgroups pull blocks from a device-wide ticket counter (load balance for ragged batches).
-__device__ __forceinline__ void decompress_batch_body(const DecBatch& P) {
+constexpr uint32_t kGatedOut = 0xFFFFFFFEu;
+template <bool kRuns>
+__device__ __forceinline__ void decompress_batch_body_of(const DecBatch& P) {
     LZ4AMD_DYN_LDS(smem);
     uint32_t* misc = (uint32_t*)(smem + kOffMisc);
+    uint32_t twin_next = 0, twin_src = kNoTwin;             // (kRuns) the block to decode next without a ticket: the twin of the one just decoded (lz4amd_dec_params.chain)
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t t = take_ticket(P.ticket);
-            misc[M_BLOCK] = (P.order && t < P.n_blocks) ? P.order[t] : t;
+            if (kRuns && twin_next) { misc[M_BLOCK] = twin_next - 1; misc[M_TWIN] = 0; }
+            else {
+                const uint32_t t = take_ticket(P.ticket);
+                uint32_t b = (P.order && t < P.n_blocks) ? P.order[t] : t;
+                if constexpr (kRuns) {
+                    if (b < P.n_blocks) {                   // a gated block: is it wanted at all?  (the block that says so has a lower ticket: it is at work)
+                        const uint32_t g = LZ4AMD_CHAIN_GATE(P.chain, P.n_blocks)[b];
+                        if (g) {
+                            uint32_t v;
+                            while ((v = flag_load_agent(&LZ4AMD_CHAIN_LOWREF(P.chain, P.n_blocks)[g - 1])) == 0xFFFFFFFFu) chain_wait_pause();
+                            if (v == 0) { P.result[b] = -1; b = kGatedOut; }
+                        }
+                    }
+                    misc[M_TWIN] = b < P.n_blocks ? LZ4AMD_CHAIN_TWIN(P.chain, P.n_blocks)[b] : 0u;
+                }
+                misc[M_BLOCK] = b;
+            }
         }
         __syncthreads();
         const uint32_t b = misc[M_BLOCK];
+        if (kRuns && b == kGatedOut) continue;
         if (b >= P.n_blocks) break;
+        uint32_t of = kNoTwin;
+        if constexpr (kRuns) { if (twin_next) of = twin_src; twin_next = misc[M_TWIN]; twin_src = b; }
         bool use_hints = true;
-        while (!decode_one_block(P, b, smem, use_hints)) { use_hints = false; __syncthreads(); }
+        while (!decode_one_block<kRuns>(P, b, smem, use_hints, of)) { use_hints = false; __syncthreads(); }
     }
+}
+__device__ __forceinline__ void decompress_batch_body(const DecBatch& P) {      // (the interpreter's entry, tests/simt)
+    if (P.chain) decompress_batch_body_of<true>(P); else decompress_batch_body_of<false>(P);
 }
 
 } // namespace lz4amd

@@ -211,6 +211,8 @@ __device__ __forceinline__ long long chain_load_acquire(const long long* w) {
 __device__ __forceinline__ void chain_store_release(long long* w, long long v) {
     __hip_atomic_store(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ uint32_t flag_load_agent(const uint32_t* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_store_agent(uint32_t* w, uint32_t v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t take_ticket(uint32_t* counter) {
     return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -259,26 +259,37 @@ static int chained_runs_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n, const 
     p = *out;
     for (k = 0; k < LZ4AMD_PLAN_MAX_BUFS && p->bufs[k]; k++) {}
     if (k + 2 > LZ4AMD_PLAN_MAX_BUFS) { lz4amd_plan_destroy(p); *out = NULL; return LZ4AMD_E_MEMORY; }
-    p->dec.chain = (long long*)(p->bufs[k] = dev_array(NULL, ((size_t)n + 1) * sizeof(long long), &err));
+    p->dec.chain = (long long*)(p->bufs[k] = dev_array(NULL, LZ4AMD_CHAIN_BYTES(n), &err));          /* (chain words, lowref, gate: lz4amd_params.h) */
+    if (!err && lz4amd_hip_memset(LZ4AMD_CHAIN_GATE(p->dec.chain, n), 0, (size_t)n * 2u * sizeof(uint32_t), NULL)) err = LZ4AMD_E_RUNTIME;      /* no block is gated, none has a twin */
     if (flags) p->dec.stored = (const uint8_t*)(p->bufs[k + 1] = dev_array(flags, (size_t)n, &err));
     if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
     if (err) { lz4amd_plan_destroy(p); *out = NULL; return err; }
     return LZ4AMD_OK;
 }
 
+/* one more device array of a plan that was just made */
+static void* plan_add_array(lz4amd_plan* p, const void* host, size_t bytes, int* err)
+{
+    int k;
+    for (k = 0; k < LZ4AMD_PLAN_MAX_BUFS && p->bufs[k]; k++) {}
+    if (k >= LZ4AMD_PLAN_MAX_BUFS) { *err = LZ4AMD_E_MEMORY; return NULL; }
+    return p->bufs[k] = dev_array(host, bytes, err);
+}
+
 /* Linked blocks side by side (kernels/chain_spec_kernel.h): the chain is cut in units of `group` blocks; the plan owns ONE launch of dependent
- * blocks in runs - unit 0 in place, every other unit three times against made-up histories, in slots of its own - and the tables of the passes
- * that put the output together.  Costs 3 x (64 KB + a unit) of device memory per unit; a plan that cannot have it, or whose chain is one unit,
- * decodes one block after the other. */
+ * blocks in runs - unit 0 in place, every other unit against made-up histories A, B and (gated: only if A's first block says so) C, in slots
+ * of its own - and the tables of the passes that put the output together.  Costs 3 x (64 KB + a unit) of device memory per unit; a plan
+ * that cannot have it, or whose chain is one unit, decodes one block after the other. */
 static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                const void* const* d_src, const int* src_sizes,
                                void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix)
 {
     size_t un = (size_t)n, ne, nu, G, len0, e, stride;
     lz4amd_plan* p;
-    const void** esrc = NULL; void** edst = NULL; int *esz = NULL, *ecap = NULL, *epre = NULL; unsigned char* efl = NULL;
+    const void** esrc = NULL; void** edst = NULL; int *esz = NULL, *ecap = NULL, *epre = NULL; unsigned char* efl = NULL; unsigned *ord = NULL, *gate = NULL, *twin = NULL;
     unsigned max_cap = 0;
-    int err = 0, nb = 0, i, rc;
+    size_t nt_pad = 0;
+    int err = 0, nb = 0, i, rc, twins;
     lz4amd_spec_params* q;
     for (i = 0; i < n; i++) {
         if (dst_caps[i] <= 0) return LZ4AMD_E_ARG;
@@ -296,6 +307,12 @@ static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
     if (nu < 2) return LZ4AMD_E_ARG;
     len0 = G < un ? G : un;
     ne = len0 + 3 * (un - len0);
+    {   /* twins (lz4amd_dec_params.chain): A's and B's copy of a block decoded by one workgroup, stage A once.  Measured: pays for blocks
+         * of up to 512 KB when the runs outnumber the CUs (4096 x 64 KiB: 4.7 -> 3.7 ms); a 4 MiB block's second copy stage finds neither its records nor
+         * its compressed bytes in the L2 any more and takes longer than a whole decode (3.87 -> 4.07 ms), and a short chain has CUs to spare */
+        const char* tw = getenv("LZ4AMD_CHAIN_TWINS");
+        twins = tw ? atoi(tw) != 0 : (G > 1 && 2 * (nu - 1) >= (size_t)ctx->n_cus);
+    }
     stride = (65536u + G * (size_t)max_cap + 64u + 255u) & ~(size_t)255u;
     {   const char* lim = getenv("LZ4AMD_CHAIN_SLOTS_MB");                     /* (the slots' budget: 64 GiB of the 288) */
         const unsigned long long budget = lim && atoll(lim) > 0 ? (unsigned long long)atoll(lim) << 20 : (unsigned long long)64 << 30;
@@ -315,53 +332,69 @@ static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
     q->size = (int32_t*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(int), &err));
     q->lastdep = (int32_t*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(int), &err));
     q->badpos = (int32_t*)(p->bufs[nb++] = dev_array(NULL, nu * sizeof(int), &err));
+    q->three = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, nu, &err));
     q->info = (uint32_t*)(p->bufs[nb++] = dev_array(NULL, 64, &err));
     if (!err) q->slots = (uint8_t*)(p->bufs[nb++] = dev_array(NULL, stride * 3 * (nu - 1), &err));
     esrc = (const void**)malloc(ne * sizeof *esrc); edst = (void**)malloc(ne * sizeof *edst);
     esz = (int*)malloc(ne * sizeof *esz); ecap = (int*)malloc(ne * sizeof *ecap); epre = (int*)malloc(ne * sizeof *epre); efl = (unsigned char*)malloc(ne);
-    if (!esrc || !edst || !esz || !ecap || !epre || !efl) err = LZ4AMD_E_MEMORY;
+    ord = (unsigned*)malloc(ne * sizeof *ord); gate = (unsigned*)calloc(ne, sizeof *gate); twin = (unsigned*)calloc(ne, sizeof *twin);
+    if (!esrc || !edst || !esz || !ecap || !epre || !efl || !ord || !gate || !twin) err = LZ4AMD_E_MEMORY;
     if (!err) {
-        /* entries 0 .. len0 - 1: unit 0 where it belongs; then unit u, variant v, block j at len0 + (u - 1) * 3 * G + v * len(u) + j */
-        size_t u, v, j;
+        /* entries 0 .. len0 - 1: unit 0 where it belongs; then unit u, variant v, block j at len0 + (u - 1) * 3 * G + v * len(u) + j.
+         * Tickets (lz4amd_dec_params.order): the first blocks of all runs - A's, then C's -, then the second ones ...: a workgroup per
+         * RUN is at work, a block's predecessor and a gated block's gate have the lower ticket. */
+        size_t u, v, j, t = 0;
+        static const size_t by_ticket[3] = {0, 2, 1};
         for (j = 0; j < len0; j++) {
             esrc[j] = d_src[j]; edst[j] = d_dst0; esz[j] = src_sizes[j]; ecap[j] = dst_caps[j]; epre[j] = initial_prefix;
             efl[j] = (unsigned char)((stored && stored[j] ? 1 : 0) | (j == 0 ? 2 : 0));
         }
         e = len0;
         for (u = 1; u < nu; u++) {
-            const size_t lenu = un - u * G < G ? un - u * G : G;
+            const size_t lenu = un - u * G < G ? un - u * G : G, a_head = len0 + (u - 1) * 3 * G;
+            /* C is asked for by A's FIRST block only if no later block can begin within the unit's first 255 bytes: a block of c compressed
+             * bytes decodes to c - c / 255 - 2 at least (a sequence of s bytes with k length bytes for its literals yields s + 1 - k; stored: c) */
+            const int ask = lenu == 1 || src_sizes[u * G] >= 512;
             for (v = 0; v < 3; v++)
                 for (j = 0; j < lenu; j++, e++) {
                     const size_t b = u * G + j;
                     esrc[e] = d_src[b]; edst[e] = q->slots + ((u - 1) * 3 + v) * stride + 65536; esz[e] = src_sizes[b]; ecap[e] = dst_caps[b]; epre[e] = 65536;
                     efl[e] = (unsigned char)((stored && stored[b] ? 1 : 0) | (j == 0 ? 2 : 0));
+                    if (v == 2 && ask) gate[e] = (unsigned)(a_head + 1);
                 }
         }
+        for (j = 0; j < G; j++) {
+            if (j < len0) ord[t++] = (unsigned)j;
+            for (v = 0; v < (twins ? 2u : 3u); v++)
+                for (u = 1; u < nu; u++) {
+                    const size_t lenu = un - u * G < G ? un - u * G : G;
+                    if (j < lenu) ord[t++] = (unsigned)(len0 + (u - 1) * 3 * G + by_ticket[v] * lenu + j);
+                }
+        }
+        /* B's blocks have no tickets: each is the TWIN of A's block over the same bytes, decoded by the same workgroup right behind it, from the
+         * same record table */
+        if (twins) {
+            for (u = 1; u < nu; u++) {
+                const size_t lenu = un - u * G < G ? un - u * G : G, a0 = len0 + (u - 1) * 3 * G;
+                for (j = 0; j < lenu; j++) twin[a0 + j] = (unsigned)(a0 + lenu + j + 1);
+            }
+            while (t < ne) { ord[t++] = 0xFFFFFFFFu; nt_pad++; }
+        }
+        if (e != ne || t != ne || nt_pad != (twins ? un - len0 : 0)) err = LZ4AMD_E_RUNTIME;
+    }
+    if (!err) {
         rc = chained_runs_create(ctx, &p->inner, (int)ne, esrc, esz, edst, ecap, efl, epre);
         if (rc) err = rc;
     }
-    if (!err && G > 1) {
-        /* tickets: the first blocks of all runs, then the second ones, ... (lz4amd_dec_params.order) */
-        unsigned* ord = (unsigned*)malloc(ne * sizeof *ord);
-        size_t j, u, v, t = 0;
-        int k;
-        if (!ord) err = LZ4AMD_E_MEMORY;
-        for (j = 0; ord && j < G; j++) {
-            if (j < len0) ord[t++] = (unsigned)j;
-            for (u = 1; u < nu; u++) {
-                const size_t lenu = un - u * G < G ? un - u * G : G;
-                for (v = 0; v < 3 && j < lenu; v++) ord[t++] = (unsigned)(len0 + (u - 1) * 3 * G + v * lenu + j);
-            }
-        }
-        for (k = 0; k < LZ4AMD_PLAN_MAX_BUFS && p->inner->bufs[k]; k++) {}
-        if (ord && k < LZ4AMD_PLAN_MAX_BUFS && t == ne) p->inner->dec.order = (const uint32_t*)(p->inner->bufs[k] = dev_array(ord, ne * sizeof *ord, &err));
-        else if (!err) err = LZ4AMD_E_MEMORY;
-        if (!err && lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
-        free(ord);
+    if (!err) {
+        p->inner->dec.order = (const uint32_t*)plan_add_array(p->inner, ord, ne * sizeof *ord, &err);
+        if (!err && (lz4amd_hip_h2d(LZ4AMD_CHAIN_GATE(p->inner->dec.chain, ne), gate, ne * sizeof *gate, NULL)
+                     || lz4amd_hip_h2d(LZ4AMD_CHAIN_TWIN(p->inner->dec.chain, ne), twin, ne * sizeof *twin, NULL) || lz4amd_hip_sync(NULL))) err = LZ4AMD_E_RUNTIME;
     }
-    free(esrc); free(edst); free(esz); free(ecap); free(epre); free(efl);
+    free(esrc); free(edst); free(esz); free(ecap); free(epre); free(efl); free(ord); free(gate); free(twin);
     if (!err) {
         q->spec_result = (const int32_t*)p->inner->d_results;
+        q->lowref = LZ4AMD_CHAIN_LOWREF(p->inner->dec.chain, ne);
         p->dec.chain = q->start;                                        /* (marks the plan as one of dependent blocks: no tables, lz4amd_plan_attach_hints) */
         p->grid = p->inner->grid;
         if (lz4amd_hip_launch_spec_fill(q, NULL) || lz4amd_hip_sync(NULL)) err = LZ4AMD_E_RUNTIME;
@@ -428,6 +461,36 @@ int lz4amd_plan_hint_stats(lz4amd_plan* p, unsigned* used, unsigned* rejected)
     if (used) *used = v[0];
     if (rejected) *rejected = v[1];
     return LZ4AMD_OK;
+}
+
+int lz4amd_plan_chain_stats(lz4amd_plan* p, unsigned long long out[4])
+{   /* linked blocks side by side, after a launch: { units, units decoded a third time, bytes of units 1.. that lie before their unit's last
+     * history-dependent byte (what the patch pass walks), decoded bytes of units 1.. }; synchronises the device */
+    size_t nu, k;
+    int32_t *ld = NULL, *sz = NULL; uint8_t* th = NULL;
+    int rc = LZ4AMD_OK;
+    if (!p || !out || !p->inner) return LZ4AMD_E_ARG;
+    nu = p->spec.n_units;
+    ld = (int32_t*)malloc(nu * sizeof *ld); sz = (int32_t*)malloc(nu * sizeof *sz); th = (uint8_t*)malloc(nu);
+    if (!ld || !sz || !th) rc = LZ4AMD_E_MEMORY;
+    (void)lz4amd_hip_use_device(p->ctx->device);
+    if (!rc && (lz4amd_hip_d2h(ld, p->spec.lastdep, nu * sizeof *ld, NULL) || lz4amd_hip_d2h(sz, p->spec.size, nu * sizeof *sz, NULL)
+                || lz4amd_hip_d2h(th, p->spec.three, nu, NULL) || lz4amd_hip_sync(NULL))) { lz4amd_set_error(lz4amd_hip_errstr()); rc = LZ4AMD_E_RUNTIME; }
+    if (!rc && getenv("LZ4AMD_CHAIN_DEBUG")) {          /* developer aid: blocks decoded from their twin's record table */
+        size_t ne = p->inner->dec.n_blocks, cnt = 0;
+        uint32_t* cw = (uint32_t*)malloc(ne * 16);
+        if (cw && !lz4amd_hip_d2h(cw, LZ4AMD_CHAIN_CARRY(p->inner->dec.chain, ne), ne * 16, NULL) && !lz4amd_hip_sync(NULL)) {
+            for (k = 0; k < ne; k++) cnt += cw[4 * k] == LZ4AMD_CHAIN_CARRIED;
+            fprintf(stderr, "lz4amd: %zu of %zu entries decoded from their twin's record table\n", cnt, ne);
+        }
+        free(cw);
+    }
+    if (!rc) {
+        out[0] = nu; out[1] = out[2] = out[3] = 0;
+        for (k = 1; k < nu; k++) { out[1] += th[k] ? 1u : 0u; out[2] += (unsigned long long)(ld[k] + 1); out[3] += (unsigned long long)(sz[k] > 0 ? sz[k] : 0); }
+    }
+    free(ld); free(sz); free(th);
+    return rc;
 }
 
 int lz4amd_plan_make_hints(lz4amd_plan* p, int on)

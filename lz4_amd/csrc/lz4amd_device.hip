@@ -14,7 +14,8 @@
 using namespace lz4amd;
 
 // ------------------------------------------------------------------------------- kernels
-__global__ void __launch_bounds__(kDecThreads) lz4amd_k_decompress(lz4amd_dec_params p) { decompress_batch_body(p); }
+__global__ void __launch_bounds__(kDecThreads) lz4amd_k_decompress(lz4amd_dec_params p) { decompress_batch_body_of<false>(p); }
+__global__ void __launch_bounds__(kDecThreads) lz4amd_k_decompress_runs(lz4amd_dec_params p) { decompress_batch_body_of<true>(p); }      // dependent blocks (p.chain)
 __global__ void __launch_bounds__(kCmpThreads) lz4amd_k_compress(lz4amd_comp_params p) { compress_batch_body(p); }
 
 __global__ void __launch_bounds__(kHcThreads) lz4amd_k_compress_hc(lz4amd_hc_params p) { hc_batch_body(p); }
@@ -67,6 +68,7 @@ extern "C" int lz4amd_hip_init(int device, int* n_cus) {
     if (n_cus) *n_cus = cus;
     // the decoder uses ~152 KB of the CU's 160 KB LDS: opt in to large dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_decompress_runs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCmpLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_compress_hc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHcLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)lz4amd_k_spec_patch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSpecPatchLds));
@@ -150,10 +152,11 @@ extern "C" int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned
     if (!p->n_blocks || !grid) return 0;
     HIPCHK(hipMemsetAsync(p->ticket, 0, sizeof(uint32_t), (hipStream_t)s));
     if (p->chain) {                      /* dependent blocks: nothing is known but where the first one starts */
-        HIPCHK(hipMemsetAsync(p->chain, 0xFF, ((size_t)p->n_blocks + 1) * sizeof(long long), (hipStream_t)s));
+        HIPCHK(hipMemsetAsync(p->chain, 0xFF, LZ4AMD_CHAIN_RESET_BYTES(p->n_blocks), (hipStream_t)s));     /* (the words, what the blocks report and carry: "not known yet") */
         HIPCHK(hipMemsetAsync(p->chain, 0, sizeof(long long), (hipStream_t)s));
     }
-    hipLaunchKernelGGL(lz4amd_k_decompress, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
+    if (p->chain) hipLaunchKernelGGL(lz4amd_k_decompress_runs, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
+    else hipLaunchKernelGGL(lz4amd_k_decompress, dim3(grid), dim3(kDecThreads), kDecLdsBytes, (hipStream_t)s, *p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -164,7 +167,7 @@ extern "C" int lz4amd_hip_launch_spec_fill(const lz4amd_spec_params* p, void* s)
     HIPCHK(hipGetLastError());
     return 0;
 }
-// ... and per launch: the decoder over block 0 and the three variants of every other block, positions, merge, patch, results
+// ... and per launch: the decoder over unit 0 and variants A, B (C where it is needed) of every other unit, positions, merge, patch, results
 extern "C" int lz4amd_hip_launch_spec(const lz4amd_spec_params* p, const lz4amd_dec_params* dec, unsigned dec_grid, unsigned max_cap, void* s) {
     if (!p->n) return 0;
     if (lz4amd_hip_launch_decompress(dec, dec_grid, s)) return -1;

@@ -22,7 +22,18 @@ typedef struct lz4amd_dec_params {
      * bit 0 of stored[i] marks a block that is copied as is (lz4frame.c:1758-1830).  Bit 1 marks the first block of a RUN: a launch may hold
      * several chains behind one another; a run's blocks share dst[] and prefix[], its first block starts at dst[i] and waits for nobody,
      * its last block publishes nothing (block 0 is a first block by itself). */
-    long long* chain;               /* [n + 1] or NULL */
+    long long* chain;               /* [n + 1] or NULL; behind the n + 1 words (LZ4AMD_CHAIN_BYTES: one allocation, the struct is what it was):
+                                     *   lowref [n] uint32: every block reports 1 when one of its matches reads one of the first 256 bytes of the 64 KB in front
+                                     *     of its run, else 0 (also when it fails); 0xFFFFFFFF = not known yet (set before the launch, like the words).
+                                     *     kernels/chain_spec_kernel.h: two made-up histories tell all the other bytes apart
+                                     *   gate [n] uint32, set when the plan is made: gate[b] = e + 1: block b is decoded only if block e reports lowref[e] != 0
+                                     *     (the workgroup that drew b's ticket waits until e has reported: e's ticket must be lower); else its result is -1
+                                     *     and it publishes nothing - all blocks of a run share their gate.  0 = no gate
+                                     *   twin [n] uint32, set when the plan is made: twin[b] = t + 1: block t has the same compressed bytes as b (another made-up
+                                     *     history, another destination) and NO ticket: the workgroup that decoded b decodes t right behind it, from b's
+                                     *     record table (stage A once for the two); 0 = none
+                                     *   carry [n] x 4 uint32 (between lowref and gate; reset with them): what stage A of block b found - { sequences, output bytes,
+                                     *     where the region index lies in the workgroup's scratch, lowest position a match reads } - for b's twin */
     const uint8_t* stored;          /* [n] or NULL */
     const uint32_t* order;          /* [n] or NULL: the block the k-th ticket stands for (runs: first blocks of all runs, then second blocks, ... -
                                      * a workgroup per RUN is at work, and a block's predecessor still has the lower ticket) */
@@ -57,23 +68,33 @@ typedef struct lz4amd_dec_params {
 #define LZ4AMD_HINT_EVERY_MAX 16u            /* sequences between two rows of a table lz4amd_k_compress writes, at most (data of fewer than 32 bytes
                                               * per sequence; 8 and fewer otherwise: about a row per 512 bytes) */
 #define LZ4AMD_HINT_EVERY_LOG2 4u
+#define LZ4AMD_CHAIN_BYTES(n) (((size_t)(n) + 1u) * 8u + (size_t)(n) * (4u + 16u + 4u + 4u))
+#define LZ4AMD_CHAIN_RESET_BYTES(n) (((size_t)(n) + 1u) * 8u + (size_t)(n) * (4u + 16u))      /* what a launch sets to "not known yet": words, lowref, carry */
+#define LZ4AMD_CHAIN_LOWREF(chain, n) ((uint32_t*)((long long*)(chain) + (size_t)(n) + 1u))
+#define LZ4AMD_CHAIN_CARRY(chain, n) (LZ4AMD_CHAIN_LOWREF(chain, n) + (size_t)(n))
+#define LZ4AMD_CHAIN_GATE(chain, n) (LZ4AMD_CHAIN_CARRY(chain, n) + 4u * (size_t)(n))
+#define LZ4AMD_CHAIN_CARRIED 0xFFFFFFFDu       /* carry[b][0] of a block that was decoded from its twin's record table */
+#define LZ4AMD_CHAIN_TWIN(chain, n) (LZ4AMD_CHAIN_GATE(chain, n) + (size_t)(n))
 typedef struct lz4amd_hint_entry { uint32_t tok_ord, out; } lz4amd_hint_entry;
 
 /* Linked blocks decoded side by side (kernels/chain_spec_kernel.h).  The chain is cut in UNITS of `group` consecutive blocks (the last one may be
- * shorter).  Unit 0 is decoded in place; unit u >= 1 three times, against three made-up 64 KB histories, into
+ * shorter).  Unit 0 is decoded in place; unit u >= 1 against made-up 64 KB histories A, B (and C, if it has to be), into
  * slots[(3 * (u - 1) + v) * slot_stride + 65536] - each copy a run of dependent blocks of ONE launch of lz4amd_k_decompress (lz4amd_dec_params.chain).
  * spec_result: the results of that launch - entries 0 .. len(0) - 1: unit 0's blocks; len(0) + (u - 1) * 3 * group + v * len(u) + j: block j of
- * unit u, variant v. */
+ * unit u, variant v = 0 (A), 1 (B), 2 (C: gated on what A's first block reports, lz4amd_dec_params.chain - its blocks answer -1 when the unit
+ * does not need it); lowref: that launch's lowref words. */
 typedef struct lz4amd_spec_params {
     uint32_t n, prefix0;            /* blocks of the chain; bytes of data right before out (<= 64 KB used) */
     uint32_t group, n_units;
     uint8_t* out;                   /* where block 0 starts; unit u at out + start[u] */
     uint8_t* slots; uint64_t slot_stride;
     const int32_t* spec_result;
+    const uint32_t* lowref;
     long long* start;               /* [n_units] output bytes before unit u */
     int32_t* size;                  /* [n_units] decoded bytes of the unit's blocks up to its first bad one */
     int32_t* lastdep;               /* [n_units] last byte of the unit that is a copy of a history byte, -1: none */
     int32_t* badpos;                /* [n_units] first byte of the unit that refers to data before the start (lz4.c:2356), INT32_MAX: none */
+    uint8_t* three;                 /* [n_units] != 0: the unit needs variant C */
     long long* done;                /* [n_units] != 0: the unit's bytes are final */
     uint32_t* info;                 /* [0] units to put together (the first one with a bad block is the last), [1] ticket counter */
     int32_t* result;                /* [n] decoded size per block, -1 from the first failure on */

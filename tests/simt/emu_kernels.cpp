@@ -58,7 +58,8 @@ extern "C" int emu_decompress_chained(const uint8_t* const* src, const int32_t* 
     uint64_t stride = (dec_scratch_bytes(max_c, max_cap) + 15) & ~15ull;
     std::vector<uint8_t> scratch((size_t)(stride * grid + 64));
     std::vector<uint8_t*> dsts(n ? n : 1, dst0);
-    std::vector<long long> chain(n + 1, -1); chain[0] = 0;
+    std::vector<long long> chain(LZ4AMD_CHAIN_BYTES(n) / 8, -1); chain[0] = 0;       // (the words, what the blocks report, the gates: lz4amd_params.h)
+    memset(LZ4AMD_CHAIN_GATE(chain.data(), n), 0, (size_t)n * 8);
     std::vector<int32_t> pre(n ? n : 1, initial_prefix);
     uint32_t ticket = 0;
     DecBatch P = {};

@@ -62,6 +62,8 @@ static inline void st_global16_raw(uint8_t* p, const lz4amd_u32x4& v) { memcpy(p
 static inline uint64_t ld_u64_g(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 static inline void st_global8_raw(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
 static inline uint64_t clock_ticks() { return 0; }
+static inline uint32_t flag_load_agent(const uint32_t* w) { return __atomic_load_n(w, __ATOMIC_RELAXED); }
+static inline void flag_store_agent(uint32_t* w, uint32_t v) { __atomic_store_n(w, v, __ATOMIC_RELAXED); }
 static inline uint32_t take_ticket(uint32_t* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED); }
 static inline uint32_t wave_readlane(uint32_t v, uint32_t l) { return (uint32_t)__shfl((int)v, (int)l); }
 static inline uint32_t wave_incl_sum_u32(uint32_t v) {

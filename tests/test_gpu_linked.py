@@ -16,8 +16,11 @@ from test_gpu_frame import L, compress_frame  # noqa: E402,F401
 from test_kernels_emulated import _frame_blocks  # noqa: E402
 
 
-def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False):
-    """-> (results, output bytes).  blocks: [(stored?, payload)]"""
+LAST_STATS = {}
+
+
+def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False, twins=None):
+    """-> (results, output bytes).  blocks: [(stored?, payload)].  LAST_STATS: lz4amd_plan_chain_stats of the last side-by-side plan"""
     import lz4_amd
     payloads = [p for _, p in blocks]
     blob = torch.frombuffer(bytearray(b"".join(payloads) + b"\0" * 64), dtype=torch.uint8).cuda()
@@ -29,11 +32,14 @@ def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False):
     old = os.environ.pop("LZ4AMD_CHAIN_SERIAL", None)
     if serial:
         os.environ["LZ4AMD_CHAIN_SERIAL"] = "1"
+    if twins is not None:                                                    # (the plan's own choice otherwise: lz4amd_batch.c)
+        os.environ["LZ4AMD_CHAIN_TWINS"] = "1" if twins else "0"
     try:
         plan = lz4_amd.Plan.chained(ctx, [blob.data_ptr() + o for o in offs], [len(p) for p in payloads], out.data_ptr() + at,
                                     [cap] * len(payloads), stored=None if drop_stored else [r for r, _ in blocks], initial_prefix=len(history))
     finally:
         os.environ.pop("LZ4AMD_CHAIN_SERIAL", None)
+        os.environ.pop("LZ4AMD_CHAIN_TWINS", None)
         if old is not None:
             os.environ["LZ4AMD_CHAIN_SERIAL"] = old
     res = None
@@ -42,6 +48,10 @@ def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False):
         r = plan.results(torch.cuda.current_stream().cuda_stream)
         assert res is None or r == res
         res = r
+    if not serial:
+        LAST_STATS.clear()
+        try: LAST_STATS.update(plan.chain_stats())
+        except RuntimeError: pass                                            # (a chain of one unit decodes block after block)
     plan.close()
     good = sum(r for r in res if r > 0) if all(r >= 0 for r in res) else sum(res[:[i for i, r in enumerate(res) if r < 0][0]])
     host = out.cpu().numpy().tobytes()
@@ -50,10 +60,12 @@ def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False):
 
 
 def both(ctx, blocks, cap, data, history=b""):
+    """the serial chain, side by side with twins (a block's two copies decoded by one workgroup from one record table) and without"""
     rs, os_ = run_chain(ctx, blocks, cap, len(data), True, history)
-    rp, op = run_chain(ctx, blocks, cap, len(data), False, history)
-    assert rs == rp
-    assert os_ == data and op == data
+    rt, ot = run_chain(ctx, blocks, cap, len(data), False, history, twins=True)
+    rp, op = run_chain(ctx, blocks, cap, len(data), False, history, twins=False)
+    assert rs == rp == rt
+    assert os_ == data and op == data and ot == data
     return rp
 
 
@@ -66,6 +78,7 @@ def linked_blocks(L, data, bsid, level=0):
 
 def test_side_by_side_equals_the_serial_chain(ctx, L, datagen):
     rng = random.Random(5)
+    noise = rng.randbytes((4 << 20) + 100000)
     cases = [
         (datagen(3 << 20, 60, 1), 4),                                          # 64 KB blocks: every block's history is the whole block before
         (datagen(5 << 20, 50, 2), 5),                                          # 256 KB
@@ -74,12 +87,20 @@ def test_side_by_side_equals_the_serial_chain(ctx, L, datagen):
         (b"a" * (1 << 20) + b"abcdefg" * 100000 + bytes(range(256)) * 4000, 4),      # every byte a copy of a byte of the first block, period 1 / 7 / 256
         (datagen(200000, 60, 6) + rng.randbytes(150000) + datagen(300000, 60, 7) + rng.randbytes(70000) + datagen(100000, 50, 8), 4),   # stored blocks in the chain
         (datagen(70000, 60, 9), 4),                                            # two blocks
+        # a block that begins with a copy from the far end of its 64 KB (offsets above 65280 in a unit's first 255 bytes: the one case that needs
+        # the third made-up history), 64 KB blocks and 4 MB blocks
+        (noise[:65536] + noise[200:1200] + noise[70000:90000] + noise[66000:66300] * 50, 4),
+        (noise[:4 << 20] + noise[(4 << 20) - 65535 + 3:(4 << 20) - 65000] * 3 + datagen(1 << 20, 60, 12), 7),
     ]
+    thirds = []
     for data, bsid in cases:
         blocks = linked_blocks(L, data, bsid)
         cap = {4: 65536, 5: 262144, 6: 1 << 20, 7: 4 << 20}[bsid]
         res = both(ctx, blocks, cap, data)
         assert all(r > 0 for r in res) and sum(res) == len(data)
+        thirds.append(LAST_STATS.get("units_decoded_three_times", 0))
+    # the third decode is the exception (gated: lz4amd_dec_params.chain; chains that do need it: test_gated_third_decode_of_ragged_chains)
+    assert thirds[0] == 0 and thirds[1] == 0, thirds
     # HC-compressed linked blocks (matches just behind the write position, and far ones)
     data = datagen(1 << 20, 70, 11)
     both(ctx, linked_blocks(L, data, 4, level=9), 65536, data)
@@ -94,11 +115,11 @@ def test_side_by_side_with_history_in_front_and_batches_that_start_anywhere(ctx,
         res = both(ctx, blocks[first:first + 6], 65536, data[lo:lo + 6 * 65536], history=h)
         assert res == [65536] * 6
     # less history than the blocks refer to: the chain fails at its first block, both ways (lz4.c:2356)
-    for serial in (True, False):
-        res, _ = run_chain(ctx, blocks[3:6], 65536, 3 * 65536, serial, history=data[3 * 65536 - 100:3 * 65536])
-        assert all(r < 0 for r in res), (serial, res)
-        res, _ = run_chain(ctx, blocks[3:6], 65536, 3 * 65536, serial)
-        assert all(r < 0 for r in res), (serial, res)
+    for serial, tw in ((True, None), (False, True), (False, False)):
+        res, _ = run_chain(ctx, blocks[3:6], 65536, 3 * 65536, serial, history=data[3 * 65536 - 100:3 * 65536], twins=tw)
+        assert all(r < 0 for r in res), (serial, tw, res)
+        res, _ = run_chain(ctx, blocks[3:6], 65536, 3 * 65536, serial, twins=tw)
+        assert all(r < 0 for r in res), (serial, tw, res)
 
 
 def test_side_by_side_small_blocks_and_errors(ctx, L, datagen):
@@ -124,7 +145,63 @@ def test_side_by_side_small_blocks_and_errors(ctx, L, datagen):
     assert res == [len(s) for s in srcs]
     # a damaged block in the middle ends the chain there, the blocks before it stand
     bad = list(blocks); bad[40] = (False, bad[40][1][:-5])
-    for serial in (True, False):
-        res, out = run_chain(ctx, bad, bs, len(data), serial)
-        assert res[:40] == [bs] * 40 and all(r < 0 for r in res[40:]), serial
+    for serial, tw in ((True, None), (False, True), (False, False)):
+        res, out = run_chain(ctx, bad, bs, len(data), serial, twins=tw)
+        assert res[:40] == [bs] * 40 and all(r < 0 for r in res[40:]), (serial, tw)
         assert out == data[:40 * bs]
+
+
+def _len_bytes(n):
+    out = b""
+    while n >= 255: out += b"\xff"; n -= 255
+    return out + bytes([n])
+
+
+def _block(lits0, match, lits1):
+    """A hand-made LZ4 block: lits0, one match (offset, length) or None, lits1 as the final literals (>= 12 bytes behind a match: lz4.c:2170)"""
+    out = b""
+    if match:
+        off, ml = match
+        out += bytes([(min(len(lits0), 15) << 4) | min(ml - 4, 15)]) + (_len_bytes(len(lits0) - 15) if len(lits0) >= 15 else b"") + lits0
+        out += bytes([off & 255, off >> 8]) + (_len_bytes(ml - 4 - 15) if ml - 4 >= 15 else b"")
+    else:
+        lits1 = lits0 + lits1
+    return out + bytes([min(len(lits1), 15) << 4]) + (_len_bytes(len(lits1) - 15) if len(lits1) >= 15 else b"") + lits1
+
+
+def test_gated_third_decode_of_ragged_chains(ctx):
+    """Chains of blocks of any size (hand-made blocks): a unit of the side-by-side decode is as many blocks as make 1 MiB of capacity.  A unit's
+    third decode is gated on what the first block of its first decode reports - unless that block is so small that a later one could begin
+    within the unit's first 255 bytes and read the far end of the 64 KB itself: then nobody is asked."""
+    rng = random.Random(77)
+    cap = 65536                                                              # -> units of 16 blocks
+    noise = rng.randbytes(16 * cap)
+    S = 16 * cap
+    for head, far_at, want_third in ((100, 100, 1), (600, 10, 1), (600, None, 0), (100, None, 0), (600, 700, 0)):
+        # unit 1 starts at S with a block of `head` bytes; 40 bytes at unit position far_at stand 65526 bytes back: in the unit's first 255 bytes
+        # they are a copy of one of the first 256 bytes of the unit's 64 KB (in the second block when head = 100), at 700 they are not
+        tail = rng.randbytes(3 * cap - 1000)
+        blocks = [(False, _block(noise[i * cap:(i + 1) * cap], None, b"")) for i in range(16)]
+        data = bytearray(noise)
+        hb = rng.randbytes(head)
+        if far_at is not None and far_at < head:
+            pre, post = hb[:far_at], hb[far_at + 40:]
+            blocks.append((False, _block(pre, (65526, 40), post))); data += pre; data += data[len(data) - 65526:len(data) - 65526 + 40]; data += post
+        else:
+            blocks.append((False, _block(hb, None, b""))); data += hb
+        if far_at is not None and far_at >= head:
+            pre = rng.randbytes(far_at - head)
+            blocks.append((False, _block(pre, (65526, 40), tail[:cap - len(pre) - 40]))); data += pre; data += data[len(data) - 65526:len(data) - 65526 + 40]; data += tail[:cap - len(pre) - 40]
+        else:
+            blocks.append((False, _block(tail[:cap], None, b""))); data += tail[:cap]
+        # a block that copies from the blocks before it (the unit's bytes depend on the history all along), and a last short one
+        blocks.append((False, _block(b"abc", (30000, 50000), tail[:1000]))); data += b"abc"
+        for _ in range(50000): data.append(data[len(data) - 30000])
+        data += tail[:1000]
+        blocks.append((False, _block(b"", (65535, 20), b"the end of it")));
+        for _ in range(20): data.append(data[len(data) - 65535])
+        data += b"the end of it"
+        data = bytes(data)
+        res = both(ctx, blocks, cap, data)
+        assert sum(res) == len(data) and all(r > 0 for r in res)
+        assert LAST_STATS["units"] == 2 and LAST_STATS["units_decoded_three_times"] == want_third, (head, far_at, LAST_STATS)

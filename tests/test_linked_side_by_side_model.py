@@ -1,7 +1,9 @@
 """The idea behind lz4_amd/csrc/kernels/chain_spec_kernel.h, checked on the CPU with the oracle's decoder (no GPU, no product code):
-a byte of LZ4 output is a copy of exactly one earlier byte, so a linked block (lz4frame.c:1901-1915) decoded against three made-up
-64 KB histories - byte i = i & 0xFF, i >> 8, ~i & 0xFF - tells for every output byte whether it comes from the history (A != C) and from
-which byte of it ({B, A}); putting the real history's bytes there gives the block as decoded behind its real predecessors.  The blocks are
+a byte of LZ4 output is a copy of exactly one earlier byte, so a linked block (lz4frame.c:1901-1915) decoded against made-up
+64 KB histories - byte i (lo = i & 0xFF, hi = i >> 8): A = lo, B = lo + (255 - hi) + 1 mod 256, C = ~lo - tells for every output byte whether it
+comes from the history (A != B - or, for the first 256 bytes of the 64 KB, where B = A: A != C) and from which byte of it ({255 - (B - A - 1), A});
+putting the real history's bytes there gives the block as decoded behind its real predecessors.  Which blocks need C is what the product asks
+its decoder (lowref): here it is computed from all three.  The blocks are
 those of a linked frame written by the reference's CLI (tests/golden) and of frames the oracle writes."""
 import ctypes
 import hashlib
@@ -14,7 +16,8 @@ from test_kernels_emulated import _frame_blocks
 
 HIST = 65536
 I = np.arange(HIST, dtype=np.uint32)
-MADE_UP = [(I & 0xFF).astype(np.uint8), (I >> 8).astype(np.uint8), (~I & 0xFF).astype(np.uint8)]
+MADE_UP = [(I & 0xFF).astype(np.uint8), (((I & 0xFF) + (255 - (I >> 8)) + 1) & 0xFF).astype(np.uint8), (~I & 0xFF).astype(np.uint8)]
+NEEDED_C = []
 
 
 def decode_against(oracle, payload, cap, history):
@@ -40,8 +43,12 @@ def side_by_side(oracle, blocks, cap):
             continue
         (ra, a), (rb, b), (rc, c) = (decode_against(oracle, payload, cap, h.tobytes()) for h in MADE_UP)
         assert ra == rb == rc and ra >= 0                                     # the sizes do not depend on what the history holds
-        dep = a != c
-        idx = (b.astype(np.int64) << 8) | a
+        dep = a != c                                                          # C differs from A in every byte of the history
+        two = a != b                                                          # ... B in all but the first 256
+        assert not (two & ~dep).any()
+        idx = ((255 - ((b.astype(np.int64) - a.astype(np.int64) - 1) & 0xFF)) << 8) | a
+        assert (idx[dep & ~two] < 256).all()                                  # what only C finds are copies of the first 256 bytes of the 64 KB
+        NEEDED_C.append(bool((dep & ~two).any()))
         back = HIST - idx[dep]                                                # 1 .. 65536 bytes before the block
         assert (back <= len(out)).all()                                       # (lz4.c:2356 otherwise)
         blk = a.copy()

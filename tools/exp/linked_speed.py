@@ -28,4 +28,6 @@ for mode in ("serial", "side by side"):
     res = dplan.results(s)
     ok = res == [bs] * nb and torch.equal(out[:nb * bs], src[:nb * bs])
     print("%-13s %d x %d KiB P%d: %.3f ms  %.1f GB/s out  plan %.1f ms  ratio %.3f  exact %s" % (mode, nb, bk, pct, best, nb * bs / best / 1e6, tc * 1e3, nb * bs / sum(cs), ok))
+    try: print("   ", dplan.chain_stats())
+    except Exception as e: print("   ", e)
     dplan.close()
