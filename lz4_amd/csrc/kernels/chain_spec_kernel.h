@@ -13,7 +13,9 @@
 // above 65280 read those; every block reports whether it has one (lz4amd_dec_params.lowref), and only such units are decoded a third
 // time, against C, which differs from A in every byte: the run of variant C is GATED on what the first block of variant A reports
 // (lz4amd_dec_params.gate; tickets: A's blocks, then C's, then B's - a run that is not wanted costs a look at a flag).  A unit whose first
-// block is so small that a later one could begin within those 255 bytes is decoded three times without asking.  (Two histories cannot
+// block is so small that a later one could begin within those 255 bytes is decoded three times without asking.  Chains of large blocks (a unit = one
+// block): A's decode writes the block's entry-point table on its way (lz4amd_dec_params.hint_make), and B is decoded by a SECOND launch - the
+// ordinary kernel over independent blocks with 64 KB in front - from those tables, without the decoder's first stage (spec_result_b).  (Two histories cannot
 // tell all 65 536 positions and "no history" apart: two bytes that differ are 65 280 pairs.)  What follows is bandwidth work:
 //   spec_scan     sizes -> output positions (the decoded sizes do not depend on the history's content); the first unit with a bad block; which
 //                 units were decoded against C
@@ -45,7 +47,7 @@ __device__ __forceinline__ uint32_t spec_entry(const SpecBatch& P, uint32_t u, u
 __device__ __forceinline__ int32_t spec_block_size(const SpecBatch& P, uint32_t u, uint32_t j) {
     const int32_t a = P.spec_result[spec_entry(P, u, 0, j)];
     if (u == 0) return a;
-    const int32_t b = P.spec_result[spec_entry(P, u, 1, j)];
+    const int32_t b = P.spec_result_b ? P.spec_result_b[2 * (u - 1)] : P.spec_result[spec_entry(P, u, 1, j)];      // (a second launch: units of one block)
     return (a >= 0 && a == b) ? a : -1;
 }
 // ---- the made-up histories.  grid: 3 * (n_units - 1) * kSpecFillParts workgroups of kSpecThreads
@@ -66,6 +68,25 @@ __device__ __forceinline__ void spec_fill_body(const SpecBatch& P) {
         w[q] = x;
     }
     st_global16_raw(base + i0, w);
+}
+
+// ---- chains of large blocks, between the two launches: unit u's table (A's decode wrote it) goes to the entries of its B and C in the second
+//      launch; C is wanted only if A's block reports a match that reads the first 256 bytes of the 64 KB (source size 0: the block answers -1 at once).
+//      grid: n_units - 1 workgroups of kSpecThreads
+__device__ __forceinline__ void spec_gate_body(const SpecBatch& P) {
+    const uint32_t u = blockIdx.x + 1, tid = threadIdx.x;
+    const uint32_t a = spec_entry(P, u, 0, 0);
+    const bool three = P.lowref[a] == 1u;
+    const lz4amd_u32x4* src = (const lz4amd_u32x4*)(P.tables_a + (uint64_t)a * P.table_stride);
+    lz4amd_u32x4* db = (lz4amd_u32x4*)(P.tables_b + (uint64_t)(2 * (u - 1)) * P.table_stride);
+    lz4amd_u32x4* dc = (lz4amd_u32x4*)(P.tables_b + (uint64_t)(2 * (u - 1) + 1) * P.table_stride);
+    const lz4amd_u32x4 h0 = src[0], h1 = src[1];                      // { magic, output bytes, compressed bytes, sequences }, { rows, 0, 0, 0 }
+    uint64_t bytes = 0;                                                // (no table: the copies say so too)
+    if (h0[0] == LZ4AMD_HINT_MAGIC && LZ4AMD_HINT_HEAD + ((uint64_t)h1[0] + 1) * LZ4AMD_HINT_ROW <= P.table_stride) bytes = LZ4AMD_HINT_HEAD + ((uint64_t)h1[0] + 1) * LZ4AMD_HINT_ROW;
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (n16 == 0) { if (tid == 0) { lz4amd_u32x4 z = {0, 0, 0, 0}; db[0] = z; dc[0] = z; } }
+    for (uint32_t i = tid; i < n16; i += kSpecThreads) { const lz4amd_u32x4 v = src[i]; db[i] = v; if (three) dc[i] = v; }
+    if (tid == 0) { P.b_src_size[2 * (u - 1)] = P.src_size[u]; P.b_src_size[2 * (u - 1) + 1] = three ? P.src_size[u] : 0; }
 }
 
 // ---- sizes and positions.  ONE workgroup of kSpecScanThreads
@@ -257,7 +278,7 @@ __device__ __forceinline__ void spec_results_body(const SpecBatch& P) {
         const uint32_t u = b / G, j = b % G;
         const int32_t sz = spec_block_size(P, u, j);
         // (a unit's third decode answers like the other two)
-        if (sz < 0 || (u >= 1 && u < P.info[0] && P.three[u] && P.spec_result[spec_entry(P, u, 2, j)] != sz)) atomicMin(&first_bad, b);
+        if (sz < 0 || (u >= 1 && u < P.info[0] && P.three[u] && (P.spec_result_b ? P.spec_result_b[2 * (u - 1) + 1] : P.spec_result[spec_entry(P, u, 2, j)]) != sz)) atomicMin(&first_bad, b);
     }
     for (uint32_t u = t; u < P.n_units; u += kSpecScanThreads) {
         const int32_t bp = P.badpos[u];

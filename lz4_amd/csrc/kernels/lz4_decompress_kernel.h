@@ -1419,7 +1419,8 @@ __device__ __forceinline__ bool decode_one_block(const DecBatch& P, uint32_t b, 
     //      entry-point table, for the next decode of the same block.
     lz4amd_gdst make = nullptr;
     uint32_t make_rows = 0;
-    if (!hint && ok && !stored && !chained && P.hint_make && P.hints && P.hint_stride >= 48) {
+    // (lz4amd_k_decompress_runs: a run of ONE block may write its table too - kernels/chain_spec_kernel.h has the block decoded again, from the table)
+    if (!hint && ok && !stored && (!chained || (kRuns && chain_run_head(P, b) && chain_run_tail(P, b))) && P.hint_make && P.hints && P.hint_stride >= 48) {
         make = LZ4AMD_TO_GDST((uint8_t*)P.hints + (uint64_t)b * P.hint_stride);
         make_rows = LZ4AMD_HINT_CAP_ROWS(P.hint_stride);
         if (tid == 0) *(uint32_t*)make = 0;                      // (no table until it is whole)

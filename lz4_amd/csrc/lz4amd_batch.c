@@ -89,7 +89,7 @@ void lz4amd_plan_destroy(lz4amd_plan* p)
     int i;
     if (!p) return;
     if (p->ctx) (void)lz4amd_hip_use_device(p->ctx->device);
-    lz4amd_plan_destroy(p->inner);
+    lz4amd_plan_destroy(p->inner); lz4amd_plan_destroy(p->inner_b);
     for (i = 0; i < LZ4AMD_PLAN_MAX_BUFS; i++) lz4amd_hip_free(p->bufs[i]);
     for (i = 0; i < 5; i++) lz4amd_hip_event_destroy(p->ev[i]);
     free(p);
@@ -289,7 +289,8 @@ static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
     const void** esrc = NULL; void** edst = NULL; int *esz = NULL, *ecap = NULL, *epre = NULL; unsigned char* efl = NULL; unsigned *ord = NULL, *gate = NULL, *twin = NULL;
     unsigned max_cap = 0;
     size_t nt_pad = 0;
-    int err = 0, nb = 0, i, rc, twins;
+    int err = 0, nb = 0, i, rc, twins, tables;
+    size_t hstride = 0;
     lz4amd_spec_params* q;
     for (i = 0; i < n; i++) {
         if (dst_caps[i] <= 0) return LZ4AMD_E_ARG;
@@ -307,11 +308,20 @@ static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
     if (nu < 2) return LZ4AMD_E_ARG;
     len0 = G < un ? G : un;
     ne = len0 + 3 * (un - len0);
+    {   /* chains of large blocks (a unit = one block, none of them stored): A's decode writes the block's entry-point table, B is decoded by a second
+         * launch from it, without the decoder's first stage (kernels/chain_spec_kernel.h) */
+        const char* tb = getenv("LZ4AMD_CHAIN_TABLES");
+        tables = tb ? atoi(tb) != 0 : 2 * (nu - 1) + 1 > (size_t)ctx->n_cus;      /* (a chain whose two copies per block find a CU each decodes them at once: 64 x 4 MiB 2.8 against 4.1 ms) */
+        if (G != 1) tables = 0;
+        for (i = (int)len0; tables && stored && i < n; i++) if (stored[i]) tables = 0;
+        for (i = (int)len0; tables && i < n; i++) if ((unsigned)src_sizes[i] >= LZ4AMD_HINT_MAX_CSIZE) tables = 0;
+    }
     {   /* twins (lz4amd_dec_params.chain): A's and B's copy of a block decoded by one workgroup, stage A once.  Measured: pays for blocks
          * of up to 512 KB when the runs outnumber the CUs (4096 x 64 KiB: 4.7 -> 3.7 ms); a 4 MiB block's second copy stage finds neither its records nor
          * its compressed bytes in the L2 any more and takes longer than a whole decode (3.87 -> 4.07 ms), and a short chain has CUs to spare */
         const char* tw = getenv("LZ4AMD_CHAIN_TWINS");
         twins = tw ? atoi(tw) != 0 : (G > 1 && 2 * (nu - 1) >= (size_t)ctx->n_cus);
+        if (tables) twins = 0;
     }
     stride = (65536u + G * (size_t)max_cap + 64u + 255u) & ~(size_t)255u;
     {   const char* lim = getenv("LZ4AMD_CHAIN_SLOTS_MB");                     /* (the slots' budget: 64 GiB of the 288) */
@@ -365,7 +375,7 @@ static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
         }
         for (j = 0; j < G; j++) {
             if (j < len0) ord[t++] = (unsigned)j;
-            for (v = 0; v < (twins ? 2u : 3u); v++)
+            for (v = 0; v < (tables ? 1u : twins ? 2u : 3u); v++)
                 for (u = 1; u < nu; u++) {
                     const size_t lenu = un - u * G < G ? un - u * G : G;
                     if (j < lenu) ord[t++] = (unsigned)(len0 + (u - 1) * 3 * G + by_ticket[v] * lenu + j);
@@ -373,14 +383,14 @@ static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
         }
         /* B's blocks have no tickets: each is the TWIN of A's block over the same bytes, decoded by the same workgroup right behind it, from the
          * same record table */
+        if (twins || tables) while (t < ne) { ord[t++] = 0xFFFFFFFFu; nt_pad++; }      /* B's blocks (tables: C's too) have no tickets in this launch */
         if (twins) {
             for (u = 1; u < nu; u++) {
                 const size_t lenu = un - u * G < G ? un - u * G : G, a0 = len0 + (u - 1) * 3 * G;
                 for (j = 0; j < lenu; j++) twin[a0 + j] = (unsigned)(a0 + lenu + j + 1);
             }
-            while (t < ne) { ord[t++] = 0xFFFFFFFFu; nt_pad++; }
         }
-        if (e != ne || t != ne || nt_pad != (twins ? un - len0 : 0)) err = LZ4AMD_E_RUNTIME;
+        if (e != ne || t != ne || nt_pad != (tables ? 2 * (un - len0) : twins ? un - len0 : 0)) err = LZ4AMD_E_RUNTIME;
     }
     if (!err) {
         rc = chained_runs_create(ctx, &p->inner, (int)ne, esrc, esz, edst, ecap, efl, epre);
@@ -390,6 +400,39 @@ static int chained_spec_create(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
         p->inner->dec.order = (const uint32_t*)plan_add_array(p->inner, ord, ne * sizeof *ord, &err);
         if (!err && (lz4amd_hip_h2d(LZ4AMD_CHAIN_GATE(p->inner->dec.chain, ne), gate, ne * sizeof *gate, NULL)
                      || lz4amd_hip_h2d(LZ4AMD_CHAIN_TWIN(p->inner->dec.chain, ne), twin, ne * sizeof *twin, NULL) || lz4amd_hip_sync(NULL))) err = LZ4AMD_E_RUNTIME;
+    }
+    if (!err && tables) {
+        /* the first launch's tables: room for one per entry (only A's and unit 0's are written); the second launch: entries 2 k (B) and 2 k + 1 (C) of
+         * unit k + 1, independent blocks with 64 KB in front, tables of their own that spec_gate fills from A's */
+        size_t k, nB = un - len0;
+        uint8_t *T, *T2 = NULL;
+        hstride = lz4amd_hint_bytes((int)max_cap);
+        T = (uint8_t*)plan_add_array(p->inner, NULL, hstride * ne, &err);
+        if (!err) T2 = (uint8_t*)plan_add_array(p->inner, NULL, hstride * 2 * nB, &err);
+        if (!err && (lz4amd_hip_memset(T, 0, hstride * ne, NULL) || lz4amd_hip_memset(T2, 0, hstride * 2 * nB, NULL))) err = LZ4AMD_E_RUNTIME;
+        if (!err) q->src_size = (const int32_t*)plan_add_array(p->inner, src_sizes, un * sizeof(int), &err);
+        if (!err) {
+            const void** bsrc = (const void**)malloc(2 * nB * sizeof *bsrc); void** bdst = (void**)malloc(2 * nB * sizeof *bdst);
+            int *bsz = (int*)malloc(2 * nB * sizeof *bsz), *bcap = (int*)malloc(2 * nB * sizeof *bcap), *bpre = (int*)malloc(2 * nB * sizeof *bpre);
+            p->inner->dec.hints = T; p->inner->dec.hint_stride = hstride; p->inner->dec.hint_make = 1u;
+            if (!bsrc || !bdst || !bsz || !bcap || !bpre) err = LZ4AMD_E_MEMORY;
+            for (k = 0; !err && k < nB; k++) {
+                const size_t e1 = len0 + 3 * k + 1;
+                bsrc[2 * k] = bsrc[2 * k + 1] = esrc[e1]; bsz[2 * k] = bsz[2 * k + 1] = esz[e1]; bcap[2 * k] = bcap[2 * k + 1] = ecap[e1];
+                bdst[2 * k] = edst[e1]; bdst[2 * k + 1] = edst[e1 + 1]; bpre[2 * k] = bpre[2 * k + 1] = 65536;
+            }
+            if (!err) {
+                rc = plan_create_with_prefix(ctx, &p->inner_b, LZ4AMD_OP_DECOMPRESS, (int)(2 * nB), bsrc, bsz, bdst, bcap, bpre, 0);
+                if (rc) err = rc;
+                else if (lz4amd_plan_attach_hints(p->inner_b, T2, hstride)) err = LZ4AMD_E_MEMORY;
+                else {
+                    q->spec_result_b = (const int32_t*)p->inner_b->d_results;
+                    q->tables_a = T; q->tables_b = T2; q->table_stride = hstride;
+                    q->b_src_size = (int32_t*)p->inner_b->dec.src_size;            /* (written by spec_gate before the second launch reads it) */
+                }
+            }
+            free(bsrc); free(bdst); free(bsz); free(bcap); free(bpre);
+        }
     }
     free(esrc); free(edst); free(esz); free(ecap); free(epre); free(efl); free(ord); free(gate); free(twin);
     if (!err) {
@@ -476,6 +519,11 @@ int lz4amd_plan_chain_stats(lz4amd_plan* p, unsigned long long out[4])
     (void)lz4amd_hip_use_device(p->ctx->device);
     if (!rc && (lz4amd_hip_d2h(ld, p->spec.lastdep, nu * sizeof *ld, NULL) || lz4amd_hip_d2h(sz, p->spec.size, nu * sizeof *sz, NULL)
                 || lz4amd_hip_d2h(th, p->spec.three, nu, NULL) || lz4amd_hip_sync(NULL))) { lz4amd_set_error(lz4amd_hip_errstr()); rc = LZ4AMD_E_RUNTIME; }
+    if (!rc && getenv("LZ4AMD_CHAIN_DEBUG") && p->inner_b) {
+        unsigned u2[2] = {0, 0};
+        (void)lz4amd_plan_hint_stats(p->inner_b, &u2[0], &u2[1]);
+        fprintf(stderr, "lz4amd: second copies decoded from the first ones' tables: %u, tables rejected: %u (all launches)\n", u2[0], u2[1]);
+    }
     if (!rc && getenv("LZ4AMD_CHAIN_DEBUG")) {          /* developer aid: blocks decoded from their twin's record table */
         size_t ne = p->inner->dec.n_blocks, cnt = 0;
         uint32_t* cw = (uint32_t*)malloc(ne * 16);
@@ -519,7 +567,7 @@ int lz4amd_plan_set_acceleration(lz4amd_plan* p, int acceleration)
 
 static int launch_stage(lz4amd_plan* p, int stage, void* stream)
 {
-    if (p->inner) return stage == 0 ? lz4amd_hip_launch_spec(&p->spec, &p->inner->dec, p->inner->grid, p->spec_max_cap, stream) : 0;
+    if (p->inner) return stage == 0 ? lz4amd_hip_launch_spec(&p->spec, &p->inner->dec, p->inner->grid, p->inner_b ? &p->inner_b->dec : NULL, p->inner_b ? p->inner_b->grid : 0u, p->spec_max_cap, stream) : 0;
     if (p->op == LZ4AMD_OP_DECOMPRESS)
         return stage == 0 ? lz4amd_hip_launch_decompress(&p->dec, p->grid, stream) : 0;
     if (p->op == LZ4AMD_OP_XXH32) return stage == 0 ? lz4amd_hip_launch_xxh32(&p->xxh, stream) : 0;

@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(256) lz4amd_k_gather(lz4amd_gather_params p) {
 
 __global__ void __launch_bounds__(kSpecThreads) lz4amd_k_spec_fill(lz4amd_spec_params p) { spec_fill_body(p); }
 __global__ void __launch_bounds__(kSpecScanThreads) lz4amd_k_spec_scan(lz4amd_spec_params p) { spec_scan_body(p); }
+__global__ void __launch_bounds__(kSpecThreads) lz4amd_k_spec_gate(lz4amd_spec_params p) { spec_gate_body(p); }
 __global__ void __launch_bounds__(kSpecThreads) lz4amd_k_spec_merge(lz4amd_spec_params p) { spec_merge_body(p); }
 __global__ void __launch_bounds__(kSpecPatchThreads) lz4amd_k_spec_patch(lz4amd_spec_params p) { spec_patch_body(p); }
 __global__ void __launch_bounds__(kSpecScanThreads) lz4amd_k_spec_results(lz4amd_spec_params p) { spec_results_body(p); }
@@ -168,9 +169,14 @@ extern "C" int lz4amd_hip_launch_spec_fill(const lz4amd_spec_params* p, void* s)
     return 0;
 }
 // ... and per launch: the decoder over unit 0 and variants A, B (C where it is needed) of every other unit, positions, merge, patch, results
-extern "C" int lz4amd_hip_launch_spec(const lz4amd_spec_params* p, const lz4amd_dec_params* dec, unsigned dec_grid, unsigned max_cap, void* s) {
+extern "C" int lz4amd_hip_launch_spec(const lz4amd_spec_params* p, const lz4amd_dec_params* dec, unsigned dec_grid,
+                                      const lz4amd_dec_params* dec_b, unsigned dec_b_grid, unsigned max_cap, void* s) {
     if (!p->n) return 0;
     if (lz4amd_hip_launch_decompress(dec, dec_grid, s)) return -1;
+    if (dec_b) {                          // chains of large blocks: the second (and where needed third) copies, from the tables the first launch wrote
+        hipLaunchKernelGGL(lz4amd_k_spec_gate, dim3(p->n_units - 1), dim3(kSpecThreads), 0, (hipStream_t)s, *p);
+        if (lz4amd_hip_launch_decompress(dec_b, dec_b_grid, s)) return -1;
+    }
     const unsigned slices = (max_cap + kSpecSlice - 1) / kSpecSlice;
     hipLaunchKernelGGL(lz4amd_k_spec_scan, dim3(1), dim3(kSpecScanThreads), 0, (hipStream_t)s, *p);
     hipLaunchKernelGGL(lz4amd_k_spec_merge, dim3(p->n_units, slices ? slices : 1), dim3(kSpecThreads), 0, (hipStream_t)s, *p);

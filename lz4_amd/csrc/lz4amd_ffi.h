@@ -38,7 +38,8 @@ int lz4amd_hip_launch_decompress(const lz4amd_dec_params* p, unsigned grid, void
 int lz4amd_hip_launch_xxh32(const lz4amd_xxh_params* p, void* stream);
 int lz4amd_hip_launch_gather(const lz4amd_gather_params* p, void* stream);
 int lz4amd_hip_launch_spec_fill(const lz4amd_spec_params* p, void* stream);
-int lz4amd_hip_launch_spec(const lz4amd_spec_params* p, const lz4amd_dec_params* dec, unsigned dec_grid, unsigned max_cap, void* stream);
+int lz4amd_hip_launch_spec(const lz4amd_spec_params* p, const lz4amd_dec_params* dec, unsigned dec_grid,
+                           const lz4amd_dec_params* dec_b, unsigned dec_b_grid, unsigned max_cap, void* stream);      /* dec_b: NULL, or the launch of the second copies */
 int lz4amd_hip_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, unsigned grid, unsigned variant, void* stream);   /* variant: granules per thread and trip / non-temporal (lz4amd_device.hip) */
 int lz4amd_hip_launch_compress(const lz4amd_comp_params* p, unsigned grid, void* stream);
 int lz4amd_hip_launch_compress_hc(const lz4amd_hc_params* p, unsigned grid, void* stream);

@@ -27,6 +27,7 @@ struct lz4amd_plan {
     lz4amd_gather_params gather;
     lz4amd_spec_params spec;            /* linked blocks decoded side by side: */
     struct lz4amd_plan* inner;          /* ... the launch of dependent blocks in runs that does the decoding (owned) */
+    struct lz4amd_plan* inner_b;        /* ... chains of large blocks: the second copies, decoded from the tables the first ones' decode wrote (owned; NULL: they are part of `inner`) */
     unsigned spec_max_cap;
     int row0[2];                        /* lz4amd_plan_set_row0: host copy of the sizes in flight */
 };

@@ -89,6 +89,15 @@ typedef struct lz4amd_spec_params {
     uint8_t* out;                   /* where block 0 starts; unit u at out + start[u] */
     uint8_t* slots; uint64_t slot_stride;
     const int32_t* spec_result;
+    /* chains of large blocks (group = 1): variants B and C are decoded by a SECOND launch - independent blocks with 64 KB in front, from the entry-point
+     * tables variant A's decode wrote - whose entry 2 (u - 1) is unit u's B and 2 (u - 1) + 1 its C.  spec_gate (between the launches) copies A's table
+     * to both and sets C's source size to 0 where the unit does not need it.  All NULL / 0 otherwise. */
+    const int32_t* spec_result_b;   /* [2 (n_units - 1)] results of the second launch */
+    const uint8_t* tables_a;        /* the first launch's tables: unit u's (written by A's decode) at tables_a + (len(0) + 3 (u - 1)) * table_stride */
+    uint8_t* tables_b;              /* the second launch's: entry e at tables_b + e * table_stride */
+    uint64_t table_stride;
+    const int32_t* src_size;        /* [n] compressed sizes of the chain's blocks */
+    int32_t* b_src_size;            /* [2 (n_units - 1)] the second launch's source sizes */
     const uint32_t* lowref;
     long long* start;               /* [n_units] output bytes before unit u */
     int32_t* size;                  /* [n_units] decoded bytes of the unit's blocks up to its first bad one */

@@ -19,7 +19,7 @@ from test_kernels_emulated import _frame_blocks  # noqa: E402
 LAST_STATS = {}
 
 
-def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False, twins=None):
+def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False, twins=None, tables=None):
     """-> (results, output bytes).  blocks: [(stored?, payload)].  LAST_STATS: lz4amd_plan_chain_stats of the last side-by-side plan"""
     import lz4_amd
     payloads = [p for _, p in blocks]
@@ -34,12 +34,15 @@ def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False, t
         os.environ["LZ4AMD_CHAIN_SERIAL"] = "1"
     if twins is not None:                                                    # (the plan's own choice otherwise: lz4amd_batch.c)
         os.environ["LZ4AMD_CHAIN_TWINS"] = "1" if twins else "0"
+    if tables is not None:                                                   # (chains of blocks of 1 MiB and more: second copies by a second launch, from tables)
+        os.environ["LZ4AMD_CHAIN_TABLES"] = "1" if tables else "0"
     try:
         plan = lz4_amd.Plan.chained(ctx, [blob.data_ptr() + o for o in offs], [len(p) for p in payloads], out.data_ptr() + at,
                                     [cap] * len(payloads), stored=None if drop_stored else [r for r, _ in blocks], initial_prefix=len(history))
     finally:
         os.environ.pop("LZ4AMD_CHAIN_SERIAL", None)
         os.environ.pop("LZ4AMD_CHAIN_TWINS", None)
+        os.environ.pop("LZ4AMD_CHAIN_TABLES", None)
         if old is not None:
             os.environ["LZ4AMD_CHAIN_SERIAL"] = old
     res = None
@@ -60,12 +63,14 @@ def run_chain(ctx, blocks, cap, total, serial, history=b"", drop_stored=False, t
 
 
 def both(ctx, blocks, cap, data, history=b""):
-    """the serial chain, side by side with twins (a block's two copies decoded by one workgroup from one record table) and without"""
+    """the serial chain; side by side with twins (a block's two copies decoded by one workgroup from one record table), with the second copies
+    decoded by a second launch from the tables the first ones' decode wrote (blocks of 1 MiB and more; ignored otherwise), and with neither"""
     rs, os_ = run_chain(ctx, blocks, cap, len(data), True, history)
-    rt, ot = run_chain(ctx, blocks, cap, len(data), False, history, twins=True)
-    rp, op = run_chain(ctx, blocks, cap, len(data), False, history, twins=False)
-    assert rs == rp == rt
-    assert os_ == data and op == data and ot == data
+    rt, ot = run_chain(ctx, blocks, cap, len(data), False, history, twins=True, tables=False)
+    rb, ob = run_chain(ctx, blocks, cap, len(data), False, history, twins=False, tables=True)
+    rp, op = run_chain(ctx, blocks, cap, len(data), False, history, twins=False, tables=False)
+    assert rs == rp == rt == rb
+    assert os_ == data and op == data and ot == data and ob == data
     return rp
 
 
@@ -205,3 +210,33 @@ def test_gated_third_decode_of_ragged_chains(ctx):
         res = both(ctx, blocks, cap, data)
         assert sum(res) == len(data) and all(r > 0 for r in res)
         assert LAST_STATS["units"] == 2 and LAST_STATS["units_decoded_three_times"] == want_third, (head, far_at, LAST_STATS)
+
+
+def test_large_blocks_second_launch_from_tables(ctx, L, datagen):
+    """Chains of blocks of 1 MiB and more: the second copies (and the third, where a unit needs it) are decoded by a second launch from the tables
+    the first copies' decode wrote (spec_gate).  Hand-made and compressed chains, a damaged block, a unit that needs its third copy."""
+    rng = random.Random(78)
+    cap = 1 << 20
+    noise = rng.randbytes(cap)
+    for far_at, want_third in ((10, 1), (300, 0)):
+        body = datagen(600000, 60, 5 + far_at)
+        pre = rng.randbytes(far_at)
+        blocks = [(False, _block(noise, None, b"")), (False, _block(pre, (65530, 40), body))]
+        data = bytearray(noise + pre)
+        for _ in range(40): data.append(data[len(data) - 65530])
+        data += body
+        blocks.append((False, _block(b"xyz", (70, 3000), b"and so it ends")))
+        data += b"xyz"
+        for _ in range(3000): data.append(data[len(data) - 70])
+        data += b"and so it ends"
+        res = both(ctx, blocks, cap, bytes(data))
+        assert sum(res) == len(data)
+        assert LAST_STATS["units"] == 3 and LAST_STATS["units_decoded_three_times"] == want_third, (far_at, LAST_STATS)
+    data = datagen(5 << 20, 60, 41)
+    blocks = linked_blocks(L, data, 6)
+    both(ctx, blocks, cap, data)
+    bad = list(blocks); bad[2] = (False, bad[2][1][:-9])
+    for tb in (True, False):
+        res, out = run_chain(ctx, bad, cap, len(data), False, tables=tb)
+        assert res[:2] == [cap, cap] and all(r < 0 for r in res[2:]), tb
+        assert out == data[:2 * cap]
