@@ -580,7 +580,8 @@ def bench_frame_device(ctx, lz4_amd, torch, data, out, stream, bs, copy_gbps):
     ok = ok and splan.results(stream) == [bs] * nb and bool(torch.equal(out, data))
     splan.close()
     return {"workload": "configs[2], device side only: %d linked %d-byte blocks (%.2f GiB) resident in HBM: compress with 64 KB of history (one launch), gather into frame layout (one launch), "
-                        "decode of the linked blocks side by side (kernels/chain_spec_kernel.h: the ordinary decoder over block 0 and two copies of every other block - a third where the two cannot tell -, merge, patch); "
+                        "decode of the linked blocks side by side (kernels/chain_spec_kernel.h: the ordinary decoder over block 0 and two copies of every other block - a third where the two cannot tell; "
+                        "the second from the entry-point table the first one's decode writes -, merge, patch); "
                         "no transfers, no host checksum" % (nb, bs, U / 2**30),
             "bit_exact": ok, "ratio": round(U / C, 4),
             "compress_GBps": round(U / (cms * 1e-3) / 1e9, 2), "gather_GBps": round(C / (gms * 1e-3) / 1e9, 2), "decompress_GBps": round(U / (dms * 1e-3) / 1e9, 3),
@@ -598,8 +599,8 @@ def bench_frame_device(ctx, lz4_amd, torch, data, out, stream, bs, copy_gbps):
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round((U + C) / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "algorithmic_bytes_per_launch": U + C, "avg_ms": round(dms, 3),
                                     "limited_by": "every block but the first is decoded twice (against two made-up histories: which bytes depend on the history, and on which "
-                                                  "byte of it; a third time where those two cannot tell), without entry-point tables (a frame has no room for them): 2 x the plain "
-                                                  "decoder's time on 2 (n - 1) + 1 blocks, then two bandwidth passes; round 5's chain of copy stages, one CU at a time: "
+                                                  "byte of it; a third time where those two cannot tell): the first copy without an entry-point table (a frame has no room for them), writing one, "
+                                                  "the second from it in a second launch, then two bandwidth passes; round 5's chain of copy stages, one CU at a time: "
                                                   "decompress_serial_chain_GBps"}}
 
 

@@ -96,8 +96,9 @@ int  lz4amd_plan_create_compress_hc_prefix(lz4amd_ctx* ctx, lz4amd_plan** out, i
  * real history are put in afterwards - a launch of the decoder, two bandwidth passes.  The plan then owns 3 x (64 KB + a unit) of device memory
  * per unit (3.2 GB for a GiB of 4 MiB blocks; budget 64 GiB, or LZ4AMD_CHAIN_SLOTS_MB); a plan that cannot have it, a chain of one unit, or
  * LZ4AMD_CHAIN_SERIAL=1 in the environment when the plan is made, decodes the blocks' copy stages one after the other (one CU at a time,
- * ~3.5 GB/s).  LZ4AMD_CHAIN_GROUP (blocks per unit) and LZ4AMD_CHAIN_TWINS (0 / 1: a block's two copies decoded by one workgroup from one record
- * table) override the plan's choices. */
+ * ~3.5 GB/s).  LZ4AMD_CHAIN_GROUP (blocks per unit), LZ4AMD_CHAIN_TWINS (0 / 1: a block's two copies decoded by one workgroup from one record
+ * table) and LZ4AMD_CHAIN_TABLES (0 / 1, blocks of 1 MiB and more: the second copies by a second launch, from entry-point tables the first copies'
+ * decode writes) override the plan's choices. */
 int  lz4amd_plan_create_decompress_chained(lz4amd_ctx* ctx, lz4amd_plan** out, int n,
                                            const void* const* d_src, const int* src_sizes,
                                            void* d_dst0, const int* dst_caps, const unsigned char* stored, int initial_prefix);

@@ -314,3 +314,22 @@ def test_hc_favor_decompression_speed_through_the_stream_api(ctx, ocodec, datage
             if level == 12 and not favor:
                 assert any(off < 8 for _, off, ml in _sequences(c) if ml)
     assert sizes[(12, 1)] >= sizes[(12, 0)] and sizes[(9, 1)] == sizes[(9, 0)]
+
+
+def test_hc_repetitive_stream_block_by_block(ctx, reflib, datagen):
+    """`datagen -P99` (copies of copies), level 9, block by block against the real LZ4_compress_HC: the aggregate is inside the window, single
+    blocks at the stream's start are not (no look-back through later positions' chains, lz4hc.c:906-960; the bench line's
+    hc.repetitive.worst_block_ratio_vs_reference).  This pins where that stands: a worse search shows here first."""
+    bs, n = 262144, 48
+    data = datagen(n * bs, 99, 0)
+    blocks = [data[i * bs:(i + 1) * bs] for i in range(n)]
+    ours = [r for r, _ in gpu_compress_hc(ctx, blocks)]
+    reflib.LZ4_compress_HC.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    cap = bs + bs // 255 + 16
+    dst = ctypes.create_string_buffer(cap)
+    ref = [reflib.LZ4_compress_HC(b, dst, bs, cap, 9) for b in blocks]
+    assert all(r > 0 for r in ours) and all(r > 0 for r in ref)
+    per = [r / o for r, o in zip(ref, ours)]                                  # reference bytes / our bytes
+    assert sum(ref) / sum(ours) >= 0.95, sum(ref) / sum(ours)
+    assert min(per) >= 0.75, (min(per), per.index(min(per)))                  # measured: 0.79 (block 1)
+    assert sum(1 for x in per if x < 1 / 1.05) <= n // 4, per
