@@ -38,6 +38,7 @@ NH="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-hc --no-extra
 # configs[2] device resident: the chained decode of linked blocks, the gather into frame layout, the batched XXH32 (so that every frac of the line has a profiles/ counterpart)
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_frame -o ${tag}fr -- python $R/tools/prof_frame.py > $R/gpurun_out/${tag}_prof_frame.log 2>&1 )
 ( timeout 120 python tools/stress_gpu.py 30 5 2>&1 | tail -1 ) > gpurun_out/${tag}_stress.log; cat gpurun_out/${tag}_stress.log
+( timeout 200 python tools/stress_linked.py 60 5 2>&1 | tail -1 ) > gpurun_out/${tag}_stress_linked.log; cat gpurun_out/${tag}_stress_linked.log
 for db in $(find gpurun_out -name "${tag}*results.db"); do python tools/rocprof_summary.py $db > ${db%.db}.txt 2>&1; tail -n 6 ${db%.db}.txt; rm -f $db; done      # (the databases are tens of MB: gpurun copies back 64 MiB at most)
 find gpurun_out -type f \( -name "*.db" -o -name "*.pftrace" -o -name "*.rocpd" \) -delete
 du -sh gpurun_out
