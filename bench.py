@@ -539,7 +539,7 @@ def bench_by_compressibility(ctx, lz4_amd, torch, stream, bs, use_hints, pcts=(0
     out["note"] = ("%d blocks per row, like the step's table; the step's own compressibility is in the top-level fields.  P0 (incompressible): the compress "
                    "rate of blocks without a single match depends on where their buffers lie - 2.4 ms or 12-17 ms per 64 blocks of 4 MiB, same bytes (DESIGN.md "
                    "section 6, open); from -P2 on it does not.  far_window_period_65520: noise of period 65520 - the reference finds the match once per block and lets it "
-                   "run; the tile-parallel parse finds it again in every 8 KB tile, and only where the candidate 65520 back still lies in the source ring (DESIGN.md section 8)" % nblk)
+                   "run; the tile-parallel parse has to find it again in every 8 KB tile, through a hash table into which 65520 positions went since (DESIGN.md section 8)" % nblk)
     return out
 
 
