@@ -157,6 +157,7 @@ enum : uint32_t { CM_BLOCK = 0, CM_OUT = 1, CM_CARRY = 2, CM_FAIL = 3, CM_READY 
                   CM_HOVER = 7,        // entry-point table: a row did not fit the table's room (the table is then left invalid)
                   CM_ROWS = 32,        // ... rows of the tiles settled so far
                   CM_HTILE = 40,       // u32[2][4] per tile in flight: { first ordinal, first row, log2 of the row distance, - }
+                  CM_INH = 56,         // u32[2] by tile parity: generation << 16 | distance of a taken match that ran into the tile's end (atomicMax): the next tile's first position tries it
                   CM_TILE = 8 };       // u32[2][4] per tile in flight: { first output position, end, written directly (not staged),
                                        //   first pending byte of its carry chunk }
 enum : uint32_t { T_OUT0 = 0, T_OUT1 = 1, T_DIRECT = 2, T_CFROM = 3 };
@@ -321,7 +322,7 @@ __device__ __forceinline__ Pair32 ring_ld8_32(const uint8_t* ring, uint32_t o) {
 // one probe round: the four positions of a lane's 4 << SH source bytes from q0 on
 struct Round { uint32_t dd[4]; uint32_t sb, eb; uint32_t hh[2]; };      // distance of the candidate that holds at slot j (0: none); run starts / ends; the four table indices probed (two per word)
 template <bool SMALL>
-__device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi, uint32_t SH) {
+__device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t* tab, uint32_t o0, uint32_t q0, uint32_t q_hi, uint32_t SH, uint32_t inh = 0u) {      // inh: a distance to try at q0 when the table has none (a tile's first position: the match that ran into the end of the tile before)
     constexpr bool small = SMALL;      // (SH: 0 for a small block; 1 or 2 - wave-uniform, the same for the whole launch - for a big one: only the bytes' extraction differs)
     Round R;
     uint32_t R0, R1, R2 = 0, R3 = 0, R4 = 0;
@@ -348,6 +349,13 @@ __device__ __forceinline__ Round probe_round(const uint8_t* ring, const uint32_t
         const uint32_t* a = (const uint32_t*)(ring + (co & ~3u));
         const uint32_t x = align_bytes(a[1], a[0], co & 3u);
         R.dd[j] = (ok && x == f0) ? d : 0u;
+        if (j == 0 && inh && R.dd[0] == 0u && q <= q_hi) {
+            // a long match is found ONCE by a serial parse (lz4.c:1104: it runs on to the block's end); a tile has to find it again, and the table's slot
+            // of a position 64 K back has been taken many times over since: the tile's first position also tries the distance the tile before ended with
+            const uint32_t ci = ring_back(o0, inh);
+            const uint32_t* ai = (const uint32_t*)(ring + (ci & ~3u));
+            if (align_bytes(ai[1], ai[0], ci & 3u) == f0) R.dd[0] = inh;
+        }
     }
     // runs: first / last probe of every stretch of hits with one distance
 #if LZ4AMD_CMP_MERGE_RUNS
@@ -402,10 +410,10 @@ __device__ __forceinline__ void list_round(const Round& R, uint32_t iS, uint32_t
 // number of runs the piece has.  probe_h: the table indices of the lane's four positions (the insert of this tile uses them again).
 template <bool SMALL>
 __device__ __forceinline__ uint32_t probe_list(const uint8_t* ring, const uint32_t* tab, uint32_t* candS, uint8_t* candE, uint32_t cs, uint32_t cs_off,
-                                               uint32_t q_hi, uint32_t lo, uint32_t SH, uint32_t (&probe_h)[2]) {
+                                               uint32_t q_hi, uint32_t lo, uint32_t SH, uint32_t (&probe_h)[2], uint32_t inh_pos = 0xFFFFFFFFu, uint32_t inh_d = 0u) {
     const uint32_t lane = lane_id();
     CMP_STAT(6, 1);
-    const Round A = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, lane * (4u << SH)), cs + lane * (4u << SH), q_hi, SH);
+    const Round A = probe_round<SMALL>(ring, tab, ring_fwd(cs_off, lane * (4u << SH)), cs + lane * (4u << SH), q_hi, SH, cs + lane * (4u << SH) == inh_pos ? inh_d : 0u);
     probe_h[0] = A.hh[0]; probe_h[1] = A.hh[1];
     const uint32_t cntA = (uint32_t)__popc(A.sb) | ((uint32_t)__popc(A.eb) << 16);
     const uint32_t inclA = wave_incl_sum(cntA), exA = inclA - cntA;
@@ -418,7 +426,7 @@ struct ParseState { uint32_t nseq, enc, ll0, cur; };      // records so far, the
 // One pass of measure / select / records, lane = run: the run's first probe position qs, its distance d, a = the first byte
 // its probes did not compare (last probe + 4).  Runs come in position order; st.cur carries the end of what was taken before.
 __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, uint16_t* ends, uint32_t rec_cap, uint32_t cs, uint32_t cs_off,
-                                           uint32_t mlimit, uint32_t last_q, bool have, uint32_t qs, uint32_t d, uint32_t a, ParseState& st) {
+                                           uint32_t mlimit, uint32_t last_q, bool have, uint32_t qs, uint32_t d, uint32_t a, ParseState& st, uint32_t* inh_w = nullptr, uint32_t inh_gen = 0u) {
     const uint32_t lane = lane_id();
     CMP_STAT(0, 1); { const unsigned long long hv = __ballot(have); CMP_STAT(1, __popcll(hv)); }
     // ---- measure
@@ -505,6 +513,7 @@ __device__ __forceinline__ void parse_pass(const uint8_t* ring, MatchRec* recs, 
     uint32_t prev_end = wave_prev_u32(pt);                   // end of the match taken before mine (taken lanes)
     if (prev_end < st.cur) prev_end = st.cur;
     const uint32_t last_e = wave_readlane(pt, 63);
+    if (inh_w && mine && e >= mlimit) atomicMax(inh_w, (inh_gen << 16) | d);      // (CM_INH: order independent - the output stays a function of the input)
     // ---- records
     const uint32_t ri = st.nseq + lanes_below(taken);
     uint32_t my_enc = 0, my_ll = 0;
@@ -586,7 +595,7 @@ __device__ __forceinline__ void match_strip(const uint8_t* ring, const uint32_t*
 __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint32_t* tab, MatchRec* recs, uint16_t* ends, uint32_t rec_cap, uint32_t* strip,
                                                  const uint32_t* LAs, const uint8_t* LAe, uint32_t nA, const uint32_t* LBs, const uint8_t* LBe, uint32_t nB,
                                                  uint32_t* candS, uint8_t* candE, uint32_t si, uint32_t n, uint32_t cs, uint32_t tend,
-                                                 uint32_t* table_free, uint32_t gen) {      // table_free: told (gen) when this wave probes no more
+                                                 uint32_t* table_free, uint32_t gen, uint32_t* inh_w) {      // table_free: told (gen) when this wave probes no more; inh_w: CM_INH of this tile
     const uint32_t lane = lane_id();
     const uint32_t ce = cs + 1024;                                   // (full tiles only: the strip lies inside the block)
     ParseState st; st.nseq = 0; st.enc = 0; st.ll0 = 0; st.cur = cs;
@@ -603,7 +612,7 @@ __device__ __forceinline__ void match_pair_strip(const uint8_t* ring, const uint
                 uint32_t S = 0, E = 0;
                 if (have) { S = inB ? LBs[i - nA] : LAs[i]; E = inB ? LBe[i - nA] : LAe[i]; }
                 const uint32_t base = cs + (inB ? 512u : 0u);
-                parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, base + ((S & 255u) << 1), have ? S >> 8 : 1u, base + (E << 1) + kMinMatch, st);
+                parse_pass(ring, recs, ends, rec_cap, cs, cs_off, mlimit, last_q, have, base + ((S & 255u) << 1), have ? S >> 8 : 1u, base + (E << 1) + kMinMatch, st, mlimit == tend ? inh_w : nullptr, gen);
             }
         } else {
             uint32_t ph[2];
@@ -1128,7 +1137,7 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
     for (uint32_t i = tid; i < (1u << kHashBits); i += kCmpThreads) tab[i] = 0;
     if (16 * tid < kStageBytes) { U32x4 z; z[0] = z[1] = z[2] = z[3] = 0; *(U32x4*)(smem + kCOffStage + 16 * tid) = z; }
     if (tid == 0) {
-        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_SEQS] = 0;
+        misc[CM_OUT] = 0; misc[CM_CARRY] = 0; misc[CM_FAIL] = 0; misc[CM_READY] = 0; misc[CM_SEQS] = 0; misc[CM_INH] = 0; misc[CM_INH + 1] = 0;
         for (uint32_t i = CM_EMITQ; i < CM_FLUSHQ + 2; i++) misc[i] = 0; misc[CM_HOVER] = 0; misc[CM_ROWS] = 0;
         for (uint32_t i = 0; i < 2 * kCmpWaves; i++) pairw[i] = 0;
 #ifdef LZ4AMD_PROF_TILE
@@ -1223,15 +1232,18 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
             const uint32_t pcs = t0 + 512 * w, gen = (tiles_parsed & 0x7FFFu) + 1u;
             const uint32_t q_hi = pcs + 511 < last_q ? pcs + 511 : last_q;
             uint32_t nw = 0, nw2 = 0;
+            // the distance of the match that ran into the end of the tile before (CM_INH of that tile's parity: written before this tile's barrier, by nobody now)
+            const uint32_t inh_key = misc[CM_INH + (par ^ 1u)];
+            const uint32_t inh_d = (tiles_parsed && (inh_key >> 16) == (((tiles_parsed - 1u) & 0x7FFFu) + 1u)) ? (inh_key & 0xFFFFu) : 0u;
             if (w != settle_w) {
-                if (pcs <= last_q) { nw = probe_list<false>(ring, tab, candS, candE, pcs, src_ring_off(pcs), q_hi, 0u, 1u, probe_h); probe_h_valid = true; }
+                if (pcs <= last_q) { nw = probe_list<false>(ring, tab, candS, candE, pcs, src_ring_off(pcs), q_hi, 0u, 1u, probe_h, t0, inh_d); probe_h_valid = true; }
                 wave_lds_fence_local();
                 if (lane_id() == 0) lds_store_release_local(&pairw[w], (gen << 16) | nw);
                 if (w == (settle_w ^ 1u)) {                        // (the settling wave's piece, into its list)
                     const uint32_t pcs2 = pcs + 512, q_hi2 = pcs2 + 511 < last_q ? pcs2 + 511 : last_q;
                     uint32_t ph2[2];
                     if (pcs2 <= last_q) nw2 = probe_list<false>(ring, tab, (uint32_t*)(smem + kCOffCandS) + settle_w * kCandCap, (uint8_t*)(smem + kCOffCandE) + settle_w * kCandCap,
-                                                                pcs2, src_ring_off(pcs2), q_hi2, 0u, 1u, ph2);
+                                                                pcs2, src_ring_off(pcs2), q_hi2, 0u, 1u, ph2, t0, inh_d);
                     wave_lds_fence_local();
                     if (lane_id() == 0) lds_store_release_local(&pairw[settle_w], (gen << 16) | nw2);
                 }
@@ -1260,9 +1272,9 @@ __device__ __forceinline__ void compress_one_block(const CompBatch& P, uint32_t 
                 const uint8_t* pE = (const uint8_t*)(smem + kCOffCandE) + pw * kCandCap;
                 const uint32_t si = w >> 1;
                 if (w & 1u) match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, kRecsPerPair, strip_k,
-                                             pS, pE, np, candS, candE, nw, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen);
+                                             pS, pE, np, candS, candE, nw, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen, &misc[CM_INH + par]);
                 else match_pair_strip(ring, tab, recs_k + si * kRecsPerPair, ends_k + si * kRecsPerPair, kRecsPerPair, strip_k,
-                                      candS, candE, nw, pS, pE, np, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen);
+                                      candS, candE, nw, pS, pE, np, candS, candE, si, n, t0 + 1024 * si, t1, &pairw[kCmpWaves + si], gen, &misc[CM_INH + par]);
 #if LZ4AMD_CMP_PRIO & 2
                 wave_priority(0);
 #endif

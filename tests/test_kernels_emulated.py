@@ -864,3 +864,17 @@ def test_compress_acceleration_trades_size_for_speed(emu, ocodec, reflib, datage
         # (... and at acceleration 2 the -P90 MiB lands 8.3 % above the reference's: every fourth position against its growing step)
         assert all(0.88 * r <= o <= (hi + (0.03 if accel == 1 else 0.04)) * r for o, r in zip(sizes[accel][:4], refs)), (accel, sizes[accel], refs)
         assert 0.90 * sum(refs) <= sum(sizes[accel][:4]) <= hi * sum(refs), (accel, sizes[accel], refs)
+
+
+def test_compress_long_match_at_a_far_distance_is_carried_from_tile_to_tile(emu, ocodec):
+    """Noise of period 65 520: the reference finds the match once and lets it run to the block's end (lz4.c:1104); the tile-parallel parse has to find it
+    again in every 8 KB tile, and the table's slot of a position 64 K back has been taken many times over since - so a taken match that reaches its
+    tile's end leaves its distance for the next tile's first position (CM_INH, lz4_compress_kernel.h).  Without that: 1.7 : 1 on this block."""
+    import random
+    rng = random.Random(7)
+    for period, least in ((65520, 10.0), (40000, 15.0)):
+        data = (rng.randbytes(period) * 30)[:1000000]
+        (r, c), = emu_compress(emu, [data])
+        ro, o = ocodec.decompress(c, len(data))
+        assert ro == len(data) and o == data
+        assert len(data) / r >= least, (period, len(data) / r)
