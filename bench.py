@@ -601,7 +601,7 @@ def bench_frame_device(ctx, lz4_amd, torch, data, out, stream, bs, copy_gbps):
             "roofline_compress": roofline_obj("compress", cms, U + C, copy_gbps, None),
             "roofline_gather": {"kernel": "gather", "bound": "hbm", "achieved": round(2 * C / (gms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(2 * C / (gms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes_per_launch": 2 * C, "avg_ms": round(gms, 4)},
-            "roofline_decompress": {"kernel": "decompress + spec_merge + spec_patch (linked blocks side by side)", "bound": "hbm", "achieved": round((U + C) / (dms * 1e-3) / 1e9, 2),
+            "roofline_decompress": {"kernel": "decompress_runs + spec_gate + decompress + spec_merge + spec_patch (linked blocks side by side)", "bound": "hbm", "achieved": round((U + C) / (dms * 1e-3) / 1e9, 2),
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round((U + C) / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "algorithmic_bytes_per_launch": U + C, "avg_ms": round(dms, 3),
                                     "limited_by": "every block but the first is decoded twice (against two made-up histories: which bytes depend on the history, and on which "
